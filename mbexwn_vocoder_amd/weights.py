@@ -1,0 +1,97 @@
+"""Weight containers for the mel-inversion engine.
+
+Raw variables follow the reference's weight-normalised convolution
+(reference MBExWN_NVoc/vocoder/model/tf2_components/layers/conv_layers.py:79-103):
+``<layer>.v`` (ks, cin, cout), ``<layer>.g`` (cout,), ``<layer>.bias`` (cout,) and the
+PReLU slopes ``<act>.alpha`` (channels,).  ``fold_weights`` turns them into the plain
+``<layer>.w`` / ``<layer>.b`` tensors the HIP engine consumes.
+
+The pretrained checkpoints are not in the reference tree; ``synthetic_weights``
+generates seeded weights of the exact architecture.
+A checkpoint saved with ``save_weights`` is a plain ``.npz`` of the raw variables.
+"""
+import numpy as np
+
+from .config import ModelDims
+from .subnet import build_subnet
+
+
+def layer_table(config):
+    """[(name, ks, cin, cout)] of every weight-normed conv and [(name, channels)] of every PReLU."""
+    dims = ModelDims(config)
+    mb = config["mbexwn_config"]
+    convs, prelus = [], []
+    use_prelu = mb.get("use_prelu", True)
+    f0_ops, _, _ = build_subnet(mb["pp_subnet"], "PulsPar", dims.mel_channels, 1, 1,
+                                mb.get("pp_activation", "soft_sigmoid"), target_ups=dims.pulse_per_frame,
+                                pad_to_valid=mb.get("pp_subnet_use_valid_padding", False), use_prelu=use_prelu,
+                                alpha=dims.alpha)
+    vtf_ops, _, _ = build_subnet(mb["ps_subnet"], "PS", dims.mel_channels, dims.n_ceps, 1, None,
+                                 pad_to_valid=mb.get("ps_subnet_use_valid_padding", False), use_prelu=use_prelu,
+                                 alpha=dims.alpha)
+    for op in f0_ops + vtf_ops:
+        if op["kind"] == "conv":
+            convs.append((op["name"], op["ks"], op["cin"], op["cout"]))
+        elif op["kind"] == "prelu":
+            prelus.append((op["name"], op["channels"]))
+    C, L = dims.wn_channels, dims.wn_layers
+    convs.append(("wn.start", 1, dims.wn_in_channels, C))
+    convs.append(("wn.cond", dims.cond_kernel_size, dims.mel_channels, 2 * C * dims.cond_conv_upsampling))
+    for ll in range(L):
+        convs.append((f"wn.conv1D_{ll}", dims.wn_kernel_size, C, 2 * C))
+        convs.append((f"wn.res_skip_{ll}", 1, C, 2 * C if ll < L - 1 else C))
+    convs.append(("wn.end", 1, C, dims.wn_out_channels))
+    convs.append(("post", 1, dims.wn_out_channels, dims.subbands))
+    return convs, prelus
+
+
+# per-layer gain of the synthetic weights (weight-norm g relative to ||v||=1 columns); chosen so
+# that activations stay O(1), F0 moves inside [fmin,fmax] and the envelope filter is well inside
+# its +-range.  Arbitrary but fixed: part of the definition of the synthetic benchmark model.
+_SYNTH_GAIN = {"PS_Layer_final": 0.02, "wn.end": 0.04, "post": 1.0, "wn.cond": 0.7, "PulsPar_Layer_final": 2.0}
+
+
+def synthetic_weights(config, seed=1234, bias_std=0.0, alpha_jitter=0.0):
+    """Seeded raw variables: v ~ N(0, 0.02^2), g = gain, bias ~ N(0, bias_std^2), alpha = 0.2 (+jitter)."""
+    rng = np.random.default_rng(seed)
+    convs, prelus = layer_table(config)
+    alpha0 = float(config["mbexwn_config"].get("alpha", 0.2))
+    raw = {}
+    for name, ks, cin, cout in convs:
+        raw[name + ".v"] = rng.normal(0.0, 0.02, size=(ks, cin, cout)).astype(np.float32)
+        raw[name + ".g"] = np.full((cout,), _SYNTH_GAIN.get(name, 1.0), dtype=np.float32)
+        raw[name + ".bias"] = (rng.normal(0.0, 1.0, size=(cout,)) * bias_std).astype(np.float32)
+    for name, channels in prelus:
+        raw[name + ".alpha"] = (alpha0 + alpha_jitter * rng.uniform(-1, 1, size=(channels,))).astype(np.float32)
+    return raw
+
+
+def fold_weight_norm(v, g):
+    """float32 fold W = g * v * rsqrt(max(sum_{k,ci} v^2, 1e-12)), the arithmetic of
+    tf.nn.l2_normalize at reference conv_layers.py:153."""
+    v = np.asarray(v, dtype=np.float32)
+    sq = np.sum(np.square(v), axis=(0, 1), keepdims=True, dtype=np.float32)
+    inv = (np.float32(1) / np.sqrt(np.maximum(sq, np.float32(1e-12)))).astype(np.float32)
+    return (np.asarray(g, dtype=np.float32) * (v * inv)).astype(np.float32)
+
+
+def fold_weights(raw):
+    """raw variables -> {'<layer>.w': (ks,cin,cout) f32, '<layer>.b': (cout,) f32, '<act>.alpha': ...}."""
+    out = {}
+    for key, val in raw.items():
+        if key.endswith(".v"):
+            name = key[:-2]
+            out[name + ".w"] = fold_weight_norm(val, raw[name + ".g"])
+            out[name + ".b"] = np.asarray(raw[name + ".bias"], dtype=np.float32)
+        elif key.endswith(".alpha"):
+            out[key] = np.asarray(val, dtype=np.float32)
+    return out
+
+
+def save_weights(path, raw):
+    np.savez(path, **raw)
+
+
+def load_weights(path):
+    with np.load(path) as data:
+        return {kk: data[kk] for kk in data.files}

@@ -1,0 +1,462 @@
+"""CPU ORACLE of the MBExWN mel-inversion forward pass -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import this module; the product package (``mbexwn_vocoder_amd``) never does.
+
+It is a plain numpy restatement (float64 by default, float32 selectable for the CPU timing
+baseline) of the reference's inference graph.  Every function cites the reference file:line it
+follows (paths relative to /root/reference/MBExWN_NVoc/vocoder/model/).
+
+PINNING STATUS
+  * The reference has no tests, fixtures or golden vectors for this path and its
+    graph executes inside TensorFlow, which is not installable here.
+  * Pinned against the reference itself, run in the build container:
+      - constants (PQMF banks, LF wavetables, windows, scale_mel) captured by importing the
+        reference's numpy code  -> tests/golden/reference_constants.npz
+        (generator: tests/golden/make_reference_constants.py)
+      - the full graph mel -> audio and every intermediate stage, produced by executing the
+        reference's own Python model code (MBExWN.call and all layers under it) on top of a
+        numpy stand-in for the TensorFlow op set -> tests/golden/reference_forward_*.npz
+        (generator: tests/golden/make_reference_forward.py, shim: tests/golden/tf_numpy_shim.py)
+  * NOT pinned: the TensorFlow kernels themselves (Eigen/oneDNN conv, pocketfft, cumsum ...);
+    their published semantics are restated in the shim. "vs TF-CPU" is therefore structural.
+
+The noise channel is an explicit input: TensorFlow's Philox stream cannot be
+reproduced, so parity is defined with injected noise.
+"""
+import numpy as np
+
+LOG_TO_DB = 20 * np.log10(np.exp(1))
+
+
+# ============================================================================================
+# primitive ops
+# ============================================================================================
+def fold_weight_norm(v, g, dtype):
+    """W[k,ci,co] = g[co] * v[k,ci,co] / sqrt(max(sum_{k,ci} v^2, 1e-12)).
+    tf2_components/layers/conv_layers.py:149-153 (tf.nn.l2_normalize over axes [0,1])."""
+    v = np.asarray(v, dtype=np.float64)
+    sq = np.sum(v * v, axis=(0, 1), keepdims=True)
+    w = np.asarray(g, dtype=np.float64) * (v / np.sqrt(np.maximum(sq, 1e-12)))
+    return w.astype(dtype)
+
+
+def pad_time(x, left, right, mode):
+    """custom_layers.py:47-71 (TFPad1d) ; mode in CONSTANT / SYMMETRIC / EDGE. x: (B,T,C)."""
+    if left == 0 and right == 0:
+        return x
+    np_mode = {"CONSTANT": "constant", "SYMMETRIC": "symmetric", "EDGE": "edge"}[mode]
+    return np.pad(x, ((0, 0), (left, right), (0, 0)), mode=np_mode)
+
+
+def conv1d_valid(x, w, b=None, dilation=1):
+    """Keras Conv1D, VALID, stride 1: y[t,co] = b[co] + sum_{j,ci} x[t + j*d, ci] W[j,ci,co]
+    (cross-correlation).  Call site conv_layers.py:154."""
+    ks = w.shape[0]
+    t_out = x.shape[1] - (ks - 1) * dilation
+    y = None
+    for jj in range(ks):
+        part = x[:, jj * dilation: jj * dilation + t_out, :] @ w[jj]
+        y = part if y is None else y + part
+    if b is not None:
+        y = y + b
+    return y
+
+
+def conv1d_same_zero(x, w, b=None, dilation=1):
+    """Keras Conv1D padding="same": zero pad d*(k-1) split left-floor / right-ceil.
+    custom_AE_layers.py:236-243 (WaveNet layers), :214-227 (cond conv)."""
+    total = (w.shape[0] - 1) * dilation
+    xp = pad_time(x, total // 2, total - total // 2, "CONSTANT")
+    return conv1d_valid(xp, w, b, dilation)
+
+
+def lin_interp(x, up, weights_dtype=np.float32):
+    """TF2C_LinInterpLayer(num_pad_end=1, drop_last=True): support_layers.py:19-27,99-121.
+    out[t*U+u] = x[t]*(U-u)/U + x[min(t+1,T-1)]*u/U ; the two weight vectors are float32 constants."""
+    uu = np.arange(up)
+    w0 = ((up - uu) / up).astype(weights_dtype).astype(x.dtype)
+    w1 = (uu / up).astype(weights_dtype).astype(x.dtype)
+    nxt = np.concatenate((x[:, 1:], x[:, -1:]), axis=1)
+    out = x[:, :, None, :] * w0[None, None, :, None] + nxt[:, :, None, :] * w1[None, None, :, None]
+    return out.reshape(x.shape[0], x.shape[1] * up, x.shape[2])
+
+
+def depth_to_time(x, factor):
+    """conv_layers.py:250-256: row-major reshape (B,T,f*F) -> (B,T*f,F)."""
+    return x.reshape(x.shape[0], x.shape[1] * factor, -1)
+
+
+def prelu(x, alpha):
+    """Keras PReLU(shared_axes=[1]): x>0 ? x : alpha_c*x. custom_pulsed_generator.py:247-250."""
+    return np.where(x > 0, x, alpha * x)
+
+
+def soft_sigmoid(x):
+    """custom_AE_layers.py:91-99."""
+    return 0.5 + 0.5 * x / (1 + np.abs(x))
+
+
+_FINAL_ACTS = {
+    "soft_sigmoid": soft_sigmoid,
+    "tanh": np.tanh,
+    "sigmoid": lambda x: 1 / (1 + np.exp(-x)),
+    "soft_sign": lambda x: x / (1 + np.abs(x)),
+    "soft_sqrt": lambda x: x / (1 + np.sqrt(np.abs(x))),
+    "exp": np.exp,
+    "relu": lambda x: np.maximum(x, 0),
+    "linear": lambda x: x,
+}
+
+
+# ============================================================================================
+# the model
+# ============================================================================================
+class OracleModel:
+    """Numpy restatement of ``MBExWN`` (custom_pulsed_generator.py:151-925) + ``PaNWaveNet.infer``
+    (wavegen_1d.py:483-526) for inference.
+
+    config     : dict with the reference's YAML keys (mbexwn_config / preprocess_config)
+    raw_weights: dict name -> array with the un-folded variables ``<layer>.v``, ``<layer>.g``,
+                 ``<layer>.bias`` and ``<act>.alpha``
+    wavetables : object with attributes tables (n_period+1,R) float32, n_period, nominalF0,
+                 min_transposition, max_transposition, grid_norm  (init-time constants; golden-pinned)
+    """
+
+    def __init__(self, config, raw_weights, wavetables, dtype=np.float64, float32_constants=True):
+        """float32_constants=True (default): everything the reference holds or computes as a float32
+        quantity that feeds an index, a phase or a constant table is evaluated in float32 exactly like
+        the float32 graph does.  False: the same graph entirely in float64 ("structural" mode, used only
+        for the comparison with the float64 run of the reference's model code)."""
+        self.dtype = dtype
+        self.f32 = np.float32 if float32_constants else np.float64
+        self.cfg = config
+        mb = config["mbexwn_config"]
+        pp = config["preprocess_config"]
+        self.sample_rate = pp["sample_rate"]
+        self.hop = pp["hop_size"]
+        self.mel_channels = pp["mel_channels"]
+        self.M = mb["multi_band_config"]["subbands"]
+        self.pulse_rate = self.sample_rate / mb["pulse_rate_factor"]
+        self.pulse_channels = mb["pulse_channels"]
+        self.steps_per_frame = self.hop // self.M                                   # :265
+        self.pulse_per_frame = self.steps_per_frame * self.pulse_channels           # :266
+        self.sigma = mb.get("pp_mod_subnet_noise_channel_sigma", 0.5)
+        self.f_min = mb.get("pp_min_frequency", 40.0)
+        self.f_max = mb.get("pp_max_frequency", 600.0)
+        self.wn = dict(mb["pp_mod_subnet"])
+        self.n_ceps = mb.get("ps_max_ceps_coefs", 120)
+        self.env_scale = mb.get("ps_env_order_scale", None)
+        self.use_ceps_constraint = mb.get("psns_use_cepstral_loss_constraint", False)
+        rng_db = mb.get("filter_max_db_range", None)
+        self.max_log_range = rng_db / LOG_TO_DB if rng_db is not None else None      # :371
+        self.stft_win = 4 * self.hop                                                # :396
+        fft_size = 16
+        while fft_size < self.stft_win:
+            fft_size *= 2
+        self.fft_size = fft_size                                                    # :397-400
+        self.wt = wavetables
+        self.raw = raw_weights
+        self.use_prelu = mb.get("use_prelu", True)
+        self.alpha = mb.get("alpha", 0.2)
+        self.pp_valid = mb.get("pp_subnet_use_valid_padding", False)
+        self.ps_valid = mb.get("ps_subnet_use_valid_padding", False)
+        self.pp_specs = mb["pp_subnet"]
+        self.ps_specs = mb["ps_subnet"]
+        self.pp_activation = mb.get("pp_activation", "soft_sigmoid")
+        self._w = {}
+        self._build_constants(mb)
+
+    # ------------------------------------------------------------------ constants
+    def _build_constants(self, mb):
+        dt = self.dtype
+        # PQMF synthesis bank -- tf_preprocess.py:30-80,119-161
+        mbc = mb["multi_band_config"]
+        taps, cutoff, beta = mbc["taps"], mbc["cutoff_ratio"], mbc["beta"]
+        nn = np.arange(taps + 1) - 0.5 * taps
+        with np.errstate(invalid="ignore", divide="ignore"):
+            proto = np.sin(np.pi * cutoff * nn) / (np.pi * nn)
+        proto[taps // 2] = cutoff
+        proto = proto * np.kaiser(taps + 1, beta)
+        kk = np.arange(self.M)[:, None]
+        syn = 2 * proto[None, :] * np.cos((2 * kk + 1) * (np.pi / (2 * self.M)) * nn[None, :]
+                                          - (-1.0) ** kk * np.pi / 4)
+        self.pqmf_taps = taps
+        self.pqmf_syn = syn.astype(np.float32).astype(dt)          # (M, taps+1), float32 constants
+        # STFT windows -- tf.signal.hann_window(periodic) / inverse_stft_window_fn (TensorFlow)
+        n = self.stft_win
+        hann = (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n) / n))
+        self.hann = hann.astype(self.f32).astype(dt)
+        den = np.square(self.hann).reshape(n // self.hop, self.hop).sum(axis=0)
+        self.inv_win = (self.hann / np.tile(den, n // self.hop)).astype(dt)
+        # cepstral lifter table -- custom_pulsed_generator.py:434-450
+        if self.env_scale:
+            rows, logs = [], []
+            for f0 in np.logspace(np.log10(self.f_min), np.log10(self.f_max), 30):
+                win_len = int(self.env_scale * 0.5 * self.sample_rate / f0)
+                if win_len % 2 == 0:
+                    win_len += 1
+                logs.append(np.log10(f0))
+                half = np.hamming(win_len)[win_len // 2:]
+                if win_len // 2 + 1 > self.n_ceps:
+                    rows.append(half[:self.n_ceps])
+                else:
+                    rows.append(np.concatenate((half, np.zeros(self.n_ceps - 1 - win_len // 2))))
+            self.ceps_log10f0 = np.asarray(logs, dtype=self.f32)
+            self.ceps_windows = np.asarray(rows, dtype=self.f32).astype(dt)
+        # F0 smoothing kernel -- :403-406
+        sw = np.bartlett(2 * self.hop + 3)[1:-1]
+        self.f0_smooth = (sw / np.sum(sw)).astype(self.f32)
+
+    def weight(self, name):
+        """folded (W, b) of a weight-normed conv layer, cached."""
+        if name not in self._w:
+            w = fold_weight_norm(self.raw[name + ".v"], self.raw[name + ".g"], self.dtype)
+            b = np.asarray(self.raw[name + ".bias"]).astype(self.dtype)
+            self._w[name] = (w, b)
+        return self._w[name]
+
+    # ------------------------------------------------------------------ sub-nets (A2)
+    def run_subnet(self, x, specs, base_name, final_n_channels, final_nks, final_activation,
+                   target_ups=None, pad_to_valid=False):
+        """custom_pulsed_generator.py:38-148 executed directly on the spec list."""
+        total_ups = 1
+        explicit = "EDGE" if pad_to_valid else "SYMMETRIC"
+        for ii, spec in enumerate(specs):
+            if spec[0] == "L":                                                   # :57-60
+                x = lin_interp(x, int(spec[1]), self.f32)
+                continue
+            ks, up, linear_up = int(spec[0]), 1, False
+            if len(spec) > 2:
+                if isinstance(spec[2], str):
+                    linear_up = spec[2][0] == "L"
+                    up = int(spec[2][1:])
+                else:
+                    up = int(spec[2])
+            w, b = self.weight(f"{base_name}_Layer_{ii}")
+            pl, pr = (ks - 1) // 2 + ((ks - 1) % 2), (ks - 1) // 2
+            if linear_up:                                                        # :74-89
+                x = lin_interp(conv1d_valid(pad_time(x, pl, pr, explicit), w, b), up, self.f32)
+            elif up > 1:                                                         # :91-108
+                if pad_to_valid:
+                    x = conv1d_valid(pad_time(x, pl, pr, "EDGE"), w, b)
+                else:
+                    x = conv1d_same_zero(x, w, b)
+                x = depth_to_time(x, up)
+            else:                                                                # :109-122
+                x = conv1d_valid(pad_time(x, pl, pr, explicit), w, b)
+            if self.use_prelu:                                                   # :123
+                x = prelu(x, np.asarray(self.raw[f"{base_name}_ActLayer_{ii}.alpha"]).astype(self.dtype))
+            else:
+                x = np.where(x > 0, x, self.alpha * x)
+            total_ups *= up
+        if final_nks is not None:                                                # :126-138
+            w, b = self.weight(f"{base_name}_Layer_final")
+            if pad_to_valid:
+                fk = final_nks
+                x = conv1d_valid(pad_time(x, (fk - 1) // 2 + ((fk - 1) % 2), (fk - 1) // 2, "EDGE"), w, b)
+            else:
+                x = conv1d_same_zero(x, w, b)
+            if target_ups is not None and total_ups != target_ups:               # :140-144
+                up = target_ups // total_ups
+                if total_ups * up != target_ups:
+                    raise RuntimeError("Upsampling to target upsampling factor is not possible")
+                x = lin_interp(x, up, self.f32)
+            if final_activation is not None:                                     # :145-146
+                x = _FINAL_ACTS[final_activation](x)
+        return x
+
+    # ------------------------------------------------------------------ F0 (A3)
+    def generate_f0(self, mel):
+        """custom_pulsed_generator.py:773-791 -> (B, T*pulse_per_frame) in Hz."""
+        x = self.run_subnet(mel, self.pp_specs, "PulsPar", 1, 1, self.pp_activation,
+                            target_ups=self.pulse_per_frame, pad_to_valid=self.pp_valid)
+        f0 = x[:, :, 0] * (self.f_max - self.f_min) + self.f_min
+        return f0[:, :mel.shape[1] * self.pulse_per_frame]
+
+    # ------------------------------------------------------------------ wavetable (A4)
+    def phase_from_f0(self, f0, chunk_size=1000):
+        """tf_wavetable.py:429-492 (stable_cumsum_and_wrap), float32 with TensorFlow-CPU's
+        sequential accumulation order (tf.cumsum = running sum along the axis)."""
+        ft = self.f32
+        vel = (np.asarray(f0, dtype=ft) / ft(self.pulse_rate)).astype(ft)          # :516
+        n_batch, n_time = vel.shape
+        rem = n_time % chunk_size
+        if rem:
+            vel = np.pad(vel, ((0, 0), (0, chunk_size - rem)))
+        n_chunks = vel.shape[1] // chunk_size
+        chunks = vel.reshape(n_batch, n_chunks, chunk_size)
+        phase = np.cumsum(chunks, axis=2, dtype=ft)                                # sequential running sum
+        offsets = np.mod(phase[:, :, -1:], ft(1))
+        offsets = np.pad(offsets, ((0, 0), (1, 0), (0, 0)))[:, :-1]
+        offsets = np.mod(np.cumsum(offsets, axis=1, dtype=ft), ft(1))
+        phase = np.mod(phase + offsets, ft(1)).astype(ft)
+        return phase.reshape(n_batch, -1)[:, :n_time]
+
+    def wavetable(self, f0):
+        """tf_wavetable.py:495-552 + _linear_lookup :605-638, float32 like the reference
+        (positions / indices are float32-exact, the two lerps are evaluated in self.dtype)."""
+        dt = self.dtype
+        ft = self.f32
+        f0_32 = np.asarray(f0, dtype=ft)
+        phase = self.phase_from_f0(f0_32)
+        pos = (phase * ft(self.wt.n_period)).astype(ft)                            # :619
+        base = np.floor(pos)
+        rem = (pos - base).astype(ft).astype(dt)                                   # :630
+        idx = base.astype(np.int64)
+        tab = np.asarray(self.wt.tables).astype(dt)
+        samples = tab[idx] * (1.0 - rem)[..., None] + tab[idx + 1] * rem[..., None]  # (B,N,R)  :633-638
+        ratio = np.maximum(ft(self.wt.min_transposition),
+                           np.minimum(ft(self.wt.max_transposition), f0_32 / ft(self.wt.nominalF0)))
+        q = np.log(ratio.astype(ft)).astype(ft) * ft(self.wt.grid_norm)            # :539-543
+        diff = q.astype(dt)[..., None] - np.arange(tab.shape[1], dtype=dt)
+        mix = np.maximum(1 - np.abs(diff), 0)
+        return np.sum(samples * mix, axis=2)                                       # :548
+
+    # ------------------------------------------------------------------ WaveNet (A5-A9)
+    def dilation(self, index):
+        step = self.wn.get("dilation_rate_step", 1)
+        mx = self.wn.get("max_log2_dilation_rate", None)
+        if mx is not None:
+            return 2 ** (int(index // step) % mx)
+        return 2 ** int(index // step)                                            # custom_AE_layers.py:229-233
+
+    def conditioning(self, mel):
+        """custom_AE_layers.py:214-227,287-289: sub-pixel conv (factor cond_conv_upsampling) then LinInterp."""
+        lin_up = self.wn.get("cond_lin_upsampling", 16)
+        conv_up = int((self.pulse_rate / self.pulse_channels) // ((self.sample_rate / self.hop) * lin_up))
+        w, b = self.weight("wn.cond")
+        c = depth_to_time(conv1d_same_zero(mel, w, b), conv_up)
+        return lin_interp(c, lin_up, self.f32)
+
+    def wavenet(self, x, mel, return_layers=False):
+        """custom_AE_layers.py:273-346 (WaveNetAE.call), n_ch_groups == 1, activation gtu."""
+        C = self.wn["n_channels"]
+        L = self.wn.get("n_layers", 12)
+        w, b = self.weight("wn.start")
+        h = conv1d_valid(x, w, b)                                                 # :280
+        cond = self.conditioning(mel)                                             # :287-289
+        skip = None
+        acts = []
+        for ll in range(L):
+            w, b = self.weight(f"wn.conv1D_{ll}")
+            z = conv1d_same_zero(h, w, b, dilation=self.dilation(ll)) + cond      # :307-309
+            a = np.tanh(z[..., :C]) * (1 / (1 + np.exp(-z[..., C:])))             # :312-321
+            w, b = self.weight(f"wn.res_skip_{ll}")
+            r = conv1d_valid(a, w, b)                                             # :324
+            if ll < L - 1:
+                h = h + r[..., :C]                                                # :326-328
+                s = r[..., C:]
+            else:
+                s = r                                                             # :330
+            skip = s if skip is None else skip + s                                # :332-335
+            if return_layers:
+                acts.append(a)
+        w, b = self.weight("wn.end")
+        out = conv1d_valid(skip, w, b)                                            # :337-340
+        if return_layers:
+            return out, h, skip, acts, cond
+        return out
+
+    # ------------------------------------------------------------------ PQMF (A10)
+    def pqmf_synthesis(self, x):
+        """tf_preprocess.py:208-226: zero-stuff by M with gain M, zero-pad taps/2, cross-correlate."""
+        B, S, K = x.shape
+        M, taps = self.M, self.pqmf_taps
+        up = np.zeros((B, S * M + taps, K), dtype=self.dtype)
+        up[:, taps // 2: taps // 2 + S * M: M, :] = M * x
+        y = np.zeros((B, S * M), dtype=self.dtype)
+        for b in range(B):
+            for k in range(K):
+                y[b] += np.correlate(up[b, :, k], self.pqmf_syn[k], mode="valid")
+        return y
+
+    # ------------------------------------------------------------------ excitation (A5)
+    def generate_excitation(self, mel, f0, noise):
+        """custom_pulsed_generator.py:886-925 ; noise (B, T*steps_per_frame) ~ N(0,1) or None (sigma=0)."""
+        pulse = self.wavetable(f0)                                                # :889
+        x = pulse.reshape(pulse.shape[0], -1, self.pulse_channels).astype(self.dtype)   # :893
+        if self.sigma:
+            if noise is None:
+                raise ValueError("noise must be given when pp_mod_subnet_noise_channel_sigma != 0")
+            nz = np.asarray(noise).astype(self.dtype)[:, :x.shape[1], None]
+            x = np.concatenate((x, self.sigma * nz), axis=-1)                     # :905-906
+        y = self.wavenet(x, mel)                                                  # :908-910
+        w, b = self.weight("post")
+        y = conv1d_valid(y, w, b)                                                 # :913-914
+        return self.pqmf_synthesis(y)                                             # :920-921
+
+    # ------------------------------------------------------------------ envelope (A12)
+    def cepstral_window_index(self, f0):
+        """custom_pulsed_generator.py:507-525 (float32 like the reference; returns int indices (B,T))."""
+        ft = self.f32
+        f0 = np.asarray(f0, dtype=ft)
+        half = self.f0_smooth.shape[0] // 2
+        padded = np.concatenate((np.repeat(f0[:, :1], half, axis=1), f0, np.repeat(f0[:, -1:], half, axis=1)), axis=1)
+        stride = self.pulse_per_frame
+        n_out = (padded.shape[1] - self.f0_smooth.shape[0]) // stride + 1
+        sm = np.empty((f0.shape[0], n_out), dtype=ft)
+        for t in range(n_out):
+            seg = padded[:, t * stride: t * stride + self.f0_smooth.shape[0]]
+            sm[:, t] = np.sum(seg.astype(np.float64) * self.f0_smooth.astype(np.float64), axis=1)
+        lg = (ft(1 / np.log(10)) * np.log(sm)).astype(ft)
+        lg = np.minimum(np.maximum(lg, self.ceps_log10f0[0]), self.ceps_log10f0[-1])
+        ratio = (lg - self.ceps_log10f0[0]) / (self.ceps_log10f0[-1] - self.ceps_log10f0[0])
+        return np.rint(ratio * ft(self.ceps_log10f0.shape[0] - 1)).astype(np.int64)   # tf.round: half to even
+
+    def generate_specenv(self, mel, f0, window_index=None):
+        """custom_pulsed_generator.py:793-855 -> complex (B,T,fft/2+1)."""
+        x = self.run_subnet(mel, self.ps_specs, "PS", self.n_ceps, 1, None, pad_to_valid=self.ps_valid)
+        if self.env_scale and not self.use_ceps_constraint:
+            if window_index is None:
+                window_index = self.cepstral_window_index(f0)
+            x = x * self.ceps_windows[window_index]                               # :813
+        ceps = np.zeros(x.shape[:2] + (self.fft_size,), dtype=self.dtype)
+        ceps[:, :, 1:self.n_ceps] = x[:, :, 1:]                                   # :820-821
+        spec = np.fft.rfft(ceps, axis=-1)                                         # :829
+        if self.max_log_range:
+            return np.exp(self.max_log_range * np.tanh(spec.real) + 1j * spec.imag)   # :831-834
+        return np.exp(spec)
+
+    # ------------------------------------------------------------------ STFT filter (A11,A13)
+    def stft(self, exc, n_frames):
+        """custom_pulsed_generator.py:681-694 (tf.signal.stft, pad_end=False, first n_frames kept)."""
+        n, hop = self.stft_win, self.hop
+        padded = np.pad(exc, ((0, 0), (n // 2, n // 2 + hop + 1)))
+        total = 1 + (padded.shape[1] - n) // hop
+        idx = np.arange(n)[None, :] + hop * np.arange(total)[:, None]
+        frames = padded[:, idx] * self.hann
+        return np.fft.rfft(frames, n=self.fft_size, axis=-1)[:, :n_frames]
+
+    def istft(self, spec, out_len):
+        """custom_pulsed_generator.py:716-724 (tf.signal.inverse_stft + inverse_stft_window_fn + slice)."""
+        n, hop = self.stft_win, self.hop
+        frames = np.fft.irfft(spec, n=self.fft_size, axis=-1)[..., :n] * self.inv_win
+        B, T = frames.shape[:2]
+        sig = np.zeros((B, (T - 1) * hop + n), dtype=self.dtype)
+        for t in range(T):
+            sig[:, t * hop: t * hop + n] += frames[:, t]
+        return sig[:, n // 2: n // 2 + out_len]
+
+    # ------------------------------------------------------------------ full graph (A1)
+    def forward(self, mel, noise=None, return_stages=False):
+        """MBExWN.call (custom_pulsed_generator.py:556-771, inference branch) wrapped like
+        PaNWaveNet.infer (wavegen_1d.py:483-526) with synth_length = T*hop.
+        mel (B,T,80) ; noise (B, T*steps_per_frame). Returns audio (B, T*hop)."""
+        mel = np.asarray(mel).astype(self.dtype)
+        T = mel.shape[1]
+        f0 = self.generate_f0(mel)                                                # :567
+        exc = self.generate_excitation(mel, f0, noise)                            # :676
+        src = self.stft(exc, T)                                                   # :681-694
+        env = self.generate_specenv(mel, f0)                                      # :704
+        out_len = f0.shape[1] * int(self.sample_rate // self.pulse_rate)
+        audio = self.istft(src * env, out_len)[:, :T * self.hop]                  # :715-724, wavegen_1d.py:504-510
+        if return_stages:
+            return audio, {"f0": f0, "excitation": exc, "envelope": env}
+        return audio
+
+
+def synthetic_mel(rng, batch, frames, channels=80):
+    """SURVEY.md section 8(d) synthetic input: mell = log(exp(N(-5,2^2)) + 1e-5), float32, clipped."""
+    mell = np.log(np.exp(rng.normal(-5.0, 2.0, size=(batch, frames, channels))) + 1e-5)
+    return np.clip(mell, -11.5, 2.0).astype(np.float32)

@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE's own model code (build container only).
+
+Imports ``MBExWN_NVoc`` from /root/reference with ``tf_numpy_shim`` registered as ``tensorflow``,
+instantiates the reference ``MBExWN`` layer from this repo's canonical configuration, loads the
+seeded synthetic variables into the reference's layer objects (v / g / bias / alpha), injects the
+noise draw and executes ``MBExWN.call`` and its stage methods unmodified.
+
+Outputs (committed, small):
+  reference_forward_f32.npz  tf.float32 := numpy float32  (emulation of the float32 TF-CPU run)
+  reference_forward_f64.npz  tf.float32 := numpy float64  (same graph, rounding noise removed)
+
+Usage: python tests/golden/make_reference_forward.py     (needs /root/reference)
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import tf_numpy_shim as shim  # noqa: E402
+
+CASES = {
+    # name: (voice type, config overrides, batch, frames)
+    "small": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3}, 2, 23),
+    "canon": ("SPEECH", {}, 1, 12),
+}
+
+
+def assign_conv(layer, raw, name):
+    layer.v.assign(raw[name + ".v"])
+    layer.g.assign(raw[name + ".g"])
+    layer.conv1d_layer.bias.assign(raw[name + ".bias"])
+
+
+def load_into_reference(model, raw):
+    used = set()
+    for sub in (model.pp_subnet_layers, model.ps_subnet_layers):
+        for ll in sub:
+            if hasattr(ll, "v"):
+                name = ll.conv1d_layer.name
+                assign_conv(ll, raw, name)
+                used.update({name + ".v", name + ".g", name + ".bias"})
+            elif type(ll).__name__ == "PReLU":
+                ll.alpha.assign(np.reshape(raw[ll.name + ".alpha"], ll.alpha.shape))
+                used.add(ll.name + ".alpha")
+    wn = model.pp_waveNetBlocks[0].wavenet
+    pairs = [(wn.start, "wn.start"), (wn.end, "wn.end"), (wn.cond_layer, "wn.cond"), (model.wn_post_net[0], "post")]
+    pairs += [(ll, f"wn.conv1D_{ii}") for ii, ll in enumerate(wn.conv_layers)]
+    pairs += [(ll, f"wn.res_skip_{ii}") for ii, ll in enumerate(wn.res_skip_layers)]
+    for layer, name in pairs:
+        assign_conv(layer, raw, name)
+        used.update({name + ".v", name + ".g", name + ".bias"})
+    missing = set(raw.keys()) - used
+    if missing:
+        raise RuntimeError(f"variables not consumed by the reference model: {sorted(missing)}")
+
+
+def run_case(voice, overrides, batch, frames, float_type):
+    from mbexwn_vocoder_amd.config import canonical_config
+    from mbexwn_vocoder_amd.weights import synthetic_weights
+    from MBExWN_NVoc.vocoder.model.custom_pulsed_generator import MBExWN
+
+    cfg = canonical_config(voice, **overrides)
+    raw = synthetic_weights(cfg, seed=1234, bias_std=0.05, alpha_jitter=0.05)
+    model = MBExWN(**cfg["mbexwn_config"], preprocess_config=cfg["preprocess_config"], quiet=True,
+                   use_tf25_compatible_implementation=True)
+    model.build(shim.Shape((batch, frames, cfg["preprocess_config"]["mel_channels"])))
+    load_into_reference(model, raw)
+
+    rng = np.random.default_rng(42)
+    mell = np.log(np.exp(rng.normal(-5.0, 2.0, size=(batch, frames, 80))) + 1e-5)
+    mell = np.clip(mell, -11.5, 2.0).astype(np.float32)
+    steps = frames * model.spect_to_subband_upsampling_factor
+    noise = rng.normal(size=(batch, steps)).astype(np.float32)
+
+    mel_t = shim.Tensor(mell.astype(float_type))
+    out = {"mell": mell, "noise": noise}
+    # stage outputs through the reference's own methods
+    f0 = model.generate_f0(mel_t)
+    out["f0"] = np.asarray(f0)
+    out["phase"] = np.asarray(model.pulse_generator.stable_cumsum_and_wrap(f0 / model.pulse_generator.sample_rate))
+    out["pulse"] = np.asarray(model.pulse_generator(f0))[:, :, 0]
+    wn = model.pp_waveNetBlocks[0].wavenet
+    cond = wn.cond_lin_upsampling_layer(wn.cond_layer(mel_t))
+    out["cond"] = np.asarray(cond)
+    shim.INJECTED_NOISE["normal"] = noise
+    out["excitation"] = np.asarray(model.generate_excitation(mel_t, pulse_frequency=f0))
+    env = model.generate_specenv(mel=mel_t, pulse_frequency=f0, training=False)
+    out["envelope_re"] = np.asarray(env).real
+    out["envelope_im"] = np.asarray(env).imag
+    if model.ps_env_order_scale:
+        win = model._get_cepstral_windows(f0, model.ps_cepstral_windows_log10f0, model.ps_cepstral_windows,
+                                          smooth_stride=model.spect_to_pulse_upsampling_factor)
+        out["ceps_window_sum"] = np.asarray(win).sum(axis=-1)
+    # the full graph exactly as PaNWaveNet.infer drives it (reference wavegen_1d.py:504-526)
+    shim.INJECTED_NOISE["normal"] = noise
+    signals, _ = model(mel_t, None, training=False, return_PP=False)
+    out["audio"] = np.asarray(signals[0])[:, :frames * model.spect_hop_size]
+    # wavetable constants the oracle takes as input
+    out["wavetables"] = np.asarray(model.pulse_generator.wavetables)
+    out["wt_nominalF0"] = np.float64(model.pulse_generator.nominalF0)
+    return out
+
+
+def main():
+    shim.install("/root/reference")
+    for tag, float_type in (("f32", np.float32), ("f64", np.float64)):
+        shim.set_float(float_type)
+        bundle = {}
+        for name, (voice, overrides, batch, frames) in CASES.items():
+            res = run_case(voice, overrides, batch, frames, float_type)
+            for kk, vv in res.items():
+                arr = np.asarray(vv)
+                if arr.dtype == np.float64 and tag == "f32":
+                    arr = arr.astype(np.float32) if kk not in ("wt_nominalF0",) else arr
+                bundle[f"{name}/{kk}"] = arr
+            print(tag, name, "audio", res["audio"].shape, float(np.abs(res["audio"]).max()))
+        path = os.path.join(HERE, f"reference_forward_{tag}.npz")
+        np.savez_compressed(path, **bundle)
+        print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,35 @@
+"""Shared builders for the tests (CPU side)."""
+import functools
+
+import numpy as np
+
+from mbexwn_vocoder_amd.config import ModelDims, canonical_config
+from mbexwn_vocoder_amd.tables import WaveTables
+from mbexwn_vocoder_amd.weights import synthetic_weights
+
+# the golden cases of tests/golden/make_reference_forward.py
+GOLDEN_CASES = {
+    "small": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3}, 2, 23),
+    "canon": ("SPEECH", {}, 1, 12),
+}
+
+
+@functools.lru_cache(maxsize=None)
+def wavetables_for(voice="SPEECH"):
+    cfg = canonical_config(voice)
+    dims = ModelDims(cfg)
+    return WaveTables(sample_rate=dims.pulse_rate, **cfg["mbexwn_config"]["wavetable_config"])
+
+
+def build_case(voice, overrides, seed=1234, bias_std=0.05, alpha_jitter=0.05):
+    cfg = canonical_config(voice, **overrides)
+    raw = synthetic_weights(cfg, seed=seed, bias_std=bias_std, alpha_jitter=alpha_jitter)
+    return cfg, raw, wavetables_for(voice)
+
+
+def synthetic_inputs(seed, batch, frames, steps_per_frame=20):
+    rng = np.random.default_rng(seed)
+    mell = np.log(np.exp(rng.normal(-5.0, 2.0, size=(batch, frames, 80))) + 1e-5)
+    mell = np.clip(mell, -11.5, 2.0).astype(np.float32)
+    noise = rng.normal(size=(batch, frames * steps_per_frame)).astype(np.float32)
+    return mell, noise

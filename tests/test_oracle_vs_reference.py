@@ -1,0 +1,69 @@
+"""The oracle against golden vectors produced by the reference's own model code
+(tests/golden/make_reference_forward.py: MBExWN.call executed on a numpy stand-in for TensorFlow)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.mbexwn_oracle import OracleModel
+from helpers import GOLDEN_CASES, build_case
+
+
+def _load(golden_dir, tag):
+    return np.load(os.path.join(golden_dir, f"reference_forward_{tag}.npz"))
+
+
+def _maxdiff(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))))
+
+
+@pytest.mark.parametrize("case", sorted(GOLDEN_CASES))
+def test_structural_float64(golden_dir, case):
+    """Same graph, float64 end to end: every stage must agree to rounding noise of float64."""
+    gold = _load(golden_dir, "f64")
+    voice, overrides, batch, frames = GOLDEN_CASES[case]
+    cfg, raw, wt = build_case(voice, overrides)
+    assert _maxdiff(wt.tables, gold[f"{case}/wavetables"]) == 0.0
+    om = OracleModel(cfg, raw, wt, dtype=np.float64, float32_constants=False)
+    mel, noise = gold[f"{case}/mell"], gold[f"{case}/noise"]
+    audio, st = om.forward(mel, noise, return_stages=True)
+    assert audio.shape == (batch, frames * 300)
+    assert _maxdiff(st["f0"], gold[f"{case}/f0"]) < 1e-10
+    assert _maxdiff(om.phase_from_f0(gold[f"{case}/f0"]), gold[f"{case}/phase"]) == 0.0
+    assert _maxdiff(om.wavetable(gold[f"{case}/f0"]), gold[f"{case}/pulse"]) < 1e-7     # grid_norm is a float32 constant
+    assert _maxdiff(om.conditioning(mel.astype(np.float64)), gold[f"{case}/cond"]) < 1e-12
+    assert _maxdiff(st["excitation"], gold[f"{case}/excitation"]) < 1e-8
+    assert _maxdiff(st["envelope"], gold[f"{case}/envelope_re"] + 1j * gold[f"{case}/envelope_im"]) < 1e-11
+    assert _maxdiff(audio, gold[f"{case}/audio"]) < 1e-8
+
+
+@pytest.mark.parametrize("case", sorted(GOLDEN_CASES))
+def test_float32_emulation(golden_dir, case):
+    """float64 oracle (float32-faithful phase/index arithmetic) vs the float32 run of the reference code.
+    Tolerance = float32 rounding of a 4-amplitude signal through ~15 layers: 1e-4 absolute."""
+    gold = _load(golden_dir, "f32")
+    voice, overrides, batch, frames = GOLDEN_CASES[case]
+    cfg, raw, wt = build_case(voice, overrides)
+    om = OracleModel(cfg, raw, wt)
+    mel, noise = gold[f"{case}/mell"], gold[f"{case}/noise"]
+    audio, st = om.forward(mel, noise, return_stages=True)
+    # the phase accumulator is bit exact given the same float32 F0
+    assert _maxdiff(om.phase_from_f0(gold[f"{case}/f0"]), gold[f"{case}/phase"]) == 0.0
+    assert _maxdiff(om.wavetable(gold[f"{case}/f0"]), gold[f"{case}/pulse"]) < 1e-6
+    assert _maxdiff(st["f0"], gold[f"{case}/f0"]) < 5e-4          # Hz, values up to 600
+    assert _maxdiff(st["excitation"], gold[f"{case}/excitation"]) < 1e-4
+    assert _maxdiff(audio, gold[f"{case}/audio"]) < 1e-4
+    if "ceps_window_sum" in gold.files:
+        idx = om.cepstral_window_index(gold[f"{case}/f0"])
+        assert _maxdiff(om.ceps_windows[idx].sum(axis=-1), gold[f"{case}/ceps_window_sum"]) < 1e-4
+
+
+def test_float32_oracle_mode(golden_dir):
+    """The float32 mode of the oracle (the CPU timing baseline) stays within float32 tolerance."""
+    gold = _load(golden_dir, "f32")
+    voice, overrides, batch, frames = GOLDEN_CASES["small"]
+    cfg, raw, wt = build_case(voice, overrides)
+    om = OracleModel(cfg, raw, wt, dtype=np.float32)
+    audio = om.forward(gold["small/mell"], gold["small/noise"])
+    assert audio.dtype == np.float32
+    assert _maxdiff(audio, gold["small/audio"]) < 2e-4
