@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Benchmark of the MBExWN mel-inversion forward pass on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (mel -> 24 kHz audio) over one batch of synthetic mels that is already
+resident in HBM.  Workload at every N: BASELINE.json configs[1] -- MW-SP-FD (C=320), batch = 1, 10 s
+(80 x 800 mel) per GPU; utterances are independent, so N ranks run N utterances (weak scaling, no
+data-path collective; RCCL only carries the barrier and the max-over-ranks of the timing).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (voice type, batch per GPU, frames)
+    "config1_sp_b1_3s": ("SPEECH", 1, 240),
+    "config2_sp_b1_10s": ("SPEECH", 1, 800),
+    "config3_si_b16_10s": ("SING", 16, 800),
+}
+FP32_MATRIX_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def build_engine(voice):
+    from mbexwn_vocoder_amd.config import ModelDims, canonical_config
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    from mbexwn_vocoder_amd.tables import WaveTables
+    from mbexwn_vocoder_amd.weights import synthetic_weights
+    cfg = canonical_config(voice)
+    dims = ModelDims(cfg)
+    raw = synthetic_weights(cfg, seed=1234)          # bias 0, PReLU alpha 0.2
+    wt = WaveTables(sample_rate=dims.pulse_rate, **cfg["mbexwn_config"]["wavetable_config"])
+    return cfg, raw, wt, dims, MBExWNEngine(cfg, raw, wt)
+
+
+def synthetic_batch(rng, batch, frames, steps_per_frame):
+    mell = np.log(np.exp(rng.normal(-5.0, 2.0, size=(batch, frames, 80))) + 1e-5)
+    mell = np.clip(mell, -11.5, 2.0).astype(np.float32)
+    noise = rng.normal(size=(batch, frames * steps_per_frame)).astype(np.float32)
+    return mell, noise
+
+
+def cpu_baseline(cfg, raw, wt, seconds=3.0):
+    """The oracle (numpy float32 port of the reference graph) timed on the host cores, on a bounded sample
+    (one 3 s utterance, the reference's own CPU-runnable case configs[0]); timing protocol of the reference
+    CLI (bin/resynth_mel.py:86-88): wall clock around the synthesis call only, one warm-up call."""
+    from oracle.mbexwn_oracle import OracleModel
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([pp.get("num_threads", 1) for pp in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    frames = int(round(seconds * 80))
+    om = OracleModel(cfg, raw, wt, dtype=np.float32)
+    rng = np.random.default_rng(42)
+    mel, noise = synthetic_batch(rng, 1, frames, 20)
+    om.forward(mel[:, :16], noise[:, :320])         # warm-up (weight folding, BLAS thread start)
+    times = []
+    for _ in range(3):
+        t0 = time.time()
+        om.forward(mel, noise)
+        times.append(time.time() - t0)
+    best = float(np.median(times))
+    return {"value": frames * 300 / best, "unit": "audio samples/s", "cores": int(threads), "kind": "port",
+            "sample": f"1 utterance x {seconds:g} s (80x{frames} mel), numpy float32 oracle, median of 3 after 1 warm-up",
+            "x_realtime": frames * 300 / best / 24000.0}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="config2_sp_b1_10s", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    voice, batch, frames = WORKLOADS[args.workload]
+    cfg, raw, wt, dims, eng = build_engine(voice)
+    rng = np.random.default_rng(42 + rank)
+    mel_h, noise_h = synthetic_batch(rng, batch, frames, dims.steps_per_frame)
+    mel = torch.as_tensor(mel_h).cuda()
+    noise = torch.as_tensor(noise_h).cuda()
+    out = torch.empty((batch, frames * dims.hop_size), dtype=torch.float32, device=mel.device)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.forward(mel, noise=noise, out=out)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.forward(mel, noise=noise, out=out)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=mel.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- dominant kernel: dilated conv + gate (75 % of the WaveNet FLOPs), timed with HIP events on the
+    #      launch stream in a separate pass so that the events do not sit inside the throughput measurement
+    eng.profile_enable(True)
+    for _ in range(max(3, min(args.steps, 10))):
+        eng.forward(mel, noise=noise, out=out)
+    torch.cuda.synchronize()
+    gate_ms, gate_n = eng.profile_read("gate")
+    rs_ms, rs_n = eng.profile_read("res_skip")
+    eng.profile_enable(False)
+
+    if rank == 0:
+        C, L, ks = dims.wn_channels, dims.wn_layers, dims.wn_kernel_size
+        rows = batch * frames * dims.steps_per_frame
+        gate_flop = 2.0 * rows * (ks * C) * (2 * C)                   # algorithmic FLOPs of one launch
+        gate_avg_s = gate_ms / max(gate_n, 1) * 1e-3
+        achieved = gate_flop / gate_avg_s / 1e12
+        samples = world * batch * frames * dims.hop_size * args.steps
+        value = samples / elapsed
+        line = {
+            "metric": "24 kHz audio samples/sec (whole job; x real-time = value / 24000)",
+            "value": value,
+            "unit": "audio samples/s",
+            "x_realtime": value / 24000.0,
+            "x_realtime_per_gpu": value / 24000.0 / world,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: MW-{voice[:2]}-FD canonical (C={C}, L={L}), batch {batch} x "
+                                   f"{frames / 80:g} s per GPU, 80x{frames} synthetic mel, seeded synthetic weights",
+                       "batch_per_gpu": batch, "frames": frames, "parallelism": f"utterance-sharded x{world}"},
+            "roofline": {"bound": "mfma", "kernel": "conv1d_mfma_kernel<EPI_GATE> (dilated conv k=3 C->2C + gate)",
+                         "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                         "flop_per_launch": gate_flop, "avg_launch_ms": gate_avg_s * 1e3, "launches_timed": gate_n,
+                         "res_skip_avg_launch_ms": rs_ms / max(rs_n, 1)},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, raw, wt)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

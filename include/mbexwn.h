@@ -1,0 +1,169 @@
+/*
+ * mbexwn.h -- C ABI of the MI355X (gfx950) mel-inversion engine.
+ *
+ * The reference (roebel/MBExWN_Vocoder) has no FFI/plugin boundary: its inference seam is the
+ * Python call  model.infer(mell, sigma=None, synth_length=T*hop)  made by
+ * MELInverter.synth_from_mel  (reference MBExWN_NVoc/mel_inverter.py:151-154) into
+ * PaNWaveNet.infer (reference MBExWN_NVoc/vocoder/model/wavegen_1d.py:483-526), which runs
+ * MBExWN.call (reference MBExWN_NVoc/vocoder/model/custom_pulsed_generator.py:556-771) on
+ * TensorFlow.  This header is the boundary a maintainer binds instead (ctypes stub in
+ * INTEGRATION.md): plain pointers and sizes, no torch / TensorFlow types.
+ *
+ * Conventions
+ *   - every function returns an mbx_status; mbx_last_error() gives the thread-local message
+ *   - the caller owns all buffers (mel, noise, audio, workspace: DEVICE memory of the handle's device)
+ *   - a handle owns the folded weights and the constant tables; one handle per device; a handle is
+ *     not re-entrant; calls only enqueue work on the given stream and never synchronise
+ *   - all tensors are float32, channels-last, row-major
+ */
+#ifndef MBEXWN_H
+#define MBEXWN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MBX_ABI_VERSION 1
+#define MBX_MAX_SUBNET_OPS 32
+#define MBX_MAX_WN_LAYERS 64
+#define MBX_NAME_LEN 64
+
+typedef enum {
+    MBX_OK = 0,
+    MBX_ERR_INVALID_ARGUMENT = 1, /* bad config / shape / missing tensor (Python side raises ValueError) */
+    MBX_ERR_HIP = 2,              /* a HIP runtime call failed */
+    MBX_ERR_WORKSPACE = 3,        /* workspace too small */
+    MBX_ERR_UNSUPPORTED = 4       /* reference feature outside the hot path (NotImplementedError) */
+} mbx_status;
+
+/* sub-net op kinds: the layer grammar of generate_subnet_from_specs
+ * (reference custom_pulsed_generator.py:38-148) flattened by the host */
+enum { MBX_OP_CONV = 0, MBX_OP_LIN = 1, MBX_OP_PRELU = 2, MBX_OP_LEAKY = 3, MBX_OP_ACT = 4 };
+/* padding of a conv op = TFPad1d modes (reference custom_layers.py:47-71) */
+enum { MBX_PAD_ZERO = 0, MBX_PAD_SYMMETRIC = 1, MBX_PAD_EDGE = 2 };
+/* final activations = ActivationLayer (reference custom_AE_layers.py:21-109) */
+enum { MBX_ACT_LINEAR = 0, MBX_ACT_SOFT_SIGMOID = 1, MBX_ACT_TANH = 2, MBX_ACT_SIGMOID = 3,
+       MBX_ACT_SOFT_SIGN = 4, MBX_ACT_SOFT_SQRT = 5, MBX_ACT_EXP = 6, MBX_ACT_RELU = 7 };
+
+typedef struct {
+    int32_t kind;            /* MBX_OP_* */
+    int32_t ks, cin, cout;   /* conv: kernel size / channels (cout includes the sub-pixel factor) */
+    int32_t pad_l, pad_r;    /* conv: samples of padding in front / behind */
+    int32_t pad_mode;        /* conv: MBX_PAD_* */
+    int32_t up;              /* conv: sub-pixel factor (depth -> time), lin: interpolation factor */
+    int32_t act;             /* act: MBX_ACT_* */
+    float alpha;             /* leaky: slope */
+    char name[MBX_NAME_LEN]; /* conv: tensors "<name>.w" (ks,cin,cout) "<name>.b" ; prelu: "<name>.alpha" */
+} mbx_subnet_op;
+
+/* Model topology: the integers MBExWN.__init__ derives from mbexwn_config / preprocess_config
+ * (reference custom_pulsed_generator.py:155-504). */
+typedef struct {
+    int32_t struct_size;     /* sizeof(mbx_config), checked by mbx_create */
+    int32_t abi_version;     /* MBX_ABI_VERSION */
+    int32_t sample_rate, hop_size, mel_channels;
+    int32_t subbands, pqmf_taps;
+    int32_t pulse_channels, pulse_per_frame, steps_per_frame;
+    float pulse_rate;        /* sample_rate / pulse_rate_factor */
+    float noise_sigma;       /* pp_mod_subnet_noise_channel_sigma ; 0 => no noise channel */
+    float f0_min, f0_max;
+    int32_t wn_channels, wn_layers, wn_kernel_size, wn_out_channels, wn_in_channels;
+    int32_t wn_dilations[MBX_MAX_WN_LAYERS];
+    int32_t cond_kernel_size, cond_conv_upsampling, cond_lin_upsampling;
+    int32_t stft_win, fft_size, n_ceps;
+    int32_t n_ceps_windows;  /* 0 => ps_env_order_scale unset: no lifter */
+    float filter_max_log_range; /* 0 => plain exp(S) */
+    int32_t wt_n_period, wt_n_tables;
+    float wt_nominal_f0, wt_min_transposition, wt_max_transposition, wt_grid_norm;
+    int32_t phase_chunk;     /* 1000: stable_cumsum_and_wrap chunk (reference tf_wavetable.py:429) */
+    int32_t n_f0_ops;
+    mbx_subnet_op f0_ops[MBX_MAX_SUBNET_OPS];
+    int32_t n_vtf_ops;
+    mbx_subnet_op vtf_ops[MBX_MAX_SUBNET_OPS];
+} mbx_config;
+
+/* A named HOST tensor handed over at creation (weights already weight-norm folded, tables).
+ * Required names: see mbexwn_vocoder_amd/engine.py::tensor_table. */
+typedef struct {
+    const char *name;
+    const float *data;
+    int32_t ndim;
+    int64_t shape[4];
+} mbx_tensor;
+
+typedef struct mbx_handle mbx_handle;
+
+/* Thread-local description of the last failure of this library on the calling thread. */
+const char *mbx_last_error(void);
+
+/* Replaces: MELInverter.load_model -> create_model -> MBExWN.__init__ + load_weights
+ * (reference mel_inverter.py:184-239).  Copies tensors to `device`. */
+mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32_t n_tensors, int32_t device,
+                      mbx_handle **out);
+mbx_status mbx_destroy(mbx_handle *handle);
+
+/* Bytes of device workspace mbx_forward needs for `batch` items of at most `max_frames` mel frames. */
+size_t mbx_workspace_size(const mbx_handle *handle, int32_t batch, int32_t max_frames);
+
+/* Replaces: model.infer(mell, synth_length=T*hop) (reference mel_inverter.py:152, wavegen_1d.py:483-526,
+ * custom_pulsed_generator.py:556-771).
+ *   mel       device (batch, max_frames, mel_channels)
+ *   n_frames  device int32 (batch) valid frames per item, or NULL (= max_frames for all); every boundary
+ *             op honours the item's own length, so a padded batch equals one-at-a-time runs
+ *   noise     device (batch, max_frames*steps_per_frame) N(0,1) draw of the noise channel
+ *             (reference custom_pulsed_generator.py:905-906); NULL is only legal if noise_sigma == 0
+ *   audio     device (batch, max_frames*hop_size); samples behind an item's own length are zeroed */
+mbx_status mbx_forward(mbx_handle *handle, const float *mel, const int32_t *n_frames, int32_t batch,
+                       int32_t max_frames, const float *noise, float *audio, void *workspace,
+                       size_t workspace_bytes, void *hip_stream);
+
+/* Intermediate tensors of the most recent mbx_forward (pointers into its workspace), for stage parity
+ * tests.  Names: "f0" "pulse" "cond" "wn_hidden" "wn_skip" "wn_out" "subbands" "excitation" "cepstrum"
+ * "ceps_index" "frames".  `count` = floats (int32 for ceps_index) per batch item, `stride` = item stride. */
+mbx_status mbx_stage(const mbx_handle *handle, const char *name, const void **device_ptr, int64_t *count,
+                     int64_t *stride);
+
+/* Kernel timing for bench.py: while enabled, mbx_forward brackets every launch of the two WaveNet GEMM
+ * kernels with HIP events on the caller's stream (not capturable into a graph while enabled).
+ * mbx_profile_read waits for the recorded events, returns the summed device time and the launch count of
+ * kernel "gate" (dilated conv + gate) or "res_skip" since the last read, and recycles the events. */
+mbx_status mbx_profile_enable(mbx_handle *handle, int32_t enabled);
+mbx_status mbx_profile_read(mbx_handle *handle, const char *kernel, double *total_ms, int64_t *launches);
+
+/* ---- stage entry points (unit parity; all pointers device memory) ------------------------------- */
+
+/* TFPQMF.synthesis (reference tf_preprocess.py:204-226): x (batch, n_steps, subbands) -> y (batch, n_steps*subbands) */
+mbx_status mbx_pqmf_synthesis(mbx_handle *handle, const float *x, int32_t batch, int32_t n_steps, float *y,
+                              void *hip_stream);
+
+/* Weight-normed Conv1D on a padded input (TFPad1d + TF2C_Conv1DWeightNorm, reference custom_layers.py:47-71,
+ * conv_layers.py:149-165): x (batch, n_rows, cin), w (ks, cin, cout), b (cout) or NULL,
+ * alpha (cout) or NULL (PReLU slopes) -> y (batch, n_rows, cout); dilation d, MBX_PAD_* mode. */
+mbx_status mbx_conv1d(mbx_handle *handle, const float *x, int32_t batch, int32_t n_rows, int32_t cin,
+                      const float *w, const float *b, const float *alpha, int32_t ks, int32_t cout,
+                      int32_t dilation, int32_t pad_l, int32_t pad_mode, float *y, void *hip_stream);
+
+/* TF2C_LinInterpLayer(num_pad_end=1, drop_last=True) (reference support_layers.py:99-121):
+ * x (batch, n_rows, channels) -> y (batch, n_rows*up, channels) */
+mbx_status mbx_lin_interp(mbx_handle *handle, const float *x, int32_t batch, int32_t n_rows, int32_t channels,
+                          int32_t up, float *y, void *hip_stream);
+
+/* PulseWaveTable.call (reference tf_wavetable.py:495-552): f0 (batch, n) Hz -> pulse (batch, n);
+ * phase (batch, n) optional output of stable_cumsum_and_wrap (may be NULL). scratch >= batch*(n + n/chunk + 2) floats. */
+mbx_status mbx_wavetable(mbx_handle *handle, const float *f0, int32_t batch, int32_t n, float *pulse, float *phase,
+                         float *scratch, void *hip_stream);
+
+/* STFT -> x envelope -> inverse STFT (reference custom_pulsed_generator.py:681-724, 793-855):
+ * excitation (batch, frames*hop), cepstrum (batch, frames, n_ceps) (VTF-net output), ceps_index int32
+ * (batch, frames) or NULL, -> audio (batch, frames*hop). scratch >= batch*frames*stft_win floats. */
+mbx_status mbx_stft_filter(mbx_handle *handle, const float *excitation, const float *cepstrum,
+                           const int32_t *ceps_index, int32_t batch, int32_t frames, float *audio, float *scratch,
+                           void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MBEXWN_H */

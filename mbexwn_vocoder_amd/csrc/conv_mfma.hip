@@ -1,0 +1,293 @@
+// conv1d (channels-last, stride 1, dilation d) as an implicit GEMM on the gfx950 fp32 matrix cores.
+//
+//   y[b, t, co] = bias[co] + sum_{j < ks} sum_{ci < cin} xp[b, t + j*d - pad_l, ci] * W[j, ci, co]
+//
+// restates Keras Conv1D as the reference drives it (weight-norm already folded into W):
+//   TF2C_Conv1DWeightNorm.call      reference .../tf2_components/layers/conv_layers.py:149-165
+//   TFPad1d (SYMMETRIC / EDGE)      reference .../custom_layers.py:47-71
+//   WaveNetAE layer loop            reference .../custom_AE_layers.py:305-335  (gate / res-skip epilogues)
+//
+// The WaveNet's dilated convolutions are dense C -> 2C contractions (K = 3C = 960, N = 640 for C = 320),
+// i.e. genuinely GEMM shaped, so they run on v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chains: the result
+// honours the float32 parity budget; bf16/fp8 MFMA would not).  One kernel template covers every
+// convolution of the path; what changes is the tile shape and the epilogue:
+//
+//   EPI_LINEAR   bias (+ PReLU / leaky)                       F0-net, VTF-net, cond conv, end, post-net
+//   EPI_GATE     + conditioning (interpolated on the fly from the (2T, 2C) tensor), tanh * sigmoid
+//   EPI_RESSKIP  h += r[:, :C], skip (+)= r[:, C:]            (in place; one owner lane per element)
+//
+// Tiling: 256 threads = 4 waves (one per SIMD), block tile BM x BN, wave tile (TM*32) x (TN*32),
+// K streamed in BK = 16 slices through a double-buffered LDS image:
+//   As[k][row]  (k-major so that the 32 lanes of an MFMA A-operand read 32 consecutive rows: conflict free)
+//   Bs[k][col]
+// The A slice is the dilated receptive-field window: rows t + j*d - pad_l of the activation, fetched with
+// the padding rule of the layer and the item's own length (padded batches equal one-at-a-time runs).
+#include "mbx_kernels.h"
+
+namespace mbx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;
+
+__device__ __forceinline__ int map_row(int s, int n, int mode) {
+    if (s >= 0 && s < n) return s;
+    if (mode == 0) return -1;               // zero padding
+    if (mode == 2) return s < 0 ? 0 : n - 1;  // edge
+    s = s < 0 ? -s - 1 : 2 * n - s - 1;     // symmetric (edge sample repeated)
+    return min(max(s, 0), n - 1);
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int WM, int WN, int TM, int TN, int EPI>
+__global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs p) {
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    constexpr int LDA = BM + 4;
+    constexpr int LDB = BN + 4;
+    constexpr int A_TOT = BM * BK / 4;         // float4 per A slice
+    constexpr int B_TOT = BN * BK / 4;
+    constexpr int A_F4 = (A_TOT + 255) / 256;  // float4 per thread per A slice
+    constexpr int B_F4 = (B_TOT + 255) / 256;
+    static_assert(WM * WN == 4, "4 waves per block");
+    static_assert(EPI != EPI_GATE || TN == 2, "gate needs the tanh and the sigmoid tile in one wave");
+
+    __shared__ float lds[2 * BK * LDA + 2 * BK * LDB];
+    float *As = lds;
+    float *Bs = lds + 2 * BK * LDA;
+
+    const int b = blockIdx.z;
+    const int rows = p.n_frames ? p.n_frames[b] * p.rows_per_frame : p.max_rows;
+    const int m0 = blockIdx.x * BM;
+    if (m0 >= rows) return;
+    const int C = p.channels;
+    // column origin of this block in the weight matrix
+    const int n0 = (EPI == EPI_GATE) ? blockIdx.y * (BN / 2) : blockIdx.y * BN;
+    const int n_lim = (EPI == EPI_GATE) ? C : p.cout;   // valid columns per half / in total
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave / WN, wc = wave % WN;
+
+    const float *xb = p.x + (long long)b * p.x_bstride;
+    const bool vec_a = ((p.cin & 3) == 0) && ((p.ldx & 3) == 0) && ((p.x_bstride & 3) == 0);
+    const bool vec_b = ((p.cout & 3) == 0) && (EPI != EPI_GATE || (C & 3) == 0);
+    const int nkc = (p.cin + BK - 1) / BK;   // K slices per tap
+    const int nk = p.ks * nkc;
+
+    float4 ra[A_F4], rb[B_F4];
+
+    auto load_slice = [&](int kt) {
+        const int tap = kt / nkc;
+        const int ci0 = (kt - tap * nkc) * BK;
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int q = tid + i * 256;
+            const int row = q >> 2, kq = q & 3;
+            const int src = map_row(m0 + row - p.pad_l + tap * p.dil, rows, p.pad_mode);
+            const int ci = ci0 + kq * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (src >= 0 && q < A_TOT) {
+                const float *px = xb + (long long)src * p.ldx + ci;
+                if (vec_a) {
+                    if (ci < p.cin) v = *reinterpret_cast<const float4 *>(px);
+                } else {
+                    if (ci + 0 < p.cin) v.x = px[0];
+                    if (ci + 1 < p.cin) v.y = px[1];
+                    if (ci + 2 < p.cin) v.z = px[2];
+                    if (ci + 3 < p.cin) v.w = px[3];
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int q = tid + i * 256;
+            const int k = q / (BN / 4), c = (q % (BN / 4)) * 4;
+            int n, lim;
+            if (EPI == EPI_GATE) {
+                const bool second = c >= BN / 2;
+                const int cc = second ? c - BN / 2 : c;
+                n = n0 + cc + (second ? C : 0);
+                lim = n_lim + (second ? C : 0);
+            } else {
+                n = n0 + c;
+                lim = n_lim;
+            }
+            const int ci = ci0 + k;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ci < p.cin && q < B_TOT) {
+                const float *pw = p.w + (long long)(tap * p.cin + ci) * p.cout + n;
+                if (vec_b) {
+                    if (n < lim) v = *reinterpret_cast<const float4 *>(pw);
+                } else {
+                    if (n + 0 < lim) v.x = pw[0];
+                    if (n + 1 < lim) v.y = pw[1];
+                    if (n + 2 < lim) v.z = pw[2];
+                    if (n + 3 < lim) v.w = pw[3];
+                }
+            }
+            rb[i] = v;
+        }
+    };
+
+    auto store_slice = [&](int buf) {
+        float *a = As + buf * BK * LDA;
+        float *bs = Bs + buf * BK * LDB;
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int q = tid + i * 256;
+            const int row = q >> 2, kq = q & 3;
+            if (q >= A_TOT) continue;
+            a[(kq * 4 + 0) * LDA + row] = ra[i].x;
+            a[(kq * 4 + 1) * LDA + row] = ra[i].y;
+            a[(kq * 4 + 2) * LDA + row] = ra[i].z;
+            a[(kq * 4 + 3) * LDA + row] = ra[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int q = tid + i * 256;
+            const int k = q / (BN / 4), c = (q % (BN / 4)) * 4;
+            if (q >= B_TOT) continue;
+            *reinterpret_cast<float4 *>(bs + k * LDB + c) = rb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // column of the wave's tile tn inside the block tile
+    auto col_base = [&](int tn) { return (EPI == EPI_GATE) ? tn * (BN / 2) + wc * 32 : (wc * TN + tn) * 32; };
+
+    load_slice(0);
+    store_slice(0);
+    __syncthreads();
+
+    const int lrow = lane & 31, lk = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_slice(kt + 1);
+        const float *a = As + buf * BK * LDA + lk * LDA + wr * TM * 32 + lrow;
+        const float *bs = Bs + buf * BK * LDB + lk * LDB + lrow;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = a[kk * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = bs[kk * LDB + col_base(j)];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_slice(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    // C/D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int ecol = lane & 31;
+    if (EPI == EPI_GATE) {
+        const int ch = n0 + wc * 32 + ecol;   // gate channel of this lane
+        if (ch < C) {
+            const float bt = p.bias ? p.bias[ch] : 0.f;
+            const float bsg = p.bias ? p.bias[C + ch] : 0.f;
+            const float *cb = p.cond + (long long)b * p.cond_bstride;
+            const int n2 = rows / p.cond_up;
+            float *ob = p.out + (long long)b * p.out_bstride;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row < rows) {
+                        const int t2 = row / p.cond_up, u = row - t2 * p.cond_up;
+                        const int t3 = min(t2 + 1, n2 - 1);
+                        const float w0 = p.lerp_w0[u], w1 = p.lerp_w1[u];
+                        const float *c0 = cb + (long long)t2 * (2 * C);
+                        const float *c1 = cb + (long long)t3 * (2 * C);
+                        const float ct = c0[ch] * w0 + c1[ch] * w1;
+                        const float cs = c0[C + ch] * w0 + c1[C + ch] * w1;
+                        const float zt = (acc[i][0][r] + bt) + ct;
+                        const float zs = (acc[i][1][r] + bsg) + cs;
+                        ob[(long long)row * p.ldo + ch] = tanhf(zt) * sigmoidf_(zs);
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + col_base(j) + ecol;
+            if (col >= p.cout) continue;
+            const float bias = p.bias ? p.bias[col] : 0.f;
+            if (EPI == EPI_LINEAR) {
+                const float slope = p.alpha ? p.alpha[col] : p.leaky;
+                const bool act = p.alpha != nullptr || p.use_leaky;
+                float *ob = p.out + (long long)b * p.out_bstride;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        if (row < rows) {
+                            float v = acc[i][j][r] + bias;
+                            if (act) v = v > 0.f ? v : slope * v;
+                            ob[(long long)row * p.ldo + col] = v;
+                        }
+                    }
+            } else {   // EPI_RESSKIP
+                const bool to_h = (!p.last_layer) && col < C;
+                const int oc = to_h ? col : (p.last_layer ? col : col - C);
+                float *dst = (to_h ? p.h : p.skip) + (long long)b * p.hs_bstride;
+                const bool accumulate = to_h || !p.skip_init;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        if (row < rows) {
+                            const float v = acc[i][j][r] + bias;
+                            float *q = dst + (long long)row * C + oc;
+                            *q = accumulate ? (*q + v) : v;
+                        }
+                    }
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN, int EPI>
+static void launch_cfg(const ConvArgs &a, hipStream_t stream) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const int ncols = (EPI == EPI_GATE) ? a.channels : a.cout;
+    const int bn_eff = (EPI == EPI_GATE) ? BN / 2 : BN;
+    dim3 grid((a.max_rows + BM - 1) / BM, (ncols + bn_eff - 1) / bn_eff, a.batch);
+    hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, TM, TN, EPI>), grid, dim3(256), 0, stream, a);
+}
+
+void launch_conv1d(const ConvArgs &a, int epilogue, hipStream_t stream) {
+    if (a.max_rows <= 0 || a.batch <= 0) return;
+    if (epilogue == EPI_GATE) {
+        launch_cfg<2, 2, 2, 2, EPI_GATE>(a, stream);          // 128 rows x 64 gate channels
+    } else if (epilogue == EPI_RESSKIP) {
+        launch_cfg<2, 2, 2, 2, EPI_RESSKIP>(a, stream);       // 128 x 128
+    } else if (a.cout <= 32) {
+        launch_cfg<4, 1, 1, 1, EPI_LINEAR>(a, stream);        // 128 x 32 (F0 head, post-net, end)
+    } else if ((long long)a.max_rows * a.batch >= 4096 && a.cout >= 128) {
+        launch_cfg<2, 2, 2, 2, EPI_LINEAR>(a, stream);        // 128 x 128
+    } else {
+        launch_cfg<2, 2, 1, 1, EPI_LINEAR>(a, stream);        // 64 x 64 (mel-rate sub-nets)
+    }
+}
+
+}  // namespace mbx

@@ -1,0 +1,152 @@
+// Bandwidth-type stages: linear interpolation, activations, WaveNet input fold + start conv.
+#include "mbx_kernels.h"
+
+namespace mbx {
+
+// ActivationLayer (reference MBExWN_NVoc/vocoder/model/custom_AE_layers.py:21-109)
+__device__ __forceinline__ float apply_act(float x, int act) {
+    switch (act) {
+        case 1: return 0.5f + 0.5f * x / (1.0f + fabsf(x));      // soft_sigmoid  :91-99
+        case 2: return tanhf(x);
+        case 3: return 1.0f / (1.0f + expf(-x));
+        case 4: return x / (1.0f + fabsf(x));
+        case 5: return x / (1.0f + sqrtf(fabsf(x)));             // soft_sqrt     :80-89
+        case 6: return expf(x);
+        case 7: return fmaxf(x, 0.f);
+        default: return x;
+    }
+}
+
+// TF2C_LinInterpLayer(num_pad_end=1, drop_last=True)
+// (reference MBExWN_NVoc/vocoder/model/tf2_components/layers/support_layers.py:19-27,99-121):
+//   out[t*U + u, c] = x[t, c] * (U-u)/U + x[min(t+1, T-1), c] * u/U
+// one thread per output element, channel fastest (coalesced on both sides for C >= 64; for C == 1
+// consecutive threads walk u, reading two broadcast inputs).
+__global__ void lin_interp_kernel(const float *x, long long x_bstride, const int *n_frames, int rows_per_frame,
+                                  int max_rows, int channels, int up, const float *w0, const float *w1, int act,
+                                  float scale, float offset, float *y, long long y_bstride) {
+    const int b = blockIdx.y;
+    const int rows = n_frames ? n_frames[b] * rows_per_frame : max_rows;
+    const long long total = (long long)rows * up * channels;
+    const float *xb = x + (long long)b * x_bstride;
+    float *yb = y + (long long)b * y_bstride;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % channels);
+        const long long ro = i / channels;
+        const int t = (int)(ro / up), u = (int)(ro - (long long)t * up);
+        const int tn = min(t + 1, rows - 1);
+        float v = xb[(long long)t * channels + c] * w0[u] + xb[(long long)tn * channels + c] * w1[u];
+        v = apply_act(v, act) * scale + offset;
+        yb[i] = v;
+    }
+}
+
+void launch_lin_interp(const float *x, long long x_bstride, const int *n_frames, int rows_per_frame, int max_rows,
+                       int batch, int channels, int up, const float *w0, const float *w1, int act, float scale,
+                       float offset, float *y, long long y_bstride, hipStream_t stream) {
+    if (max_rows <= 0 || batch <= 0) return;
+    const long long total = (long long)max_rows * up * channels;
+    const int blocks = (int)min((total + 255) / 256, (long long)2048);
+    hipLaunchKernelGGL(lin_interp_kernel, dim3(blocks, batch), dim3(256), 0, stream, x, x_bstride, n_frames,
+                       rows_per_frame, max_rows, channels, up, w0, w1, act, scale, offset, y, y_bstride);
+}
+
+__global__ void activation_kernel(const float *x, long long x_bstride, const int *n_frames, int rows_per_frame,
+                                  int max_rows, int channels, int act, float scale, float offset, float *y,
+                                  long long y_bstride) {
+    const int b = blockIdx.y;
+    const int rows = n_frames ? n_frames[b] * rows_per_frame : max_rows;
+    const long long total = (long long)rows * channels;
+    const float *xb = x + (long long)b * x_bstride;
+    float *yb = y + (long long)b * y_bstride;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x)
+        yb[i] = apply_act(xb[i], act) * scale + offset;
+}
+
+void launch_activation(const float *x, long long x_bstride, const int *n_frames, int rows_per_frame, int max_rows,
+                       int batch, int channels, int act, float scale, float offset, float *y, long long y_bstride,
+                       hipStream_t stream) {
+    if (max_rows <= 0 || batch <= 0) return;
+    const long long total = (long long)max_rows * channels;
+    const int blocks = (int)min((total + 255) / 256, (long long)2048);
+    hipLaunchKernelGGL(activation_kernel, dim3(blocks, batch), dim3(256), 0, stream, x, x_bstride, n_frames,
+                       rows_per_frame, max_rows, channels, act, scale, offset, y, y_bstride);
+}
+
+// Keras PReLU(shared_axes=[1]) / LeakyReLU (reference custom_pulsed_generator.py:247-253)
+__global__ void prelu_kernel(float *x, long long x_bstride, const int *n_frames, int rows_per_frame, int max_rows,
+                             int channels, const float *alpha, float leaky) {
+    const int b = blockIdx.y;
+    const int rows = n_frames ? n_frames[b] * rows_per_frame : max_rows;
+    const long long total = (long long)rows * channels;
+    float *xb = x + (long long)b * x_bstride;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float v = xb[i];
+        const float s = alpha ? alpha[i % channels] : leaky;
+        xb[i] = v > 0.f ? v : s * v;
+    }
+}
+
+void launch_prelu(float *x, long long x_bstride, const int *n_frames, int rows_per_frame, int max_rows, int batch,
+                  int channels, const float *alpha, float leaky, hipStream_t stream) {
+    if (max_rows <= 0 || batch <= 0) return;
+    const long long total = (long long)max_rows * channels;
+    const int blocks = (int)min((total + 255) / 256, (long long)2048);
+    hipLaunchKernelGGL(prelu_kernel, dim3(blocks, batch), dim3(256), 0, stream, x, x_bstride, n_frames,
+                       rows_per_frame, max_rows, channels, alpha, leaky);
+}
+
+// Excitation fold + noise channel + WaveNet "start" 1x1 convolution
+// (reference custom_pulsed_generator.py:893,905-906 and custom_AE_layers.py:280):
+//   x[s, c] = pulse[pc*s + c] (c < pc), x[s, pc] = sigma * noise[s]
+//   h[s, co] = bias[co] + sum_c x[s, c] * W[c, co]
+// K <= 9, so this is a pure bandwidth kernel: one thread per (step, 4 channels), float4 store.
+__global__ void wn_start_kernel(const float *pulse, long long pulse_bstride, const float *noise,
+                                long long noise_bstride, float sigma, const int *n_frames, int steps_per_frame,
+                                int max_steps, int pc, const float *w, const float *bias, int channels, float *h,
+                                long long h_bstride) {
+    const int b = blockIdx.y;
+    const int steps = n_frames ? n_frames[b] * steps_per_frame : max_steps;
+    const int cq = channels >> 2;   // channels % 4 == 0 (checked on the host)
+    const long long total = (long long)steps * cq;
+    const float *pb = pulse + (long long)b * pulse_bstride;
+    const float *nb = noise ? noise + (long long)b * noise_bstride : nullptr;
+    float *hb = h + (long long)b * h_bstride;
+    const int cin = pc + (nb ? 1 : 0);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int s = (int)(i / cq), c4 = (int)(i - (long long)s * cq) * 4;
+        float4 acc = bias ? *reinterpret_cast<const float4 *>(bias + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c < cin; ++c) {
+            const float xv = c < pc ? pb[(long long)s * pc + c] : sigma * nb[s];
+            const float4 wv = *reinterpret_cast<const float4 *>(w + (long long)c * channels + c4);
+            sum.x += xv * wv.x;
+            sum.y += xv * wv.y;
+            sum.z += xv * wv.z;
+            sum.w += xv * wv.w;
+        }
+        acc.x += sum.x;
+        acc.y += sum.y;
+        acc.z += sum.z;
+        acc.w += sum.w;
+        *reinterpret_cast<float4 *>(hb + (long long)s * channels + c4) = acc;
+    }
+}
+
+void launch_wn_start(const float *pulse, long long pulse_bstride, const float *noise, long long noise_bstride,
+                     float sigma, const int *n_frames, int steps_per_frame, int max_steps, int batch,
+                     int pulse_channels, const float *w, const float *bias, int channels, float *h,
+                     long long h_bstride, hipStream_t stream) {
+    if (max_steps <= 0 || batch <= 0) return;
+    const long long total = (long long)max_steps * (channels >> 2);
+    const int blocks = (int)min((total + 255) / 256, (long long)4096);
+    hipLaunchKernelGGL(wn_start_kernel, dim3(blocks, batch), dim3(256), 0, stream, pulse, pulse_bstride, noise,
+                       noise_bstride, sigma, n_frames, steps_per_frame, max_steps, pulse_channels, w, bias, channels,
+                       h, h_bstride);
+}
+
+}  // namespace mbx

@@ -1,0 +1,706 @@
+// C ABI of the mel-inversion engine (include/mbexwn.h): handle, workspace carving, launch sequence.
+//
+// The launch sequence restates the inference branch of MBExWN.call
+// (reference MBExWN_NVoc/vocoder/model/custom_pulsed_generator.py:556-771) driven the way
+// PaNWaveNet.infer drives it (reference MBExWN_NVoc/vocoder/model/wavegen_1d.py:483-526).
+// Nothing in here allocates, frees or synchronises after mbx_create: every call only enqueues kernels
+// on the caller's stream, so a forward pass can be captured into a hipGraph by the caller.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mbexwn.h"
+#include "mbx_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+mbx_status fail(mbx_status st, const std::string &msg) {
+    g_last_error = msg;
+    return st;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t err__ = (expr);                                                                     \
+        if (err__ != hipSuccess)                                                                       \
+            return fail(MBX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(err__));            \
+    } while (0)
+
+struct DevTensor {
+    float *ptr = nullptr;
+    int ndim = 0;
+    long long shape[4] = {0, 0, 0, 0};
+    long long count = 0;
+};
+
+struct StageRef {
+    const void *ptr = nullptr;
+    long long count = 0, stride = 0;
+};
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct mbx_handle {
+    mbx_config cfg;
+    int device = 0;
+    char *arena = nullptr;
+    size_t arena_bytes = 0;
+    std::map<std::string, DevTensor> tensors;
+    std::map<int, std::pair<float *, float *>> lerp;   // interpolation factor -> (w0, w1)
+    float *twiddle = nullptr;
+    float *poly = nullptr;
+    int poly_ndm = 0, poly_dm_min = 0;
+    std::map<std::string, StageRef> stages;
+    // derived
+    int f0_time_factor = 1, vtf_time_factor = 1;
+    long long subnet_buf_per_frame = 0;   // floats per frame of one ping-pong buffer
+    // bench-only kernel timing (mbx_profile_*)
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool[2];   // 0: gate, 1: res_skip
+    size_t ev_used[2] = {0, 0};
+};
+
+namespace {
+
+const DevTensor *find(const mbx_handle *h, const std::string &name) {
+    auto it = h->tensors.find(name);
+    return it == h->tensors.end() ? nullptr : &it->second;
+}
+
+// floats per mel frame needed by the widest intermediate of a sub-net, and its time factor
+mbx_status analyse_subnet(const mbx_subnet_op *ops, int n_ops, int cin, long long *per_frame, int *factor,
+                          int *cout) {
+    long long fac = 1, chan = cin, widest = cin;
+    for (int i = 0; i < n_ops; ++i) {
+        const mbx_subnet_op &op = ops[i];
+        if (op.kind == MBX_OP_CONV) {
+            if (op.cin != chan) return fail(MBX_ERR_INVALID_ARGUMENT, std::string("sub-net op ") + op.name + ": cin mismatch");
+            if (op.up < 1 || op.cout % op.up) return fail(MBX_ERR_INVALID_ARGUMENT, "sub-pixel factor must divide cout");
+            widest = std::max(widest, fac * op.cout);
+            chan = op.cout / op.up;
+            fac *= op.up;
+        } else if (op.kind == MBX_OP_LIN) {
+            fac *= op.up;
+            widest = std::max(widest, fac * chan);
+        }
+    }
+    *per_frame = widest;
+    *factor = (int)fac;
+    *cout = (int)chan;
+    return MBX_OK;
+}
+
+struct Workspace {
+    float *sub0, *sub1, *f0, *cum, *chunk_last, *pulse, *cond, *h, *a, *skip, *wn_out, *sub, *exc, *ceps, *frames;
+    int *ceps_index;
+    size_t total;
+};
+
+Workspace carve(const mbx_handle *hd, char *base, int B, int T) {
+    const mbx_config &c = hd->cfg;
+    Workspace w;
+    size_t off = 0;
+    auto take = [&](size_t n_floats) {
+        char *p = base ? base + off : nullptr;
+        off += align_up(n_floats * sizeof(float), 256);
+        return reinterpret_cast<float *>(p);
+    };
+    const size_t BT = (size_t)B * T;
+    const size_t npulse = (size_t)T * c.pulse_per_frame, nsteps = (size_t)T * c.steps_per_frame;
+    const int chunks = (int)((npulse + c.phase_chunk - 1) / c.phase_chunk);
+    w.sub0 = take(BT * hd->subnet_buf_per_frame);
+    w.sub1 = take(BT * hd->subnet_buf_per_frame);
+    w.f0 = take(B * npulse);
+    w.cum = take(B * npulse);
+    w.chunk_last = take((size_t)B * chunks);
+    w.pulse = take(B * npulse);
+    w.cond = take(BT * 2 * c.wn_channels * c.cond_conv_upsampling);
+    w.h = take(B * nsteps * c.wn_channels);
+    w.a = take(B * nsteps * c.wn_channels);
+    w.skip = take(B * nsteps * c.wn_channels);
+    w.wn_out = take(B * nsteps * c.wn_out_channels);
+    w.sub = take(B * nsteps * c.subbands);
+    w.exc = take(BT * c.hop_size);
+    w.ceps = take(BT * c.n_ceps);
+    w.ceps_index = reinterpret_cast<int *>(take(BT));
+    w.frames = take(BT * c.stft_win);
+    w.total = off;
+    return w;
+}
+
+mbx::ConvArgs conv_args(const float *x, long long x_bstride, int ldx, const int *n_frames, int rpf, int max_rows,
+                        int batch, const DevTensor *w, const DevTensor *bias, int ks, int cin, int cout, int dil,
+                        int pad_l, int pad_mode, float *out, long long out_bstride, int ldo) {
+    mbx::ConvArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.x = x;
+    a.x_bstride = x_bstride;
+    a.ldx = ldx;
+    a.n_frames = n_frames;
+    a.rows_per_frame = rpf;
+    a.max_rows = max_rows;
+    a.batch = batch;
+    a.w = w->ptr;
+    a.bias = bias ? bias->ptr : nullptr;
+    a.cin = cin;
+    a.cout = cout;
+    a.ks = ks;
+    a.dil = dil;
+    a.pad_l = pad_l;
+    a.pad_mode = pad_mode;
+    a.out = out;
+    a.out_bstride = out_bstride;
+    a.ldo = ldo;
+    return a;
+}
+
+// Executes a sub-net op list (reference custom_pulsed_generator.py:38-148 flattened by the host).
+// in (B, T, cin) -> final (B, T*factor, cout); optional affine y*scale+offset applied after the last op.
+mbx_status run_subnet(mbx_handle *hd, const mbx_subnet_op *ops, int n_ops, const float *in, int cin,
+                      const int *n_frames, int B, int T, float *buf0, float *buf1, float *final_out,
+                      bool affine, float scale, float offset, hipStream_t stream) {
+    const float *cur = in;
+    int chan = cin, rpf = 1;
+    long long cur_bstride = (long long)T * cin;
+    bool affine_done = !affine;
+    int pp = 0;
+    // index of the last op that launches a kernel writing a new buffer
+    int last_writer = -1;
+    for (int i = 0; i < n_ops; ++i)
+        if (ops[i].kind == MBX_OP_CONV || ops[i].kind == MBX_OP_LIN) last_writer = i;
+    for (int i = 0; i < n_ops; ++i) {
+        const mbx_subnet_op &op = ops[i];
+        if (op.kind == MBX_OP_CONV) {
+            const DevTensor *w = find(hd, std::string(op.name) + ".w");
+            const DevTensor *bias = find(hd, std::string(op.name) + ".b");
+            if (!w || !bias) return fail(MBX_ERR_INVALID_ARGUMENT, std::string("missing tensor ") + op.name + ".w/.b");
+            float *out = (i == last_writer) ? final_out : (pp ? buf1 : buf0);
+            pp ^= 1;
+            const long long out_bstride = (long long)T * rpf * op.cout;
+            mbx::ConvArgs a = conv_args(cur, cur_bstride, chan, n_frames, rpf, T * rpf, B, w, bias, op.ks, op.cin,
+                                        op.cout, 1, op.pad_l, op.pad_mode, out, out_bstride, op.cout);
+            if (i + 1 < n_ops && ops[i + 1].kind == MBX_OP_PRELU && op.up == 1) {
+                const DevTensor *al = find(hd, std::string(ops[i + 1].name) + ".alpha");
+                if (!al) return fail(MBX_ERR_INVALID_ARGUMENT, std::string("missing tensor ") + ops[i + 1].name + ".alpha");
+                a.alpha = al->ptr;
+                ++i;
+            } else if (i + 1 < n_ops && ops[i + 1].kind == MBX_OP_LEAKY) {
+                a.use_leaky = 1;
+                a.leaky = ops[i + 1].alpha;
+                ++i;
+            }
+            mbx::launch_conv1d(a, mbx::EPI_LINEAR, stream);
+            cur = out;
+            chan = op.cout / op.up;
+            rpf *= op.up;
+            cur_bstride = out_bstride;
+        } else if (op.kind == MBX_OP_LIN) {
+            auto it = hd->lerp.find(op.up);
+            if (it == hd->lerp.end()) return fail(MBX_ERR_INVALID_ARGUMENT, "interpolation table missing");
+            float *out = (i == last_writer) ? final_out : (pp ? buf1 : buf0);
+            pp ^= 1;
+            int act = MBX_ACT_LINEAR;
+            float sc = 1.f, of = 0.f;
+            int consumed = 0;
+            if (i + 1 < n_ops && ops[i + 1].kind == MBX_OP_ACT) {
+                act = ops[i + 1].act;
+                consumed = 1;
+            }
+            if (i + consumed == n_ops - 1 && !affine_done) {
+                sc = scale;
+                of = offset;
+                affine_done = true;
+            }
+            const long long out_bstride = (long long)T * rpf * op.up * chan;
+            mbx::launch_lin_interp(cur, cur_bstride, n_frames, rpf, T * rpf, B, chan, op.up, it->second.first,
+                                   it->second.second, act, sc, of, out, out_bstride, stream);
+            i += consumed;
+            cur = out;
+            rpf *= op.up;
+            cur_bstride = out_bstride;
+        } else if (op.kind == MBX_OP_PRELU || op.kind == MBX_OP_LEAKY) {
+            const DevTensor *al = op.kind == MBX_OP_PRELU ? find(hd, std::string(op.name) + ".alpha") : nullptr;
+            if (op.kind == MBX_OP_PRELU && !al) return fail(MBX_ERR_INVALID_ARGUMENT, "missing PReLU slopes");
+            mbx::launch_prelu(const_cast<float *>(cur), cur_bstride, n_frames, rpf, T * rpf, B, chan,
+                              al ? al->ptr : nullptr, op.alpha, stream);
+        } else if (op.kind == MBX_OP_ACT) {
+            float sc = 1.f, of = 0.f;
+            if (i == n_ops - 1 && !affine_done) {
+                sc = scale;
+                of = offset;
+                affine_done = true;
+            }
+            mbx::launch_activation(cur, cur_bstride, n_frames, rpf, T * rpf, B, chan, op.act, sc, of,
+                                   const_cast<float *>(cur), cur_bstride, stream);
+        } else {
+            return fail(MBX_ERR_INVALID_ARGUMENT, "unknown sub-net op kind");
+        }
+    }
+    if (!affine_done)
+        mbx::launch_activation(cur, cur_bstride, n_frames, rpf, T * rpf, B, chan, MBX_ACT_LINEAR, scale, offset,
+                               const_cast<float *>(cur), cur_bstride, stream);
+    if (cur != final_out) return fail(MBX_ERR_INVALID_ARGUMENT, "sub-net without a convolution");
+    return MBX_OK;
+}
+
+// brackets one launch with events when profiling is on
+struct ScopedEvents {
+    mbx_handle *hd;
+    int kind;
+    hipStream_t stream;
+    hipEvent_t stop = nullptr;
+    ScopedEvents(mbx_handle *h, int k, hipStream_t s) : hd(h), kind(k), stream(s) {
+        if (!hd->profiling) return;
+        auto &pool = hd->ev_pool[kind];
+        if (hd->ev_used[kind] == pool.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            pool.push_back({a, b});
+        }
+        auto &pr = pool[hd->ev_used[kind]++];
+        (void)hipEventRecord(pr.first, stream);
+        stop = pr.second;
+    }
+    ~ScopedEvents() {
+        if (stop) (void)hipEventRecord(stop, stream);
+    }
+};
+
+mbx::WaveTableConsts wavetable_consts(const mbx_handle *hd) {
+    const mbx_config &c = hd->cfg;
+    mbx::WaveTableConsts k;
+    k.tables = find(hd, "table.wavetables")->ptr;
+    k.n_period = c.wt_n_period;
+    k.n_tables = c.wt_n_tables;
+    k.pulse_rate = c.pulse_rate;
+    k.nominal_f0 = c.wt_nominal_f0;
+    k.min_tf = c.wt_min_transposition;
+    k.max_tf = c.wt_max_transposition;
+    k.grid_norm = c.wt_grid_norm;
+    k.chunk = c.phase_chunk;
+    return k;
+}
+
+mbx::StftConsts stft_consts(const mbx_handle *hd) {
+    const mbx_config &c = hd->cfg;
+    mbx::StftConsts k;
+    k.hop = c.hop_size;
+    k.win = c.stft_win;
+    k.fft_size = c.fft_size;
+    k.n_ceps = c.n_ceps;
+    k.n_ceps_windows = c.n_ceps_windows;
+    k.max_log_range = c.filter_max_log_range;
+    k.hann = find(hd, "table.hann")->ptr;
+    k.inv_win = find(hd, "table.inv_win")->ptr;
+    k.twiddle = hd->twiddle;
+    k.ceps_windows = c.n_ceps_windows ? find(hd, "table.ceps_windows")->ptr : nullptr;
+    k.ceps_log10f0 = c.n_ceps_windows ? find(hd, "table.ceps_log10f0")->ptr : nullptr;
+    k.f0_smooth = c.n_ceps_windows ? find(hd, "table.f0_smooth")->ptr : nullptr;
+    k.pulse_per_frame = c.pulse_per_frame;
+    return k;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mbx_last_error(void) { return g_last_error.c_str(); }
+
+mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32_t n_tensors, int32_t device,
+                      mbx_handle **out) {
+    if (!config || !tensors || !out) return fail(MBX_ERR_INVALID_ARGUMENT, "null argument");
+    if (config->struct_size != (int32_t)sizeof(mbx_config) || config->abi_version != MBX_ABI_VERSION)
+        return fail(MBX_ERR_INVALID_ARGUMENT, "mbx_config ABI mismatch (struct_size / abi_version)");
+    const mbx_config &c = *config;
+    if (c.wn_layers < 1 || c.wn_layers > MBX_MAX_WN_LAYERS) return fail(MBX_ERR_INVALID_ARGUMENT, "wn_layers out of range");
+    if (c.n_f0_ops < 1 || c.n_f0_ops > MBX_MAX_SUBNET_OPS || c.n_vtf_ops < 1 || c.n_vtf_ops > MBX_MAX_SUBNET_OPS)
+        return fail(MBX_ERR_INVALID_ARGUMENT, "sub-net op count out of range");
+    if (c.wn_channels % 4 || c.wn_kernel_size % 2 != 1) return fail(MBX_ERR_INVALID_ARGUMENT, "wn_channels must be a multiple of 4, kernel size odd");
+    if (c.fft_size > 2048 || (c.fft_size & (c.fft_size - 1)) || c.stft_win > c.fft_size || c.stft_win != 4 * c.hop_size)
+        return fail(MBX_ERR_UNSUPPORTED, "STFT geometry: need power-of-two fft_size <= 2048 and win == 4*hop");
+    if (c.hop_size % c.subbands || c.steps_per_frame * c.subbands != c.hop_size)
+        return fail(MBX_ERR_INVALID_ARGUMENT, "hop_size must be steps_per_frame * subbands");
+    if (c.steps_per_frame * c.pulse_channels != c.pulse_per_frame)
+        return fail(MBX_ERR_INVALID_ARGUMENT, "pulse_per_frame must be steps_per_frame * pulse_channels");
+    if ((c.steps_per_frame % c.cond_lin_upsampling) || c.steps_per_frame / c.cond_lin_upsampling != c.cond_conv_upsampling)
+        return fail(MBX_ERR_INVALID_ARGUMENT, "conditioning rates do not reach the WaveNet rate");
+    if (c.wn_in_channels != c.pulse_channels + (c.noise_sigma != 0.f ? 1 : 0))
+        return fail(MBX_ERR_INVALID_ARGUMENT, "wn_in_channels must be pulse_channels (+1 with noise)");
+    if (c.pqmf_taps % 2) return fail(MBX_ERR_INVALID_ARGUMENT, "PQMF taps must be even");
+
+    mbx_handle *hd = new mbx_handle();
+    hd->cfg = c;
+    hd->device = device;
+    auto bail = [&](mbx_status st) {
+        mbx_destroy(hd);
+        return st;
+    };
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) {
+        delete hd;
+        return fail(MBX_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    }
+
+    // interpolation factors in use
+    std::vector<int> ups = {c.cond_lin_upsampling};
+    for (int i = 0; i < c.n_f0_ops; ++i)
+        if (c.f0_ops[i].kind == MBX_OP_LIN) ups.push_back(c.f0_ops[i].up);
+    for (int i = 0; i < c.n_vtf_ops; ++i)
+        if (c.vtf_ops[i].kind == MBX_OP_LIN) ups.push_back(c.vtf_ops[i].up);
+
+    // polyphase table of the PQMF synthesis bank
+    const mbx_tensor *syn = nullptr;
+    size_t total = 0;
+    for (int i = 0; i < n_tensors; ++i) {
+        long long cnt = 1;
+        if (tensors[i].ndim < 1 || tensors[i].ndim > 4 || !tensors[i].data || !tensors[i].name)
+            return bail(fail(MBX_ERR_INVALID_ARGUMENT, "malformed tensor entry"));
+        for (int d = 0; d < tensors[i].ndim; ++d) cnt *= tensors[i].shape[d];
+        total += align_up((size_t)cnt * sizeof(float), 256);
+        if (std::strcmp(tensors[i].name, "table.pqmf_syn") == 0) syn = &tensors[i];
+    }
+    if (!syn || syn->ndim != 2 || syn->shape[0] != c.pqmf_taps + 1 || syn->shape[1] != c.subbands)
+        return bail(fail(MBX_ERR_INVALID_ARGUMENT, "table.pqmf_syn must be (taps+1, subbands)"));
+    const int M = c.subbands, half = c.pqmf_taps / 2;
+    hd->poly_dm_min = -((half + M - 1) / M);
+    const int dm_max = (half + M - 1) / M;
+    hd->poly_ndm = dm_max - hd->poly_dm_min + 1;
+    std::vector<float> poly((size_t)M * hd->poly_ndm * M, 0.f);
+    for (int p = 0; p < M; ++p)
+        for (int i = 0; i < hd->poly_ndm; ++i) {
+            const int j = (hd->poly_dm_min + i) * M + half - p;
+            if (j >= 0 && j <= c.pqmf_taps)
+                for (int k = 0; k < M; ++k) poly[((size_t)p * hd->poly_ndm + i) * M + k] = syn->data[(size_t)j * M + k];
+        }
+    std::vector<float> tw((size_t)c.fft_size);
+    for (int k = 0; k < c.fft_size / 2; ++k) {
+        const double ang = -2.0 * M_PI * (double)k / (double)c.fft_size;
+        tw[2 * k] = (float)std::cos(ang);
+        tw[2 * k + 1] = (float)std::sin(ang);
+    }
+    total += align_up(poly.size() * sizeof(float), 256) + align_up(tw.size() * sizeof(float), 256);
+    for (int u : ups) total += 2 * align_up((size_t)u * sizeof(float), 256);
+
+    e = hipMalloc(reinterpret_cast<void **>(&hd->arena), total);
+    if (e != hipSuccess) return bail(fail(MBX_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e)));
+    hd->arena_bytes = total;
+    size_t off = 0;
+    auto upload = [&](const float *src, size_t count) -> float * {
+        float *dst = reinterpret_cast<float *>(hd->arena + off);
+        off += align_up(count * sizeof(float), 256);
+        hipError_t ee = hipMemcpy(dst, src, count * sizeof(float), hipMemcpyHostToDevice);
+        return ee == hipSuccess ? dst : nullptr;
+    };
+    for (int i = 0; i < n_tensors; ++i) {
+        DevTensor t;
+        t.ndim = tensors[i].ndim;
+        t.count = 1;
+        for (int d = 0; d < t.ndim; ++d) {
+            t.shape[d] = tensors[i].shape[d];
+            t.count *= t.shape[d];
+        }
+        t.ptr = upload(tensors[i].data, (size_t)t.count);
+        if (!t.ptr) return bail(fail(MBX_ERR_HIP, "hipMemcpy of a tensor failed"));
+        hd->tensors[tensors[i].name] = t;
+    }
+    hd->poly = upload(poly.data(), poly.size());
+    hd->twiddle = upload(tw.data(), tw.size());
+    if (!hd->poly || !hd->twiddle) return bail(fail(MBX_ERR_HIP, "hipMemcpy of a table failed"));
+    for (int u : ups) {
+        if (hd->lerp.count(u)) continue;
+        std::vector<float> w0(u), w1(u);
+        for (int j = 0; j < u; ++j) {   // float32 of the float64 ratios (reference support_layers.py:19-27)
+            w0[j] = (float)((double)(u - j) / (double)u);
+            w1[j] = (float)((double)j / (double)u);
+        }
+        float *d0 = upload(w0.data(), u), *d1 = upload(w1.data(), u);
+        if (!d0 || !d1) return bail(fail(MBX_ERR_HIP, "hipMemcpy of a table failed"));
+        hd->lerp[u] = {d0, d1};
+    }
+
+    // required tensors
+    std::vector<std::string> need = {"table.hann", "table.inv_win", "table.wavetables", "wn.start.w", "wn.start.b",
+                                     "wn.cond.w", "wn.cond.b", "wn.end.w", "wn.end.b", "post.w", "post.b"};
+    if (c.n_ceps_windows) {
+        need.push_back("table.ceps_windows");
+        need.push_back("table.ceps_log10f0");
+        need.push_back("table.f0_smooth");
+    }
+    for (int l = 0; l < c.wn_layers; ++l) {
+        need.push_back("wn.conv1D_" + std::to_string(l) + ".w");
+        need.push_back("wn.conv1D_" + std::to_string(l) + ".b");
+        need.push_back("wn.res_skip_" + std::to_string(l) + ".w");
+        need.push_back("wn.res_skip_" + std::to_string(l) + ".b");
+    }
+    for (const auto &nm : need)
+        if (!find(hd, nm)) return bail(fail(MBX_ERR_INVALID_ARGUMENT, "missing tensor " + nm));
+    auto expect = [&](const std::string &nm, long long count) {
+        const DevTensor *t = find(hd, nm);
+        return t && t->count == count;
+    };
+    const int C = c.wn_channels;
+    bool ok = expect("wn.start.w", (long long)c.wn_in_channels * C) &&
+              expect("wn.cond.w", (long long)c.cond_kernel_size * c.mel_channels * 2 * C * c.cond_conv_upsampling) &&
+              expect("wn.end.w", (long long)C * c.wn_out_channels) && expect("post.w", (long long)c.wn_out_channels * M) &&
+              expect("table.hann", c.stft_win) && expect("table.inv_win", c.stft_win) &&
+              expect("table.wavetables", (long long)(c.wt_n_period + 1) * c.wt_n_tables);
+    for (int l = 0; l < c.wn_layers && ok; ++l) {
+        ok = expect("wn.conv1D_" + std::to_string(l) + ".w", (long long)c.wn_kernel_size * C * 2 * C) &&
+             expect("wn.res_skip_" + std::to_string(l) + ".w", (long long)C * (l < c.wn_layers - 1 ? 2 * C : C));
+    }
+    if (c.n_ceps_windows)
+        ok = ok && expect("table.ceps_windows", (long long)c.n_ceps_windows * c.n_ceps) &&
+             expect("table.f0_smooth", 2 * c.hop_size + 1);
+    if (!ok) return bail(fail(MBX_ERR_INVALID_ARGUMENT, "a tensor has the wrong number of elements"));
+
+    long long pf0 = 0, pvtf = 0;
+    int f0_out = 0, vtf_out = 0;
+    mbx_status st = analyse_subnet(c.f0_ops, c.n_f0_ops, c.mel_channels, &pf0, &hd->f0_time_factor, &f0_out);
+    if (st != MBX_OK) return bail(st);
+    st = analyse_subnet(c.vtf_ops, c.n_vtf_ops, c.mel_channels, &pvtf, &hd->vtf_time_factor, &vtf_out);
+    if (st != MBX_OK) return bail(st);
+    if (hd->f0_time_factor != c.pulse_per_frame || f0_out != 1)
+        return bail(fail(MBX_ERR_INVALID_ARGUMENT, "F0 sub-net must end with 1 channel at pulse_per_frame samples per frame"));
+    if (hd->vtf_time_factor != 1 || vtf_out != c.n_ceps)
+        return bail(fail(MBX_ERR_INVALID_ARGUMENT, "VTF sub-net must end with n_ceps channels at the mel frame rate"));
+    hd->subnet_buf_per_frame = std::max(pf0, pvtf);
+    *out = hd;
+    return MBX_OK;
+}
+
+mbx_status mbx_destroy(mbx_handle *handle) {
+    if (!handle) return MBX_OK;
+    if (handle->arena) (void)hipFree(handle->arena);
+    for (auto &pool : handle->ev_pool)
+        for (auto &pr : pool) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+    delete handle;
+    return MBX_OK;
+}
+
+size_t mbx_workspace_size(const mbx_handle *handle, int32_t batch, int32_t max_frames) {
+    if (!handle || batch <= 0 || max_frames <= 0) return 0;
+    return carve(handle, nullptr, batch, max_frames).total;
+}
+
+mbx_status mbx_forward(mbx_handle *hd, const float *mel, const int32_t *n_frames, int32_t batch, int32_t max_frames,
+                       const float *noise, float *audio, void *workspace, size_t workspace_bytes, void *hip_stream) {
+    if (!hd || !mel || !audio || !workspace) return fail(MBX_ERR_INVALID_ARGUMENT, "null argument");
+    if (batch <= 0 || max_frames <= 0) return fail(MBX_ERR_INVALID_ARGUMENT, "batch and max_frames must be positive");
+    const mbx_config &c = hd->cfg;
+    if (c.noise_sigma != 0.f && !noise) return fail(MBX_ERR_INVALID_ARGUMENT, "noise is required when noise_sigma != 0");
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return fail(MBX_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
+    const int B = batch, T = max_frames;
+    Workspace w = carve(hd, static_cast<char *>(workspace), B, T);
+    if (w.total > workspace_bytes) return fail(MBX_ERR_WORKSPACE, "workspace too small, see mbx_workspace_size");
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    const int C = c.wn_channels, L = c.wn_layers, M = c.subbands;
+    const long long npulse = (long long)T * c.pulse_per_frame, nsteps = (long long)T * c.steps_per_frame;
+
+    // ---- F0 (reference custom_pulsed_generator.py:773-791)
+    mbx_status st = run_subnet(hd, c.f0_ops, c.n_f0_ops, mel, c.mel_channels, n_frames, B, T, w.sub0, w.sub1, w.f0,
+                               true, c.f0_max - c.f0_min, c.f0_min, stream);
+    if (st != MBX_OK) return st;
+    // ---- wavetable excitation (reference :889)
+    mbx::launch_wavetable(wavetable_consts(hd), w.f0, npulse, n_frames, c.pulse_per_frame, (int)npulse, B, w.pulse,
+                          nullptr, w.cum, w.chunk_last, stream);
+    // ---- WaveNet (reference custom_AE_layers.py:273-346)
+    const DevTensor *cw = find(hd, "wn.cond.w"), *cbias = find(hd, "wn.cond.b");
+    const int cond_cout = 2 * C * c.cond_conv_upsampling;
+    {
+        mbx::ConvArgs a = conv_args(mel, (long long)T * c.mel_channels, c.mel_channels, n_frames, 1, T, B, cw, cbias,
+                                    c.cond_kernel_size, c.mel_channels, cond_cout, 1, (c.cond_kernel_size - 1) / 2,
+                                    MBX_PAD_ZERO, w.cond, (long long)T * cond_cout, cond_cout);
+        mbx::launch_conv1d(a, mbx::EPI_LINEAR, stream);
+    }
+    mbx::launch_wn_start(w.pulse, npulse, c.noise_sigma != 0.f ? noise : nullptr, nsteps, c.noise_sigma, n_frames,
+                         c.steps_per_frame, (int)nsteps, B, c.pulse_channels, find(hd, "wn.start.w")->ptr,
+                         find(hd, "wn.start.b")->ptr, C, w.h, nsteps * C, stream);
+    auto lerp = hd->lerp[c.cond_lin_upsampling];
+    for (int l = 0; l < L; ++l) {
+        const std::string ls = std::to_string(l);
+        const int d = c.wn_dilations[l];
+        mbx::ConvArgs g = conv_args(w.h, nsteps * C, C, n_frames, c.steps_per_frame, (int)nsteps, B,
+                                    find(hd, "wn.conv1D_" + ls + ".w"), find(hd, "wn.conv1D_" + ls + ".b"),
+                                    c.wn_kernel_size, C, 2 * C, d, d * (c.wn_kernel_size - 1) / 2, MBX_PAD_ZERO, w.a,
+                                    nsteps * C, C);
+        g.cond = w.cond;
+        g.cond_bstride = (long long)T * cond_cout;
+        g.cond_up = c.cond_lin_upsampling;
+        g.lerp_w0 = lerp.first;
+        g.lerp_w1 = lerp.second;
+        g.channels = C;
+        {
+            ScopedEvents ev(hd, 0, stream);
+            mbx::launch_conv1d(g, mbx::EPI_GATE, stream);
+        }
+        const bool last = (l == L - 1);
+        mbx::ConvArgs r = conv_args(w.a, nsteps * C, C, n_frames, c.steps_per_frame, (int)nsteps, B,
+                                    find(hd, "wn.res_skip_" + ls + ".w"), find(hd, "wn.res_skip_" + ls + ".b"), 1, C,
+                                    last ? C : 2 * C, 1, 0, MBX_PAD_ZERO, nullptr, 0, 0);
+        r.channels = C;
+        r.h = w.h;
+        r.skip = w.skip;
+        r.hs_bstride = nsteps * C;
+        r.skip_init = (l == 0);
+        r.last_layer = last;
+        {
+            ScopedEvents ev(hd, 1, stream);
+            mbx::launch_conv1d(r, mbx::EPI_RESSKIP, stream);
+        }
+    }
+    {
+        mbx::ConvArgs a = conv_args(w.skip, nsteps * C, C, n_frames, c.steps_per_frame, (int)nsteps, B,
+                                    find(hd, "wn.end.w"), find(hd, "wn.end.b"), 1, C, c.wn_out_channels, 1, 0,
+                                    MBX_PAD_ZERO, w.wn_out, nsteps * c.wn_out_channels, c.wn_out_channels);
+        mbx::launch_conv1d(a, mbx::EPI_LINEAR, stream);
+        // post-net 1x1 (reference custom_pulsed_generator.py:490-493,913-914)
+        mbx::ConvArgs pn = conv_args(w.wn_out, nsteps * c.wn_out_channels, c.wn_out_channels, n_frames,
+                                     c.steps_per_frame, (int)nsteps, B, find(hd, "post.w"), find(hd, "post.b"), 1,
+                                     c.wn_out_channels, M, 1, 0, MBX_PAD_ZERO, w.sub, nsteps * M, M);
+        mbx::launch_conv1d(pn, mbx::EPI_LINEAR, stream);
+    }
+    // ---- PQMF synthesis (reference :920-921)
+    mbx::launch_pqmf(w.sub, nsteps * M, n_frames, c.steps_per_frame, (int)nsteps, B, M, hd->poly, hd->poly_ndm,
+                     hd->poly_dm_min, w.exc, (long long)T * c.hop_size, stream);
+    // ---- spectral envelope (reference :793-855) and STFT-domain filtering (reference :681-724)
+    st = run_subnet(hd, c.vtf_ops, c.n_vtf_ops, mel, c.mel_channels, n_frames, B, T, w.sub0, w.sub1, w.ceps, false,
+                    1.f, 0.f, stream);
+    if (st != MBX_OK) return st;
+    mbx::StftConsts sc = stft_consts(hd);
+    if (c.n_ceps_windows)
+        mbx::launch_ceps_index(sc, w.f0, npulse, n_frames, T, B, w.ceps_index, stream);
+    mbx::launch_stft_filter(sc, w.exc, (long long)T * c.hop_size, w.ceps, (long long)T * c.n_ceps,
+                            c.n_ceps_windows ? w.ceps_index : nullptr, n_frames, T, B, w.frames, stream);
+    mbx::launch_overlap_add(sc, w.frames, n_frames, T, B, audio, (long long)T * c.hop_size, stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MBX_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+
+    auto &sg = hd->stages;
+    sg["f0"] = {w.f0, npulse, npulse};
+    sg["pulse"] = {w.pulse, npulse, npulse};
+    sg["cond"] = {w.cond, (long long)T * cond_cout, (long long)T * cond_cout};
+    sg["wn_hidden"] = {w.h, nsteps * C, nsteps * C};
+    sg["wn_skip"] = {w.skip, nsteps * C, nsteps * C};
+    sg["wn_out"] = {w.wn_out, nsteps * c.wn_out_channels, nsteps * c.wn_out_channels};
+    sg["subbands"] = {w.sub, nsteps * M, nsteps * M};
+    sg["excitation"] = {w.exc, (long long)T * c.hop_size, (long long)T * c.hop_size};
+    sg["cepstrum"] = {w.ceps, (long long)T * c.n_ceps, (long long)T * c.n_ceps};
+    sg["ceps_index"] = {w.ceps_index, (long long)T, (long long)T};
+    sg["frames"] = {w.frames, (long long)T * c.stft_win, (long long)T * c.stft_win};
+    return MBX_OK;
+}
+
+mbx_status mbx_profile_enable(mbx_handle *handle, int32_t enabled) {
+    if (!handle) return fail(MBX_ERR_INVALID_ARGUMENT, "null argument");
+    handle->profiling = enabled != 0;
+    return MBX_OK;
+}
+
+mbx_status mbx_profile_read(mbx_handle *handle, const char *kernel, double *total_ms, int64_t *launches) {
+    if (!handle || !kernel || !total_ms || !launches) return fail(MBX_ERR_INVALID_ARGUMENT, "null argument");
+    int kind;
+    if (std::strcmp(kernel, "gate") == 0) kind = 0;
+    else if (std::strcmp(kernel, "res_skip") == 0) kind = 1;
+    else return fail(MBX_ERR_INVALID_ARGUMENT, "kernel must be gate or res_skip");
+    double sum = 0.0;
+    for (size_t i = 0; i < handle->ev_used[kind]; ++i) {
+        auto &pr = handle->ev_pool[kind][i];
+        HIP_TRY(hipEventSynchronize(pr.second));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = (int64_t)handle->ev_used[kind];
+    handle->ev_used[kind] = 0;
+    return MBX_OK;
+}
+
+mbx_status mbx_stage(const mbx_handle *handle, const char *name, const void **device_ptr, int64_t *count,
+                     int64_t *stride) {
+    if (!handle || !name || !device_ptr || !count || !stride) return fail(MBX_ERR_INVALID_ARGUMENT, "null argument");
+    auto it = handle->stages.find(name);
+    if (it == handle->stages.end()) return fail(MBX_ERR_INVALID_ARGUMENT, std::string("unknown stage ") + name);
+    *device_ptr = it->second.ptr;
+    *count = it->second.count;
+    *stride = it->second.stride;
+    return MBX_OK;
+}
+
+mbx_status mbx_pqmf_synthesis(mbx_handle *hd, const float *x, int32_t batch, int32_t n_steps, float *y,
+                              void *hip_stream) {
+    if (!hd || !x || !y || batch <= 0 || n_steps <= 0) return fail(MBX_ERR_INVALID_ARGUMENT, "bad argument");
+    const int M = hd->cfg.subbands;
+    mbx::launch_pqmf(x, (long long)n_steps * M, nullptr, 1, n_steps, batch, M, hd->poly, hd->poly_ndm,
+                     hd->poly_dm_min, y, (long long)n_steps * M, static_cast<hipStream_t>(hip_stream));
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MBX_OK : fail(MBX_ERR_HIP, hipGetErrorString(e));
+}
+
+mbx_status mbx_conv1d(mbx_handle *hd, const float *x, int32_t batch, int32_t n_rows, int32_t cin, const float *w,
+                      const float *b, const float *alpha, int32_t ks, int32_t cout, int32_t dilation, int32_t pad_l,
+                      int32_t pad_mode, float *y, void *hip_stream) {
+    if (!hd || !x || !w || !y || batch <= 0 || n_rows <= 0 || cin <= 0 || cout <= 0 || ks <= 0 || dilation <= 0)
+        return fail(MBX_ERR_INVALID_ARGUMENT, "bad argument");
+    if (pad_mode < MBX_PAD_ZERO || pad_mode > MBX_PAD_EDGE) return fail(MBX_ERR_INVALID_ARGUMENT, "bad pad_mode");
+    DevTensor wt, bt;
+    wt.ptr = const_cast<float *>(w);
+    bt.ptr = const_cast<float *>(b);
+    mbx::ConvArgs a = conv_args(x, (long long)n_rows * cin, cin, nullptr, 1, n_rows, batch, &wt, b ? &bt : nullptr, ks,
+                                cin, cout, dilation, pad_l, pad_mode, y, (long long)n_rows * cout, cout);
+    a.alpha = alpha;
+    mbx::launch_conv1d(a, mbx::EPI_LINEAR, static_cast<hipStream_t>(hip_stream));
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MBX_OK : fail(MBX_ERR_HIP, hipGetErrorString(e));
+}
+
+mbx_status mbx_lin_interp(mbx_handle *hd, const float *x, int32_t batch, int32_t n_rows, int32_t channels, int32_t up,
+                          float *y, void *hip_stream) {
+    if (!hd || !x || !y || batch <= 0 || n_rows <= 0 || channels <= 0) return fail(MBX_ERR_INVALID_ARGUMENT, "bad argument");
+    auto it = hd->lerp.find(up);
+    if (it == hd->lerp.end()) return fail(MBX_ERR_INVALID_ARGUMENT, "interpolation factor not part of this model");
+    mbx::launch_lin_interp(x, (long long)n_rows * channels, nullptr, 1, n_rows, batch, channels, up, it->second.first,
+                           it->second.second, MBX_ACT_LINEAR, 1.f, 0.f, y, (long long)n_rows * up * channels,
+                           static_cast<hipStream_t>(hip_stream));
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MBX_OK : fail(MBX_ERR_HIP, hipGetErrorString(e));
+}
+
+mbx_status mbx_wavetable(mbx_handle *hd, const float *f0, int32_t batch, int32_t n, float *pulse, float *phase,
+                         float *scratch, void *hip_stream) {
+    if (!hd || !f0 || !pulse || !scratch || batch <= 0 || n <= 0) return fail(MBX_ERR_INVALID_ARGUMENT, "bad argument");
+    float *cum = scratch;
+    float *chunk_last = scratch + (size_t)batch * n;
+    mbx::launch_wavetable(wavetable_consts(hd), f0, n, nullptr, 1, n, batch, pulse, phase, cum, chunk_last,
+                          static_cast<hipStream_t>(hip_stream));
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MBX_OK : fail(MBX_ERR_HIP, hipGetErrorString(e));
+}
+
+mbx_status mbx_stft_filter(mbx_handle *hd, const float *excitation, const float *cepstrum, const int32_t *ceps_index,
+                           int32_t batch, int32_t frames, float *audio, float *scratch, void *hip_stream) {
+    if (!hd || !excitation || !cepstrum || !audio || !scratch || batch <= 0 || frames <= 0)
+        return fail(MBX_ERR_INVALID_ARGUMENT, "bad argument");
+    const mbx_config &c = hd->cfg;
+    mbx::StftConsts sc = stft_consts(hd);
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    mbx::launch_stft_filter(sc, excitation, (long long)frames * c.hop_size, cepstrum, (long long)frames * c.n_ceps,
+                            c.n_ceps_windows ? ceps_index : nullptr, nullptr, frames, batch, scratch, stream);
+    mbx::launch_overlap_add(sc, scratch, nullptr, frames, batch, audio, (long long)frames * c.hop_size, stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MBX_OK : fail(MBX_ERR_HIP, hipGetErrorString(e));
+}
+
+}  // extern "C"

@@ -1,0 +1,121 @@
+// Internal launch interface between the C ABI (mbx_api.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mbx {
+
+// ---------------------------------------------------------------------------------------------
+// conv1d as an implicit GEMM on the fp32 matrix cores (conv_mfma.hip)
+// ---------------------------------------------------------------------------------------------
+enum ConvEpilogue {
+    EPI_LINEAR = 0,   // y = acc + bias, optional PReLU / leaky slope
+    EPI_GATE = 1,     // a = tanh(acc_t + bias_t + cond_t) * sigmoid(acc_s + bias_s + cond_s)
+    EPI_RESSKIP = 2   // h += r[:, :C] ; skip (+)= r[:, C:]   (last layer: skip += r)
+};
+
+struct ConvArgs {
+    // input (batch, rows, cin) channels-last
+    const float *x;
+    long long x_bstride;      // floats between batch items
+    int ldx;                  // floats between rows
+    // rows per item: n_frames ? n_frames[b] * rows_per_frame : max_rows
+    const int *n_frames;
+    int rows_per_frame;
+    int max_rows;
+    int batch;
+    // weights (ks*cin, cout) row-major, bias (cout) or null
+    const float *w;
+    const float *bias;
+    int cin, cout, ks, dil, pad_l, pad_mode;
+    // output
+    float *out;
+    long long out_bstride;
+    int ldo;
+    // EPI_LINEAR extras
+    const float *alpha;       // PReLU slopes (cout) or null
+    float leaky;              // slope when use_leaky
+    int use_leaky;
+    // EPI_GATE extras: conditioning (batch, rows/cond_up, 2*C), interpolated on the fly
+    const float *cond;
+    long long cond_bstride;
+    int cond_up;
+    const float *lerp_w0, *lerp_w1;   // (cond_up) float32 interpolation weights
+    int channels;             // C (gate: cout == 2C, out has C columns; res/skip: split point)
+    // EPI_RESSKIP extras
+    float *h;                 // (batch, rows, C) updated in place
+    float *skip;              // (batch, rows, C)
+    long long hs_bstride;
+    int skip_init;            // 1: skip = s (first layer)  0: skip += s
+    int last_layer;           // 1: cout == C, everything goes to skip
+};
+
+void launch_conv1d(const ConvArgs &a, int epilogue, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// element-wise / bandwidth-type stages (elementwise.hip)
+// ---------------------------------------------------------------------------------------------
+// linear interpolation (B,rows,C) -> (B,rows*up,C), optional final activation and affine (y*scale+offset)
+void launch_lin_interp(const float *x, long long x_bstride, const int *n_frames, int rows_per_frame, int max_rows,
+                       int batch, int channels, int up, const float *w0, const float *w1, int act, float scale,
+                       float offset, float *y, long long y_bstride, hipStream_t stream);
+// y = act(x)*scale + offset on (B, rows, C)
+void launch_activation(const float *x, long long x_bstride, const int *n_frames, int rows_per_frame, int max_rows,
+                       int batch, int channels, int act, float scale, float offset, float *y, long long y_bstride,
+                       hipStream_t stream);
+// PReLU / leaky in place (used when a conv is not directly followed by its activation)
+void launch_prelu(float *x, long long x_bstride, const int *n_frames, int rows_per_frame, int max_rows, int batch,
+                  int channels, const float *alpha, float leaky, hipStream_t stream);
+// WaveNet input: fold pulse (B, steps*pc) + noise (B, steps) and apply the start 1x1 conv -> h (B, steps, C)
+void launch_wn_start(const float *pulse, long long pulse_bstride, const float *noise, long long noise_bstride,
+                     float sigma, const int *n_frames, int steps_per_frame, int max_steps, int batch,
+                     int pulse_channels, const float *w, const float *bias, int channels, float *h,
+                     long long h_bstride, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// wavetable oscillator (wavetable.hip)
+// ---------------------------------------------------------------------------------------------
+struct WaveTableConsts {
+    const float *tables;   // (n_period+1, n_tables)
+    int n_period, n_tables;
+    float pulse_rate, nominal_f0, min_tf, max_tf, grid_norm;
+    int chunk;
+};
+// f0 (B, n_max) -> pulse (B, n_max); cum / chunk_last are scratch: cum (B, n_max), chunk_last (B, n_chunks_max)
+void launch_wavetable(const WaveTableConsts &c, const float *f0, long long bstride, const int *n_frames,
+                      int samples_per_frame, int n_max, int batch, float *pulse, float *phase_out, float *cum,
+                      float *chunk_last, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// PQMF synthesis (pqmf.hip)
+// ---------------------------------------------------------------------------------------------
+// x (B, steps, M) -> y (B, steps*M); g = polyphase table (M, n_dm, M) with dm_min
+void launch_pqmf(const float *x, long long x_bstride, const int *n_frames, int steps_per_frame, int max_steps,
+                 int batch, int subbands, const float *poly, int n_dm, int dm_min, float *y, long long y_bstride,
+                 hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// STFT-domain envelope filter (stft_filter.hip)
+// ---------------------------------------------------------------------------------------------
+struct StftConsts {
+    int hop, win, fft_size, n_ceps, n_ceps_windows;
+    float max_log_range;
+    const float *hann, *inv_win;      // (win)
+    const float *twiddle;             // (fft_size/2, 2)
+    const float *ceps_windows;        // (n_ceps_windows, n_ceps) or null
+    const float *ceps_log10f0;        // (n_ceps_windows)
+    const float *f0_smooth;           // (2*hop+1)
+    int pulse_per_frame;
+};
+// smoothed-F0 -> lifter row index (B, frames)
+void launch_ceps_index(const StftConsts &c, const float *f0, long long f0_bstride, const int *n_frames,
+                       int max_frames, int batch, int *index, hipStream_t stream);
+// per frame: window+FFT of the excitation, FFT of the liftered cepstrum, exp, multiply, inverse FFT, window
+void launch_stft_filter(const StftConsts &c, const float *exc, long long exc_bstride, const float *ceps,
+                        long long ceps_bstride, const int *index, const int *n_frames, int max_frames, int batch,
+                        float *frames, hipStream_t stream);
+// overlap-add of the windowed frames + slice -> audio (B, max_frames*hop), tail zeroed
+void launch_overlap_add(const StftConsts &c, const float *frames, const int *n_frames, int max_frames, int batch,
+                        float *audio, long long audio_bstride, hipStream_t stream);
+
+}  // namespace mbx

@@ -1,0 +1,99 @@
+// Wavetable oscillator: F0 -> wrapped phase -> band-limited LF pulse.
+//
+// restates PulseWaveTable.call                 reference MBExWN_NVoc/vocoder/model/tf_wavetable.py:495-552
+//          stable_cumsum_and_wrap               reference tf_wavetable.py:429-492
+//          _linear_lookup                       reference tf_wavetable.py:605-638
+//
+// The phase is a float32 running sum; a parallel scan would round differently and the error is
+// amplified by the table slope, so the reference's order of additions is kept bit for bit:
+//   (1) inside each chunk of 1000 samples a sequential float32 running sum (one thread per chunk --
+//       chunks are independent, so a 10 s utterance still exposes 80 x batch threads; the whole stage
+//       is < 0.1 % of the forward pass),
+//   (2) chunk offsets = running sum over chunks of (last value of the previous chunk mod 1), then mod 1,
+//   (3) phase = (chunk sum + offset) mod 1, table lookup and grid mix: one thread per sample, coalesced.
+#include "mbx_kernels.h"
+
+namespace mbx {
+
+__device__ __forceinline__ float mod1(float x) { return x - floorf(x); }   // x >= 0: identical to fmod(x, 1)
+
+// (1) one thread per (item, chunk)
+__global__ void phase_chunk_kernel(const float *f0, long long bstride, const int *n_frames, int samples_per_frame,
+                                   int n_max, int chunk, float pulse_rate, float *cum, float *chunk_last,
+                                   int chunks_max) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = n_frames ? n_frames[b] * samples_per_frame : n_max;
+    const int n_chunks = (n + chunk - 1) / chunk;
+    if (c >= n_chunks) return;
+    const float *fb = f0 + (long long)b * bstride;
+    float *cb = cum + (long long)b * bstride;
+    const int begin = c * chunk;
+    const int end = min(begin + chunk, n);
+    float acc = 0.f;
+    for (int i = begin; i < end; ++i) {
+        acc = acc + fb[i] / pulse_rate;       // phase velocity = frequency / sample_rate (tf_wavetable.py:516)
+        cb[i] = acc;
+    }
+    // the reference zero-pads the last chunk: adding zeros leaves the running sum unchanged
+    chunk_last[(long long)b * chunks_max + c] = acc;
+}
+
+// (2)+(3) one thread per sample
+__global__ void wavetable_kernel(WaveTableConsts k, const float *f0, long long bstride, const int *n_frames,
+                                 int samples_per_frame, int n_max, const float *cum, const float *chunk_last,
+                                 int chunks_max, float *pulse, float *phase_out) {
+    const int b = blockIdx.y;
+    const int n = n_frames ? n_frames[b] * samples_per_frame : n_max;
+    const float *fb = f0 + (long long)b * bstride;
+    const float *cb = cum + (long long)b * bstride;
+    const float *lb = chunk_last + (long long)b * chunks_max;
+    float *pb = pulse + (long long)b * bstride;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int c = i / k.chunk;
+        // offset of chunk c = (sum_{j < c} (last_j mod 1)) mod 1, summed in chunk order (tf_wavetable.py:476-483)
+        float off = 0.f;
+        for (int j = 0; j < c; ++j) off = off + mod1(lb[j]);
+        off = mod1(off);
+        const float phase = mod1(cb[i] + off);
+        if (phase_out) phase_out[(long long)b * bstride + i] = phase;
+        // linear table lookup (tf_wavetable.py:619-638)
+        const float pos = phase * (float)k.n_period;
+        const float base = floorf(pos);
+        const float rem = pos - base;
+        const int idx = (int)base;
+        // grid mix (tf_wavetable.py:539-548): q = ln(clip(f0 / nominalF0)) / ln(grid); weights max(1-|q-r|, 0)
+        const float f = fb[i];
+        const float ratio = fmaxf(k.min_tf, fminf(k.max_tf, f / k.nominal_f0));
+        const float q = logf(ratio) * k.grid_norm;
+        int r0 = (int)floorf(q);
+        r0 = max(0, min(r0, k.n_tables - 1));
+        const int r1 = min(r0 + 1, k.n_tables - 1);
+        const float *t0 = k.tables + (long long)idx * k.n_tables;
+        const float *t1 = t0 + k.n_tables;
+        const float one_m = 1.0f - rem;
+        const float s0 = t0[r0] * one_m + t1[r0] * rem;
+        const float w0 = fmaxf(1.0f - fabsf(q - (float)r0), 0.f);
+        float out = s0 * w0;
+        if (r1 != r0) {
+            const float s1 = t0[r1] * one_m + t1[r1] * rem;
+            const float w1 = fmaxf(1.0f - fabsf(q - (float)r1), 0.f);
+            out = out + s1 * w1;
+        }
+        pb[i] = out;
+    }
+}
+
+void launch_wavetable(const WaveTableConsts &c, const float *f0, long long bstride, const int *n_frames,
+                      int samples_per_frame, int n_max, int batch, float *pulse, float *phase_out, float *cum,
+                      float *chunk_last, hipStream_t stream) {
+    if (n_max <= 0 || batch <= 0) return;
+    const int chunks_max = (n_max + c.chunk - 1) / c.chunk;
+    hipLaunchKernelGGL(phase_chunk_kernel, dim3((chunks_max + 63) / 64, batch), dim3(64), 0, stream, f0, bstride,
+                       n_frames, samples_per_frame, n_max, c.chunk, c.pulse_rate, cum, chunk_last, chunks_max);
+    const int blocks = min((n_max + 255) / 256, 1024);
+    hipLaunchKernelGGL(wavetable_kernel, dim3(blocks, batch), dim3(256), 0, stream, c, f0, bstride, n_frames,
+                       samples_per_frame, n_max, cum, chunk_last, chunks_max, pulse, phase_out);
+}
+
+}  // namespace mbx

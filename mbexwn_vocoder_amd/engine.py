@@ -1,0 +1,429 @@
+"""ctypes binding of the HIP engine (include/mbexwn.h) and its host-side driver.
+
+``MBExWNEngine`` plays the role of the reference's Keras model object: it is what
+``MELInverter.model`` holds and what ``model.infer(mell, synth_length=...)`` is called on
+(reference MBExWN_NVoc/mel_inverter.py:151-154, MBExWN_NVoc/vocoder/model/wavegen_1d.py:483-526).
+PyTorch is used for device memory and streams only.
+
+There is NO CPU fallback: the engine refuses to load without the compiled HIP library, and refuses
+to run without a GPU.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import tables as tb
+from .build import LIB_PATH
+from .config import ModelDims
+from .subnet import build_subnet
+from .weights import fold_weights
+
+MBX_ABI_VERSION = 1
+MBX_MAX_SUBNET_OPS = 32
+MBX_MAX_WN_LAYERS = 64
+MBX_NAME_LEN = 64
+
+_OP_KIND = {"conv": 0, "lin": 1, "prelu": 2, "leaky": 3, "act": 4}
+_ACT = {"linear": 0, "soft_sigmoid": 1, "tanh": 2, "sigmoid": 3, "soft_sign": 4, "soft_sqrt": 5, "exp": 6, "relu": 7}
+
+
+class mbx_subnet_op(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("ks", ctypes.c_int32), ("cin", ctypes.c_int32), ("cout", ctypes.c_int32),
+                ("pad_l", ctypes.c_int32), ("pad_r", ctypes.c_int32), ("pad_mode", ctypes.c_int32),
+                ("up", ctypes.c_int32), ("act", ctypes.c_int32), ("alpha", ctypes.c_float),
+                ("name", ctypes.c_char * MBX_NAME_LEN)]
+
+
+class mbx_config(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_int32), ("abi_version", ctypes.c_int32),
+                ("sample_rate", ctypes.c_int32), ("hop_size", ctypes.c_int32), ("mel_channels", ctypes.c_int32),
+                ("subbands", ctypes.c_int32), ("pqmf_taps", ctypes.c_int32),
+                ("pulse_channels", ctypes.c_int32), ("pulse_per_frame", ctypes.c_int32),
+                ("steps_per_frame", ctypes.c_int32),
+                ("pulse_rate", ctypes.c_float), ("noise_sigma", ctypes.c_float),
+                ("f0_min", ctypes.c_float), ("f0_max", ctypes.c_float),
+                ("wn_channels", ctypes.c_int32), ("wn_layers", ctypes.c_int32), ("wn_kernel_size", ctypes.c_int32),
+                ("wn_out_channels", ctypes.c_int32), ("wn_in_channels", ctypes.c_int32),
+                ("wn_dilations", ctypes.c_int32 * MBX_MAX_WN_LAYERS),
+                ("cond_kernel_size", ctypes.c_int32), ("cond_conv_upsampling", ctypes.c_int32),
+                ("cond_lin_upsampling", ctypes.c_int32),
+                ("stft_win", ctypes.c_int32), ("fft_size", ctypes.c_int32), ("n_ceps", ctypes.c_int32),
+                ("n_ceps_windows", ctypes.c_int32), ("filter_max_log_range", ctypes.c_float),
+                ("wt_n_period", ctypes.c_int32), ("wt_n_tables", ctypes.c_int32),
+                ("wt_nominal_f0", ctypes.c_float), ("wt_min_transposition", ctypes.c_float),
+                ("wt_max_transposition", ctypes.c_float), ("wt_grid_norm", ctypes.c_float),
+                ("phase_chunk", ctypes.c_int32),
+                ("n_f0_ops", ctypes.c_int32), ("f0_ops", mbx_subnet_op * MBX_MAX_SUBNET_OPS),
+                ("n_vtf_ops", ctypes.c_int32), ("vtf_ops", mbx_subnet_op * MBX_MAX_SUBNET_OPS)]
+
+
+class mbx_tensor(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("data", ctypes.POINTER(ctypes.c_float)), ("ndim", ctypes.c_int32),
+                ("shape", ctypes.c_int64 * 4)]
+
+
+_STATUS_EXC = {1: ValueError, 2: RuntimeError, 3: RuntimeError, 4: NotImplementedError}
+
+_lib = None
+
+
+def load_library():
+    """Load libmbexwn_hip.so (built in-tree by mbexwn_vocoder_amd.build). Fails loudly when absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"HIP extension {LIB_PATH} is missing: run `python -m mbexwn_vocoder_amd.build` "
+                           "(there is no CPU fallback for the mel-inversion path)")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64p, fp = ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p
+    lib.mbx_last_error.restype = ctypes.c_char_p
+    lib.mbx_last_error.argtypes = []
+    lib.mbx_create.restype = i32
+    lib.mbx_create.argtypes = [ctypes.POINTER(mbx_config), ctypes.POINTER(mbx_tensor), i32, i32,
+                               ctypes.POINTER(ctypes.c_void_p)]
+    lib.mbx_destroy.restype = i32
+    lib.mbx_destroy.argtypes = [vp]
+    lib.mbx_workspace_size.restype = ctypes.c_size_t
+    lib.mbx_workspace_size.argtypes = [vp, i32, i32]
+    lib.mbx_forward.restype = i32
+    lib.mbx_forward.argtypes = [vp, fp, vp, i32, i32, fp, fp, vp, ctypes.c_size_t, vp]
+    lib.mbx_stage.restype = i32
+    lib.mbx_stage.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p), i64p, i64p]
+    lib.mbx_profile_enable.restype = i32
+    lib.mbx_profile_enable.argtypes = [vp, i32]
+    lib.mbx_profile_read.restype = i32
+    lib.mbx_profile_read.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), i64p]
+    lib.mbx_pqmf_synthesis.restype = i32
+    lib.mbx_pqmf_synthesis.argtypes = [vp, fp, i32, i32, fp, vp]
+    lib.mbx_conv1d.restype = i32
+    lib.mbx_conv1d.argtypes = [vp, fp, i32, i32, i32, fp, fp, fp, i32, i32, i32, i32, i32, fp, vp]
+    lib.mbx_lin_interp.restype = i32
+    lib.mbx_lin_interp.argtypes = [vp, fp, i32, i32, i32, i32, fp, vp]
+    lib.mbx_wavetable.restype = i32
+    lib.mbx_wavetable.argtypes = [vp, fp, i32, i32, fp, fp, fp, vp]
+    lib.mbx_stft_filter.restype = i32
+    lib.mbx_stft_filter.argtypes = [vp, fp, fp, vp, i32, i32, fp, fp, vp]
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = ["mbx_last_error", "mbx_create", "mbx_destroy", "mbx_workspace_size", "mbx_forward", "mbx_stage",
+                    "mbx_profile_enable", "mbx_profile_read", "mbx_pqmf_synthesis", "mbx_conv1d", "mbx_lin_interp", "mbx_wavetable", "mbx_stft_filter"]
+
+
+def _check(status):
+    if status != 0:
+        msg = load_library().mbx_last_error().decode("utf-8", "replace")
+        raise _STATUS_EXC.get(status, RuntimeError)(f"mbexwn_hip: {msg}")
+
+
+# ------------------------------------------------------------------------------------------------
+# host-side model description
+# ------------------------------------------------------------------------------------------------
+def subnet_ops(config):
+    """(f0 ops, vtf ops): the reference's sub-net grammar flattened (see subnet.build_subnet)."""
+    dims = ModelDims(config)
+    mb = config["mbexwn_config"]
+    use_prelu = mb.get("use_prelu", True)
+    f0_ops, _, _ = build_subnet(mb["pp_subnet"], "PulsPar", dims.mel_channels, 1, 1,
+                                mb.get("pp_activation", "soft_sigmoid"), target_ups=dims.pulse_per_frame,
+                                pad_to_valid=mb.get("pp_subnet_use_valid_padding", False),
+                                remove_inactive_pad_layers=mb.get("remove_inactive_pad_layers", False),
+                                use_prelu=use_prelu, alpha=dims.alpha, force_causal=mb.get("force_causal", False))
+    vtf_ops, _, _ = build_subnet(mb["ps_subnet"], "PS", dims.mel_channels, dims.n_ceps, 1, None,
+                                 pad_to_valid=mb.get("ps_subnet_use_valid_padding", False),
+                                 remove_inactive_pad_layers=mb.get("remove_inactive_pad_layers", False),
+                                 use_prelu=use_prelu, alpha=dims.alpha, force_causal=mb.get("force_causal", False))
+    return f0_ops, vtf_ops
+
+
+def _fill_ops(dst, ops):
+    if len(ops) > MBX_MAX_SUBNET_OPS:
+        raise ValueError("sub-net too deep for the engine")
+    for ii, op in enumerate(ops):
+        cop = dst[ii]
+        cop.kind = _OP_KIND[op["kind"]]
+        cop.ks = op.get("ks", 0)
+        cop.cin = op.get("cin", 0)
+        cop.cout = op.get("cout", 0)
+        cop.pad_l = op.get("pad_l", 0)
+        cop.pad_r = op.get("pad_r", 0)
+        cop.pad_mode = op.get("pad_mode", 0)
+        cop.up = op.get("up", 1)
+        if op["kind"] == "act":
+            if op["fn"] not in _ACT:
+                raise RuntimeError(f"ActivationLayer::error::unkown activation selected {op['fn']}")
+            cop.act = _ACT[op["fn"]]
+        cop.alpha = op.get("alpha", 0.0)
+        cop.name = op.get("name", "").encode()
+    return len(ops)
+
+
+def make_config(config, wavetables):
+    dims = ModelDims(config)
+    mb = config["mbexwn_config"]
+    cc = mbx_config()
+    cc.struct_size = ctypes.sizeof(mbx_config)
+    cc.abi_version = MBX_ABI_VERSION
+    cc.sample_rate, cc.hop_size, cc.mel_channels = dims.sample_rate, dims.hop_size, dims.mel_channels
+    cc.subbands = dims.subbands
+    cc.pqmf_taps = int(mb["multi_band_config"]["taps"])
+    cc.pulse_channels, cc.pulse_per_frame, cc.steps_per_frame = dims.pulse_channels, dims.pulse_per_frame, dims.steps_per_frame
+    cc.pulse_rate = dims.pulse_rate
+    cc.noise_sigma = dims.noise_sigma
+    cc.f0_min, cc.f0_max = dims.f0_min, dims.f0_max
+    cc.wn_channels, cc.wn_layers, cc.wn_kernel_size = dims.wn_channels, dims.wn_layers, dims.wn_kernel_size
+    cc.wn_out_channels, cc.wn_in_channels = dims.wn_out_channels, dims.wn_in_channels
+    if dims.wn_layers > MBX_MAX_WN_LAYERS:
+        raise ValueError("too many WaveNet layers for the engine")
+    for ll in range(dims.wn_layers):
+        cc.wn_dilations[ll] = dims.wn_dilation(ll)
+    cc.cond_kernel_size = dims.cond_kernel_size
+    cc.cond_conv_upsampling = dims.cond_conv_upsampling
+    cc.cond_lin_upsampling = dims.cond_lin_upsampling
+    cc.stft_win, cc.fft_size, cc.n_ceps = dims.stft_win, dims.fft_size, dims.n_ceps
+    use_windows = bool(dims.ps_env_order_scale) and not mb.get("psns_use_cepstral_loss_constraint", False)
+    cc.n_ceps_windows = 30 if use_windows else 0
+    cc.filter_max_log_range = dims.filter_max_log_range
+    cc.wt_n_period, cc.wt_n_tables = wavetables.n_period, wavetables.n_tables
+    cc.wt_nominal_f0 = wavetables.nominalF0
+    cc.wt_min_transposition = float(wavetables.min_transposition)
+    cc.wt_max_transposition = float(wavetables.max_transposition)
+    cc.wt_grid_norm = float(wavetables.grid_norm)
+    cc.phase_chunk = 1000
+    f0_ops, vtf_ops = subnet_ops(config)
+    cc.n_f0_ops = _fill_ops(cc.f0_ops, f0_ops)
+    cc.n_vtf_ops = _fill_ops(cc.vtf_ops, vtf_ops)
+    return cc, dims
+
+
+def tensor_table(config, raw_weights, wavetables):
+    """name -> float32 array of everything mbx_create needs: folded weights + constant tables."""
+    dims = ModelDims(config)
+    mb = config["mbexwn_config"]
+    mbc = mb["multi_band_config"]
+    out = dict(fold_weights(raw_weights))
+    _, syn = tb.pqmf_filters(int(mbc["subbands"]), int(mbc["taps"]), float(mbc["cutoff_ratio"]), float(mbc["beta"]),
+                             mbc.get("max_band", None))
+    out["table.pqmf_syn"] = syn
+    out["table.hann"] = tb.hann_periodic_f32(dims.stft_win)
+    out["table.inv_win"] = tb.inverse_stft_window_f32(dims.stft_win, dims.hop_size)
+    out["table.wavetables"] = np.ascontiguousarray(wavetables.tables, dtype=np.float32)
+    if dims.ps_env_order_scale and not mb.get("psns_use_cepstral_loss_constraint", False):
+        logs, rows = tb.cepstral_windows(dims.ps_env_order_scale, dims.sample_rate, dims.f0_min, dims.f0_max, dims.n_ceps)
+        out["table.ceps_windows"] = rows
+        out["table.ceps_log10f0"] = logs
+        out["table.f0_smooth"] = tb.f0_smoothing_kernel(dims.hop_size)
+    return {kk: np.ascontiguousarray(vv, dtype=np.float32) for kk, vv in out.items()}
+
+
+# ------------------------------------------------------------------------------------------------
+# the engine
+# ------------------------------------------------------------------------------------------------
+class MBExWNEngine:
+    """Device-resident MBExWN generator. One instance per GPU (one process per GPU)."""
+
+    def __init__(self, config, raw_weights, wavetables=None, device=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("MBExWNEngine needs an AMD GPU (no CPU fallback for the mel-inversion path)")
+        self._torch = torch
+        self._lib = load_library()
+        self.config = config
+        if wavetables is None:
+            dims = ModelDims(config)
+            wavetables = tb.WaveTables(sample_rate=dims.pulse_rate, **config["mbexwn_config"]["wavetable_config"])
+        self.wavetables = wavetables
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        cconf, self.dims = make_config(config, wavetables)
+        self._tensors = tensor_table(config, raw_weights, wavetables)   # keep the host arrays alive
+        arr = (mbx_tensor * len(self._tensors))()
+        for ii, (name, val) in enumerate(self._tensors.items()):
+            arr[ii].name = name.encode()
+            arr[ii].data = val.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+            arr[ii].ndim = val.ndim
+            for dd in range(val.ndim):
+                arr[ii].shape[dd] = val.shape[dd]
+        handle = ctypes.c_void_p()
+        _check(self._lib.mbx_create(ctypes.byref(cconf), arr, len(self._tensors), self.device.index,
+                                    ctypes.byref(handle)))
+        self._handle = handle
+        self._workspace = None
+        self._last_shape = None
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            self._lib.mbx_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- properties the reference's model object exposes to MELInverter / scripts
+    @property
+    def sample_rate(self):
+        return self.dims.sample_rate
+
+    @property
+    def spect_hop_size(self):
+        return self.dims.hop_size
+
+    @property
+    def mel_channels(self):
+        return self.dims.mel_channels
+
+    def _stream(self):
+        return ctypes.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def workspace_bytes(self, batch, max_frames):
+        return int(self._lib.mbx_workspace_size(self._handle, batch, max_frames))
+
+    def _get_workspace(self, batch, max_frames):
+        need = self.workspace_bytes(batch, max_frames)
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = self._torch.empty(need, dtype=self._torch.uint8, device=self.device)
+        return self._workspace, need
+
+    def forward(self, mel, n_frames=None, noise=None, out=None):
+        """mel (B,T,80) float32 cuda tensor; n_frames int32 cuda tensor (B,) or None;
+        noise (B, T*steps_per_frame) float32 cuda tensor (N(0,1) draw) -> audio (B, T*hop) cuda tensor."""
+        torch = self._torch
+        if mel.dim() != 3 or mel.shape[2] != self.dims.mel_channels:
+            raise ValueError(f"mel must be (batch, frames, {self.dims.mel_channels})")
+        if mel.device != self.device or mel.dtype != torch.float32:
+            raise ValueError("mel must be a float32 tensor on the engine's device")
+        mel = mel.contiguous()
+        B, T = int(mel.shape[0]), int(mel.shape[1])
+        if B == 0 or T == 0:
+            return torch.zeros((B, T * self.dims.hop_size), dtype=torch.float32, device=self.device)
+        steps = T * self.dims.steps_per_frame
+        if self.dims.noise_sigma:
+            if noise is None:
+                raise ValueError("noise is required (the noise channel is an explicit input, see SURVEY.md F7)")
+            if tuple(noise.shape) != (B, steps) or noise.dtype != torch.float32 or noise.device != self.device:
+                raise ValueError(f"noise must be float32 ({B}, {steps}) on the engine's device")
+            noise = noise.contiguous()
+        if n_frames is not None:
+            if n_frames.dtype != torch.int32 or tuple(n_frames.shape) != (B,) or n_frames.device != self.device:
+                raise ValueError("n_frames must be an int32 tensor of shape (batch,) on the engine's device")
+            n_frames = n_frames.contiguous()
+        if out is None:
+            out = torch.empty((B, T * self.dims.hop_size), dtype=torch.float32, device=self.device)
+        ws, need = self._get_workspace(B, T)
+        _check(self._lib.mbx_forward(self._handle, mel.data_ptr(),
+                                     n_frames.data_ptr() if n_frames is not None else None, B, T,
+                                     noise.data_ptr() if noise is not None else None, out.data_ptr(),
+                                     ws.data_ptr(), need, self._stream()))
+        self._last_shape = (B, T)
+        return out
+
+    def profile_enable(self, enabled=True):
+        _check(self._lib.mbx_profile_enable(self._handle, 1 if enabled else 0))
+
+    def profile_read(self, kernel):
+        """(summed device ms, launches) of the WaveNet GEMM kernel 'gate' or 'res_skip' since the last read."""
+        ms, cnt = ctypes.c_double(), ctypes.c_int64()
+        _check(self._lib.mbx_profile_read(self._handle, kernel.encode(), ctypes.byref(ms), ctypes.byref(cnt)))
+        return ms.value, cnt.value
+
+    def stage(self, name):
+        """Intermediate tensor of the last forward (copy), shaped (B, count); see mbx_stage."""
+        torch = self._torch
+        ptr, cnt, stride = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int64()
+        _check(self._lib.mbx_stage(self._handle, name.encode(), ctypes.byref(ptr), ctypes.byref(cnt),
+                                   ctypes.byref(stride)))
+        B = self._last_shape[0]
+        dtype = torch.int32 if name == "ceps_index" else torch.float32
+        ws = self._workspace
+        offset = ptr.value - ws.data_ptr()
+        flat = ws[offset: offset + B * stride.value * 4].view(dtype)
+        return flat.view(B, stride.value)[:, :cnt.value].clone()
+
+    def infer(self, spect, sigma=None, synth_length=0, noise=None, **_):
+        """Keras-model look-alike of PaNWaveNet.infer (reference wavegen_1d.py:483-526):
+        spect numpy/torch (B,T,80) -> tensor with .numpy() of shape (B, synth_length)."""
+        torch = self._torch
+        mel = torch.as_tensor(np.asarray(spect, dtype=np.float32) if not torch.is_tensor(spect) else spect)
+        mel = mel.to(self.device, torch.float32)
+        hop = self.dims.hop_size
+        synth_length = int(synth_length) if synth_length else mel.shape[1] * hop
+        if mel.shape[1] * hop < synth_length:                        # reference wavegen_1d.py:490-491
+            mel = torch.cat((mel, mel[:, -1:]), dim=1)
+        if noise is None and self.dims.noise_sigma:
+            # the reference draws tf.random.normal here (custom_pulsed_generator.py:905-906)
+            noise = torch.randn((mel.shape[0], mel.shape[1] * self.dims.steps_per_frame), device=self.device,
+                                dtype=torch.float32)
+        elif noise is not None:
+            noise = torch.as_tensor(noise).to(self.device, torch.float32)
+        audio = self.forward(mel, noise=noise)
+        return _HostTensor(audio[:, :synth_length])
+
+    # -- stage entry points (unit parity tests)
+    def pqmf_synthesis(self, x):
+        torch = self._torch
+        x = x.contiguous()
+        B, S, M = x.shape
+        y = torch.empty((B, S * M), dtype=torch.float32, device=self.device)
+        _check(self._lib.mbx_pqmf_synthesis(self._handle, x.data_ptr(), B, S, y.data_ptr(), self._stream()))
+        return y
+
+    def conv1d(self, x, w, b=None, alpha=None, dilation=1, pad_l=0, pad_mode=0):
+        torch = self._torch
+        x, w = x.contiguous(), w.contiguous()
+        B, R, cin = x.shape
+        ks, _, cout = w.shape
+        y = torch.empty((B, R, cout), dtype=torch.float32, device=self.device)
+        _check(self._lib.mbx_conv1d(self._handle, x.data_ptr(), B, R, cin, w.data_ptr(),
+                                    b.data_ptr() if b is not None else None,
+                                    alpha.data_ptr() if alpha is not None else None, ks, cout, dilation, pad_l,
+                                    pad_mode, y.data_ptr(), self._stream()))
+        return y
+
+    def lin_interp(self, x, up):
+        torch = self._torch
+        x = x.contiguous()
+        B, R, C = x.shape
+        y = torch.empty((B, R * up, C), dtype=torch.float32, device=self.device)
+        _check(self._lib.mbx_lin_interp(self._handle, x.data_ptr(), B, R, C, up, y.data_ptr(), self._stream()))
+        return y
+
+    def wavetable(self, f0):
+        torch = self._torch
+        f0 = f0.contiguous()
+        B, N = f0.shape
+        pulse = torch.empty_like(f0)
+        phase = torch.empty_like(f0)
+        scratch = torch.empty(B * (N + N // 1000 + 2), dtype=torch.float32, device=self.device)
+        _check(self._lib.mbx_wavetable(self._handle, f0.data_ptr(), B, N, pulse.data_ptr(), phase.data_ptr(),
+                                       scratch.data_ptr(), self._stream()))
+        return pulse, phase
+
+    def stft_filter(self, excitation, cepstrum, ceps_index=None):
+        torch = self._torch
+        excitation, cepstrum = excitation.contiguous(), cepstrum.contiguous()
+        B, T = cepstrum.shape[:2]
+        audio = torch.empty((B, T * self.dims.hop_size), dtype=torch.float32, device=self.device)
+        scratch = torch.empty(B * T * self.dims.stft_win, dtype=torch.float32, device=self.device)
+        _check(self._lib.mbx_stft_filter(self._handle, excitation.data_ptr(), cepstrum.data_ptr(),
+                                         ceps_index.contiguous().data_ptr() if ceps_index is not None else None,
+                                         B, T, audio.data_ptr(), scratch.data_ptr(), self._stream()))
+        return audio
+
+
+class _HostTensor:
+    """What ``model.infer(...)`` returns: something with ``.numpy()`` (reference mel_inverter.py:152)."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+
+    def numpy(self):
+        return self.tensor.detach().cpu().numpy()
+
+    @property
+    def shape(self):
+        return tuple(self.tensor.shape)

@@ -1,0 +1,277 @@
+"""HIP engine (through the C ABI) against the CPU oracle and the reference-generated golden vectors.
+
+Tolerances (float32 HIP path vs float64 oracle), stated per SURVEY.md section 8(c):
+  isolated stage : max-abs-delta <= 2e-5 * max(1, max|ref|)
+  end to end     : max-abs-delta <= 1e-4 * max(1, max|ref|)   (audio of amplitude ~1..4)
+  integer work   : bit exact (phase accumulator, lifter indices away from rounding ties)
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import mbexwn_oracle as orc
+from helpers import GOLDEN_CASES, build_case, synthetic_inputs
+
+pytestmark = pytest.mark.gpu
+
+STAGE_TOL = 2e-5
+E2E_TOL = 1e-4
+
+
+def _tol(ref, rel):
+    return rel * max(1.0, float(np.max(np.abs(ref))))
+
+
+def _maxdiff(a, b):
+    return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as _torch
+    assert _torch.cuda.is_available(), "GPU tests need an MI355X"
+    return _torch
+
+
+_ENGINES = {}
+
+
+def get_engine(case_key, voice, overrides):
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    if case_key not in _ENGINES:
+        cfg, raw, wt = build_case(voice, overrides)
+        _ENGINES[case_key] = (MBExWNEngine(cfg, raw, wt), orc.OracleModel(cfg, raw, wt), cfg, raw, wt)
+    return _ENGINES[case_key]
+
+
+SMALL = ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3})
+CANON = ("SPEECH", {})
+VOICE = ("VOICE", {})
+
+
+def dev(torch, arr, dtype=None):
+    return torch.as_tensor(np.ascontiguousarray(arr), dtype=dtype or torch.float32).cuda()
+
+
+# ------------------------------------------------------------------------------------------------
+# stage parity
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cin,cout,ks,dil,mode,rows,prelu", [
+    (80, 128, 3, 1, "SYMMETRIC", 37, True),
+    (128, 64, 3, 1, "EDGE", 5, True),
+    (64, 1, 1, 1, "CONSTANT", 130, False),
+    (6, 32, 1, 1, "CONSTANT", 200, False),
+    (30, 15, 1, 1, "CONSTANT", 260, False),
+    (32, 64, 3, 4, "CONSTANT", 300, False),
+    (320, 640, 3, 16, "CONSTANT", 150, False),
+    (340, 680, 3, 2, "CONSTANT", 129, False),
+    (256, 240, 1, 1, "CONSTANT", 3, False),
+    (80, 1280, 3, 1, "CONSTANT", 1, False),
+])
+def test_conv1d(torch, cin, cout, ks, dil, mode, rows, prelu):
+    eng = get_engine("small", *SMALL)[0]
+    rng = np.random.default_rng(cin * 1000 + cout)
+    B = 2
+    x = rng.normal(size=(B, rows, cin)).astype(np.float32)
+    w = (rng.normal(size=(ks, cin, cout)) / np.sqrt(ks * cin)).astype(np.float32)
+    b = rng.normal(size=(cout,)).astype(np.float32)
+    alpha = rng.uniform(0.05, 0.4, size=(cout,)).astype(np.float32) if prelu else None
+    total = (ks - 1) * dil
+    if mode == "CONSTANT":
+        pl, pr = total // 2, total - total // 2
+    else:
+        pl, pr = (ks - 1) // 2 + ((ks - 1) % 2), (ks - 1) // 2
+    ref = orc.conv1d_valid(orc.pad_time(x.astype(np.float64), pl, pr, mode), w.astype(np.float64),
+                           b.astype(np.float64), dilation=dil)
+    if prelu:
+        ref = orc.prelu(ref, alpha.astype(np.float64))
+    got = eng.conv1d(dev(torch, x), dev(torch, w), dev(torch, b), dev(torch, alpha) if prelu else None,
+                     dilation=dil, pad_l=pl, pad_mode={"CONSTANT": 0, "SYMMETRIC": 1, "EDGE": 2}[mode])
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape
+    assert _maxdiff(got.cpu().numpy(), ref) <= _tol(ref, STAGE_TOL)
+
+
+@pytest.mark.parametrize("rows,channels,up", [(7, 1, 100), (5, 640, 10), (1, 3, 10)])
+def test_lin_interp(torch, rows, channels, up):
+    eng = get_engine("small", *SMALL)[0]
+    rng = np.random.default_rng(rows)
+    x = rng.normal(size=(2, rows, channels)).astype(np.float32)
+    ref = orc.lin_interp(x.astype(np.float64), up)
+    got = eng.lin_interp(dev(torch, x), up).cpu().numpy()
+    assert _maxdiff(got, ref) <= 1e-6
+
+
+@pytest.mark.parametrize("n", [100, 1000, 2300, 12345])
+def test_wavetable_phase_bit_exact(torch, n):
+    eng, om = get_engine("small", *SMALL)[:2]
+    rng = np.random.default_rng(n)
+    # slowly varying contour inside and outside the table grid
+    f0 = (30 + 650 * np.abs(np.sin(np.cumsum(rng.normal(0, 0.002, size=(3, n)), axis=1)))).astype(np.float32)
+    pulse, phase = eng.wavetable(dev(torch, f0))
+    torch.cuda.synchronize()
+    ref_phase = om.phase_from_f0(f0)
+    assert np.array_equal(phase.cpu().numpy(), ref_phase), "phase accumulator must be bit exact"
+    ref_pulse = om.wavetable(f0)
+    assert _maxdiff(pulse.cpu().numpy(), ref_pulse) <= 2e-6
+
+
+@pytest.mark.parametrize("steps", [1, 9, 64, 65, 333])
+def test_pqmf_synthesis(torch, steps):
+    eng, om = get_engine("small", *SMALL)[:2]
+    rng = np.random.default_rng(steps)
+    x = rng.normal(size=(2, steps, 15)).astype(np.float32)
+    ref = om.pqmf_synthesis(x.astype(np.float64))
+    got = eng.pqmf_synthesis(dev(torch, x)).cpu().numpy()
+    assert _maxdiff(got, ref) <= _tol(ref, STAGE_TOL)
+
+
+def test_pqmf_impulse_response_is_filter_bank(torch):
+    """An impulse in band k at step m reproduces 15*g_k shifted to sample 15*m (edge case: known answer)."""
+    eng, om = get_engine("small", *SMALL)[:2]
+    x = np.zeros((1, 40, 15), dtype=np.float32)
+    x[0, 20, 3] = 1.0
+    got = eng.pqmf_synthesis(dev(torch, x)).cpu().numpy()[0]
+    g = om.pqmf_syn[3]
+    expect = np.zeros(600)
+    # y[n] = 15 * g[j], j = 15*20 + 60 - n
+    for n in range(600):
+        j = 300 + 60 - n
+        if 0 <= j <= 120:
+            expect[n] = 15 * g[j]
+    assert _maxdiff(got, expect) <= 1e-6
+
+
+@pytest.mark.parametrize("frames", [1, 2, 3, 4, 11])
+def test_stft_filter(torch, frames):
+    eng, om = get_engine("small", *SMALL)[:2]
+    rng = np.random.default_rng(frames)
+    B = 2
+    exc = rng.normal(size=(B, frames * 300)).astype(np.float32)
+    ceps = (0.05 * rng.normal(size=(B, frames, 240))).astype(np.float32)
+    idx = rng.integers(0, 30, size=(B, frames)).astype(np.int32)
+    x = ceps.astype(np.float64) * om.ceps_windows[idx]
+    full = np.zeros((B, frames, om.fft_size))
+    full[:, :, 1:240] = x[:, :, 1:]
+    spec = np.fft.rfft(full, axis=-1)
+    env = np.exp(om.max_log_range * np.tanh(spec.real) + 1j * spec.imag)
+    ref = om.istft(om.stft(exc.astype(np.float64), frames) * env, frames * 300)
+    got = eng.stft_filter(dev(torch, exc), dev(torch, ceps), dev(torch, idx, torch.int32)).cpu().numpy()
+    assert got.shape == ref.shape
+    assert _maxdiff(got, ref) <= _tol(ref, STAGE_TOL)
+
+
+def test_stft_identity_envelope_reproduces_head_tail_taper(torch):
+    """Zero cepstrum => H == 1: output = input x overlap-normalisation; the reference keeps frames 0..T-1
+    only, so the first hop and the last two hops are attenuated (3/4, 3/4, 2/4 of the overlaps)."""
+    eng, om = get_engine("small", *SMALL)[:2]
+    T = 8
+    exc = np.ones((1, T * 300), dtype=np.float32)
+    ceps = np.zeros((1, T, 240), dtype=np.float32)
+    idx = np.zeros((1, T), dtype=np.int32)
+    got = eng.stft_filter(dev(torch, exc), dev(torch, ceps), dev(torch, idx, torch.int32)).cpu().numpy()[0]
+    ref = om.istft(om.stft(exc.astype(np.float64), T), T * 300)[0]
+    assert _maxdiff(got, ref) <= 1e-5
+    assert np.all(np.abs(got[300:T * 300 - 600] - 1.0) < 1e-5)
+    assert got[T * 300 - 1] < 0.6 and got[0] < 1.0
+
+
+# ------------------------------------------------------------------------------------------------
+# end to end
+# ------------------------------------------------------------------------------------------------
+def _forward_both(torch, key, spec, batch, frames, seed=42):
+    eng, om = get_engine(key, *spec)[:2]
+    mel, noise = synthetic_inputs(seed, batch, frames)
+    audio = eng.forward(dev(torch, mel), noise=dev(torch, noise))
+    torch.cuda.synchronize()
+    ref, stages = om.forward(mel, noise, return_stages=True)
+    return eng, om, mel, noise, audio.cpu().numpy(), ref, stages
+
+
+@pytest.mark.parametrize("key,spec,batch,frames", [
+    ("small", SMALL, 2, 23), ("small", SMALL, 1, 1), ("small", SMALL, 3, 2),
+    ("canon", CANON, 1, 12), ("canon", CANON, 2, 40), ("voice", VOICE, 1, 17),
+])
+def test_forward_matches_oracle(torch, key, spec, batch, frames):
+    eng, om, mel, noise, got, ref, stages = _forward_both(torch, key, spec, batch, frames)
+    assert got.shape == (batch, frames * 300)
+    assert np.all(np.isfinite(got))
+    f0 = eng.stage("f0").cpu().numpy()
+    assert _maxdiff(f0, stages["f0"]) <= 1e-3            # Hz, float32 sub-net on values up to 600
+    exc = eng.stage("excitation").cpu().numpy()
+    assert _maxdiff(exc, stages["excitation"]) <= _tol(stages["excitation"], E2E_TOL)
+    assert _maxdiff(got, ref) <= _tol(ref, E2E_TOL)
+
+
+@pytest.mark.parametrize("case", sorted(GOLDEN_CASES))
+def test_forward_matches_reference_goldens(torch, golden_dir, case):
+    """HIP path vs the output of the reference's own model code (float32 emulation run)."""
+    gold = np.load(os.path.join(golden_dir, "reference_forward_f32.npz"))
+    voice, overrides, batch, frames = GOLDEN_CASES[case]
+    eng = get_engine("gold_" + case, voice, overrides)[0]
+    mel, noise = gold[f"{case}/mell"], gold[f"{case}/noise"]
+    got = eng.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
+    ref = gold[f"{case}/audio"]
+    assert _maxdiff(got, ref) <= _tol(ref, E2E_TOL)
+    assert _maxdiff(eng.stage("excitation").cpu().numpy(), gold[f"{case}/excitation"]) <= _tol(gold[f"{case}/excitation"], E2E_TOL)
+    assert _maxdiff(eng.stage("pulse").cpu().numpy(), gold[f"{case}/pulse"]) <= 5e-4     # F0 rounding moves the phase
+    cond = eng.stage("cond").cpu().numpy().reshape(batch, -1)
+    # the engine keeps the conditioning at the sub-pixel rate (2T, 2C) and interpolates on the fly
+    pulse_from_ref_f0, phase = eng.wavetable(dev(torch, gold[f"{case}/f0"]))
+    assert np.array_equal(phase.cpu().numpy(), gold[f"{case}/phase"])
+    assert _maxdiff(pulse_from_ref_f0.cpu().numpy(), gold[f"{case}/pulse"]) <= 2e-6
+    assert cond.shape[1] == frames * 2 * 2 * eng.dims.wn_channels
+
+
+def test_padded_batch_equals_one_at_a_time(torch):
+    """Every boundary op honours the item's own length: a ragged batch gives the per-utterance results
+    (the reference processes one utterance at a time, bin/resynth_mel.py:74)."""
+    eng = get_engine("small", *SMALL)[0]
+    lengths = [23, 7, 1, 16]
+    T = max(lengths)
+    mel, noise = synthetic_inputs(7, len(lengths), T)
+    nf = torch.as_tensor(lengths, dtype=torch.int32).cuda()
+    batch_out = eng.forward(dev(torch, mel), n_frames=nf, noise=dev(torch, noise)).cpu().numpy()
+    for ii, ll in enumerate(lengths):
+        single = eng.forward(dev(torch, mel[ii:ii + 1, :ll]), noise=dev(torch, noise[ii:ii + 1, :ll * 20])).cpu().numpy()
+        assert np.array_equal(batch_out[ii, :ll * 300], single[0]), f"item {ii} differs from its single run"
+        assert np.all(batch_out[ii, ll * 300:] == 0.0)
+
+
+def test_deterministic(torch):
+    eng = get_engine("canon", *CANON)[0]
+    mel, noise = synthetic_inputs(3, 2, 30)
+    a = eng.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
+    b = eng.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
+    assert np.array_equal(a, b)
+
+
+def test_full_size_prefix_property(torch):
+    """BASELINE config 2 size (10 s, T=800): size-independent property instead of a full oracle run --
+    the graph has a finite receptive field and a causal phase accumulator, so the first part of the
+    audio of a long utterance equals the audio of its prefix (away from the cut)."""
+    eng = get_engine("canon", *CANON)[0]
+    mel, noise = synthetic_inputs(11, 1, 800)
+    full = eng.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()[0]
+    assert full.shape == (240000,) and np.all(np.isfinite(full))
+    cut = 200
+    part = eng.forward(dev(torch, mel[:, :cut]), noise=dev(torch, noise[:, :cut * 20])).cpu().numpy()[0]
+    margin = 12 * 300       # WaveNet RF (31 steps) + PQMF + 2 STFT hops + sub-net kernels + F0 smoother (3 frames)
+    keep = cut * 300 - margin
+    assert _maxdiff(full[:keep], part[:keep]) <= 1e-5 * max(1.0, np.abs(full).max())
+    # and the oracle agrees on the prefix
+    om = get_engine("canon", *CANON)[1]
+    ref = om.forward(mel[:, :40], noise[:, :800])[0]
+    assert _maxdiff(full[:40 * 300 - margin], ref[:40 * 300 - margin]) <= _tol(ref, E2E_TOL)
+
+
+def test_error_paths(torch):
+    eng = get_engine("small", *SMALL)[0]
+    mel, noise = synthetic_inputs(1, 1, 4)
+    with pytest.raises(ValueError):
+        eng.forward(dev(torch, mel))                                   # noise missing
+    with pytest.raises(ValueError):
+        eng.forward(dev(torch, mel[:, :, :40]), noise=dev(torch, noise))  # wrong channel count
+    out = eng.forward(dev(torch, mel[:0]), noise=dev(torch, noise[:0]))
+    assert out.shape == (0, 1200)
