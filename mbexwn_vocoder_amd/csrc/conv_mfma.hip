@@ -22,6 +22,8 @@
 //   Bs[k][col]
 // The A slice is the dilated receptive-field window: rows t + j*d - pad_l of the activation, fetched with
 // the padding rule of the layer and the item's own length (padded batches equal one-at-a-time runs).
+#include <cstdlib>
+
 #include "mbx_kernels.h"
 
 namespace mbx {
@@ -30,17 +32,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 16;
 
+// source row of the padded input: -1 = zero sample.  Branch free (selects only) so that the K loop stays one
+// scheduling region.  mode: 0 zero, 1 symmetric (edge sample repeated), 2 edge.
 __device__ __forceinline__ int map_row(int s, int n, int mode) {
-    if (s >= 0 && s < n) return s;
-    if (mode == 0) return -1;               // zero padding
-    if (mode == 2) return s < 0 ? 0 : n - 1;  // edge
-    s = s < 0 ? -s - 1 : 2 * n - s - 1;     // symmetric (edge sample repeated)
-    return min(max(s, 0), n - 1);
+    const bool inside = (s >= 0) & (s < n);
+    const int refl = min(max(s < 0 ? -s - 1 : 2 * n - s - 1, 0), n - 1);
+    const int edge = min(max(s, 0), n - 1);
+    const int outside = mode == 0 ? -1 : (mode == 1 ? refl : edge);
+    return inside ? s : outside;
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <int WM, int WN, int TM, int TN, int EPI>
+// VEC: every row/column group of 4 floats is 16-byte aligned and all-or-nothing valid (cin, cout, C, ldx and
+// the batch strides are multiples of 4): the slice loads are then unconditional float4 loads from a clamped
+// address, zeroed by a select -- no branch in the K loop, so the prefetch of slice k+1 really overlaps the
+// MFMAs of slice k.  The scalar path only serves the tiny odd-sized convolutions (cin = 6, 30, cout = 1, 15).
+template <int WM, int WN, int TM, int TN, int EPI, bool VEC>
 __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs p) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -72,12 +80,11 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs p) {
     const int wr = wave / WN, wc = wave % WN;
 
     const float *xb = p.x + (long long)b * p.x_bstride;
-    const bool vec_a = ((p.cin & 3) == 0) && ((p.ldx & 3) == 0) && ((p.x_bstride & 3) == 0);
-    const bool vec_b = ((p.cout & 3) == 0) && (EPI != EPI_GATE || (C & 3) == 0);
     const int nkc = (p.cin + BK - 1) / BK;   // K slices per tap
     const int nk = p.ks * nkc;
 
     float4 ra[A_F4], rb[B_F4];
+    unsigned okmask = 0;   // bit i: A float4 i valid, bit 16+i: B float4 i valid (masking is deferred to the LDS store)
 
     auto load_slice = [&](int kt) {
         const int tap = kt / nkc;
@@ -85,26 +92,29 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs p) {
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int q = tid + i * 256;
+            if (A_TOT % 256 != 0 && q >= A_TOT) break;
             const int row = q >> 2, kq = q & 3;
             const int src = map_row(m0 + row - p.pad_l + tap * p.dil, rows, p.pad_mode);
             const int ci = ci0 + kq * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (src >= 0 && q < A_TOT) {
+            if (VEC) {
+                const bool ok = (src >= 0) & (ci < p.cin);
+                const float *px = xb + (long long)max(src, 0) * p.ldx + min(ci, p.cin - 4);
+                v = *reinterpret_cast<const float4 *>(px);
+                okmask = ok ? (okmask | (1u << i)) : (okmask & ~(1u << i));
+            } else if (src >= 0) {
                 const float *px = xb + (long long)src * p.ldx + ci;
-                if (vec_a) {
-                    if (ci < p.cin) v = *reinterpret_cast<const float4 *>(px);
-                } else {
-                    if (ci + 0 < p.cin) v.x = px[0];
-                    if (ci + 1 < p.cin) v.y = px[1];
-                    if (ci + 2 < p.cin) v.z = px[2];
-                    if (ci + 3 < p.cin) v.w = px[3];
-                }
+                if (ci + 0 < p.cin) v.x = px[0];
+                if (ci + 1 < p.cin) v.y = px[1];
+                if (ci + 2 < p.cin) v.z = px[2];
+                if (ci + 3 < p.cin) v.w = px[3];
             }
             ra[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
             const int q = tid + i * 256;
+            if (B_TOT % 256 != 0 && q >= B_TOT) break;
             const int k = q / (BN / 4), c = (q % (BN / 4)) * 4;
             int n, lim;
             if (EPI == EPI_GATE) {
@@ -118,16 +128,17 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs p) {
             }
             const int ci = ci0 + k;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ci < p.cin && q < B_TOT) {
+            if (VEC) {
+                const bool ok = (ci < p.cin) & (n < lim);
+                const float *pw = p.w + (long long)(tap * p.cin + min(ci, p.cin - 1)) * p.cout + min(n, p.cout - 4);
+                v = *reinterpret_cast<const float4 *>(pw);
+                okmask = ok ? (okmask | (1u << (16 + i))) : (okmask & ~(1u << (16 + i)));
+            } else if (ci < p.cin) {
                 const float *pw = p.w + (long long)(tap * p.cin + ci) * p.cout + n;
-                if (vec_b) {
-                    if (n < lim) v = *reinterpret_cast<const float4 *>(pw);
-                } else {
-                    if (n + 0 < lim) v.x = pw[0];
-                    if (n + 1 < lim) v.y = pw[1];
-                    if (n + 2 < lim) v.z = pw[2];
-                    if (n + 3 < lim) v.w = pw[3];
-                }
+                if (n + 0 < lim) v.x = pw[0];
+                if (n + 1 < lim) v.y = pw[1];
+                if (n + 2 < lim) v.z = pw[2];
+                if (n + 3 < lim) v.w = pw[3];
             }
             rb[i] = v;
         }
@@ -140,18 +151,25 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs p) {
         for (int i = 0; i < A_F4; ++i) {
             const int q = tid + i * 256;
             const int row = q >> 2, kq = q & 3;
-            if (q >= A_TOT) continue;
-            a[(kq * 4 + 0) * LDA + row] = ra[i].x;
-            a[(kq * 4 + 1) * LDA + row] = ra[i].y;
-            a[(kq * 4 + 2) * LDA + row] = ra[i].z;
-            a[(kq * 4 + 3) * LDA + row] = ra[i].w;
+            if (A_TOT % 256 != 0 && q >= A_TOT) break;
+            const bool ok = !VEC || ((okmask >> i) & 1u);
+            a[(kq * 4 + 0) * LDA + row] = ok ? ra[i].x : 0.f;
+            a[(kq * 4 + 1) * LDA + row] = ok ? ra[i].y : 0.f;
+            a[(kq * 4 + 2) * LDA + row] = ok ? ra[i].z : 0.f;
+            a[(kq * 4 + 3) * LDA + row] = ok ? ra[i].w : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
             const int q = tid + i * 256;
             const int k = q / (BN / 4), c = (q % (BN / 4)) * 4;
-            if (q >= B_TOT) continue;
-            *reinterpret_cast<float4 *>(bs + k * LDB + c) = rb[i];
+            if (B_TOT % 256 != 0 && q >= B_TOT) break;
+            const bool ok = !VEC || ((okmask >> (16 + i)) & 1u);
+            float4 v = rb[i];
+            v.x = ok ? v.x : 0.f;
+            v.y = ok ? v.y : 0.f;
+            v.z = ok ? v.z : 0.f;
+            v.w = ok ? v.w : 0.f;
+            *reinterpret_cast<float4 *>(bs + k * LDB + c) = v;
         }
     };
 
@@ -176,18 +194,22 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs p) {
         if (kt + 1 < nk) load_slice(kt + 1);
         const float *a = As + buf * BK * LDA + lk * LDA + wr * TM * 32 + lrow;
         const float *bs = Bs + buf * BK * LDB + lk * LDB + lrow;
+        // all operands of the slice are requested first (counted lgkmcnt waits then release the MFMAs in order)
+        float av[BK / 2][TM], bv[BK / 2][TN];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float av[TM], bv[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = a[kk * LDA + i * 32];
+            for (int i = 0; i < TM; ++i) av[kk / 2][i] = a[kk * LDA + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = bs[kk * LDB + col_base(j)];
+            for (int j = 0; j < TN; ++j) bv[kk / 2][j] = bs[kk * LDB + col_base(j)];
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk / 2][i], bv[kk / 2][j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) store_slice(buf ^ 1);
         __syncthreads();
@@ -266,21 +288,39 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs p) {
     }
 }
 
+static int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 template <int WM, int WN, int TM, int TN, int EPI>
-static void launch_cfg(const ConvArgs &a, hipStream_t stream) {
+static void launch_cfg(const ConvArgs &a, hipStream_t stream, int extra_lds = 0) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const int ncols = (EPI == EPI_GATE) ? a.channels : a.cout;
     const int bn_eff = (EPI == EPI_GATE) ? BN / 2 : BN;
     dim3 grid((a.max_rows + BM - 1) / BM, (ncols + bn_eff - 1) / bn_eff, a.batch);
-    hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, TM, TN, EPI>), grid, dim3(256), 0, stream, a);
+    const bool vec = (a.cin % 4 == 0) && (a.ldx % 4 == 0) && (a.x_bstride % 4 == 0) && (a.cout % 4 == 0) &&
+                     (EPI != EPI_GATE || a.channels % 4 == 0) && ((uintptr_t)a.x % 16 == 0) &&
+                     ((uintptr_t)a.w % 16 == 0);
+    if (vec)
+        hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, TM, TN, EPI, true>), grid, dim3(256), extra_lds, stream, a);
+    else
+        hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, TM, TN, EPI, false>), grid, dim3(256), extra_lds, stream, a);
 }
 
 void launch_conv1d(const ConvArgs &a, int epilogue, hipStream_t stream) {
     if (a.max_rows <= 0 || a.batch <= 0) return;
+    // tuning knobs (experiments only): tile shape of the two WaveNet GEMMs and extra dynamic LDS to cap blocks/CU
+    static const int gate_cfg = env_int("MBX_GATE_CFG", 0);
+    static const int extra_lds = env_int("MBX_EXTRA_LDS", 0);
     if (epilogue == EPI_GATE) {
-        launch_cfg<2, 2, 2, 2, EPI_GATE>(a, stream);          // 128 rows x 64 gate channels
+        if (gate_cfg == 1) launch_cfg<2, 2, 1, 2, EPI_GATE>(a, stream, extra_lds);       // 64 rows x 64 gate channels
+        else if (gate_cfg == 2) launch_cfg<4, 1, 1, 2, EPI_GATE>(a, stream, extra_lds);  // 128 rows x 32 gate channels
+        else launch_cfg<2, 2, 2, 2, EPI_GATE>(a, stream, extra_lds);                     // 128 rows x 64 gate channels
     } else if (epilogue == EPI_RESSKIP) {
-        launch_cfg<2, 2, 2, 2, EPI_RESSKIP>(a, stream);       // 128 x 128
+        if (gate_cfg == 1) launch_cfg<2, 2, 1, 2, EPI_RESSKIP>(a, stream, extra_lds);    // 64 x 128
+        else if (gate_cfg == 2) launch_cfg<4, 1, 1, 2, EPI_RESSKIP>(a, stream, extra_lds);  // 128 x 64
+        else launch_cfg<2, 2, 2, 2, EPI_RESSKIP>(a, stream, extra_lds);                  // 128 x 128
     } else if (a.cout <= 32) {
         launch_cfg<4, 1, 1, 1, EPI_LINEAR>(a, stream);        // 128 x 32 (F0 head, post-net, end)
     } else if ((long long)a.max_rows * a.batch >= 4096 && a.cout >= 128) {

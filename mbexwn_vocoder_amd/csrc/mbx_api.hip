@@ -336,6 +336,7 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
     if (c.wn_in_channels != c.pulse_channels + (c.noise_sigma != 0.f ? 1 : 0))
         return fail(MBX_ERR_INVALID_ARGUMENT, "wn_in_channels must be pulse_channels (+1 with noise)");
     if (c.pqmf_taps % 2) return fail(MBX_ERR_INVALID_ARGUMENT, "PQMF taps must be even");
+    if (c.phase_chunk < 1 || c.phase_chunk > 1024) return fail(MBX_ERR_INVALID_ARGUMENT, "phase_chunk must be in [1, 1024]");
 
     mbx_handle *hd = new mbx_handle();
     hd->cfg = c;

@@ -6,9 +6,8 @@
 //
 // The phase is a float32 running sum; a parallel scan would round differently and the error is
 // amplified by the table slope, so the reference's order of additions is kept bit for bit:
-//   (1) inside each chunk of 1000 samples a sequential float32 running sum (one thread per chunk --
-//       chunks are independent, so a 10 s utterance still exposes 80 x batch threads; the whole stage
-//       is < 0.1 % of the forward pass),
+//   (1) inside each chunk of 1000 samples a sequential float32 running sum (one lane per chunk does the
+//       adds out of LDS -- chunks are independent, so a 10 s utterance still exposes 80 x batch chains),
 //   (2) chunk offsets = running sum over chunks of (last value of the previous chunk mod 1), then mod 1,
 //   (3) phase = (chunk sum + offset) mod 1, table lookup and grid mix: one thread per sample, coalesced.
 #include "mbx_kernels.h"
@@ -17,26 +16,44 @@ namespace mbx {
 
 __device__ __forceinline__ float mod1(float x) { return x - floorf(x); }   // x >= 0: identical to fmod(x, 1)
 
-// (1) one thread per (item, chunk)
-__global__ void phase_chunk_kernel(const float *f0, long long bstride, const int *n_frames, int samples_per_frame,
-                                   int n_max, int chunk, float pulse_rate, float *cum, float *chunk_last,
-                                   int chunks_max) {
+// (1) one wavefront per (item, chunk): the 64 lanes load the chunk coalesced and convert to phase velocity,
+// lane 0 then runs the sequential float32 sum out of LDS (4 values per ds_read_b128), and the lanes write
+// the running sums back coalesced.  The chain of 1000 dependent adds (~4 us) is the floor of this stage.
+constexpr int PHASE_MAX_CHUNK = 1024;
+
+__global__ __launch_bounds__(64) void phase_chunk_kernel(const float *__restrict__ f0, long long bstride,
+                                                          const int *__restrict__ n_frames, int samples_per_frame,
+                                                          int n_max, int chunk, float pulse_rate,
+                                                          float *__restrict__ cum, float *__restrict__ chunk_last,
+                                                          int chunks_max) {
+    __shared__ __attribute__((aligned(16))) float v[PHASE_MAX_CHUNK];
     const int b = blockIdx.y;
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x;
     const int n = n_frames ? n_frames[b] * samples_per_frame : n_max;
     const int n_chunks = (n + chunk - 1) / chunk;
     if (c >= n_chunks) return;
     const float *fb = f0 + (long long)b * bstride;
     float *cb = cum + (long long)b * bstride;
     const int begin = c * chunk;
-    const int end = min(begin + chunk, n);
-    float acc = 0.f;
-    for (int i = begin; i < end; ++i) {
-        acc = acc + fb[i] / pulse_rate;       // phase velocity = frequency / sample_rate (tf_wavetable.py:516)
-        cb[i] = acc;
+    const int len = min(chunk, n - begin);
+    const int padded = (len + 3) & ~3;
+    // phase velocity = frequency / sample_rate (tf_wavetable.py:516); the reference zero-pads the last chunk
+    for (int i = threadIdx.x; i < padded; i += 64) v[i] = i < len ? fb[begin + i] / pulse_rate : 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float acc = 0.f;
+        for (int i = 0; i < padded; i += 4) {
+            float4 q = *reinterpret_cast<float4 *>(&v[i]);
+            acc = acc + q.x; q.x = acc;
+            acc = acc + q.y; q.y = acc;
+            acc = acc + q.z; q.z = acc;
+            acc = acc + q.w; q.w = acc;
+            *reinterpret_cast<float4 *>(&v[i]) = q;
+        }
+        chunk_last[(long long)b * chunks_max + c] = acc;   // adding the padding zeros leaves the sum unchanged
     }
-    // the reference zero-pads the last chunk: adding zeros leaves the running sum unchanged
-    chunk_last[(long long)b * chunks_max + c] = acc;
+    __syncthreads();
+    for (int i = threadIdx.x; i < len; i += 64) cb[begin + i] = v[i];
 }
 
 // (2)+(3) one thread per sample
@@ -89,7 +106,7 @@ void launch_wavetable(const WaveTableConsts &c, const float *f0, long long bstri
                       float *chunk_last, hipStream_t stream) {
     if (n_max <= 0 || batch <= 0) return;
     const int chunks_max = (n_max + c.chunk - 1) / c.chunk;
-    hipLaunchKernelGGL(phase_chunk_kernel, dim3((chunks_max + 63) / 64, batch), dim3(64), 0, stream, f0, bstride,
+    hipLaunchKernelGGL(phase_chunk_kernel, dim3(chunks_max, batch), dim3(64), 0, stream, f0, bstride,
                        n_frames, samples_per_frame, n_max, c.chunk, c.pulse_rate, cum, chunk_last, chunks_max);
     const int blocks = min((n_max + 255) / 256, 1024);
     hipLaunchKernelGGL(wavetable_kernel, dim3(blocks, batch), dim3(256), 0, stream, c, f0, bstride, n_frames,

@@ -73,6 +73,10 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch must be loaded first: the engine works on torch's device pointers and streams, so both have to
+    # live in ONE HIP runtime instance (torch bundles libamdhip64.so.7; loading ours first would give the
+    # process a second, separate runtime).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"HIP extension {LIB_PATH} is missing: run `python -m mbexwn_vocoder_amd.build` "
                            "(there is no CPU fallback for the mel-inversion path)")

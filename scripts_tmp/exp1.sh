@@ -1,0 +1,10 @@
+cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_gpu_parity.py -q -x -k "wavetable or forward_matches_oracle" 2>&1 | tail -3
+for cfg in 0 1 2; do for lds in 0 50000 90000; do
+echo "== MBX_GATE_CFG=$cfg MBX_EXTRA_LDS=$lds"
+MBX_GATE_CFG=$cfg MBX_EXTRA_LDS=$lds python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['x_realtime'], d['roofline']['avg_launch_ms'], d['roofline']['res_skip_avg_launch_ms'], d['roofline']['frac'])"
+done; done
+echo "== batch16"
+for cfg in 0 1 2; do
+MBX_GATE_CFG=$cfg python bench.py --workload config3_si_b16_10s --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['x_realtime'], d['roofline']['avg_launch_ms'], d['roofline']['res_skip_avg_launch_ms'], d['roofline']['frac'])"
+done
