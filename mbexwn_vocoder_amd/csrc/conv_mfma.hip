@@ -42,7 +42,16 @@ __device__ __forceinline__ int map_row(int s, int n, int mode) {
     return inside ? s : outside;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// tanh(zt) * sigmoid(zs) with two hardware exponentials and two reciprocals:
+//   tanh(x) = 1 - 2 / (1 + e^{2x}),  sigmoid(x) = 1 / (1 + e^{-x})
+// absolute error of the product <= ~3e-7 (v_exp_f32 / v_rcp_f32 are 1 ulp), well inside the stage budget of
+// 2e-5; saturates correctly (e^{2x} = inf -> 1, 0 -> -1).
+__device__ __forceinline__ float gate_act(float zt, float zs) {
+    const float e2 = __expf(2.0f * zt);
+    const float e1 = __expf(-zs);
+    const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e2);
+    return th * __builtin_amdgcn_rcpf(1.0f + e1);
+}
 
 // VEC: every row/column group of 4 floats is 16-byte aligned and all-or-nothing valid (cin, cout, C, ldx and
 // the batch strides are multiples of 4): the slice loads are then unconditional float4 loads from a clamped
@@ -86,24 +95,55 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs p) {
     float4 ra[A_F4], rb[B_F4];
     unsigned okmask = 0;   // bit i: A float4 i valid, bit 16+i: B float4 i valid (masking is deferred to the LDS store)
 
+    // per-thread addressing that does not change inside a tap / inside the kernel
+    int a_off[A_F4];       // element offset of the source row of A float4 i for the current tap (clamped)
+    unsigned a_rowok = 0;  // bit i: that source row is a real sample (not zero padding)
+    int b_col[B_F4];       // clamped weight column of B float4 i
+    unsigned b_colok = 0;
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+        const int q = tid + i * 256;
+        const int c = (q % (BN / 4)) * 4;
+        int n, lim;
+        if (EPI == EPI_GATE) {
+            const bool second = c >= BN / 2;
+            n = n0 + (second ? c - BN / 2 + C : c);
+            lim = n_lim + (second ? C : 0);
+        } else {
+            n = n0 + c;
+            lim = n_lim;
+        }
+        b_col[i] = VEC ? min(n, p.cout - 4) : n;
+        if (n < lim) b_colok |= 1u << i;
+    }
+    auto set_tap = [&](int tap) {
+        a_rowok = 0;
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int row = (tid + i * 256) >> 2;
+            const int src = map_row(m0 + row - p.pad_l + tap * p.dil, rows, p.pad_mode);
+            a_off[i] = max(src, 0) * p.ldx;
+            if (src >= 0) a_rowok |= 1u << i;
+        }
+    };
+
     auto load_slice = [&](int kt) {
         const int tap = kt / nkc;
         const int ci0 = (kt - tap * nkc) * BK;
+        if (ci0 == 0) set_tap(tap);
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int q = tid + i * 256;
             if (A_TOT % 256 != 0 && q >= A_TOT) break;
-            const int row = q >> 2, kq = q & 3;
-            const int src = map_row(m0 + row - p.pad_l + tap * p.dil, rows, p.pad_mode);
-            const int ci = ci0 + kq * 4;
+            const int ci = ci0 + (q & 3) * 4;
+            const bool rowok = (a_rowok >> i) & 1u;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (VEC) {
-                const bool ok = (src >= 0) & (ci < p.cin);
-                const float *px = xb + (long long)max(src, 0) * p.ldx + min(ci, p.cin - 4);
-                v = *reinterpret_cast<const float4 *>(px);
+                v = *reinterpret_cast<const float4 *>(xb + a_off[i] + min(ci, p.cin - 4));
+                const bool ok = rowok & (ci < p.cin);
                 okmask = ok ? (okmask | (1u << i)) : (okmask & ~(1u << i));
-            } else if (src >= 0) {
-                const float *px = xb + (long long)src * p.ldx + ci;
+            } else if (rowok) {
+                const float *px = xb + a_off[i] + ci;
                 if (ci + 0 < p.cin) v.x = px[0];
                 if (ci + 1 < p.cin) v.y = px[1];
                 if (ci + 2 < p.cin) v.z = px[2];
@@ -115,25 +155,18 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs p) {
         for (int i = 0; i < B_F4; ++i) {
             const int q = tid + i * 256;
             if (B_TOT % 256 != 0 && q >= B_TOT) break;
-            const int k = q / (BN / 4), c = (q % (BN / 4)) * 4;
-            int n, lim;
-            if (EPI == EPI_GATE) {
-                const bool second = c >= BN / 2;
-                const int cc = second ? c - BN / 2 : c;
-                n = n0 + cc + (second ? C : 0);
-                lim = n_lim + (second ? C : 0);
-            } else {
-                n = n0 + c;
-                lim = n_lim;
-            }
-            const int ci = ci0 + k;
+            const int ci = ci0 + q / (BN / 4);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (VEC) {
-                const bool ok = (ci < p.cin) & (n < lim);
-                const float *pw = p.w + (long long)(tap * p.cin + min(ci, p.cin - 1)) * p.cout + min(n, p.cout - 4);
-                v = *reinterpret_cast<const float4 *>(pw);
+                v = *reinterpret_cast<const float4 *>(p.w + (long long)(tap * p.cin + min(ci, p.cin - 1)) * p.cout + b_col[i]);
+                const bool ok = ((b_colok >> i) & 1u) & (ci < p.cin);
                 okmask = ok ? (okmask | (1u << (16 + i))) : (okmask & ~(1u << (16 + i)));
             } else if (ci < p.cin) {
+                const int c = (q % (BN / 4)) * 4;
+                int lim;
+                if (EPI == EPI_GATE) lim = n_lim + (c >= BN / 2 ? C : 0);
+                else lim = n_lim;
+                const int n = b_col[i];
                 const float *pw = p.w + (long long)(tap * p.cin + ci) * p.cout + n;
                 if (n + 0 < lim) v.x = pw[0];
                 if (n + 1 < lim) v.y = pw[1];
@@ -173,6 +206,11 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs p) {
         }
     };
 
+    // column of the wave's tile tn inside the block tile
+    auto col_base = [&](int tn) { return (EPI == EPI_GATE) ? tn * (BN / 2) + wc * 32 : (wc * TN + tn) * 32; };
+
+    // C/D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int ecol = lane & 31;
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -180,10 +218,6 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // column of the wave's tile tn inside the block tile
-    auto col_base = [&](int tn) { return (EPI == EPI_GATE) ? tn * (BN / 2) + wc * 32 : (wc * TN + tn) * 32; };
-
     load_slice(0);
     store_slice(0);
     __syncthreads();
@@ -216,32 +250,29 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs p) {
     }
 
     // ------------------------------------------------------------------ epilogue
-    // C/D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const int ecol = lane & 31;
     if (EPI == EPI_GATE) {
         const int ch = n0 + wc * 32 + ecol;   // gate channel of this lane
         if (ch < C) {
             const float bt = p.bias ? p.bias[ch] : 0.f;
             const float bsg = p.bias ? p.bias[C + ch] : 0.f;
-            const float *cb = p.cond + (long long)b * p.cond_bstride;
+            const float *cb = p.cond + (long long)b * p.cond_bstride + ch;
             const int n2 = rows / p.cond_up;
-            float *ob = p.out + (long long)b * p.out_bstride;
+            float *ob = p.out + (long long)b * p.out_bstride + ch;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     if (row < rows) {
+                        // conditioning interpolated on the fly from the (rows/U, 2C) tensor
                         const int t2 = row / p.cond_up, u = row - t2 * p.cond_up;
                         const int t3 = min(t2 + 1, n2 - 1);
                         const float w0 = p.lerp_w0[u], w1 = p.lerp_w1[u];
-                        const float *c0 = cb + (long long)t2 * (2 * C);
-                        const float *c1 = cb + (long long)t3 * (2 * C);
-                        const float ct = c0[ch] * w0 + c1[ch] * w1;
-                        const float cs = c0[C + ch] * w0 + c1[C + ch] * w1;
-                        const float zt = (acc[i][0][r] + bt) + ct;
-                        const float zs = (acc[i][1][r] + bsg) + cs;
-                        ob[(long long)row * p.ldo + ch] = tanhf(zt) * sigmoidf_(zs);
+                        const float *c0 = cb + t2 * (2 * C);
+                        const float *c1 = cb + t3 * (2 * C);
+                        const float zt = (acc[i][0][r] + bt) + (c0[0] * w0 + c1[0] * w1);
+                        const float zs = (acc[i][1][r] + bsg) + (c0[C] * w0 + c1[C] * w1);
+                        ob[row * p.ldo] = gate_act(zt, zs);
                     }
                 }
             }
@@ -311,7 +342,7 @@ static void launch_cfg(const ConvArgs &a, hipStream_t stream, int extra_lds = 0)
 void launch_conv1d(const ConvArgs &a, int epilogue, hipStream_t stream) {
     if (a.max_rows <= 0 || a.batch <= 0) return;
     // tuning knobs (experiments only): tile shape of the two WaveNet GEMMs and extra dynamic LDS to cap blocks/CU
-    static const int gate_cfg = env_int("MBX_GATE_CFG", 0);
+    static const int gate_cfg = env_int("MBX_GATE_CFG", 1);
     static const int extra_lds = env_int("MBX_EXTRA_LDS", 0);
     if (epilogue == EPI_GATE) {
         if (gate_cfg == 1) launch_cfg<2, 2, 1, 2, EPI_GATE>(a, stream, extra_lds);       // 64 rows x 64 gate channels
