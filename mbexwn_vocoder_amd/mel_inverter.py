@@ -1,0 +1,196 @@
+"""``MELInverter``: the reference's inference object, backed by the MI355X HIP engine.
+
+Mirrors reference MBExWN_NVoc/mel_inverter.py:21-239 (same constructor, attributes, methods and error
+behaviour).  What differs is what ``self.model`` is: an ``MBExWNEngine`` (HIP kernels behind the C ABI of
+include/mbexwn.h) instead of a Keras model on TensorFlow.
+"""
+import os
+import sys
+from typing import Dict, Union
+
+import numpy as np
+from scipy.interpolate import interp1d
+
+log_to_db = 20 * np.log10(np.exp(1))   # reference vocoder/model/preprocess.py:78
+
+
+class MELInverter(object):
+    def __init__(self, model_id_or_path: Union[str, None] = None, verbose: bool = False):
+        self.model = None
+        self.model_id_or_path = model_id_or_path
+        self.config_file = None
+        self.preprocess_config = None
+        self.mel_channels = None
+        self.hop_size = None
+        self.fft_size = None
+        self.fmin = None
+        self.fmax = None
+        self._srate = None
+        self.win_len = None
+
+        self.lin_amp_scale = 1
+        self.lin_amp_off = 1.e-5
+        self.mel_amp_scale = 1
+        self.use_max_limit = False
+
+        if model_id_or_path:
+            self.load_model(model_id_or_path=model_id_or_path, verbose=verbose)
+
+    @property
+    def srate(self):
+        return self._srate
+
+    # ------------------------------------------------------------------------------------------
+    def scale_mel(self, mel_config: Dict, verbose=False):
+        """Convert the content of a ``.mell`` dictionary into the (1, T, mel_channels) float32 log-mel
+        conditioning of the model (reference mel_inverter.py:48-148; host side, numpy).
+
+        Arithmetic is carried out in the dtype of the stored spectrogram, in the reference's order, so the
+        result is bit-identical to the reference's (tests/golden/reference_scale_mel.npz).  Unlike the
+        reference the caller's array is not modified in place.
+        """
+        hop_ratio = (mel_config['hoplen'] / mel_config['sr']) / (self.hop_size / self.srate)
+        resample_hop = np.abs(hop_ratio - 1) > 0.001
+        if resample_hop and verbose:
+            print(f"compensate change in analysis hop size. mel analysis has {mel_config['hoplen'] / mel_config['sr']}"
+                  f" while the model expects {self.hop_size / self.srate}.", file=sys.stderr)
+        if mel_config['sr'] != self.srate and verbose:
+            print(f"    WARNING::sample rate of mel analysis is  {mel_config['sr']} model expects {self.srate}.",
+                  file=sys.stderr)
+
+        if mel_config['fmin'] != self.fmin:
+            raise RuntimeError(f"mell fmin {mel_config['fmin']} does not match model fmin {self.fmin}")
+        if ((mel_config['fmax'] is None) and self.fmax != mel_config['sr'] / 2) \
+                or ((mel_config['fmax'] is not None) and mel_config['fmax'] != self.fmax):
+            raise RuntimeError(f"mell fmax {mel_config['fmax']} does not match model fmax {self.fmax}")
+
+        if "mell" in mel_config:
+            log_mel = np.array(mel_config['mell'].T[np.newaxis])
+            if mel_config.get("log_spec_offset", 0) != 0:
+                log_mel -= mel_config["log_spec_offset"]
+            if mel_config.get("log_spec_scale", 1) != 1:
+                log_mel /= mel_config["log_spec_scale"]
+            mel = np.exp(log_mel)
+        elif "mel" in mel_config:
+            mel = np.array(mel_config['mel'].T[np.newaxis])
+        else:
+            raise RuntimeError("error::no supported mel spectrum (keys:mell or mel) in the mel dictionary")
+
+        n_fft = mel_config.get("nfft", None)
+        if n_fft is None:
+            n_fft = mel_config.get("n_fft", None)
+        if n_fft is None:
+            n_fft = mel_config.get("fft_size", None)
+        fft_scale_factor = self.fft_size // n_fft
+        if fft_scale_factor != 1:
+            mel *= fft_scale_factor
+        if mel_config.get("lin_spec_offset", None) is not None and mel_config["lin_spec_offset"] != 0:
+            mel -= mel_config["lin_spec_offset"]
+        if mel_config.get("lin_spec_scale", 1) != 1:
+            mel /= mel_config["lin_spec_scale"]
+        if self.lin_amp_scale != 1:
+            mel *= self.lin_amp_scale
+
+        if self.use_max_limit:
+            mell = np.log(np.fmax(mel, self.lin_amp_off)).astype(np.float32)
+        else:
+            mell = np.log(mel + self.lin_amp_off).astype(np.float32)
+
+        if verbose:
+            print(f"    stats conditioning mell:: mean: {log_to_db * np.mean(mell):.3f}dB, "
+                  f"median: {log_to_db * np.median(mell):.3f}dB, max: {log_to_db * np.max(mell):.3f}dB, "
+                  f"min: {log_to_db * np.min(mell):.3f}dB mell.shape {mell.shape}", file=sys.stderr)
+            print(f"    mel params:: hoplen: {mel_config['hoplen']}, winlen: {mel_config.get('winlen')}, "
+                  f"fft size: {n_fft} srate: {mel_config['sr']}", file=sys.stderr)
+
+        if resample_hop:
+            # same expression order as the reference (mel_inverter.py:133-146): the grids decide the rounding
+            mell = interp1d(np.arange(mell.shape[1]) * mel_config['hoplen'] / mel_config['sr'], mell, axis=1,
+                            bounds_error=False, fill_value="extrapolate")(
+                np.arange(0, (mell.shape[1] - 1 + 0.1) * mel_config['hoplen'] / mel_config['sr'],
+                          self.hop_size / self.srate)).astype(np.float32)
+
+        return mell * self.mel_amp_scale
+
+    # ------------------------------------------------------------------------------------------
+    def synth_from_mel(self, scaled_mell, noise=None):
+        """(1, T, mel_channels) log-mel -> float32 audio of T*hop_size samples
+        (reference mel_inverter.py:151-154; like there, a batch is flattened by ``ravel``).
+
+        ``noise`` optionally injects the N(0,1) draw of the noise channel (shape (B, T*steps_per_frame));
+        by default it is drawn on the device, as the reference draws tf.random.normal."""
+        syn_audio = self.model.infer(scaled_mell, sigma=None, synth_length=scaled_mell.shape[1] * self.hop_size,
+                                     noise=noise).numpy()
+        return syn_audio.ravel()
+
+    def generate_mel_from_snd(self, snd, srate):
+        """Audio -> ``.mell`` dictionary (reference mel_inverter.py:156-182).  The analysis side
+        (compute_mel_spectrogram_internal, librosa mel basis) is the step *before* the hot path and is not
+        part of this build yet."""
+        raise NotImplementedError("generate_mel_from_snd: the audio->mel analysis side is not part of this build "
+                                  "(SURVEY.md section 8(f), rank 2)")
+
+    # ------------------------------------------------------------------------------------------
+    def load_model(self, model_id_or_path, verbose=False):
+        """reference mel_inverter.py:184-239: resolve the model directory, read ``config.yaml``, build the
+        generator, restore the weights and copy the pre-processing parameters onto the instance."""
+        from . import get_config_file
+        from .config import read_config
+        from .engine import MBExWNEngine
+        from .weights import load_weights
+
+        config_file = get_config_file(model_id_or_path=model_id_or_path)
+        model_dir = os.path.dirname(config_file)
+        hparams = read_config(config_file=config_file)
+        if "mbexwn_config" not in hparams:
+            raise NotImplementedError(f"create_model::error::unkown config requested {list(hparams.keys())}. "
+                                      "Only mbexwn_config is currently supported.")   # reference models.py:22-31
+        self.config_file = config_file
+        self.preprocess_config = hparams["preprocess_config"]
+
+        weights_npz = os.path.join(model_dir, "weights.npz")
+        if not os.path.exists(weights_npz):
+            if os.path.exists(os.path.join(model_dir, "weights.tf.index")):
+                raise NotImplementedError(
+                    "this model directory holds a TensorFlow checkpoint (weights.tf); the TF-checkpoint reader is "
+                    "the next widening step (SURVEY.md section 8(f) rank 1). Convert the variables to weights.npz "
+                    "(names: <layer>.v/.g/.bias, <act>.alpha; see mbexwn_vocoder_amd/weights.py).")
+            raise FileNotFoundError(f"error::no weights found under {model_dir} (expected weights.npz)")
+        if verbose:
+            print(f"restore from {weights_npz}", file=sys.stderr)
+        self.model = MBExWNEngine(hparams, load_weights(weights_npz))
+
+        self.mel_channels = self.preprocess_config["mel_channels"]
+        self.hop_size = self.preprocess_config["hop_size"]
+        self.fft_size = self.preprocess_config["fft_size"]
+        self.fmin = self.preprocess_config["fmin"]
+        self.fmax = self.preprocess_config["fmax"]
+        self._srate = self.preprocess_config['sample_rate']
+        # the reference falls back to an undefined name here (mel_inverter.py:221); the fft size is what it means
+        self.win_len = self.preprocess_config.get('win_size', self.fft_size)
+
+        self.lin_amp_scale = 1
+        if self.preprocess_config.get("lin_amp_scale", 1) != 1:
+            self.lin_amp_scale = self.preprocess_config["lin_amp_scale"]
+        self.lin_amp_off = 1.e-5
+        if self.preprocess_config.get("lin_amp_off", None) is not None:
+            self.lin_amp_off = self.preprocess_config["lin_amp_off"]
+        self.mel_amp_scale = 1
+        if self.preprocess_config.get("mel_amp_scale", 1) != 1:
+            self.mel_amp_scale = self.preprocess_config["mel_amp_scale"]
+        self.use_max_limit = False
+        if self.preprocess_config.get("use_max_limit", False):
+            self.use_max_limit = self.preprocess_config["use_max_limit"]
+        return
+
+
+def create_synthetic_model_dir(path, voice_type="SPEECH", seed=1234, **config_overrides):
+    """Write a model directory (config.yaml + weights.npz) with the canonical architecture and seeded synthetic
+    weights -- the stand-in for the pretrained model zip that is not part of the reference tree."""
+    from .config import canonical_config, dump_config
+    from .weights import save_weights, synthetic_weights
+    os.makedirs(path, exist_ok=True)
+    cfg = canonical_config(voice_type, **config_overrides)
+    dump_config(os.path.join(path, "config.yaml"), cfg)
+    save_weights(os.path.join(path, "weights.npz"), synthetic_weights(cfg, seed=seed))
+    return path

@@ -1,0 +1,70 @@
+"""The C-ABI library loads on a CPU-only host and exports every entry point include/mbexwn.h declares;
+the ctypes mirror of the structs has the layout the C compiler gives them (no compute calls here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from mbexwn_vocoder_amd import engine
+from mbexwn_vocoder_amd.build import LIB_PATH, build_library
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mbexwn.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mbx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    build_library()
+    assert os.path.exists(LIB_PATH)
+    lib = engine.load_library()
+    names = declared_functions()
+    assert "mbx_forward" in names and "mbx_create" in names and len(names) >= 12
+    for name in names:
+        assert hasattr(lib, name), f"{name} is declared in mbexwn.h but not exported"
+    assert sorted(engine.EXPORTED_SYMBOLS) == names
+
+
+def test_struct_layout_matches_c(tmp_path):
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mbexwn.h"\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(mbx_config), sizeof(mbx_subnet_op),'
+                   ' sizeof(mbx_tensor), offsetof(mbx_config, n_f0_ops), offsetof(mbx_config, vtf_ops),'
+                   ' offsetof(mbx_config, wt_nominal_f0)); return 0;}\n')
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    got = [int(vv) for vv in out]
+    cc = engine.mbx_config
+    assert got == [ctypes.sizeof(cc), ctypes.sizeof(engine.mbx_subnet_op), ctypes.sizeof(engine.mbx_tensor),
+                   cc.n_f0_ops.offset, cc.vtf_ops.offset, cc.wt_nominal_f0.offset]
+
+
+def test_make_config_and_tensor_table():
+    from helpers import build_case
+    cfg, raw, wt = build_case("VOICE", {})
+    cconf, dims = engine.make_config(cfg, wt)
+    assert cconf.struct_size == ctypes.sizeof(engine.mbx_config) and cconf.wn_channels == 340
+    assert [cconf.wn_dilations[ii] for ii in range(5)] == [1, 2, 4, 8, 16]
+    assert cconf.n_f0_ops == 6 and cconf.n_vtf_ops == 5
+    assert cconf.f0_ops[0].name == b"PulsPar_Layer_0" and cconf.f0_ops[5].act == 1
+    tensors = engine.tensor_table(cfg, raw, wt)
+    assert tensors["wn.conv1D_0.w"].shape == (3, 340, 680) and tensors["table.pqmf_syn"].shape == (121, 15)
+    assert tensors["wn.res_skip_4.w"].shape == (1, 340, 340) and tensors["table.wavetables"].shape == (513, 15)
+    assert all(vv.dtype.name == "float32" and vv.flags["C_CONTIGUOUS"] for vv in tensors.values())
+
+
+def test_engine_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from helpers import build_case
+    cfg, raw, wt = build_case("SPEECH", {})
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        engine.MBExWNEngine(cfg, raw, wt)

@@ -1,0 +1,103 @@
+"""Utterance sharding + result gather: partition properties and a world_size-2 gloo run on CPU.
+
+The forward function used here is a deterministic test double (NOT the oracle and not a product fallback):
+what is under test is the partition / padding / gather logic around the engine."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from mbexwn_vocoder_amd.sharding import ShardedSynthesizer, lpt_partition, plan_batches
+
+HOP, SPF = 300, 20
+
+
+def fake_forward(mel, n_frames, noise):
+    """audio[b, t*HOP + k] = sum(mel[b,t]) + 0.001*k + noise[b, t*SPF]; zero behind the item's length."""
+    B, T, _ = mel.shape
+    out = np.zeros((B, T * HOP), dtype=np.float32)
+    for b in range(B):
+        n = int(n_frames[b])
+        base = mel[b, :n].sum(axis=1)
+        if noise is not None:
+            base = base + noise[b, :n * SPF:SPF]
+        out[b, :n * HOP] = (base[:, None] + 0.001 * np.arange(HOP)[None, :]).reshape(-1)
+    return out
+
+
+def make_utterances(n, seed=0):
+    rng = np.random.default_rng(seed)
+    lengths = rng.integers(1, 60, size=n)
+    mels = [rng.normal(size=(int(ll), 80)).astype(np.float32) for ll in lengths]
+    noises = [rng.normal(size=(int(ll) * SPF,)).astype(np.float32) for ll in lengths]
+    return mels, noises
+
+
+def test_lpt_partition_properties():
+    rng = np.random.default_rng(1)
+    lengths = rng.integers(160, 1200, size=256)           # BASELINE config 4: 256 utterances, 2..15 s
+    for world in (1, 2, 4, 8):
+        shards = lpt_partition(lengths, world)
+        flat = sorted(ii for ss in shards for ii in ss)
+        assert flat == list(range(256))                    # every utterance exactly once
+        loads = [sum(int(lengths[ii]) for ii in ss) for ss in shards]
+        assert max(loads) - min(loads) <= int(lengths.max())
+        assert max(loads) <= 1.02 * sum(loads) / world     # near-perfect balance => near-linear scaling
+    assert lpt_partition([], 4) == [[], [], [], []]
+    assert lpt_partition([5], 2) == [[0], []]
+
+
+def test_plan_batches_limits():
+    lengths = [100, 1200, 5, 700, 700, 3, 1200, 1]
+    batches = plan_batches(list(range(8)), lengths, max_batch=3, max_padded_frames=2500)
+    assert sorted(ii for bb in batches for ii in bb) == list(range(8))
+    for bb in batches:
+        assert len(bb) <= 3
+        assert len(bb) * max(lengths[ii] for ii in bb) <= 2500 or len(bb) == 1
+
+
+def test_single_process_equals_one_at_a_time():
+    mels, noises = make_utterances(13)
+    syn = ShardedSynthesizer(fake_forward, HOP, SPF, max_batch=4, max_padded_frames=200)
+    got = syn.run(mels, noises)
+    for ii, (mm, nn) in enumerate(zip(mels, noises)):
+        ref = fake_forward(mm[None], np.asarray([mm.shape[0]], np.int32), nn[None])[0]
+        assert np.array_equal(got[ii], ref)
+    assert syn.run([], []) == []
+
+
+def _worker(rank, world, port, tmpdir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mels, noises = make_utterances(21, seed=3)
+        syn = ShardedSynthesizer(fake_forward, HOP, SPF, rank=rank, world_size=world, max_batch=4)
+        everywhere = syn.run(mels, noises, gather="all")
+        on_root = syn.run(mels, noises, gather="rank0")
+        ok = all(np.array_equal(everywhere[ii], fake_forward(mm[None], np.asarray([mm.shape[0]], np.int32),
+                                                             noises[ii][None])[0]) for ii, mm in enumerate(mels))
+        if rank == 0:
+            ok = ok and all(np.array_equal(aa, bb) for aa, bb in zip(everywhere, on_root))
+        else:
+            ok = ok and on_root is None
+        local = syn.run(mels, noises, gather=None)
+        ok = ok and sorted(local) == sorted(lpt_partition([mm.shape[0] for mm in mels], world)[rank])
+        with open(os.path.join(tmpdir, f"ok{rank}"), "w") as fo:
+            fo.write("1" if ok else "0")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world_size_2_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    with socket.socket() as ss:
+        ss.bind(("127.0.0.1", 0))
+        port = ss.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        assert (tmp_path / f"ok{rank}").read_text() == "1"
