@@ -52,8 +52,8 @@ def test_make_config_and_tensor_table():
     cconf, dims = engine.make_config(cfg, wt)
     assert cconf.struct_size == ctypes.sizeof(engine.mbx_config) and cconf.wn_channels == 340
     assert [cconf.wn_dilations[ii] for ii in range(5)] == [1, 2, 4, 8, 16]
-    assert cconf.n_f0_ops == 6 and cconf.n_vtf_ops == 5
-    assert cconf.f0_ops[0].name == b"PulsPar_Layer_0" and cconf.f0_ops[5].act == 1
+    assert cconf.n_f0_ops == 9 and cconf.n_vtf_ops == 5   # 3x(conv,prelu) + final conv + lin + act ; 2x(conv,prelu) + final conv
+    assert cconf.f0_ops[0].name == b"PulsPar_Layer_0" and cconf.f0_ops[8].act == 1
     tensors = engine.tensor_table(cfg, raw, wt)
     assert tensors["wn.conv1D_0.w"].shape == (3, 340, 680) and tensors["table.pqmf_syn"].shape == (121, 15)
     assert tensors["wn.res_skip_4.w"].shape == (1, 340, 340) and tensors["table.wavetables"].shape == (513, 15)
