@@ -30,7 +30,6 @@ namespace mbx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;
 
 // source row of the padded input: -1 = zero sample.  Branch free (selects only) so that the K loop stays one
 // scheduling region.  mode: 0 zero, 1 symmetric (edge sample repeated), 2 edge.
@@ -53,203 +52,40 @@ __device__ __forceinline__ float gate_act(float zt, float zs) {
     return th * __builtin_amdgcn_rcpf(1.0f + e1);
 }
 
-// VEC: every row/column group of 4 floats is 16-byte aligned and all-or-nothing valid (cin, cout, C, ldx and
-// the batch strides are multiples of 4): the slice loads are then unconditional float4 loads from a clamped
-// address, zeroed by a select -- no branch in the K loop, so the prefetch of slice k+1 really overlaps the
-// MFMAs of slice k.  The scalar path only serves the tiny odd-sized convolutions (cin = 6, 30, cout = 1, 15).
-template <int WM, int WN, int TM, int TN, int EPI, bool VEC>
-__global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs p) {
-    constexpr int BM = WM * TM * 32;
+// Block -> (item, row tile, column tile).  With p.remap the grid is 1-D and XCD aware: workgroups are dealt
+// round-robin over the 8 XCDs (ids b and b+8 share an L2), so XCD x takes the row tiles x, x+8, ... and walks
+// all column tiles of a row tile back to back -- the blocks that share an activation tile (and its dilation
+// halo) run on one L2 at about the same time.  Placement only affects speed, never results.
+__device__ __forceinline__ bool decode_tile(const ConvArgs &p, int &b, int &mt, int &nt) {
+    if (!p.remap) {
+        b = blockIdx.z;
+        mt = blockIdx.x;
+        nt = blockIdx.y;
+        return true;
+    }
+    const int id = blockIdx.x;
+    const int l = id >> 3;
+    const int g = (l / p.n_tiles) * 8 + (id & 7);
+    nt = l % p.n_tiles;
+    if (g >= p.m_tiles_total) return false;
+    b = g / p.m_tiles_per_item;
+    mt = g - b * p.m_tiles_per_item;
+    return true;
+}
+
+// Epilogue shared by the register-staged and the LDS-DMA kernels.
+// C/D layout of a 32x32 tile: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+template <int WM, int WN, int TM, int TN, int EPI>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x16 (&acc)[TM][TN], int b, int rows, int m0, int n0,
+                                              int wr, int wc, int lane) {
     constexpr int BN = WN * TN * 32;
-    constexpr int LDA = BM + 4;
-    constexpr int LDB = BN + 4;
-    constexpr int A_TOT = BM * BK / 4;         // float4 per A slice
-    constexpr int B_TOT = BN * BK / 4;
-    constexpr int A_F4 = (A_TOT + 255) / 256;  // float4 per thread per A slice
-    constexpr int B_F4 = (B_TOT + 255) / 256;
-    static_assert(WM * WN == 4, "4 waves per block");
-    static_assert(EPI != EPI_GATE || TN == 2, "gate needs the tanh and the sigmoid tile in one wave");
-
-    __shared__ float lds[2 * BK * LDA + 2 * BK * LDB];
-    float *As = lds;
-    float *Bs = lds + 2 * BK * LDA;
-
-    const int b = blockIdx.z;
-    const int rows = p.n_frames ? p.n_frames[b] * p.rows_per_frame : p.max_rows;
-    const int m0 = blockIdx.x * BM;
-    if (m0 >= rows) return;
     const int C = p.channels;
-    // column origin of this block in the weight matrix
-    const int n0 = (EPI == EPI_GATE) ? blockIdx.y * (BN / 2) : blockIdx.y * BN;
-    const int n_lim = (EPI == EPI_GATE) ? C : p.cout;   // valid columns per half / in total
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wr = wave / WN, wc = wave % WN;
-
-    const float *xb = p.x + (long long)b * p.x_bstride;
-    const int nkc = (p.cin + BK - 1) / BK;   // K slices per tap
-    const int nk = p.ks * nkc;
-
-    float4 ra[A_F4], rb[B_F4];
-    unsigned okmask = 0;   // bit i: A float4 i valid, bit 16+i: B float4 i valid (masking is deferred to the LDS store)
-
-    // per-thread addressing that does not change inside a tap / inside the kernel
-    int a_off[A_F4];       // element offset of the source row of A float4 i for the current tap (clamped)
-    unsigned a_rowok = 0;  // bit i: that source row is a real sample (not zero padding)
-    int b_col[B_F4];       // clamped weight column of B float4 i
-    unsigned b_colok = 0;
-#pragma unroll
-    for (int i = 0; i < B_F4; ++i) {
-        const int q = tid + i * 256;
-        const int c = (q % (BN / 4)) * 4;
-        int n, lim;
-        if (EPI == EPI_GATE) {
-            const bool second = c >= BN / 2;
-            n = n0 + (second ? c - BN / 2 + C : c);
-            lim = n_lim + (second ? C : 0);
-        } else {
-            n = n0 + c;
-            lim = n_lim;
-        }
-        b_col[i] = VEC ? min(n, p.cout - 4) : n;
-        if (n < lim) b_colok |= 1u << i;
-    }
-    auto set_tap = [&](int tap) {
-        a_rowok = 0;
-#pragma unroll
-        for (int i = 0; i < A_F4; ++i) {
-            const int row = (tid + i * 256) >> 2;
-            const int src = map_row(m0 + row - p.pad_l + tap * p.dil, rows, p.pad_mode);
-            a_off[i] = max(src, 0) * p.ldx;
-            if (src >= 0) a_rowok |= 1u << i;
-        }
-    };
-
-    auto load_slice = [&](int kt) {
-        const int tap = kt / nkc;
-        const int ci0 = (kt - tap * nkc) * BK;
-        if (ci0 == 0) set_tap(tap);
-#pragma unroll
-        for (int i = 0; i < A_F4; ++i) {
-            const int q = tid + i * 256;
-            if (A_TOT % 256 != 0 && q >= A_TOT) break;
-            const int ci = ci0 + (q & 3) * 4;
-            const bool rowok = (a_rowok >> i) & 1u;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (VEC) {
-                v = *reinterpret_cast<const float4 *>(xb + a_off[i] + min(ci, p.cin - 4));
-                const bool ok = rowok & (ci < p.cin);
-                okmask = ok ? (okmask | (1u << i)) : (okmask & ~(1u << i));
-            } else if (rowok) {
-                const float *px = xb + a_off[i] + ci;
-                if (ci + 0 < p.cin) v.x = px[0];
-                if (ci + 1 < p.cin) v.y = px[1];
-                if (ci + 2 < p.cin) v.z = px[2];
-                if (ci + 3 < p.cin) v.w = px[3];
-            }
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < B_F4; ++i) {
-            const int q = tid + i * 256;
-            if (B_TOT % 256 != 0 && q >= B_TOT) break;
-            const int ci = ci0 + q / (BN / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (VEC) {
-                v = *reinterpret_cast<const float4 *>(p.w + (long long)(tap * p.cin + min(ci, p.cin - 1)) * p.cout + b_col[i]);
-                const bool ok = ((b_colok >> i) & 1u) & (ci < p.cin);
-                okmask = ok ? (okmask | (1u << (16 + i))) : (okmask & ~(1u << (16 + i)));
-            } else if (ci < p.cin) {
-                const int c = (q % (BN / 4)) * 4;
-                int lim;
-                if (EPI == EPI_GATE) lim = n_lim + (c >= BN / 2 ? C : 0);
-                else lim = n_lim;
-                const int n = b_col[i];
-                const float *pw = p.w + (long long)(tap * p.cin + ci) * p.cout + n;
-                if (n + 0 < lim) v.x = pw[0];
-                if (n + 1 < lim) v.y = pw[1];
-                if (n + 2 < lim) v.z = pw[2];
-                if (n + 3 < lim) v.w = pw[3];
-            }
-            rb[i] = v;
-        }
-    };
-
-    auto store_slice = [&](int buf) {
-        float *a = As + buf * BK * LDA;
-        float *bs = Bs + buf * BK * LDB;
-#pragma unroll
-        for (int i = 0; i < A_F4; ++i) {
-            const int q = tid + i * 256;
-            const int row = q >> 2, kq = q & 3;
-            if (A_TOT % 256 != 0 && q >= A_TOT) break;
-            const bool ok = !VEC || ((okmask >> i) & 1u);
-            a[(kq * 4 + 0) * LDA + row] = ok ? ra[i].x : 0.f;
-            a[(kq * 4 + 1) * LDA + row] = ok ? ra[i].y : 0.f;
-            a[(kq * 4 + 2) * LDA + row] = ok ? ra[i].z : 0.f;
-            a[(kq * 4 + 3) * LDA + row] = ok ? ra[i].w : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < B_F4; ++i) {
-            const int q = tid + i * 256;
-            const int k = q / (BN / 4), c = (q % (BN / 4)) * 4;
-            if (B_TOT % 256 != 0 && q >= B_TOT) break;
-            const bool ok = !VEC || ((okmask >> (16 + i)) & 1u);
-            float4 v = rb[i];
-            v.x = ok ? v.x : 0.f;
-            v.y = ok ? v.y : 0.f;
-            v.z = ok ? v.z : 0.f;
-            v.w = ok ? v.w : 0.f;
-            *reinterpret_cast<float4 *>(bs + k * LDB + c) = v;
-        }
-    };
-
-    // column of the wave's tile tn inside the block tile
-    auto col_base = [&](int tn) { return (EPI == EPI_GATE) ? tn * (BN / 2) + wc * 32 : (wc * TN + tn) * 32; };
-
-    // C/D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int ecol = lane & 31;
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    load_slice(0);
-    store_slice(0);
-    __syncthreads();
-
-    const int lrow = lane & 31, lk = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_slice(kt + 1);
-        const float *a = As + buf * BK * LDA + lk * LDA + wr * TM * 32 + lrow;
-        const float *bs = Bs + buf * BK * LDB + lk * LDB + lrow;
-        // all operands of the slice are requested first (counted lgkmcnt waits then release the MFMAs in order)
-        float av[BK / 2][TM], bv[BK / 2][TN];
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) av[kk / 2][i] = a[kk * LDA + i * 32];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bv[kk / 2][j] = bs[kk * LDB + col_base(j)];
-        }
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk / 2][i], bv[kk / 2][j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) store_slice(buf ^ 1);
-        __syncthreads();
+    auto col_base = [&](int tn) { return (EPI == EPI_GATE) ? tn * (BN / 2) + wc * 32 : (wc * TN + tn) * 32; };
+    if (p.ablate & 8) {
+        if (acc[0][0][0] == 123.456f) p.out[0] = acc[0][TN - 1][3];
+        return;
     }
-
-    // ------------------------------------------------------------------ epilogue
     if (EPI == EPI_GATE) {
         const int ch = n0 + wc * 32 + ecol;   // gate channel of this lane
         if (ch < C) {
@@ -319,12 +155,391 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs p) {
     }
 }
 
+// VEC: every row/column group of 4 floats is 16-byte aligned and all-or-nothing valid (cin, cout, C, ldx and
+// the batch strides are multiples of 4): the slice loads are then unconditional float4 loads from a clamped
+// address, zeroed by a select -- no branch in the K loop, so the prefetch of slice k+1 really overlaps the
+// MFMAs of slice k.  The scalar path only serves the tiny odd-sized convolutions (cin = 6, 30, cout = 1, 15).
+template <int WM, int WN, int TM, int TN, int EPI, bool VEC, int BK>
+__global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs p) {
+    constexpr int KQ = BK / 4;                 // float4 per row of an A slice
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    constexpr int LDA = BM + 4;
+    constexpr int LDB = BN + 4;
+    constexpr int A_TOT = BM * BK / 4;         // float4 per A slice
+    constexpr int B_TOT = BN * BK / 4;
+    constexpr int A_F4 = (A_TOT + 255) / 256;  // float4 per thread per A slice
+    constexpr int B_F4 = (B_TOT + 255) / 256;
+    static_assert(WM * WN == 4, "4 waves per block");
+    static_assert(EPI != EPI_GATE || TN == 2, "gate needs the tanh and the sigmoid tile in one wave");
+
+    __shared__ float lds[2 * BK * LDA + 2 * BK * LDB];
+    float *As = lds;
+    float *Bs = lds + 2 * BK * LDA;
+
+    int b, mt_, nt_;
+    if (!decode_tile(p, b, mt_, nt_)) return;
+    const int rows = p.n_frames ? p.n_frames[b] * p.rows_per_frame : p.max_rows;
+    const int m0 = mt_ * BM;
+    if (m0 >= rows) return;
+    const int C = p.channels;
+    // column origin of this block in the weight matrix
+    const int n0 = (EPI == EPI_GATE) ? nt_ * (BN / 2) : nt_ * BN;
+    const int n_lim = (EPI == EPI_GATE) ? C : p.cout;   // valid columns per half / in total
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave / WN, wc = wave % WN;
+
+    const float *xb = p.x + (long long)b * p.x_bstride;
+    const int nkc = (p.cin + BK - 1) / BK;   // K slices per tap
+    const int nk = p.ks * nkc;
+
+    float4 ra[A_F4], rb[B_F4];
+    unsigned okmask = 0;   // bit i: A float4 i valid, bit 16+i: B float4 i valid (masking is deferred to the LDS store)
+
+    // per-thread addressing that does not change inside a tap / inside the kernel
+    int a_off[A_F4];       // element offset of the source row of A float4 i for the current tap (clamped)
+    unsigned a_rowok = 0;  // bit i: that source row is a real sample (not zero padding)
+    int b_col[B_F4];       // clamped weight column of B float4 i
+    unsigned b_colok = 0;
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+        const int q = tid + i * 256;
+        const int c = (q % (BN / 4)) * 4;
+        int n, lim;
+        if (EPI == EPI_GATE) {
+            const bool second = c >= BN / 2;
+            n = n0 + (second ? c - BN / 2 + C : c);
+            lim = n_lim + (second ? C : 0);
+        } else {
+            n = n0 + c;
+            lim = n_lim;
+        }
+        b_col[i] = VEC ? min(n, p.cout - 4) : n;
+        if (n < lim) b_colok |= 1u << i;
+    }
+    auto set_tap = [&](int tap) {
+        a_rowok = 0;
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int row = (tid + i * 256) / KQ;
+            const int src = map_row(m0 + row - p.pad_l + tap * p.dil, rows, p.pad_mode);
+            a_off[i] = max(src, 0) * p.ldx;
+            if (src >= 0) a_rowok |= 1u << i;
+        }
+    };
+
+    auto load_slice = [&](int kt) {
+        const int tap = kt / nkc;
+        const int ci0 = (kt - tap * nkc) * BK;
+        if (ci0 == 0) set_tap(tap);
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int q = tid + i * 256;
+            if (A_TOT % 256 != 0 && q >= A_TOT) break;
+            const int ci = ci0 + (q % KQ) * 4;
+            const bool rowok = (a_rowok >> i) & 1u;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (VEC) {
+                v = *reinterpret_cast<const float4 *>(xb + a_off[i] + min(ci, p.cin - 4));
+                const bool ok = rowok & (ci < p.cin);
+                okmask = ok ? (okmask | (1u << i)) : (okmask & ~(1u << i));
+            } else if (rowok) {
+                const float *px = xb + a_off[i] + ci;
+                if (ci + 0 < p.cin) v.x = px[0];
+                if (ci + 1 < p.cin) v.y = px[1];
+                if (ci + 2 < p.cin) v.z = px[2];
+                if (ci + 3 < p.cin) v.w = px[3];
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int q = tid + i * 256;
+            if (B_TOT % 256 != 0 && q >= B_TOT) break;
+            const int ci = ci0 + q / (BN / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (VEC) {
+                v = *reinterpret_cast<const float4 *>(p.w + (long long)(tap * p.cin + min(ci, p.cin - 1)) * p.cout + b_col[i]);
+                const bool ok = ((b_colok >> i) & 1u) & (ci < p.cin);
+                okmask = ok ? (okmask | (1u << (16 + i))) : (okmask & ~(1u << (16 + i)));
+            } else if (ci < p.cin) {
+                const int c = (q % (BN / 4)) * 4;
+                int lim;
+                if (EPI == EPI_GATE) lim = n_lim + (c >= BN / 2 ? C : 0);
+                else lim = n_lim;
+                const int n = b_col[i];
+                const float *pw = p.w + (long long)(tap * p.cin + ci) * p.cout + n;
+                if (n + 0 < lim) v.x = pw[0];
+                if (n + 1 < lim) v.y = pw[1];
+                if (n + 2 < lim) v.z = pw[2];
+                if (n + 3 < lim) v.w = pw[3];
+            }
+            rb[i] = v;
+        }
+    };
+
+    auto store_slice = [&](int buf) {
+        float *a = As + buf * BK * LDA;
+        float *bs = Bs + buf * BK * LDB;
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int q = tid + i * 256;
+            const int row = q / KQ, kq = q % KQ;
+            if (A_TOT % 256 != 0 && q >= A_TOT) break;
+            const bool ok = !VEC || ((okmask >> i) & 1u);
+            a[(kq * 4 + 0) * LDA + row] = ok ? ra[i].x : 0.f;
+            a[(kq * 4 + 1) * LDA + row] = ok ? ra[i].y : 0.f;
+            a[(kq * 4 + 2) * LDA + row] = ok ? ra[i].z : 0.f;
+            a[(kq * 4 + 3) * LDA + row] = ok ? ra[i].w : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int q = tid + i * 256;
+            const int k = q / (BN / 4), c = (q % (BN / 4)) * 4;
+            if (B_TOT % 256 != 0 && q >= B_TOT) break;
+            const bool ok = !VEC || ((okmask >> (16 + i)) & 1u);
+            float4 v = rb[i];
+            v.x = ok ? v.x : 0.f;
+            v.y = ok ? v.y : 0.f;
+            v.z = ok ? v.z : 0.f;
+            v.w = ok ? v.w : 0.f;
+            *reinterpret_cast<float4 *>(bs + k * LDB + c) = v;
+        }
+    };
+
+    // column of the wave's tile tn inside the block tile
+    auto col_base = [&](int tn) { return (EPI == EPI_GATE) ? tn * (BN / 2) + wc * 32 : (wc * TN + tn) * 32; };
+
+    // C/D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int ecol = lane & 31;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    load_slice(0);
+    store_slice(0);
+    __syncthreads();
+
+    const int lrow = lane & 31, lk = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk && !(p.ablate & 1)) load_slice(kt + 1);
+        const float *a = As + buf * BK * LDA + lk * LDA + wr * TM * 32 + lrow;
+        const float *bs = Bs + buf * BK * LDB + lk * LDB + lrow;
+        // software pipeline over the k-steps of the slice: the LDS reads of k-step kk+2 are issued before the
+        // MFMAs of k-step kk (sched_group_barrier pins that order), so a wave never sits in an LDS round trip
+        // with an idle matrix pipe
+        float av[2][TM], bv[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[0][i] = a[i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bv[0][j] = bs[col_base(j)];
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+            if (kk + 2 < BK) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) av[nxt][i] = a[(kk + 2) * LDA + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bv[nxt][j] = bs[(kk + 2) * LDB + col_base(j)];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
+            if (kk + 2 < BK) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);   // DS reads of k-step kk+2
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);                    // MFMAs of k-step kk
+        }
+        if (kt + 1 < nk && !(p.ablate & 2)) store_slice(buf ^ 1);
+        if (!(p.ablate & 4)) __syncthreads();
+    }
+
+    conv_epilogue<WM, WN, TM, TN, EPI>(p, acc, b, rows, m0, n0, wr, wc, lane);
+}
+
+// One LDS-DMA wave-instruction: 64 lanes x 16 bytes, global (per-lane address) -> LDS (M0 = wave-uniform byte
+// address, lane l lands at M0 + 16*l).  Issued through inline asm on purpose: with the builtin hipcc waits
+// vmcnt(0) in front of the next ds_read of the same __shared__ array (it cannot tell the two LDS buffers
+// apart), which would serialise the prefetch of slice k+1 with the MFMAs of slice k.  The kernel orders DMA and
+// reads itself: s_waitcnt vmcnt(0) + barrier before a buffer is read, barrier before it is overwritten.
+__device__ __forceinline__ void lds_dma16(const float *src, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(src) : "memory", "m0");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LDS-DMA variant for the two WaveNet GEMMs (needs the VEC conditions and p.zeros).
+// The K slices go global -> LDS directly (global_load_lds_dwordx4: no VGPR round trip, no ds_write, the K loop
+// spends its registers on accumulators only).  A wave-instruction writes 64 x 16 B contiguously, the SOURCE
+// address is per lane, so the LDS image is linear and the layout is chosen through the source addresses:
+//   A slice: BM rows x 4 chunks of 4 channels, chunk (row, c) stored at position 4*row + (c ^ ((row >> 2) & 3)).
+//            An MFMA lane (row, h) fetches its chunks c = 2*cc + h with ds_read_b128; the XOR spreads the 16
+//            rows of a ds_read_b128 lane group over all 16 bank quads (conflict free).  K order inside the slice
+//            is thereby permuted (k = 8*cc + 4*h + s for step (cc, s)); the B operand uses the same order.
+//   B slice: 16 k-rows x BN columns, k-major (ds_read_b32, consecutive lanes = consecutive columns).
+// Zero padding (rows outside the item, channels/columns beyond the tensor) = lanes pointed at a 16-byte zero buffer.
+template <int WM, int WN, int TM, int TN, int EPI>
+__global__ __launch_bounds__(256) void conv1d_mfma_dma_kernel(ConvArgs p) {
+    constexpr int BK = 16;
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    constexpr int A_INST = BM * 4 / 64 / 4;    // LDS-DMA wave-instructions per wave and slice (A)
+    constexpr int B_INST = BK * BN / 4 / 64 / 4;
+    static_assert(WM * WN == 4 && A_INST >= 1 && B_INST >= 1, "tile shape");
+    static_assert(EPI != EPI_GATE || TN == 2, "gate needs the tanh and the sigmoid tile in one wave");
+    typedef __attribute__((address_space(3))) float lds_float;
+
+    constexpr int NBUF = 3;                      // slices in flight: one being read, two landing
+    __shared__ __attribute__((aligned(16))) float lds[NBUF * (BM * BK + BK * BN)];   // ONE array (A ring, B ring)
+
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float *)lds);
+    int b, mt_, nt_;
+    if (!decode_tile(p, b, mt_, nt_)) return;
+    const int rows = p.n_frames ? p.n_frames[b] * p.rows_per_frame : p.max_rows;
+    const int m0 = mt_ * BM;
+    if (m0 >= rows) return;
+    const int C = p.channels;
+    const int n0 = (EPI == EPI_GATE) ? nt_ * (BN / 2) : nt_ * BN;
+    const int n_lim = (EPI == EPI_GATE) ? C : p.cout;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    const float *xb = p.x + (long long)b * p.x_bstride;
+    const int nkc = (p.cin + BK - 1) / BK;
+    const int nk = p.ks * nkc;
+
+    // ---- per-lane DMA sources
+    int a_row[A_INST], a_ch[A_INST], a_off[A_INST];
+    unsigned a_rowok = 0;
+#pragma unroll
+    for (int i = 0; i < A_INST; ++i) {
+        const int pos = (wave + 4 * i) * 64 + lane;           // chunk position in the A image
+        const int row = pos >> 2;
+        a_row[i] = row;
+        a_ch[i] = 4 * ((pos & 3) ^ ((row >> 2) & 3));         // first channel (inside the slice) of the chunk stored here
+    }
+    int b_k[B_INST], b_col[B_INST];
+    unsigned b_colok = 0;
+#pragma unroll
+    for (int i = 0; i < B_INST; ++i) {
+        const int pos = (wave + 4 * i) * 64 + lane;
+        const int c = (pos % (BN / 4)) * 4;
+        b_k[i] = pos / (BN / 4);
+        int n, lim;
+        if (EPI == EPI_GATE) {
+            const bool second = c >= BN / 2;
+            n = n0 + (second ? c - BN / 2 + C : c);
+            lim = n_lim + (second ? C : 0);
+        } else {
+            n = n0 + c;
+            lim = n_lim;
+        }
+        b_col[i] = min(n, p.cout - 4);
+        if (n < lim) b_colok |= 1u << i;
+    }
+    auto set_tap = [&](int tap) {
+        a_rowok = 0;
+#pragma unroll
+        for (int i = 0; i < A_INST; ++i) {
+            const int src = map_row(m0 + a_row[i] - p.pad_l + tap * p.dil, rows, p.pad_mode);
+            a_off[i] = max(src, 0) * p.ldx;
+            if (src >= 0) a_rowok |= 1u << i;
+        }
+    };
+    auto issue = [&](int kt, int buf) {
+        const int tap = kt / nkc;
+        const int ci0 = (kt - tap * nkc) * BK;
+        if (ci0 == 0) set_tap(tap);
+        // LDS byte addresses of the two destination images (wave uniform)
+        const unsigned adst = lds_base + 4u * (unsigned)(buf * (BM * BK));
+        const unsigned bdst = lds_base + 4u * (unsigned)(NBUF * (BM * BK) + buf * (BK * BN));
+#pragma unroll
+        for (int i = 0; i < A_INST; ++i) {
+            const int ci = ci0 + a_ch[i];
+            const bool ok = ((a_rowok >> i) & 1u) & (ci < p.cin);
+            const float *src = ok ? xb + a_off[i] + ci : p.zeros;
+            lds_dma16(src, adst + 1024u * (unsigned)(wave + 4 * i));
+        }
+#pragma unroll
+        for (int i = 0; i < B_INST; ++i) {
+            const int ci = ci0 + b_k[i];
+            const bool ok = ((b_colok >> i) & 1u) & (ci < p.cin);
+            const float *src = ok ? p.w + (long long)(tap * p.cin + ci) * p.cout + b_col[i] : p.zeros;
+            lds_dma16(src, bdst + 1024u * (unsigned)(wave + 4 * i));
+        }
+    };
+
+    auto col_base = [&](int tn) { return (EPI == EPI_GATE) ? tn * (BN / 2) + wc * 32 : (wc * TN + tn) * 32; };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ring of NBUF slices: iteration kt waits for slice kt (all but the newest slice's DMA instructions retired),
+    // a barrier makes it visible block-wide and proves slice kt-1 is no longer read, then slice kt+2 is issued
+    // into the buffer slice kt-1 occupied.  One barrier per slice; two slices of prefetch distance.
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    const int lrow = lane & 31, lk = lane >> 5;
+    const int swz = (lrow >> 2) & 3;
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INST + B_INST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 2 < nk) issue(kt + 2, buf == 0 ? 2 : buf - 1);
+        const float *ab = lds + buf * (BM * BK) + (wr * TM * 32 + lrow) * BK;
+        const float *bb = lds + NBUF * (BM * BK) + buf * (BK * BN) + lrow;
+        // k order of the slice: step (cc, st) multiplies channel 8*cc + 4*h + st (h = lane half); the operands of
+        // step n+1 are requested before the MFMAs of step n issue (sched_group_barrier pins the interleave)
+        float4 a4[2][TM];
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a4[cc][i] = *reinterpret_cast<const float4 *>(ab + i * 32 * BK + 4 * ((2 * cc + lk) ^ swz));
+        float bv[2][TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bv[0][j] = bb[(4 * lk) * BN + col_base(j)];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const int cc = n >> 2, st = n & 3, cur = n & 1, nxt = cur ^ 1;
+            if (n + 1 < 8) {
+                const int c2 = (n + 1) >> 2, s2 = (n + 1) & 3;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bv[nxt][j] = bb[(8 * c2 + 4 * lk + s2) * BN + col_base(j)];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float av = st == 0 ? a4[cc][i].x : st == 1 ? a4[cc][i].y : st == 2 ? a4[cc][i].z : a4[cc][i].w;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[cur][j], acc[i][j], 0, 0, 0);
+            }
+            if (n + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+        }
+        buf = buf == NBUF - 1 ? 0 : buf + 1;
+    }
+    conv_epilogue<WM, WN, TM, TN, EPI>(p, acc, b, rows, m0, n0, wr, wc, lane);
+}
+
 static int env_int(const char *name, int dflt) {
     const char *v = getenv(name);
     return v ? atoi(v) : dflt;
 }
 
-template <int WM, int WN, int TM, int TN, int EPI>
+template <int WM, int WN, int TM, int TN, int EPI, int BK = 16>
 static void launch_cfg(const ConvArgs &a, hipStream_t stream, int extra_lds = 0) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const int ncols = (EPI == EPI_GATE) ? a.channels : a.cout;
@@ -334,24 +549,70 @@ static void launch_cfg(const ConvArgs &a, hipStream_t stream, int extra_lds = 0)
                      (EPI != EPI_GATE || a.channels % 4 == 0) && ((uintptr_t)a.x % 16 == 0) &&
                      ((uintptr_t)a.w % 16 == 0);
     if (vec)
-        hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, TM, TN, EPI, true>), grid, dim3(256), extra_lds, stream, a);
+        hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, TM, TN, EPI, true, BK>), grid, dim3(256), extra_lds, stream, a);
     else
-        hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, TM, TN, EPI, false>), grid, dim3(256), extra_lds, stream, a);
+        hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, TM, TN, EPI, false, BK>), grid, dim3(256), extra_lds, stream, a);
+}
+
+template <int WM, int WN, int TM, int TN, int EPI>
+static bool launch_dma(const ConvArgs &a, hipStream_t stream) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const bool vec = (a.cin % 4 == 0) && (a.ldx % 4 == 0) && (a.x_bstride % 4 == 0) && (a.cout % 4 == 0) &&
+                     (EPI != EPI_GATE || a.channels % 4 == 0) && ((uintptr_t)a.x % 16 == 0) &&
+                     ((uintptr_t)a.w % 16 == 0) && a.zeros != nullptr;
+    if (!vec) return false;
+    const int ncols = (EPI == EPI_GATE) ? a.channels : a.cout;
+    const int bn_eff = (EPI == EPI_GATE) ? BN / 2 : BN;
+    ConvArgs r = a;
+    r.remap = 1;
+    r.n_tiles = (ncols + bn_eff - 1) / bn_eff;
+    r.m_tiles_per_item = (a.max_rows + BM - 1) / BM;
+    r.m_tiles_total = r.m_tiles_per_item * a.batch;
+    static const int no_remap = env_int("MBX_NO_REMAP", 0);
+    if (no_remap) {
+        r.remap = 0;
+        dim3 grid(r.m_tiles_per_item, r.n_tiles, a.batch);
+        hipLaunchKernelGGL((conv1d_mfma_dma_kernel<WM, WN, TM, TN, EPI>), grid, dim3(256), 0, stream, r);
+        return true;
+    }
+    const long long blocks = 8LL * ((r.m_tiles_total + 7) / 8) * r.n_tiles;
+    hipLaunchKernelGGL((conv1d_mfma_dma_kernel<WM, WN, TM, TN, EPI>), dim3((unsigned)blocks), dim3(256), 0, stream, r);
+    return true;
 }
 
 void launch_conv1d(const ConvArgs &a, int epilogue, hipStream_t stream) {
     if (a.max_rows <= 0 || a.batch <= 0) return;
-    // tuning knobs (experiments only): tile shape of the two WaveNet GEMMs and extra dynamic LDS to cap blocks/CU
-    static const int gate_cfg = env_int("MBX_GATE_CFG", 1);
+    // Tile shapes of the two WaveNet GEMMs.  Defaults = the fastest measured on MI355X (profiles/README.md):
+    //   gate     : LDS-DMA kernel, 64 rows x 64 gate channels (MBX_GATE_CFG=10)
+    //   res/skip : register-staged kernel, 64 x 128 (MBX_RS_CFG=1)
+    // The environment knobs exist for the tuning experiments only.
+    static const int gate_cfg = env_int("MBX_GATE_CFG", 10);
+    static const int rs_cfg = env_int("MBX_RS_CFG", 1);
     static const int extra_lds = env_int("MBX_EXTRA_LDS", 0);
+    static const int ablate = env_int("MBX_ABLATE", 0);   // timing experiments only (results are wrong when set)
+    if (ablate && (epilogue == EPI_GATE || epilogue == EPI_RESSKIP)) {
+        ConvArgs b = a;
+        b.ablate = ablate;
+        if (epilogue == EPI_GATE) launch_cfg<2, 2, 1, 2, EPI_GATE>(b, stream, extra_lds);
+        else launch_cfg<2, 2, 1, 2, EPI_RESSKIP>(b, stream, extra_lds);
+        return;
+    }
     if (epilogue == EPI_GATE) {
-        if (gate_cfg == 1) launch_cfg<2, 2, 1, 2, EPI_GATE>(a, stream, extra_lds);       // 64 rows x 64 gate channels
-        else if (gate_cfg == 2) launch_cfg<4, 1, 1, 2, EPI_GATE>(a, stream, extra_lds);  // 128 rows x 32 gate channels
-        else launch_cfg<2, 2, 2, 2, EPI_GATE>(a, stream, extra_lds);                     // 128 rows x 64 gate channels
+        bool done = false;
+        if (gate_cfg == 10) done = launch_dma<2, 2, 1, 2, EPI_GATE>(a, stream);            // 64 x 64 gate channels
+        else if (gate_cfg == 11) done = launch_dma<2, 2, 2, 2, EPI_GATE>(a, stream);       // 128 x 64
+        else if (gate_cfg == 12) done = launch_dma<4, 1, 1, 2, EPI_GATE>(a, stream);       // 128 x 32
+        if (done) return;
+        if (gate_cfg == 0) launch_cfg<2, 2, 2, 2, EPI_GATE>(a, stream, extra_lds);         // 128 x 64, register staged
+        else if (gate_cfg == 2) launch_cfg<4, 1, 1, 2, EPI_GATE>(a, stream, extra_lds);    // 128 x 32
+        else launch_cfg<2, 2, 1, 2, EPI_GATE>(a, stream, extra_lds);                       // 64 x 64 (also the non-VEC fallback)
     } else if (epilogue == EPI_RESSKIP) {
-        if (gate_cfg == 1) launch_cfg<2, 2, 1, 2, EPI_RESSKIP>(a, stream, extra_lds);    // 64 x 128
-        else if (gate_cfg == 2) launch_cfg<4, 1, 1, 2, EPI_RESSKIP>(a, stream, extra_lds);  // 128 x 64
-        else launch_cfg<2, 2, 2, 2, EPI_RESSKIP>(a, stream, extra_lds);                  // 128 x 128
+        bool done = false;
+        if (rs_cfg == 10) done = launch_dma<2, 2, 1, 2, EPI_RESSKIP>(a, stream);
+        else if (rs_cfg == 11) done = launch_dma<2, 2, 2, 2, EPI_RESSKIP>(a, stream);
+        if (done) return;
+        if (rs_cfg == 0) launch_cfg<2, 2, 2, 2, EPI_RESSKIP>(a, stream, extra_lds);        // 128 x 128
+        else launch_cfg<2, 2, 1, 2, EPI_RESSKIP>(a, stream, extra_lds);                    // 64 x 128
     } else if (a.cout <= 32) {
         launch_cfg<4, 1, 1, 1, EPI_LINEAR>(a, stream);        // 128 x 32 (F0 head, post-net, end)
     } else if ((long long)a.max_rows * a.batch >= 4096 && a.cout >= 128) {

@@ -57,6 +57,7 @@ struct mbx_handle {
     std::map<std::string, DevTensor> tensors;
     std::map<int, std::pair<float *, float *>> lerp;   // interpolation factor -> (w0, w1)
     float *twiddle = nullptr;
+    float *zeros = nullptr;   // 256 bytes of zeros (padding source of the LDS-DMA GEMMs)
     float *poly = nullptr;
     int poly_ndm = 0, poly_dm_min = 0;
     std::map<std::string, StageRef> stages;
@@ -388,7 +389,7 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
         tw[2 * k] = (float)std::cos(ang);
         tw[2 * k + 1] = (float)std::sin(ang);
     }
-    total += align_up(poly.size() * sizeof(float), 256) + align_up(tw.size() * sizeof(float), 256);
+    total += align_up(poly.size() * sizeof(float), 256) + align_up(tw.size() * sizeof(float), 256) + 256;
     for (int u : ups) total += 2 * align_up((size_t)u * sizeof(float), 256);
 
     e = hipMalloc(reinterpret_cast<void **>(&hd->arena), total);
@@ -415,7 +416,11 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
     }
     hd->poly = upload(poly.data(), poly.size());
     hd->twiddle = upload(tw.data(), tw.size());
-    if (!hd->poly || !hd->twiddle) return bail(fail(MBX_ERR_HIP, "hipMemcpy of a table failed"));
+    {
+        std::vector<float> zz(64, 0.f);
+        hd->zeros = upload(zz.data(), zz.size());
+    }
+    if (!hd->poly || !hd->twiddle || !hd->zeros) return bail(fail(MBX_ERR_HIP, "hipMemcpy of a table failed"));
     for (int u : ups) {
         if (hd->lerp.count(u)) continue;
         std::vector<float> w0(u), w1(u);
@@ -542,6 +547,7 @@ mbx_status mbx_forward(mbx_handle *hd, const float *mel, const int32_t *n_frames
         g.lerp_w0 = lerp.first;
         g.lerp_w1 = lerp.second;
         g.channels = C;
+        g.zeros = hd->zeros;
         {
             ScopedEvents ev(hd, 0, stream);
             mbx::launch_conv1d(g, mbx::EPI_GATE, stream);
@@ -551,6 +557,7 @@ mbx_status mbx_forward(mbx_handle *hd, const float *mel, const int32_t *n_frames
                                     find(hd, "wn.res_skip_" + ls + ".w"), find(hd, "wn.res_skip_" + ls + ".b"), 1, C,
                                     last ? C : 2 * C, 1, 0, MBX_PAD_ZERO, nullptr, 0, 0);
         r.channels = C;
+        r.zeros = hd->zeros;
         r.h = w.h;
         r.skip = w.skip;
         r.hs_bstride = nsteps * C;

@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+for abl in 0 1 3 7 8 15; do
+echo "== MBX_ABLATE=$abl"
+MBX_ABLATE=$abl python bench.py --workload config3_si_b16_10s --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['res_skip_avg_launch_ms'], d['roofline']['frac'])"
+done
