@@ -534,6 +534,104 @@ __global__ __launch_bounds__(256) void conv1d_mfma_dma_kernel(ConvArgs p) {
     conv_epilogue<WM, WN, TM, TN, EPI>(p, acc, b, rows, m0, n0, wr, wc, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Small-M convolution (mel-rate sub-nets at batch 1: a few hundred rows, K = ks*cin up to 768).
+// A 32x32 output tile per block keeps >= 200 blocks in flight for 800 rows; what then bounds a block is the serial
+// chain of K/2 dependent-rate MFMAs, so K is split over the 4 waves of the block (each wave runs a quarter of
+// the chain) and the four partial tiles are summed through LDS.  Operands go straight from global memory (L2) to
+// the MFMA registers: the tile is too small to amortise an LDS stage.  Lane (row r, half h) loads A[r][8g+4h..+3]
+// as one float4 and feeds it to four MFMA steps; the B lane (col c, half h) loads W[8g+4h+s][c] for the same steps.
+// Needs cin % 8 == 0 and 16-byte aligned rows (checked by the launcher).
+__global__ __launch_bounds__(256) void conv1d_small_kernel(ConvArgs p) {
+    __shared__ float red[3][16][64];
+    const int b = blockIdx.z;
+    const int rows = p.n_frames ? p.n_frames[b] * p.rows_per_frame : p.max_rows;
+    const int m0 = blockIdx.x * 32;
+    if (m0 >= rows) return;
+    const int n0 = blockIdx.y * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 31, lk = lane >> 5;
+    const float *xb = p.x + (long long)b * p.x_bstride;
+    const int groups_per_tap = p.cin >> 3;                 // groups of 8 input channels
+    const int n_groups = p.ks * groups_per_tap;
+    const int g_begin = (n_groups * wave) / 4, g_end = (n_groups * (wave + 1)) / 4;
+    const int col = n0 + lrow;
+    const bool col_ok = col < p.cout;
+    const float *wcol = p.w + min(col, p.cout - 1);
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    auto load_group = [&](int g, float4 &av, float (&bv)[4]) {
+        const int tap = g / groups_per_tap;
+        const int ci = (g - tap * groups_per_tap) * 8 + 4 * lk;
+        const int src = map_row(m0 + lrow - p.pad_l + tap * p.dil, rows, p.pad_mode);
+        const float4 t = *reinterpret_cast<const float4 *>(xb + (long long)max(src, 0) * p.ldx + ci);
+        const bool ok = src >= 0;
+        av.x = ok ? t.x : 0.f;
+        av.y = ok ? t.y : 0.f;
+        av.z = ok ? t.z : 0.f;
+        av.w = ok ? t.w : 0.f;
+        const float *wk = wcol + (long long)(tap * p.cin + ci) * p.cout;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const float t2 = wk[(long long)st * p.cout];
+            bv[st] = col_ok ? t2 : 0.f;
+        }
+    };
+
+    // the loads of a batch of DEPTH groups are all in flight while the previous batch feeds the matrix pipe
+    // (one group = 4 MFMAs = 0.1 us, an L2 round trip is several times that)
+    constexpr int DEPTH = 6;
+    float4 a_cur[DEPTH], a_nxt[DEPTH];
+    float b_cur[DEPTH][4], b_nxt[DEPTH][4];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (g_begin + d < g_end) load_group(g_begin + d, a_cur[d], b_cur[d]);
+    for (int g = g_begin; g < g_end; g += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+            if (g + DEPTH + d < g_end) load_group(g + DEPTH + d, a_nxt[d], b_nxt[d]);
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (g + d < g_end) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[d].x, b_cur[d][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[d].y, b_cur[d][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[d].z, b_cur[d][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[d].w, b_cur[d][3], acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            a_cur[d] = a_nxt[d];
+#pragma unroll
+            for (int st = 0; st < 4; ++st) b_cur[d][st] = b_nxt[d][st];
+        }
+    }
+    // reduce the four K quarters: waves 1..3 park their partial tile in LDS, wave 0 adds them in wave order
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0 && col_ok) {
+        const float bias = p.bias ? p.bias[col] : 0.f;
+        const float slope = p.alpha ? p.alpha[col] : p.leaky;
+        const bool act = p.alpha != nullptr || p.use_leaky;
+        float *ob = p.out + (long long)b * p.out_bstride;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (row < rows) {
+                float v = ((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane] + bias;
+                if (act) v = v > 0.f ? v : slope * v;
+                ob[(long long)row * p.ldo + col] = v;
+            }
+        }
+    }
+}
+
 static int env_int(const char *name, int dflt) {
     const char *v = getenv(name);
     return v ? atoi(v) : dflt;
@@ -613,6 +711,11 @@ void launch_conv1d(const ConvArgs &a, int epilogue, hipStream_t stream) {
         if (done) return;
         if (rs_cfg == 0) launch_cfg<2, 2, 2, 2, EPI_RESSKIP>(a, stream, extra_lds);        // 128 x 128
         else launch_cfg<2, 2, 1, 2, EPI_RESSKIP>(a, stream, extra_lds);                    // 64 x 128
+    } else if ((long long)a.max_rows * a.batch <= 8192 && a.cin % 8 == 0 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 &&
+               (uintptr_t)a.x % 16 == 0 && env_int("MBX_NO_SMALL", 0) == 0) {
+        // mel-rate sub-nets at small batch: latency bound, split-K 32x32 tiles
+        dim3 grid((a.max_rows + 31) / 32, (a.cout + 31) / 32, a.batch);
+        hipLaunchKernelGGL(conv1d_small_kernel, grid, dim3(256), 0, stream, a);
     } else if (a.cout <= 32) {
         launch_cfg<4, 1, 1, 1, EPI_LINEAR>(a, stream);        // 128 x 32 (F0 head, post-net, end)
     } else if ((long long)a.max_rows * a.batch >= 4096 && a.cout >= 128) {

@@ -19,14 +19,15 @@ __device__ __forceinline__ float mod1(float x) { return x - floorf(x); }   // x 
 // (1) one wavefront per (item, chunk): the 64 lanes load the chunk coalesced and convert to phase velocity,
 // lane 0 then runs the sequential float32 sum out of LDS (4 values per ds_read_b128), and the lanes write
 // the running sums back coalesced.  The chain of 1000 dependent adds (~4 us) is the floor of this stage.
-constexpr int PHASE_MAX_CHUNK = 1024;
+constexpr int PHASE_MAX_CHUNK = 1024;   // multiple of 16
 
 __global__ __launch_bounds__(64) void phase_chunk_kernel(const float *__restrict__ f0, long long bstride,
                                                           const int *__restrict__ n_frames, int samples_per_frame,
                                                           int n_max, int chunk, float pulse_rate,
                                                           float *__restrict__ cum, float *__restrict__ chunk_last,
                                                           int chunks_max) {
-    __shared__ __attribute__((aligned(16))) float v[PHASE_MAX_CHUNK];
+    __shared__ __attribute__((aligned(16))) float vin[PHASE_MAX_CHUNK];
+    __shared__ __attribute__((aligned(16))) float vout[PHASE_MAX_CHUNK];
     const int b = blockIdx.y;
     const int c = blockIdx.x;
     const int n = n_frames ? n_frames[b] * samples_per_frame : n_max;
@@ -36,24 +37,31 @@ __global__ __launch_bounds__(64) void phase_chunk_kernel(const float *__restrict
     float *cb = cum + (long long)b * bstride;
     const int begin = c * chunk;
     const int len = min(chunk, n - begin);
-    const int padded = (len + 3) & ~3;
+    const int padded = (len + 15) & ~15;
     // phase velocity = frequency / sample_rate (tf_wavetable.py:516); the reference zero-pads the last chunk
-    for (int i = threadIdx.x; i < padded; i += 64) v[i] = i < len ? fb[begin + i] / pulse_rate : 0.f;
+    for (int i = threadIdx.x; i < padded; i += 64) vin[i] = i < len ? fb[begin + i] / pulse_rate : 0.f;
     __syncthreads();
     if (threadIdx.x == 0) {
+        // separate input / output images and 16 values per trip: the LDS reads of the next values are in flight
+        // while the dependent chain of float32 adds (the only serial part) advances
         float acc = 0.f;
-        for (int i = 0; i < padded; i += 4) {
-            float4 q = *reinterpret_cast<float4 *>(&v[i]);
-            acc = acc + q.x; q.x = acc;
-            acc = acc + q.y; q.y = acc;
-            acc = acc + q.z; q.z = acc;
-            acc = acc + q.w; q.w = acc;
-            *reinterpret_cast<float4 *>(&v[i]) = q;
+        for (int i = 0; i < padded; i += 16) {
+            float4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const float4 *>(&vin[i + 4 * u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc = acc + q[u].x; q[u].x = acc;
+                acc = acc + q[u].y; q[u].y = acc;
+                acc = acc + q[u].z; q[u].z = acc;
+                acc = acc + q[u].w; q[u].w = acc;
+                *reinterpret_cast<float4 *>(&vout[i + 4 * u]) = q[u];
+            }
         }
         chunk_last[(long long)b * chunks_max + c] = acc;   // adding the padding zeros leaves the sum unchanged
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < len; i += 64) cb[begin + i] = v[i];
+    for (int i = threadIdx.x; i < len; i += 64) cb[begin + i] = vout[i];
 }
 
 // (2)+(3) one thread per sample
