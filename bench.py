@@ -49,6 +49,22 @@ def synthetic_batch(rng, batch, frames, steps_per_frame):
     return mell, noise
 
 
+def pmc_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+    in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); null when no profile of
+    this workload has been committed.  Regenerate with scripts/profile_round.sh + scripts/summarize_profiles.py."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as fi:
+            data = json.load(fi)
+        return data[workload]["gate"]["hbm_bytes_per_launch"]
+    except (KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(cfg, raw, wt, seconds=3.0):
     """The oracle (numpy float32 port of the reference graph) timed on the host cores, on a bounded sample
     (one 3 s utterance, the reference's own CPU-runnable case configs[0]); timing protocol of the reference
@@ -162,9 +178,10 @@ def main():
             "config": {"workload": f"{args.workload}: MW-{voice[:2]}-FD canonical (C={C}, L={L}), batch {batch} x "
                                    f"{frames / 80:g} s per GPU, 80x{frames} synthetic mel, seeded synthetic weights",
                        "batch_per_gpu": batch, "frames": frames, "parallelism": f"utterance-sharded x{world}"},
-            "roofline": {"bound": "mfma", "kernel": "conv1d_mfma_kernel<EPI_GATE> (dilated conv k=3 C->2C + gate)",
+            "roofline": {"bound": "mfma", "kernel": "conv1d_mfma_dma_kernel<EPI_GATE> (dilated conv k=3 C->2C + cond + tanh*sigmoid)",
                          "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": pmc_traffic(args.workload),
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
                          "flop_per_launch": gate_flop, "avg_launch_ms": gate_avg_s * 1e3, "launches_timed": gate_n,
                          "res_skip_avg_launch_ms": rs_ms / max(rs_n, 1)},
         }
