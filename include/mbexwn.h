@@ -120,6 +120,27 @@ mbx_status mbx_forward(mbx_handle *handle, const float *mel, const int32_t *n_fr
                        int32_t max_frames, const float *noise, float *audio, void *workspace,
                        size_t workspace_bytes, void *hip_stream);
 
+/* Streaming (BASELINE config 5): the graph is non-causal but has a finite receptive field, except for the wavetable
+ * phase accumulator (reference tf_wavetable.py:429-492), which is causal with unbounded memory.  A stream is served
+ * by windows [t0 - left, t0 + chunk + lookahead) of its mel frames; the caller keeps the middle `chunk` frames of
+ * audio.  mbx_forward_stream is mbx_forward plus the carried accumulator state, so that the phase inside the window
+ * is bit-identical to the whole-utterance run (state layout: see mbexwn_vocoder_amd/streaming.py).
+ *   state_in[b]  : state valid just in front of window pulse-sample start_sample (samples before it give pulse 0)
+ *   state_out[b] : state just in front of window pulse-sample save_sample (the next window's start); may be NULL */
+typedef struct {
+    float cum;             /* running float32 sum of the 1000-sample chunk in progress */
+    float offset_sum;      /* un-wrapped float32 sum of (chunk total mod 1) over the finished chunks */
+    int32_t pos_in_chunk;  /* position of start_sample inside its chunk (0 .. phase_chunk-1) */
+    int32_t start_sample;  /* window-relative pulse-rate sample index the state applies to */
+    int32_t save_sample;   /* window-relative sample whose state goes to state_out (< start_sample: none) */
+    int32_t reserved;
+} mbx_stream_state;
+
+mbx_status mbx_forward_stream(mbx_handle *handle, const float *mel, const int32_t *n_frames, int32_t batch,
+                              int32_t max_frames, const float *noise, float *audio, void *workspace,
+                              size_t workspace_bytes, const mbx_stream_state *state_in, mbx_stream_state *state_out,
+                              void *hip_stream);
+
 /* Intermediate tensors of the most recent mbx_forward (pointers into its workspace), for stage parity
  * tests.  Names: "f0" "pulse" "cond" "wn_hidden" "wn_skip" "wn_out" "subbands" "excitation" "cepstrum"
  * "ceps_index" "frames".  `count` = floats (int32 for ceps_index) per batch item, `stride` = item stride. */
@@ -152,7 +173,7 @@ mbx_status mbx_lin_interp(mbx_handle *handle, const float *x, int32_t batch, int
                           int32_t up, float *y, void *hip_stream);
 
 /* PulseWaveTable.call (reference tf_wavetable.py:495-552): f0 (batch, n) Hz -> pulse (batch, n);
- * phase (batch, n) optional output of stable_cumsum_and_wrap (may be NULL). scratch >= batch*(n + n/chunk + 2) floats. */
+ * phase (batch, n) optional output of stable_cumsum_and_wrap (may be NULL). scratch >= batch*(n + n/chunk + 3) floats. */
 mbx_status mbx_wavetable(mbx_handle *handle, const float *f0, int32_t batch, int32_t n, float *pulse, float *phase,
                          float *scratch, void *hip_stream);
 

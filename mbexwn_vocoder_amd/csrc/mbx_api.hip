@@ -117,7 +117,7 @@ Workspace carve(const mbx_handle *hd, char *base, int B, int T) {
     };
     const size_t BT = (size_t)B * T;
     const size_t npulse = (size_t)T * c.pulse_per_frame, nsteps = (size_t)T * c.steps_per_frame;
-    const int chunks = (int)((npulse + c.phase_chunk - 1) / c.phase_chunk);
+    const int chunks = (int)((npulse + c.phase_chunk - 1) / c.phase_chunk) + 1;
     w.sub0 = take(BT * hd->subnet_buf_per_frame);
     w.sub1 = take(BT * hd->subnet_buf_per_frame);
     w.f0 = take(B * npulse);
@@ -500,8 +500,10 @@ size_t mbx_workspace_size(const mbx_handle *handle, int32_t batch, int32_t max_f
     return carve(handle, nullptr, batch, max_frames).total;
 }
 
-mbx_status mbx_forward(mbx_handle *hd, const float *mel, const int32_t *n_frames, int32_t batch, int32_t max_frames,
-                       const float *noise, float *audio, void *workspace, size_t workspace_bytes, void *hip_stream) {
+static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *n_frames, int32_t batch,
+                               int32_t max_frames, const float *noise, float *audio, void *workspace,
+                               size_t workspace_bytes, const mbx::StreamState *st_in, mbx::StreamState *st_out,
+                               void *hip_stream) {
     if (!hd || !mel || !audio || !workspace) return fail(MBX_ERR_INVALID_ARGUMENT, "null argument");
     if (batch <= 0 || max_frames <= 0) return fail(MBX_ERR_INVALID_ARGUMENT, "batch and max_frames must be positive");
     const mbx_config &c = hd->cfg;
@@ -520,7 +522,7 @@ mbx_status mbx_forward(mbx_handle *hd, const float *mel, const int32_t *n_frames
     if (st != MBX_OK) return st;
     // ---- wavetable excitation (reference :889)
     mbx::launch_wavetable(wavetable_consts(hd), w.f0, npulse, n_frames, c.pulse_per_frame, (int)npulse, B, w.pulse,
-                          nullptr, w.cum, w.chunk_last, stream);
+                          nullptr, w.cum, w.chunk_last, st_in, st_out, stream);
     // ---- WaveNet (reference custom_AE_layers.py:273-346)
     const DevTensor *cw = find(hd, "wn.cond.w"), *cbias = find(hd, "wn.cond.b");
     const int cond_cout = 2 * C * c.cond_conv_upsampling;
@@ -610,6 +612,23 @@ mbx_status mbx_forward(mbx_handle *hd, const float *mel, const int32_t *n_frames
     return MBX_OK;
 }
 
+mbx_status mbx_forward(mbx_handle *hd, const float *mel, const int32_t *n_frames, int32_t batch, int32_t max_frames,
+                       const float *noise, float *audio, void *workspace, size_t workspace_bytes, void *hip_stream) {
+    return forward_impl(hd, mel, n_frames, batch, max_frames, noise, audio, workspace, workspace_bytes, nullptr, nullptr,
+                        hip_stream);
+}
+
+mbx_status mbx_forward_stream(mbx_handle *hd, const float *mel, const int32_t *n_frames, int32_t batch,
+                              int32_t max_frames, const float *noise, float *audio, void *workspace,
+                              size_t workspace_bytes, const mbx_stream_state *state_in, mbx_stream_state *state_out,
+                              void *hip_stream) {
+    static_assert(sizeof(mbx_stream_state) == sizeof(mbx::StreamState), "stream state layout");
+    if (!state_in) return fail(MBX_ERR_INVALID_ARGUMENT, "state_in is required (use mbx_forward for whole utterances)");
+    return forward_impl(hd, mel, n_frames, batch, max_frames, noise, audio, workspace, workspace_bytes,
+                        reinterpret_cast<const mbx::StreamState *>(state_in),
+                        reinterpret_cast<mbx::StreamState *>(state_out), hip_stream);
+}
+
 mbx_status mbx_profile_enable(mbx_handle *handle, int32_t enabled) {
     if (!handle) return fail(MBX_ERR_INVALID_ARGUMENT, "null argument");
     handle->profiling = enabled != 0;
@@ -691,8 +710,8 @@ mbx_status mbx_wavetable(mbx_handle *hd, const float *f0, int32_t batch, int32_t
     if (!hd || !f0 || !pulse || !scratch || batch <= 0 || n <= 0) return fail(MBX_ERR_INVALID_ARGUMENT, "bad argument");
     float *cum = scratch;
     float *chunk_last = scratch + (size_t)batch * n;
-    mbx::launch_wavetable(wavetable_consts(hd), f0, n, nullptr, 1, n, batch, pulse, phase, cum, chunk_last,
-                          static_cast<hipStream_t>(hip_stream));
+    mbx::launch_wavetable(wavetable_consts(hd), f0, n, nullptr, 1, n, batch, pulse, phase, cum, chunk_last, nullptr,
+                          nullptr, static_cast<hipStream_t>(hip_stream));
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MBX_OK : fail(MBX_ERR_HIP, hipGetErrorString(e));
 }

@@ -84,10 +84,19 @@ struct WaveTableConsts {
     float pulse_rate, nominal_f0, min_tf, max_tf, grid_norm;
     int chunk;
 };
-// f0 (B, n_max) -> pulse (B, n_max); cum / chunk_last are scratch: cum (B, n_max), chunk_last (B, n_chunks_max)
+// carried phase-accumulator state of a stream (== mbx_stream_state of include/mbexwn.h)
+struct StreamState {
+    float cum;            // running sum of the chunk in progress, just in front of start_sample
+    float offset_sum;     // un-wrapped sum of (chunk totals mod 1) of all finished chunks
+    int pos_in_chunk;     // position of start_sample inside its 1000-sample chunk
+    int start_sample;     // window-relative pulse sample the state applies to
+    int save_sample;      // window-relative pulse sample whose state is written to the output (< start: none)
+    int reserved;
+};
+// f0 (B, n_max) -> pulse (B, n_max); cum / chunk_last are scratch: cum (B, n_max), chunk_last (B, n_chunks_max + 1)
 void launch_wavetable(const WaveTableConsts &c, const float *f0, long long bstride, const int *n_frames,
                       int samples_per_frame, int n_max, int batch, float *pulse, float *phase_out, float *cum,
-                      float *chunk_last, hipStream_t stream);
+                      float *chunk_last, const StreamState *st_in, StreamState *st_out, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // PQMF synthesis (pqmf.hip)

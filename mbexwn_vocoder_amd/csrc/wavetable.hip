@@ -21,22 +21,41 @@ __device__ __forceinline__ float mod1(float x) { return x - floorf(x); }   // x 
 // the running sums back coalesced.  The chain of 1000 dependent adds (~4 us) is the floor of this stage.
 constexpr int PHASE_MAX_CHUNK = 1024;   // multiple of 16
 
+// Streaming: an item may start in the middle of a reference chunk.  `st` (optional) gives, per item, the window
+// sample `start` where the carried state applies, the position `pos` of that sample inside its 1000-sample chunk
+// and the running sum `cum` reached just before it; chunk 0 of the window is then the remainder of that chunk.
+__device__ __forceinline__ void chunk_range(const StreamState *st, int b, int chunk, int c, int n, int &begin, int &end,
+                                            float &acc0) {
+    const int start = st ? st[b].start_sample : 0;
+    const int first_len = st ? chunk - st[b].pos_in_chunk : chunk;
+    if (c == 0) {
+        begin = start;
+        end = min(start + first_len, n);
+        acc0 = st ? st[b].cum : 0.f;
+    } else {
+        begin = start + first_len + (c - 1) * chunk;
+        end = min(begin + chunk, n);
+        acc0 = 0.f;
+    }
+}
+
 __global__ __launch_bounds__(64) void phase_chunk_kernel(const float *__restrict__ f0, long long bstride,
                                                           const int *__restrict__ n_frames, int samples_per_frame,
                                                           int n_max, int chunk, float pulse_rate,
                                                           float *__restrict__ cum, float *__restrict__ chunk_last,
-                                                          int chunks_max) {
+                                                          int chunks_max, const StreamState *__restrict__ st) {
     __shared__ __attribute__((aligned(16))) float vin[PHASE_MAX_CHUNK];
     __shared__ __attribute__((aligned(16))) float vout[PHASE_MAX_CHUNK];
     const int b = blockIdx.y;
     const int c = blockIdx.x;
     const int n = n_frames ? n_frames[b] * samples_per_frame : n_max;
-    const int n_chunks = (n + chunk - 1) / chunk;
-    if (c >= n_chunks) return;
+    int begin, end;
+    float acc0;
+    chunk_range(st, b, chunk, c, n, begin, end, acc0);
+    if (begin >= end) return;
     const float *fb = f0 + (long long)b * bstride;
     float *cb = cum + (long long)b * bstride;
-    const int begin = c * chunk;
-    const int len = min(chunk, n - begin);
+    const int len = end - begin;
     const int padded = (len + 15) & ~15;
     // phase velocity = frequency / sample_rate (tf_wavetable.py:516); the reference zero-pads the last chunk
     for (int i = threadIdx.x; i < padded; i += 64) vin[i] = i < len ? fb[begin + i] / pulse_rate : 0.f;
@@ -44,7 +63,7 @@ __global__ __launch_bounds__(64) void phase_chunk_kernel(const float *__restrict
     if (threadIdx.x == 0) {
         // separate input / output images and 16 values per trip: the LDS reads of the next values are in flight
         // while the dependent chain of float32 adds (the only serial part) advances
-        float acc = 0.f;
+        float acc = acc0;
         for (int i = 0; i < padded; i += 16) {
             float4 q[4];
 #pragma unroll
@@ -67,17 +86,26 @@ __global__ __launch_bounds__(64) void phase_chunk_kernel(const float *__restrict
 // (2)+(3) one thread per sample
 __global__ void wavetable_kernel(WaveTableConsts k, const float *f0, long long bstride, const int *n_frames,
                                  int samples_per_frame, int n_max, const float *cum, const float *chunk_last,
-                                 int chunks_max, float *pulse, float *phase_out) {
+                                 int chunks_max, float *pulse, float *phase_out, const StreamState *st) {
     const int b = blockIdx.y;
     const int n = n_frames ? n_frames[b] * samples_per_frame : n_max;
     const float *fb = f0 + (long long)b * bstride;
     const float *cb = cum + (long long)b * bstride;
     const float *lb = chunk_last + (long long)b * chunks_max;
     float *pb = pulse + (long long)b * bstride;
+    const int start = st ? st[b].start_sample : 0;
+    const int first_len = st ? k.chunk - st[b].pos_in_chunk : k.chunk;
+    const float off0 = st ? st[b].offset_sum : 0.f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int c = i / k.chunk;
+        if (i < start) {          // streaming: samples in front of the carried state are not reproducible
+            pb[i] = 0.f;
+            if (phase_out) phase_out[(long long)b * bstride + i] = 0.f;
+            continue;
+        }
+        const int rel = i - start;
+        const int c = rel < first_len ? 0 : 1 + (rel - first_len) / k.chunk;
         // offset of chunk c = (sum_{j < c} (last_j mod 1)) mod 1, summed in chunk order (tf_wavetable.py:476-483)
-        float off = 0.f;
+        float off = off0;
         for (int j = 0; j < c; ++j) off = off + mod1(lb[j]);
         off = mod1(off);
         const float phase = mod1(cb[i] + off);
@@ -109,16 +137,40 @@ __global__ void wavetable_kernel(WaveTableConsts k, const float *f0, long long b
     }
 }
 
+// state of the accumulator just in front of window sample `save_sample` (one thread per item)
+__global__ void phase_state_kernel(int chunk, const float *cum, long long bstride, const float *chunk_last,
+                                   int chunks_max, const StreamState *st, StreamState *out, int batch) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    StreamState o = st[b];
+    const int save = st[b].save_sample;
+    if (save >= st[b].start_sample) {
+        const int rel = save - st[b].start_sample;
+        const int first_len = chunk - st[b].pos_in_chunk;
+        const int c = rel < first_len ? 0 : 1 + (rel - first_len) / chunk;
+        const int pos = rel < first_len ? st[b].pos_in_chunk + rel : (rel - first_len) % chunk;
+        float off = st[b].offset_sum;
+        for (int j = 0; j < c; ++j) off = off + mod1(chunk_last[(long long)b * chunks_max + j]);
+        o.cum = pos == 0 ? 0.f : (rel == 0 ? st[b].cum : cum[(long long)b * bstride + save - 1]);
+        o.offset_sum = off;
+        o.pos_in_chunk = pos;
+    }
+    out[b] = o;
+}
+
 void launch_wavetable(const WaveTableConsts &c, const float *f0, long long bstride, const int *n_frames,
                       int samples_per_frame, int n_max, int batch, float *pulse, float *phase_out, float *cum,
-                      float *chunk_last, hipStream_t stream) {
+                      float *chunk_last, const StreamState *st_in, StreamState *st_out, hipStream_t stream) {
     if (n_max <= 0 || batch <= 0) return;
-    const int chunks_max = (n_max + c.chunk - 1) / c.chunk;
+    const int chunks_max = (n_max + c.chunk - 1) / c.chunk + 1;
     hipLaunchKernelGGL(phase_chunk_kernel, dim3(chunks_max, batch), dim3(64), 0, stream, f0, bstride,
-                       n_frames, samples_per_frame, n_max, c.chunk, c.pulse_rate, cum, chunk_last, chunks_max);
+                       n_frames, samples_per_frame, n_max, c.chunk, c.pulse_rate, cum, chunk_last, chunks_max, st_in);
     const int blocks = min((n_max + 255) / 256, 1024);
     hipLaunchKernelGGL(wavetable_kernel, dim3(blocks, batch), dim3(256), 0, stream, c, f0, bstride, n_frames,
-                       samples_per_frame, n_max, cum, chunk_last, chunks_max, pulse, phase_out);
+                       samples_per_frame, n_max, cum, chunk_last, chunks_max, pulse, phase_out, st_in);
+    if (st_in && st_out)
+        hipLaunchKernelGGL(phase_state_kernel, dim3((batch + 63) / 64), dim3(64), 0, stream, c.chunk, cum, bstride,
+                           chunk_last, chunks_max, st_in, st_out, batch);
 }
 
 }  // namespace mbx

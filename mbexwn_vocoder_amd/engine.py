@@ -93,6 +93,8 @@ def load_library():
     lib.mbx_workspace_size.argtypes = [vp, i32, i32]
     lib.mbx_forward.restype = i32
     lib.mbx_forward.argtypes = [vp, fp, vp, i32, i32, fp, fp, vp, ctypes.c_size_t, vp]
+    lib.mbx_forward_stream.restype = i32
+    lib.mbx_forward_stream.argtypes = [vp, fp, vp, i32, i32, fp, fp, vp, ctypes.c_size_t, vp, vp, vp]
     lib.mbx_stage.restype = i32
     lib.mbx_stage.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p), i64p, i64p]
     lib.mbx_profile_enable.restype = i32
@@ -113,7 +115,8 @@ def load_library():
     return lib
 
 
-EXPORTED_SYMBOLS = ["mbx_last_error", "mbx_create", "mbx_destroy", "mbx_workspace_size", "mbx_forward", "mbx_stage",
+EXPORTED_SYMBOLS = ["mbx_last_error", "mbx_create", "mbx_destroy", "mbx_workspace_size", "mbx_forward",
+                    "mbx_forward_stream", "mbx_stage",
                     "mbx_profile_enable", "mbx_profile_read", "mbx_pqmf_synthesis", "mbx_conv1d", "mbx_lin_interp", "mbx_wavetable", "mbx_stft_filter"]
 
 
@@ -293,9 +296,12 @@ class MBExWNEngine:
             self._workspace = self._torch.empty(need, dtype=self._torch.uint8, device=self.device)
         return self._workspace, need
 
-    def forward(self, mel, n_frames=None, noise=None, out=None):
+    def forward(self, mel, n_frames=None, noise=None, out=None, stream_state=None):
         """mel (B,T,80) float32 cuda tensor; n_frames int32 cuda tensor (B,) or None;
-        noise (B, T*steps_per_frame) float32 cuda tensor (N(0,1) draw) -> audio (B, T*hop) cuda tensor."""
+        noise (B, T*steps_per_frame) float32 cuda tensor (N(0,1) draw) -> audio (B, T*hop) cuda tensor.
+
+        stream_state: optional int32 cuda tensor (B, 6) holding one ``mbx_stream_state`` per item (see
+        streaming.pack_state); the call then returns (audio, state_out) with the carried phase state."""
         torch = self._torch
         if mel.dim() != 3 or mel.shape[2] != self.dims.mel_channels:
             raise ValueError(f"mel must be (batch, frames, {self.dims.mel_channels})")
@@ -319,6 +325,18 @@ class MBExWNEngine:
         if out is None:
             out = torch.empty((B, T * self.dims.hop_size), dtype=torch.float32, device=self.device)
         ws, need = self._get_workspace(B, T)
+        if stream_state is not None:
+            if stream_state.dtype != torch.int32 or tuple(stream_state.shape) != (B, 6) or stream_state.device != self.device:
+                raise ValueError("stream_state must be an int32 tensor of shape (batch, 6) on the engine's device")
+            stream_state = stream_state.contiguous()
+            state_out = torch.empty_like(stream_state)
+            _check(self._lib.mbx_forward_stream(self._handle, mel.data_ptr(),
+                                                n_frames.data_ptr() if n_frames is not None else None, B, T,
+                                                noise.data_ptr() if noise is not None else None, out.data_ptr(),
+                                                ws.data_ptr(), need, stream_state.data_ptr(), state_out.data_ptr(),
+                                                self._stream()))
+            self._last_shape = (B, T)
+            return out, state_out
         _check(self._lib.mbx_forward(self._handle, mel.data_ptr(),
                                      n_frames.data_ptr() if n_frames is not None else None, B, T,
                                      noise.data_ptr() if noise is not None else None, out.data_ptr(),
@@ -402,7 +420,7 @@ class MBExWNEngine:
         B, N = f0.shape
         pulse = torch.empty_like(f0)
         phase = torch.empty_like(f0)
-        scratch = torch.empty(B * (N + N // 1000 + 2), dtype=torch.float32, device=self.device)
+        scratch = torch.empty(B * (N + N // 1000 + 3), dtype=torch.float32, device=self.device)
         _check(self._lib.mbx_wavetable(self._handle, f0.data_ptr(), B, N, pulse.data_ptr(), phase.data_ptr(),
                                        scratch.data_ptr(), self._stream()))
         return pulse, phase

@@ -1,0 +1,162 @@
+"""Chunked (streaming) mel inversion that reproduces the whole-utterance output.
+
+The reference has no streaming mode: its graph is non-causal (``padding="SAME"``) and the author notes that causal
+operation "would require a dedicated implementation" (reference custom_pulsed_generator.py:213-217).  This module
+serves BASELINE config 5 (many concurrent streams, short ticks) on top of the offline engine:
+
+* every op of the graph has a finite receptive field, so the audio of mel frames [t0, t0+chunk) only depends on
+  the mel frames [t0-LEFT, t0+chunk+RIGHT): a tick runs the engine on that window and keeps the middle;
+* the one unbounded dependency is the wavetable phase accumulator (float32 running sum in 1000-sample chunks,
+  reference tf_wavetable.py:429-492): its state (running sum of the chunk in progress, un-wrapped offset sum,
+  position in the chunk) is carried from tick to tick through ``mbx_forward_stream`` -- the phase inside a window is
+  then bit-identical to the offline phase;
+* at the true start / end of an utterance the window edge IS the utterance edge, so the reference's boundary
+  semantics (symmetric / zero padding, un-normalised head and tail of the inverse STFT) apply where they should.
+
+Receptive field in mel frames (canonical model): F0-net 3 convs k=3 (+-3) and the interpolator (+1); the phase needs
+valid F0, so pulses are valid from window frame 4; WaveNet (dilations 1..16, k=3: +-31 steps = +-2 frames) -> 6;
+PQMF (+-4 steps) -> 7; STFT frame + overlap-add (-3 / +4 frames) -> LEFT = 10, RIGHT = 11 (look-ahead 137.5 ms).
+``StreamingSynthesizer`` derives the margins from the model configuration.
+"""
+import numpy as np
+
+
+def pack_state(cum=0.0, offset_sum=0.0, pos_in_chunk=0, start_sample=0, save_sample=-1):
+    """One ``mbx_stream_state`` as 6 int32 words (floats bit-cast)."""
+    ff = np.asarray([cum, offset_sum], dtype=np.float32).view(np.int32)
+    return np.asarray([ff[0], ff[1], pos_in_chunk, start_sample, save_sample, 0], dtype=np.int32)
+
+
+def stream_margins(dims, config):
+    """(left, right, pulse_lead) in mel frames, from the layer geometry of the model."""
+    mb = config["mbexwn_config"]
+
+    def subnet_reach(specs):
+        left = right = 0
+        for spec in specs:
+            if spec[0] == "L":
+                continue
+            ks = int(spec[0])
+            left += (ks - 1) // 2 + ((ks - 1) % 2)
+            right += (ks - 1) // 2
+        return left, right
+
+    f0_l, f0_r = subnet_reach(mb["pp_subnet"])
+    f0_r += 1                                             # interpolation towards the next frame
+    spf = dims.steps_per_frame
+    wn_steps = sum(dims.wn_dilation(ll) * (dims.wn_kernel_size - 1) // 2 for ll in range(dims.wn_layers))
+    wn_frames = -(-wn_steps // spf)
+    pqmf_frames = -(-(int(mb["multi_band_config"]["taps"]) // 2) // dims.hop_size)
+    cond_r = (dims.cond_kernel_size - 1) // 2 + 1
+    stft_l, stft_r = 3, 4                                  # frame t reaches excitation frames t-3 .. t+4
+    pulse_lead = f0_l + 1                                  # first window frame with reproducible F0 / phase
+    left = pulse_lead + wn_frames + pqmf_frames + stft_l
+    right = max(f0_r, cond_r) + wn_frames + pqmf_frames + stft_r
+    smooth = 3                                             # F0 smoother of the lifter selection: +-3 frames of valid F0
+    left = max(left, pulse_lead + smooth + 1)
+    right = max(right, f0_r + smooth + 2)
+    return left, right, pulse_lead
+
+
+class _Stream:
+    def __init__(self, mel_channels):
+        self.mel = np.zeros((0, mel_channels), dtype=np.float32)
+        self.noise = np.zeros((0,), dtype=np.float32)
+        self.emitted = 0          # frames of audio already produced
+        self.closed = False
+        # phase state valid just in front of absolute pulse sample `state_frame * pulse_per_frame`
+        self.state = (0.0, 0.0, 0)
+        self.state_frame = 0
+
+
+class StreamingSynthesizer:
+    """Serves any number of concurrent streams with one batched engine call per tick."""
+
+    def __init__(self, engine, chunk_frames=8):
+        self.engine = engine
+        self.dims = engine.dims
+        self.chunk = int(chunk_frames)
+        self.left, self.right, self.lead = stream_margins(engine.dims, engine.config)
+        self.streams = {}
+
+    @property
+    def lookahead_ms(self):
+        return 1000.0 * self.right * self.dims.hop_size / self.dims.sample_rate
+
+    def open(self, stream_id):
+        self.streams[stream_id] = _Stream(self.dims.mel_channels)
+
+    def push(self, stream_id, mel_frames, noise=None, last=False):
+        """Append mel frames (n, mel_channels) and the matching N(0,1) draw (n*steps_per_frame,) to a stream."""
+        st = self.streams[stream_id]
+        mel_frames = np.asarray(mel_frames, dtype=np.float32).reshape(-1, self.dims.mel_channels)
+        st.mel = np.concatenate((st.mel, mel_frames), axis=0)
+        if self.dims.noise_sigma:
+            if noise is None:
+                raise ValueError("noise is required (explicit input of the path)")
+            st.noise = np.concatenate((st.noise, np.asarray(noise, dtype=np.float32).ravel()))
+        st.closed = st.closed or last
+
+    def _ready(self, st):
+        have = st.mel.shape[0]
+        if st.emitted >= have:
+            return 0
+        if st.closed:
+            return min(self.chunk, have - st.emitted)
+        return self.chunk if have >= st.emitted + self.chunk + self.right else 0
+
+    def tick(self):
+        """One batched engine call over every stream that can emit. Returns {stream_id: audio ndarray}."""
+        import torch
+        todo = [(sid, st, self._ready(st)) for sid, st in self.streams.items()]
+        todo = [(sid, st, nn) for sid, st, nn in todo if nn > 0]
+        if not todo:
+            return {}
+        ppf, spf, hop = self.dims.pulse_per_frame, self.dims.steps_per_frame, self.dims.hop_size
+        windows = []
+        for sid, st, nn in todo:
+            have = st.mel.shape[0]
+            ws = max(0, st.emitted - self.left)
+            we = have if st.closed and st.emitted + nn + self.right >= have else st.emitted + nn + self.right
+            we = min(we, have)
+            windows.append((ws, we))
+        tmax = max(we - ws for ws, we in windows)
+        B = len(todo)
+        mel = np.zeros((B, tmax, self.dims.mel_channels), dtype=np.float32)
+        noise = np.zeros((B, tmax * spf), dtype=np.float32)
+        nfr = np.zeros((B,), dtype=np.int32)
+        states = np.zeros((B, 6), dtype=np.int32)
+        next_state_frame = []
+        for bb, ((sid, st, nn), (ws, we)) in enumerate(zip(todo, windows)):
+            mel[bb, :we - ws] = st.mel[ws:we]
+            if self.dims.noise_sigma:
+                noise[bb, :(we - ws) * spf] = st.noise[ws * spf:we * spf]
+            nfr[bb] = we - ws
+            # the carried state sits at frame st.state_frame (>= ws + lead, or 0 at the utterance start): pulses are
+            # reproducible from there on.  The next state is captured where the NEXT window's reproducible region
+            # starts: `lag` = left - lead frames in front of the next emit position.
+            nxt = max(st.state_frame, st.emitted + nn - (self.left - self.lead))
+            cum, off, pos = st.state
+            states[bb] = pack_state(cum, off, pos, (st.state_frame - ws) * ppf,
+                                    (nxt - ws) * ppf if nxt < we else -1)
+            next_state_frame.append(nxt)
+        dev = self.engine.device
+        audio, state_out = self.engine.forward(torch.as_tensor(mel, device=dev), n_frames=torch.as_tensor(nfr, device=dev),
+                                               noise=torch.as_tensor(noise, device=dev) if self.dims.noise_sigma else None,
+                                               stream_state=torch.as_tensor(states, device=dev))
+        audio = audio.cpu().numpy()
+        state_out = state_out.cpu().numpy()
+        result = {}
+        for bb, ((sid, st, nn), (ws, we)) in enumerate(zip(todo, windows)):
+            a0 = (st.emitted - ws) * hop
+            result[sid] = audio[bb, a0:a0 + nn * hop].copy()
+            st.emitted += nn
+            if next_state_frame[bb] < we:
+                ff = state_out[bb, :2].copy().view(np.float32)
+                st.state = (float(ff[0]), float(ff[1]), int(state_out[bb, 2]))
+                st.state_frame = next_state_frame[bb]
+        return result
+
+    def finished(self, stream_id):
+        st = self.streams[stream_id]
+        return st.closed and st.emitted >= st.mel.shape[0]
