@@ -74,9 +74,12 @@ def main(model_id, input_mell_files, output_dir, use_gpu=False, sigma=None, form
         syn_audio = MelInv.synth_from_mel(log_mel_spectrogram)
         end_time = time.time()
 
-        if verbose:
+        if verbose:                                  # reference :90-96
+            mel_resyn = MelInv.generate_mel_from_snd(syn_audio, srate=MelInv.srate)['mell'].T[np.newaxis]
+            mell_err = mel_inverter.log_to_db * np.mean(np.abs(log_mel_spectrogram
+                                                               - mel_resyn[:, :log_mel_spectrogram.shape[1]]))
             print(f"    synthesized audio with {syn_audio.size} samples in {end_time - start_time:.3f}s "
-                  f"({syn_audio.size / (end_time - start_time):.2f}Hz)", file=sys.stderr)
+                  f"({syn_audio.size / (end_time - start_time):.2f}Hz), mel_error: {mell_err:.3f}dB", file=sys.stderr)
         if np.max(np.abs(syn_audio)) > 1:
             norm = 0.99 / np.max(np.abs(syn_audio))
             print(f'    to prevent clipping you would need to normalize {outfile} by {norm:.3f}', file=sys.stderr)

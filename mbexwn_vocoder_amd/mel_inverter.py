@@ -124,11 +124,31 @@ class MELInverter(object):
         return syn_audio.ravel()
 
     def generate_mel_from_snd(self, snd, srate):
-        """Audio -> ``.mell`` dictionary (reference mel_inverter.py:156-182).  The analysis side
-        (compute_mel_spectrogram_internal, librosa mel basis) is the step *before* the hot path and is not
-        part of this build yet."""
-        raise NotImplementedError("generate_mel_from_snd: the audio->mel analysis side is not part of this build "
-                                  "(SURVEY.md section 8(f), rank 2)")
+        """Audio -> ``.mell`` dictionary (reference mel_inverter.py:156-182), host side (analysis.py).
+        The reference resamples when ``srate`` differs from the model rate through a function it never imports
+        (mel_inverter.py:173); here a different rate is an error."""
+        from .analysis import compute_log_mel
+        if srate != self.srate:
+            raise NotImplementedError(f"generate_mel_from_snd: resampling from {srate} Hz to {self.srate} Hz is not "
+                                      "part of this build")
+        data_dict = {'nfft': self.fft_size,
+                     'hoplen': self.hop_size,
+                     'winlen': self.win_len,
+                     'nmels': self.mel_channels,
+                     'sr': self.srate,
+                     'fmin': self.fmin,
+                     'fmax': self.fmax,
+                     'lin_spec_offset': self.lin_amp_off,
+                     'lin_spec_scale': self.lin_amp_scale,
+                     'log_spec_offset': 0.,
+                     'log_spec_scale': self.mel_amp_scale,
+                     "time_axis": 1}
+        snd = np.asarray(snd)
+        if snd.ndim == 1:
+            snd = snd[np.newaxis]
+        mel_ref, _ = compute_log_mel(snd, self.preprocess_config, dtype=np.float32)
+        data_dict['mell'] = mel_ref[0].T
+        return data_dict
 
     # ------------------------------------------------------------------------------------------
     def load_model(self, model_id_or_path, verbose=False):

@@ -64,6 +64,13 @@ def main():
     out["wt/full/consts"] = np.asarray([full.nominalF0, float(full.minTranspositionFactorInGrid),
                                         float(full.maxTranspositionFactorInGrid), float(full.grid_f0_diff_norm_factor),
                                         full.n_period])
+    # analysis side: magnitude STFT of the reference's numpy code (sig_proc/spec/stft.py:14-96)
+    from MBExWN_NVoc.sig_proc.spec.stft import calc_stft
+    rng2 = np.random.default_rng(11)
+    snd = rng2.normal(size=(2, 3000)).astype(np.float32)
+    out["stft/snd"] = snd
+    out["stft/mag_1200_300_2048"] = calc_stft(snd, win_len=1200, hop_len=300, fft_size=2048, win_type="hann",
+                                              center=True, pad_mode="reflect", do_mag=True, axis=-1, dtype=np.float32)
     # G6
     out["nextpow2_val"] = np.asarray([[nn, nextpow2_val(nn)] for nn in (1, 2, 3, 1200, 2048, 2049)])
     np.savez_compressed(os.path.join(HERE, "reference_constants.npz"), **out)

@@ -147,6 +147,12 @@ def test_fileio_roundtrip(tmp_path):
     assert fileio.load_var(str(tmp_path / "plain.mell"))["hoplen"] == 300
 
 
-def test_generate_mel_is_flagged_out_of_scope():
+def test_generate_mel_from_snd():
+    inv = make_inverter(mel_channels=80, win_len=1200, preprocess_config=canonical_config()["preprocess_config"])
+    rng = np.random.default_rng(3)
+    dd = inv.generate_mel_from_snd(rng.normal(size=(6000,)).astype(np.float32), 24000)
+    assert dd["mell"].shape == (80, 21) and dd["hoplen"] == 300 and dd["nfft"] == 2048 and dd["sr"] == 24000
+    # the dictionary feeds straight back into scale_mel (round trip of the CLI's -v check)
+    assert inv.scale_mel(dd).shape == (1, 21, 80)
     with pytest.raises(NotImplementedError):
-        make_inverter().generate_mel_from_snd(np.zeros(100), 24000)
+        inv.generate_mel_from_snd(np.zeros(100), 16000)

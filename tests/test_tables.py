@@ -130,3 +130,41 @@ def test_nextpow2(gold):
             v *= 2
         assert v == vv
     assert ModelDims(canonical_config()).fft_size == 2048
+
+
+# ---------------------------------------------------------------- analysis side (next row: audio -> mel)
+def test_stft_magnitude_matches_reference(gold):
+    from mbexwn_vocoder_amd import analysis
+    np.testing.assert_allclose(analysis.hann_symmetric(1200), gold["window/hann1200"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(analysis.hann_symmetric(9), gold["window/hann9"], rtol=0, atol=1e-15)
+    mag = analysis.stft_magnitude(gold["stft/snd"], 1200, 300, 2048)
+    ref = gold["stft/mag_1200_300_2048"]
+    assert mag.shape == ref.shape == (2, 11, 1025)
+    np.testing.assert_allclose(mag, ref, rtol=0, atol=2e-4)          # float32 FFT of amplitude-40 spectra
+
+
+def test_slaney_mel_basis_properties():
+    from mbexwn_vocoder_amd import analysis
+    basis = analysis.mel_basis_slaney(24000, 2048, 80, 0.0, 12000.0)
+    assert basis.shape == (80, 1025) and basis.dtype == np.float32 and np.all(basis >= 0)
+    freqs = analysis.mel_frequencies(82, 0.0, 12000.0)
+    assert freqs[0] == 0.0 and abs(freqs[-1] - 12000.0) < 1e-6 and np.all(np.diff(freqs) > 0)
+    # linear below 1 kHz (200/3 Hz per mel step ratio), logarithmic above
+    low = freqs[freqs < 900]
+    assert np.allclose(np.diff(low), np.diff(low)[0])
+    high = freqs[freqs > 1100]
+    assert np.allclose(high[1:] / high[:-1], high[1] / high[0])
+    # slaney norm: every triangle has (almost) unit area in Hz
+    df = 24000 / 2048
+    area = basis.sum(axis=1) * df
+    assert np.all(np.abs(area[5:] - 1.0) < 0.05)
+    peaks = np.argmax(basis, axis=1)
+    assert np.all(np.diff(peaks) > 0)
+
+
+def test_compute_log_mel_shapes():
+    from mbexwn_vocoder_amd import analysis
+    cfg = canonical_config()["preprocess_config"]
+    rng = np.random.default_rng(0)
+    mell, rate = analysis.compute_log_mel(rng.normal(size=(7200,)).astype(np.float32), cfg)
+    assert mell.shape == (1, 25, 80) and rate == 80.0 and np.all(np.isfinite(mell))
