@@ -283,10 +283,8 @@ class ModelDims:
         if mb.get("pulse_channels_use_pqmf", False) or not mb.get("pp_mod_subnet_use_pqmf", True):
             raise NotImplementedError("pulse_channels_use_pqmf / no-PQMF variants are not supported")
         self.alpha = float(mb.get("alpha", 0.2))
-        if mb.get("normalize_rms_from_mell", False):
-            # NormMelComponents (reference wavegen_1d.py:578-769), SURVEY.md section 8(a) row A14: optional, needs the
-            # librosa mel frequencies; not part of this build yet
-            raise NotImplementedError("normalize_rms_from_mell (NormMelComponents) is not supported yet")
+        # NormMelComponents (reference wavegen_1d.py:578-769, row A14) is host-side pre/post-processing: norm_mel.py
+        self.normalize_rms_from_mell = bool(mb.get("normalize_rms_from_mell", False))
 
     def wn_dilation(self, index):
         # reference custom_AE_layers.py:229-233

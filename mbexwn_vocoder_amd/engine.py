@@ -245,6 +245,10 @@ class MBExWNEngine:
         self.wavetables = wavetables
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         cconf, self.dims = make_config(config, wavetables)
+        self.norm_mel = None
+        if config["mbexwn_config"].get("normalize_rms_from_mell", False):
+            from .norm_mel import NormMel
+            self.norm_mel = NormMel(config)
         self._tensors = tensor_table(config, raw_weights, wavetables)   # keep the host arrays alive
         arr = (mbx_tensor * len(self._tensors))()
         for ii, (name, val) in enumerate(self._tensors.items()):
@@ -376,14 +380,20 @@ class MBExWNEngine:
         synth_length = int(synth_length) if synth_length else mel.shape[1] * hop
         if mel.shape[1] * hop < synth_length:                        # reference wavegen_1d.py:490-491
             mel = torch.cat((mel, mel[:, -1:]), dim=1)
+        gain = None
+        if self.norm_mel is not None:                                # reference wavegen_1d.py:493-495 (row A14)
+            mel_n, gain = self.norm_mel.normalize(mel.cpu().numpy(), synth_length)
+            mel = torch.as_tensor(mel_n, device=self.device)
         if noise is None and self.dims.noise_sigma:
             # the reference draws tf.random.normal here (custom_pulsed_generator.py:905-906)
             noise = torch.randn((mel.shape[0], mel.shape[1] * self.dims.steps_per_frame), device=self.device,
                                 dtype=torch.float32)
         elif noise is not None:
             noise = torch.as_tensor(noise).to(self.device, torch.float32)
-        audio = self.forward(mel, noise=noise)
-        return _HostTensor(audio[:, :synth_length])
+        audio = self.forward(mel, noise=noise)[:, :synth_length]
+        if gain is not None:                                         # reference wavegen_1d.py:506-507
+            audio = audio * torch.as_tensor(gain, device=self.device)
+        return _HostTensor(audio)
 
     # -- stage entry points (unit parity tests)
     def pqmf_synthesis(self, x):

@@ -460,3 +460,82 @@ def synthetic_mel(rng, batch, frames, channels=80):
     """SURVEY.md section 8(d) synthetic input: mell = log(exp(N(-5,2^2)) + 1e-5), float32, clipped."""
     mell = np.log(np.exp(rng.normal(-5.0, 2.0, size=(batch, frames, channels))) + 1e-5)
     return np.clip(mell, -11.5, 2.0).astype(np.float32)
+
+
+# ============================================================================================
+# optional RMS normalisation (row A14)
+# ============================================================================================
+def slaney_mel_frequencies(n_mels, fmin, fmax):
+    """librosa.mel_frequencies(htk=False) restated from the published Slaney formulas (third party, absent here):
+    200/3 Hz per mel below 1 kHz, logarithmic above with step ln(6.4)/27."""
+    f_sp, min_log_hz, logstep = 200.0 / 3, 1000.0, np.log(6.4) / 27.0
+    min_log_mel = min_log_hz / f_sp
+
+    def to_mel(f):
+        return min_log_mel + np.log(f / min_log_hz) / logstep if f >= min_log_hz else f / f_sp
+
+    mels = np.linspace(to_mel(float(fmin)), to_mel(float(fmax)), n_mels)
+    return np.where(mels >= min_log_mel, min_log_hz * np.exp(logstep * (mels - min_log_mel)), f_sp * mels)
+
+
+def normalize_inputs_by_rms(mell, config, synth_length, dtype=np.float64):
+    """wavegen_1d.py:638-769 (NormMelComponents.normalize_inputs_by_rms, audio=None, smoothing variant,
+    use_pinv=False) with the constructor constants of :580-636.  Returns (mell', gain (B, synth_length))."""
+    pp, mb = config["preprocess_config"], config["mbexwn_config"]
+    hop, win, n_mels = pp["hop_size"], pp.get("win_size", pp["fft_size"]), pp["mel_channels"]
+    iters = mb.get("normalize_rms_num_smooth_iters", 0)
+    assert 4 * hop == win and iters > 0
+    eps = 1e-7
+
+    def hann(n):     # sig_proc/Mwindows.py:176-185 (symmetric, zero end points)
+        w = np.zeros(n)
+        mid = (n - 1) // 2
+        half = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(mid + 1) / (n - 1))
+        w[:mid + 1] = half
+        w[n - 1:n - 2 - mid:-1] = half
+        return w
+
+    mel_f = slaney_mel_frequencies(n_mels + 2, pp["fmin"], pp["fmax"])
+    inv_enorm = ((mel_f[2:] - mel_f[:n_mels]) / 2.0).astype(np.float32).astype(dtype)          # :611
+    rms_norm_fact = pp["fft_size"] * win * 0.5                                                   # :598
+    gwin = hann(win).astype(np.float32).astype(dtype)
+    gwin = gwin / np.sum(gwin)                                                                   # :622
+    sws = int(win * mb.get("normalize_smooth_win_scale", 1))
+    ssw = hann(sws).astype(np.float32).astype(dtype)
+    if mb.get("normalize_smooth_with_squared_win", True):
+        ssw = ssw ** 2                                                                           # :626-627
+
+    def ola(frames):
+        n_fr, flen = frames.shape[-2:]
+        out = np.zeros(frames.shape[:-2] + ((n_fr - 1) * hop + flen,), dtype=dtype)
+        for tt in range(n_fr):
+            out[..., tt * hop: tt * hop + flen] += frames[..., tt, :]
+        return out
+
+    mell = np.asarray(mell).astype(dtype)
+    T = mell.shape[1]
+    mel = np.exp(mell)
+    rms = np.sqrt(np.sum(np.square(mel * inv_enorm), axis=-1) / rms_norm_fact)                   # :689
+    if mb.get("max_norm_fact", None):
+        rms = np.maximum(rms, 1.0 / mb["max_norm_fact"])                                         # :690-691
+    if mb.get("normalize_compressor_exp", None) is not None:
+        rms = np.power(rms, mb["normalize_compressor_exp"])                                      # :692-693
+    cut = sws // 2 + 2 * hop - win // 2
+    norm_gain = ola(np.ones((1, T + 4, 1), dtype) * ssw)[:, cut:]                                # :700-705
+    gain = None
+    for _ in range(iters):                                                                       # :714-726
+        ext = np.concatenate((rms[:, :1], rms[:, :1], rms, rms[:, -1:], rms[:, -1:]), axis=1)
+        gain = ola(ext[:, :, None] * ssw)[:, cut:] / np.maximum(eps, norm_gain)
+        n_out = (gain.shape[1] - win) // hop + 1
+        idx = np.arange(win)[None, :] + hop * np.arange(n_out)[:, None]
+        rms = np.sum(gain[:, idx] * gwin, axis=-1)[:, :T]
+    mel = mel / np.maximum(eps, rms[:, :, None]) * mb.get("lin_amp_scale", 1.0)                  # :731
+    off = mb.get("lin_amp_off", 1.0e-5)
+    if mb.get("use_max_limit", False):
+        out = mb.get("mel_amp_scale", 1.0) * np.log(np.maximum(mel, off))
+    else:
+        out = mb.get("mel_amp_scale", 1.0) * np.log(mel + off)                                   # :733-736
+    up = np.maximum(gain[:, win // 2: win // 2 + synth_length], eps)                             # :740-742
+    if up.shape[1] < synth_length:
+        up = np.concatenate((up, np.repeat(up[:, -1:], synth_length - up.shape[1], axis=1)), axis=1)
+    return out, up

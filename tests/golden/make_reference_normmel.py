@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Golden vectors of the optional RMS normalisation (row A14) from the reference's own NormMelComponents
+(reference MBExWN_NVoc/vocoder/model/wavegen_1d.py:578-769) executed on the numpy TensorFlow stand-in.
+
+librosa is absent: ``librosa.core.convert.mel_frequencies`` is provided by this repo's restatement of the published
+Slaney formulas (mbexwn_vocoder_amd/analysis.py) -- the golden pins the reference's arithmetic around it, not librosa.
+Writes tests/golden/reference_normmel.npz.   (build container only; needs /root/reference)
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import tf_numpy_shim as shim  # noqa: E402
+
+CASES = {
+    "iters1": {"normalize_rms_num_smooth_iters": 1},
+    "iters2_comp": {"normalize_rms_num_smooth_iters": 2, "normalize_compressor_exp": 0.8, "max_norm_fact": 200.0},
+    "scaled_win": {"normalize_rms_num_smooth_iters": 1, "normalize_smooth_win_scale": 2,
+                   "normalize_smooth_with_squared_win": False, "lin_amp_scale": 1.5, "mel_amp_scale": 0.5},
+}
+
+
+def main():
+    shim.install("/root/reference")
+    from mbexwn_vocoder_amd import analysis
+    from mbexwn_vocoder_amd.config import canonical_config
+    sys.modules["librosa.core.convert"].mel_frequencies = \
+        lambda n_mels=128, fmin=0.0, fmax=11025.0, htk=False: analysis.mel_frequencies(n_mels, fmin, fmax)
+    out = {}
+    for tag, ftype in (("f32", np.float32), ("f64", np.float64)):
+        shim.set_float(ftype)
+        for mod in [mm for mm in sys.modules if mm.startswith("MBExWN_NVoc")]:
+            del sys.modules[mod]
+        from MBExWN_NVoc.vocoder.model.wavegen_1d import NormMelComponents
+        for name, extra in CASES.items():
+            cfg = canonical_config("SPEECH")
+            model_config = dict(cfg["mbexwn_config"], normalize_rms_from_mell=True, **extra)
+            nm = NormMelComponents(preprocess_config=cfg["preprocess_config"], dtype=shim.tf.float32, **model_config)
+            rng = np.random.default_rng(5)
+            mell = np.clip(np.log(np.exp(rng.normal(-5, 2, size=(2, 17, 80))) + 1e-5), -11.5, 2).astype(np.float32)
+            _, mell_n, up = nm.normalize_inputs_by_rms(None, shim.Tensor(mell.astype(ftype)), synth_length=17 * 300)
+            out[f"{tag}/{name}/mell"] = mell
+            out[f"{tag}/{name}/mell_norm"] = np.asarray(mell_n)
+            out[f"{tag}/{name}/gain"] = np.asarray(up)[:, :, 0]
+            print(tag, name, np.asarray(mell_n).shape, np.asarray(up).shape, float(np.asarray(up).mean()))
+    np.savez_compressed(os.path.join(HERE, "reference_normmel.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()

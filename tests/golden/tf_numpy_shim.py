@@ -154,6 +154,7 @@ tf.reshape = lambda x, shape, name=None: _t(np.reshape(np.asarray(x), tuple(shap
 tf.transpose = lambda x, perm=None: _t(np.transpose(np.asarray(x), perm))
 tf.expand_dims = lambda x, axis: _t(np.expand_dims(np.asarray(x), axis))
 tf.stop_gradient = lambda x: x
+tf.repeat = lambda x, repeats, axis=None: _t(np.repeat(np.asarray(x), repeats, axis=axis))
 tf.abs = lambda x: _t(np.abs(np.asarray(x)))
 tf.exp = lambda x: _t(np.exp(np.asarray(x)))
 tf.sqrt = lambda x: _t(np.sqrt(np.asarray(x)))

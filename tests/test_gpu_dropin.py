@@ -103,3 +103,27 @@ def test_sharded_synthesis_matches_single_runs(model_dir):
         assert sorted(local) == sorted(lpt_partition(lengths, 4)[rank])
         for ii, audio in local.items():
             assert np.array_equal(audio, singles[ii])
+
+
+def test_rms_normalised_model_end_to_end(tmp_path):
+    """row A14: a model with normalize_rms_from_mell runs through infer() = normalise -> HIP forward -> de-normalise."""
+    import torch
+    from mbexwn_vocoder_amd.config import read_config
+    from mbexwn_vocoder_amd.mel_inverter import MELInverter, create_synthetic_model_dir
+    from mbexwn_vocoder_amd.tables import WaveTables
+    from mbexwn_vocoder_amd.weights import load_weights
+    from oracle.mbexwn_oracle import OracleModel, normalize_inputs_by_rms
+    over = dict(SMALL)
+    over.update({"mbexwn_config:normalize_rms_from_mell": True, "mbexwn_config:normalize_rms_num_smooth_iters": 1})
+    mdir = create_synthetic_model_dir(str(tmp_path / "norm_model"), "SPEECH", **over)
+    inv = MELInverter(mdir)
+    mell = inv.scale_mel(mell_dict(21))
+    rng = np.random.default_rng(1)
+    noise = rng.normal(size=(1, 21 * 20)).astype(np.float32)
+    audio = inv.synth_from_mel(mell, noise=noise)
+    cfg = read_config(os.path.join(mdir, "config.yaml"))
+    mel_n, gain = normalize_inputs_by_rms(mell, cfg, 21 * 300)
+    wt = WaveTables(sample_rate=8000.0, **cfg["mbexwn_config"]["wavetable_config"])
+    ref = OracleModel(cfg, load_weights(os.path.join(mdir, "weights.npz")), wt).forward(mel_n.astype(np.float32), noise)[0] * gain[0]
+    assert audio.shape == ref.shape
+    assert np.max(np.abs(audio - ref)) <= 1e-4 * max(1.0, np.abs(ref).max())
