@@ -30,6 +30,11 @@ namespace mbx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// raise the wave priority while it issues the MFMA cluster of a slice (+1 % at large batch, neutral at batch 1)
+#ifndef MBX_SETPRIO
+#define MBX_SETPRIO 1
+#endif
+
 
 // source row of the padded input: -1 = zero sample.  Branch free (selects only) so that the K loop stays one
 // scheduling region.  mode: 0 zero, 1 symmetric (edge sample repeated), 2 edge.
@@ -511,6 +516,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_dma_kernel(ConvArgs p) {
         float bv[2][TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) bv[0][j] = bb[(4 * lk) * BN + col_base(j)];
+        if (MBX_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int n = 0; n < 8; ++n) {
             const int cc = n >> 2, st = n & 3, cur = n & 1, nxt = cur ^ 1;
@@ -529,6 +535,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_dma_kernel(ConvArgs p) {
             if (n + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, TN, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
         }
+        if (MBX_SETPRIO) __builtin_amdgcn_s_setprio(0);
         buf = buf == NBUF - 1 ? 0 : buf + 1;
     }
     conv_epilogue<WM, WN, TM, TN, EPI>(p, acc, b, rows, m0, n0, wr, wc, lane);

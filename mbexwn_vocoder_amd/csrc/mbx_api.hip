@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -64,6 +65,11 @@ struct mbx_handle {
     // derived
     int f0_time_factor = 1, vtf_time_factor = 1;
     long long subnet_buf_per_frame = 0;   // floats per frame of one ping-pong buffer
+    // fork/join inside a forward: the conditioning conv and the VTF-net (+ lifter selection) do not depend on the
+    // F0 -> wavetable -> WaveNet chain, so they run on two side streams and fill otherwise idle CUs
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_f0 = nullptr, ev_cond = nullptr, ev_vtf = nullptr;
+    bool overlap = false;
     // bench-only kernel timing (mbx_profile_*)
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool[2];   // 0: gate, 1: res_skip
@@ -101,7 +107,7 @@ mbx_status analyse_subnet(const mbx_subnet_op *ops, int n_ops, int cin, long lon
 }
 
 struct Workspace {
-    float *sub0, *sub1, *f0, *cum, *chunk_last, *pulse, *cond, *h, *a, *skip, *wn_out, *sub, *exc, *ceps, *frames;
+    float *sub0, *sub1, *sub2, *sub3, *f0, *cum, *chunk_last, *pulse, *cond, *h, *a, *skip, *wn_out, *sub, *exc, *ceps, *frames;
     int *ceps_index;
     size_t total;
 };
@@ -120,6 +126,8 @@ Workspace carve(const mbx_handle *hd, char *base, int B, int T) {
     const int chunks = (int)((npulse + c.phase_chunk - 1) / c.phase_chunk) + 1;
     w.sub0 = take(BT * hd->subnet_buf_per_frame);
     w.sub1 = take(BT * hd->subnet_buf_per_frame);
+    w.sub2 = take(BT * hd->subnet_buf_per_frame);   // VTF-net ping-pong (runs concurrently with the F0-net)
+    w.sub3 = take(BT * hd->subnet_buf_per_frame);
     w.f0 = take(B * npulse);
     w.cum = take(B * npulse);
     w.chunk_last = take((size_t)B * chunks);
@@ -479,6 +487,18 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
     if (hd->vtf_time_factor != 1 || vtf_out != c.n_ceps)
         return bail(fail(MBX_ERR_INVALID_ARGUMENT, "VTF sub-net must end with n_ceps channels at the mel frame rate"));
     hd->subnet_buf_per_frame = std::max(pf0, pvtf);
+    // measured on MI355X: the fork/join costs more than it hides (config 2: 1.57 ms with, 1.54 ms without), so the
+    // launch sequence stays on the caller's stream unless MBX_OVERLAP is set
+    hd->overlap = getenv("MBX_OVERLAP") != nullptr;
+    for (int i = 0; i < 2; ++i) {
+        e = hipStreamCreateWithFlags(&hd->side[i], hipStreamNonBlocking);
+        if (e != hipSuccess) return bail(fail(MBX_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)));
+    }
+    hipEvent_t *evs[4] = {&hd->ev_fork, &hd->ev_f0, &hd->ev_cond, &hd->ev_vtf};
+    for (auto ev : evs) {
+        e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+        if (e != hipSuccess) return bail(fail(MBX_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)));
+    }
     *out = hd;
     return MBX_OK;
 }
@@ -486,6 +506,10 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
 mbx_status mbx_destroy(mbx_handle *handle) {
     if (!handle) return MBX_OK;
     if (handle->arena) (void)hipFree(handle->arena);
+    for (auto st : handle->side)
+        if (st) (void)hipStreamDestroy(st);
+    for (auto ev : {handle->ev_fork, handle->ev_f0, handle->ev_cond, handle->ev_vtf})
+        if (ev) (void)hipEventDestroy(ev);
     for (auto &pool : handle->ev_pool)
         for (auto &pr : pool) {
             (void)hipEventDestroy(pr.first);
@@ -516,25 +540,49 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     const int C = c.wn_channels, L = c.wn_layers, M = c.subbands;
     const long long npulse = (long long)T * c.pulse_per_frame, nsteps = (long long)T * c.steps_per_frame;
 
-    // ---- F0 (reference custom_pulsed_generator.py:773-791)
-    mbx_status st = run_subnet(hd, c.f0_ops, c.n_f0_ops, mel, c.mel_channels, n_frames, B, T, w.sub0, w.sub1, w.f0,
-                               true, c.f0_max - c.f0_min, c.f0_min, stream);
-    if (st != MBX_OK) return st;
-    // ---- wavetable excitation (reference :889)
-    mbx::launch_wavetable(wavetable_consts(hd), w.f0, npulse, n_frames, c.pulse_per_frame, (int)npulse, B, w.pulse,
-                          nullptr, w.cum, w.chunk_last, st_in, st_out, stream);
-    // ---- WaveNet (reference custom_AE_layers.py:273-346)
     const DevTensor *cw = find(hd, "wn.cond.w"), *cbias = find(hd, "wn.cond.b");
     const int cond_cout = 2 * C * c.cond_conv_upsampling;
+    mbx::StftConsts sc = stft_consts(hd);
+    const bool fork = hd->overlap;
+    hipStream_t s_cond = fork ? hd->side[0] : stream;
+    hipStream_t s_vtf = fork ? hd->side[1] : stream;
+    if (fork) {
+        HIP_TRY(hipEventRecord(hd->ev_fork, stream));
+        HIP_TRY(hipStreamWaitEvent(s_cond, hd->ev_fork, 0));
+        HIP_TRY(hipStreamWaitEvent(s_vtf, hd->ev_fork, 0));
+    }
+    // ---- side stream 1: conditioning conv (reference custom_AE_layers.py:214-227,287)
     {
         mbx::ConvArgs a = conv_args(mel, (long long)T * c.mel_channels, c.mel_channels, n_frames, 1, T, B, cw, cbias,
                                     c.cond_kernel_size, c.mel_channels, cond_cout, 1, (c.cond_kernel_size - 1) / 2,
                                     MBX_PAD_ZERO, w.cond, (long long)T * cond_cout, cond_cout);
-        mbx::launch_conv1d(a, mbx::EPI_LINEAR, stream);
+        mbx::launch_conv1d(a, mbx::EPI_LINEAR, s_cond);
+        if (fork) HIP_TRY(hipEventRecord(hd->ev_cond, s_cond));
     }
+    // ---- side stream 2: VTF-net -> cepstrum (reference custom_pulsed_generator.py:793-800)
+    mbx_status st = run_subnet(hd, c.vtf_ops, c.n_vtf_ops, mel, c.mel_channels, n_frames, B, T, w.sub2, w.sub3, w.ceps,
+                               false, 1.f, 0.f, s_vtf);
+    if (st != MBX_OK) return st;
+    // ---- F0 (reference custom_pulsed_generator.py:773-791)
+    st = run_subnet(hd, c.f0_ops, c.n_f0_ops, mel, c.mel_channels, n_frames, B, T, w.sub0, w.sub1, w.f0, true,
+                    c.f0_max - c.f0_min, c.f0_min, stream);
+    if (st != MBX_OK) return st;
+    if (c.n_ceps_windows) {   // lifter selection needs F0 only (reference :507-525)
+        if (fork) {
+            HIP_TRY(hipEventRecord(hd->ev_f0, stream));
+            HIP_TRY(hipStreamWaitEvent(s_vtf, hd->ev_f0, 0));
+        }
+        mbx::launch_ceps_index(sc, w.f0, npulse, n_frames, T, B, w.ceps_index, s_vtf);
+    }
+    if (fork) HIP_TRY(hipEventRecord(hd->ev_vtf, s_vtf));
+    // ---- wavetable excitation (reference :889)
+    mbx::launch_wavetable(wavetable_consts(hd), w.f0, npulse, n_frames, c.pulse_per_frame, (int)npulse, B, w.pulse,
+                          nullptr, w.cum, w.chunk_last, st_in, st_out, stream);
+    // ---- WaveNet (reference custom_AE_layers.py:273-346)
     mbx::launch_wn_start(w.pulse, npulse, c.noise_sigma != 0.f ? noise : nullptr, nsteps, c.noise_sigma, n_frames,
                          c.steps_per_frame, (int)nsteps, B, c.pulse_channels, find(hd, "wn.start.w")->ptr,
                          find(hd, "wn.start.b")->ptr, C, w.h, nsteps * C, stream);
+    if (fork) HIP_TRY(hipStreamWaitEvent(stream, hd->ev_cond, 0));
     auto lerp = hd->lerp[c.cond_lin_upsampling];
     for (int l = 0; l < L; ++l) {
         const std::string ls = std::to_string(l);
@@ -584,13 +632,8 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     // ---- PQMF synthesis (reference :920-921)
     mbx::launch_pqmf(w.sub, nsteps * M, n_frames, c.steps_per_frame, (int)nsteps, B, M, hd->poly, hd->poly_ndm,
                      hd->poly_dm_min, w.exc, (long long)T * c.hop_size, stream);
-    // ---- spectral envelope (reference :793-855) and STFT-domain filtering (reference :681-724)
-    st = run_subnet(hd, c.vtf_ops, c.n_vtf_ops, mel, c.mel_channels, n_frames, B, T, w.sub0, w.sub1, w.ceps, false,
-                    1.f, 0.f, stream);
-    if (st != MBX_OK) return st;
-    mbx::StftConsts sc = stft_consts(hd);
-    if (c.n_ceps_windows)
-        mbx::launch_ceps_index(sc, w.f0, npulse, n_frames, T, B, w.ceps_index, stream);
+    // ---- STFT-domain filtering with the spectral envelope (reference :681-724, 801-855); joins side stream 2
+    if (fork) HIP_TRY(hipStreamWaitEvent(stream, hd->ev_vtf, 0));
     mbx::launch_stft_filter(sc, w.exc, (long long)T * c.hop_size, w.ceps, (long long)T * c.n_ceps,
                             c.n_ceps_windows ? w.ceps_index : nullptr, n_frames, T, B, w.frames, stream);
     mbx::launch_overlap_add(sc, w.frames, n_frames, T, B, audio, (long long)T * c.hop_size, stream);
