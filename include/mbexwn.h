@@ -141,6 +141,24 @@ mbx_status mbx_forward_stream(mbx_handle *handle, const float *mel, const int32_
                               size_t workspace_bytes, const mbx_stream_state *state_in, mbx_stream_state *state_out,
                               void *hip_stream);
 
+/* Component / transposition interface = PaNWaveNet.infer_components (reference wavegen_1d.py:528-557): the F0 contour
+ * may be supplied from outside and / or multiplied by a transposition factor before it drives the wavetable and the
+ * lifter selection; the components (F0, excitation, cepstrum) are then read back with mbx_stage.
+ *   f0             device (batch, max_frames*pulse_per_frame) Hz, or NULL = F0-net output
+ *   transposition  factor applied to the F0 contour (1 = none; reference: F0 = transposition_factor * F0)
+ *   state_in/out   streaming state as in mbx_forward_stream, or NULL */
+typedef struct {
+    int32_t struct_size;              /* sizeof(mbx_forward_options) */
+    float transposition;
+    const float *f0;
+    const mbx_stream_state *state_in;
+    mbx_stream_state *state_out;
+} mbx_forward_options;
+
+mbx_status mbx_forward_ex(mbx_handle *handle, const float *mel, const int32_t *n_frames, int32_t batch,
+                          int32_t max_frames, const float *noise, float *audio, void *workspace,
+                          size_t workspace_bytes, const mbx_forward_options *options, void *hip_stream);
+
 /* Intermediate tensors of the most recent mbx_forward (pointers into its workspace), for stage parity
  * tests.  Names: "f0" "pulse" "cond" "wn_hidden" "wn_skip" "wn_out" "subbands" "excitation" "cepstrum"
  * "ceps_index" "frames".  `count` = floats (int32 for ceps_index) per batch item, `stride` = item stride. */

@@ -527,7 +527,7 @@ size_t mbx_workspace_size(const mbx_handle *handle, int32_t batch, int32_t max_f
 static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *n_frames, int32_t batch,
                                int32_t max_frames, const float *noise, float *audio, void *workspace,
                                size_t workspace_bytes, const mbx::StreamState *st_in, mbx::StreamState *st_out,
-                               void *hip_stream) {
+                               void *hip_stream, const float *f0_in = nullptr, float transposition = 1.f) {
     if (!hd || !mel || !audio || !workspace) return fail(MBX_ERR_INVALID_ARGUMENT, "null argument");
     if (batch <= 0 || max_frames <= 0) return fail(MBX_ERR_INVALID_ARGUMENT, "batch and max_frames must be positive");
     const mbx_config &c = hd->cfg;
@@ -564,9 +564,17 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                                false, 1.f, 0.f, s_vtf);
     if (st != MBX_OK) return st;
     // ---- F0 (reference custom_pulsed_generator.py:773-791)
-    st = run_subnet(hd, c.f0_ops, c.n_f0_ops, mel, c.mel_channels, n_frames, B, T, w.sub0, w.sub1, w.f0, true,
-                    c.f0_max - c.f0_min, c.f0_min, stream);
-    if (st != MBX_OK) return st;
+    if (f0_in) {   // externally supplied contour (reference wavegen_1d.py:546-550)
+        mbx::launch_activation(f0_in, npulse, n_frames, c.pulse_per_frame, (int)npulse, B, 1, MBX_ACT_LINEAR, transposition,
+                               0.f, w.f0, npulse, stream);
+    } else {
+        st = run_subnet(hd, c.f0_ops, c.n_f0_ops, mel, c.mel_channels, n_frames, B, T, w.sub0, w.sub1, w.f0, true,
+                        c.f0_max - c.f0_min, c.f0_min, stream);
+        if (st != MBX_OK) return st;
+        if (transposition != 1.f)
+            mbx::launch_activation(w.f0, npulse, n_frames, c.pulse_per_frame, (int)npulse, B, 1, MBX_ACT_LINEAR,
+                                   transposition, 0.f, w.f0, npulse, stream);
+    }
     if (c.n_ceps_windows) {   // lifter selection needs F0 only (reference :507-525)
         if (fork) {
             HIP_TRY(hipEventRecord(hd->ev_f0, stream));
@@ -670,6 +678,18 @@ mbx_status mbx_forward_stream(mbx_handle *hd, const float *mel, const int32_t *n
     return forward_impl(hd, mel, n_frames, batch, max_frames, noise, audio, workspace, workspace_bytes,
                         reinterpret_cast<const mbx::StreamState *>(state_in),
                         reinterpret_cast<mbx::StreamState *>(state_out), hip_stream);
+}
+
+mbx_status mbx_forward_ex(mbx_handle *hd, const float *mel, const int32_t *n_frames, int32_t batch, int32_t max_frames,
+                          const float *noise, float *audio, void *workspace, size_t workspace_bytes,
+                          const mbx_forward_options *options, void *hip_stream) {
+    if (!options || options->struct_size != (int32_t)sizeof(mbx_forward_options))
+        return fail(MBX_ERR_INVALID_ARGUMENT, "mbx_forward_options ABI mismatch (struct_size)");
+    if (!(options->transposition > 0.f)) return fail(MBX_ERR_INVALID_ARGUMENT, "transposition must be positive");
+    return forward_impl(hd, mel, n_frames, batch, max_frames, noise, audio, workspace, workspace_bytes,
+                        reinterpret_cast<const mbx::StreamState *>(options->state_in),
+                        reinterpret_cast<mbx::StreamState *>(options->state_out), hip_stream, options->f0,
+                        options->transposition);
 }
 
 mbx_status mbx_profile_enable(mbx_handle *handle, int32_t enabled) {

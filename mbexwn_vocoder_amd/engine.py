@@ -58,6 +58,11 @@ class mbx_config(ctypes.Structure):
                 ("n_vtf_ops", ctypes.c_int32), ("vtf_ops", mbx_subnet_op * MBX_MAX_SUBNET_OPS)]
 
 
+class mbx_forward_options(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_int32), ("transposition", ctypes.c_float), ("f0", ctypes.c_void_p),
+                ("state_in", ctypes.c_void_p), ("state_out", ctypes.c_void_p)]
+
+
 class mbx_tensor(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char_p), ("data", ctypes.POINTER(ctypes.c_float)), ("ndim", ctypes.c_int32),
                 ("shape", ctypes.c_int64 * 4)]
@@ -95,6 +100,9 @@ def load_library():
     lib.mbx_forward.argtypes = [vp, fp, vp, i32, i32, fp, fp, vp, ctypes.c_size_t, vp]
     lib.mbx_forward_stream.restype = i32
     lib.mbx_forward_stream.argtypes = [vp, fp, vp, i32, i32, fp, fp, vp, ctypes.c_size_t, vp, vp, vp]
+    lib.mbx_forward_ex.restype = i32
+    lib.mbx_forward_ex.argtypes = [vp, fp, vp, i32, i32, fp, fp, vp, ctypes.c_size_t,
+                                   ctypes.POINTER(mbx_forward_options), vp]
     lib.mbx_stage.restype = i32
     lib.mbx_stage.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p), i64p, i64p]
     lib.mbx_profile_enable.restype = i32
@@ -116,7 +124,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = ["mbx_last_error", "mbx_create", "mbx_destroy", "mbx_workspace_size", "mbx_forward",
-                    "mbx_forward_stream", "mbx_stage",
+                    "mbx_forward_stream", "mbx_forward_ex", "mbx_stage",
                     "mbx_profile_enable", "mbx_profile_read", "mbx_pqmf_synthesis", "mbx_conv1d", "mbx_lin_interp", "mbx_wavetable", "mbx_stft_filter"]
 
 
@@ -394,6 +402,61 @@ class MBExWNEngine:
         if gain is not None:                                         # reference wavegen_1d.py:506-507
             audio = audio * torch.as_tensor(gain, device=self.device)
         return _HostTensor(audio)
+
+    def infer_components(self, spect, synth_length=0, F0=None, transposition_factor=None, noise=None):
+        """PaNWaveNet.infer_components (reference wavegen_1d.py:528-557): returns
+        (F0 (B, T*pulse_per_frame), excitation (B, T*hop), spectral envelope complex (B, T, fft/2+1), upsampled_rms)
+        as numpy arrays; ``F0`` may be given (Hz at the pulse rate), ``transposition_factor`` scales it.
+        Additionally the transposed synthesis itself is available as ``self.last_audio`` (device tensor)."""
+        torch = self._torch
+        mel = torch.as_tensor(np.asarray(spect, dtype=np.float32) if not torch.is_tensor(spect) else spect)
+        mel = mel.to(self.device, torch.float32).contiguous()
+        hop, ppf = self.dims.hop_size, self.dims.pulse_per_frame
+        if F0 is not None:
+            synth_length = int(np.asarray(F0).shape[1]) * self.dims.f0_down_sampling_factor
+        synth_length = int(synth_length) if synth_length else mel.shape[1] * hop
+        if mel.shape[1] * hop < synth_length:
+            mel = torch.cat((mel, mel[:, -1:]), dim=1)
+        gain = None
+        if self.norm_mel is not None:
+            mel_n, gain = self.norm_mel.normalize(mel.cpu().numpy(), synth_length)
+            mel = torch.as_tensor(mel_n, device=self.device)
+        B, T = int(mel.shape[0]), int(mel.shape[1])
+        if noise is None and self.dims.noise_sigma:
+            noise = torch.randn((B, T * self.dims.steps_per_frame), device=self.device, dtype=torch.float32)
+        elif noise is not None:
+            noise = torch.as_tensor(noise).to(self.device, torch.float32).contiguous()
+        f0_dev = None
+        if F0 is not None:
+            f0_np = np.zeros((B, T * ppf), dtype=np.float32)
+            src = np.asarray(F0, dtype=np.float32).reshape(B, -1)
+            nn = min(src.shape[1], f0_np.shape[1])
+            f0_np[:, :nn] = src[:, :nn]
+            f0_np[:, nn:] = src[:, -1:]
+            f0_dev = torch.as_tensor(f0_np, device=self.device)
+        out = torch.empty((B, T * hop), dtype=torch.float32, device=self.device)
+        ws, need = self._get_workspace(B, T)
+        opt = mbx_forward_options()
+        opt.struct_size = ctypes.sizeof(mbx_forward_options)
+        opt.transposition = float(transposition_factor) if transposition_factor else 1.0
+        opt.f0 = f0_dev.data_ptr() if f0_dev is not None else None
+        _check(self._lib.mbx_forward_ex(self._handle, mel.data_ptr(), None, B, T,
+                                        noise.data_ptr() if noise is not None else None, out.data_ptr(), ws.data_ptr(),
+                                        need, ctypes.byref(opt), self._stream()))
+        self._last_shape = (B, T)
+        self.last_audio = out[:, :synth_length]
+        f0 = self.stage("f0").cpu().numpy()
+        exc = self.stage("excitation").cpu().numpy()[:, :synth_length]
+        ceps = self.stage("cepstrum").cpu().numpy().reshape(B, T, self.dims.n_ceps)
+        if "table.ceps_windows" in self._tensors:
+            idx = self.stage("ceps_index").cpu().numpy()
+            ceps = ceps * self._tensors["table.ceps_windows"][idx]
+        full = np.zeros((B, T, self.dims.fft_size), dtype=np.float32)
+        full[:, :, 1:self.dims.n_ceps] = ceps[:, :, 1:]
+        spec = np.fft.rfft(full, axis=-1)
+        rng = self.dims.filter_max_log_range
+        env = np.exp(rng * np.tanh(spec.real) + 1j * spec.imag) if rng else np.exp(spec)
+        return f0, exc, env.astype(np.complex64), gain
 
     # -- stage entry points (unit parity tests)
     def pqmf_synthesis(self, x):

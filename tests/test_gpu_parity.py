@@ -24,7 +24,9 @@ def _tol(ref, rel):
 
 
 def _maxdiff(a, b):
-    return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
+    a, b = np.asarray(a), np.asarray(b)
+    wide = np.complex128 if (np.iscomplexobj(a) or np.iscomplexobj(b)) else np.float64
+    return float(np.max(np.abs(a.astype(wide) - b.astype(wide))))
 
 
 @pytest.fixture(scope="module")
@@ -275,3 +277,55 @@ def test_error_paths(torch):
         eng.forward(dev(torch, mel[:, :, :40]), noise=dev(torch, noise))  # wrong channel count
     out = eng.forward(dev(torch, mel[:0]), noise=dev(torch, noise[:0]))
     assert out.shape == (0, 1200)
+
+
+def test_infer_components_and_transposition(torch):
+    """F0 / excitation / envelope outputs, external and transposed F0."""
+    eng, om = get_engine("small", *SMALL)[:2]
+    mel, noise = synthetic_inputs(31, 1, 18)
+    f0, exc, env, rms = eng.infer_components(mel, noise=noise)
+    ref_audio, st = om.forward(mel, noise, return_stages=True)
+    assert rms is None and f0.shape == (1, 1800) and exc.shape == (1, 5400) and env.shape == (1, 18, 1025)
+    assert _maxdiff(f0, st["f0"]) <= 1e-3
+    assert _maxdiff(exc, st["excitation"]) <= _tol(st["excitation"], E2E_TOL)
+    assert _maxdiff(env, st["envelope"]) <= _tol(np.abs(st["envelope"]), 2e-4)
+    assert _maxdiff(eng.last_audio.cpu().numpy(), ref_audio) <= _tol(ref_audio, E2E_TOL)
+    # transposed: the reference multiplies the contour, then excitation and envelope follow the new contour
+    f0_t, exc_t, env_t, _ = eng.infer_components(mel, noise=noise, transposition_factor=1.5)
+    np.testing.assert_allclose(f0_t, 1.5 * f0, rtol=1e-6)
+    f0_ref = 1.5 * st["f0"]
+    exc_ref = om.generate_excitation(mel.astype(np.float64), f0_ref, noise)
+    assert _maxdiff(exc_t, exc_ref) <= _tol(exc_ref, E2E_TOL)
+    # external contour
+    contour = np.full((1, 1800), 220.0, dtype=np.float32)
+    f0_e, exc_e, _, _ = eng.infer_components(mel, noise=noise, F0=contour)
+    assert np.array_equal(f0_e, contour)
+    exc_ref = om.generate_excitation(mel.astype(np.float64), contour.astype(np.float64), noise)
+    assert _maxdiff(exc_e, exc_ref) <= _tol(exc_ref, E2E_TOL)
+
+
+def test_forward_is_graph_capturable(torch):
+    """mbx_forward only enqueues kernels (no allocation, no synchronisation): it can be captured into a hipGraph."""
+    eng = get_engine("small", *SMALL)[0]
+    mel, noise = synthetic_inputs(17, 2, 12)
+    mel_d, noise_d = dev(torch, mel), dev(torch, noise)
+    out = torch.empty((2, 12 * 300), dtype=torch.float32, device="cuda")
+    eager = eng.forward(mel_d, noise=noise_d).clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        eng.forward(mel_d, noise=noise_d, out=out)          # warm-up on the capture stream (workspace allocation)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        eng.forward(mel_d, noise=noise_d, out=out)
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    mel2, noise2 = synthetic_inputs(18, 2, 12)
+    mel_d.copy_(dev(torch, mel2))
+    noise_d.copy_(dev(torch, noise2))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eng.forward(mel_d, noise=noise_d))
