@@ -28,7 +28,8 @@ def short(name):
 
 for wl in ("config2_sp_b1_10s", "config3_si_b16_10s"):
     entry = {}
-    stats = glob.glob(os.path.join(src, f"{tag}_trace_{wl}", "*", "*kernel_stats.csv"))
+    stats = sorted(glob.glob(os.path.join(src, f"{tag}_trace_{wl}", "*", "*kernel_stats.csv")), key=os.path.getmtime,
+                   reverse=True)
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
         with open(os.path.join(dst, f"{tag}_kernel_stats_{wl}.csv"), "w") as fo:
@@ -39,7 +40,8 @@ for wl in ("config2_sp_b1_10s", "config3_si_b16_10s"):
                 entry.setdefault(kk, {})["avg_us_trace"] = float(rr["AverageNs"]) / 1e3
                 entry[kk]["calls"] = int(rr["Calls"])
     for counter_dir, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("pmc_sq", None)):
-        files = glob.glob(os.path.join(src, f"{tag}_{counter_dir}_{wl}", "*", "*counter_collection.csv"))
+        files = sorted(glob.glob(os.path.join(src, f"{tag}_{counter_dir}_{wl}", "*", "*counter_collection.csv")),
+                       key=os.path.getmtime, reverse=True)
         if not files:
             continue
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
