@@ -150,9 +150,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x16 (&acc)[T
                     for (int r = 0; r < 16; ++r) {
                         const int row = m0 + (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                         if (row < rows) {
-                            const float v = acc[i][j][r] + bias;
                             float *q = dst + (long long)row * C + oc;
-                            *q = accumulate ? (*q + v) : v;
+                            if (p.acc_preloaded) {          // old value and bias already sit in the accumulator
+                                *q = acc[i][j][r];
+                            } else {
+                                const float v = acc[i][j][r] + bias;
+                                *q = accumulate ? (*q + v) : v;
+                            }
                         }
                     }
             }
@@ -327,6 +331,29 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if (EPI == EPI_RESSKIP && p.acc_preloaded) {
+        // res/skip: the accumulators start from bias + the value they will be added to (h or skip); the reads
+        // overlap the first K slices instead of stalling the epilogue, which is then a plain store
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + col_base(j) + ecol;
+            if (col < p.cout) {
+                const float bias = p.bias ? p.bias[col] : 0.f;
+                const bool to_h = (!p.last_layer) && col < C;
+                const int oc = to_h ? col : (p.last_layer ? col : col - C);
+                const float *src = (to_h ? p.h : p.skip) + (long long)b * p.hs_bstride + oc;
+                const bool accumulate = to_h || !p.skip_init;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        const float old = (accumulate && row < rows) ? src[(long long)row * C] : 0.f;
+                        acc[i][j][r] = old + bias;
+                    }
+            }
+        }
+    }
     load_slice(0);
     store_slice(0);
     __syncthreads();
@@ -716,8 +743,10 @@ void launch_conv1d(const ConvArgs &a, int epilogue, hipStream_t stream) {
         if (rs_cfg == 10) done = launch_dma<2, 2, 1, 2, EPI_RESSKIP>(a, stream);
         else if (rs_cfg == 11) done = launch_dma<2, 2, 2, 2, EPI_RESSKIP>(a, stream);
         if (done) return;
-        if (rs_cfg == 0) launch_cfg<2, 2, 2, 2, EPI_RESSKIP>(a, stream, extra_lds);        // 128 x 128
-        else launch_cfg<2, 2, 1, 2, EPI_RESSKIP>(a, stream, extra_lds);                    // 64 x 128
+        ConvArgs r = a;
+        r.acc_preloaded = env_int("MBX_RS_PRELOAD", 1);
+        if (rs_cfg == 0) launch_cfg<2, 2, 2, 2, EPI_RESSKIP>(r, stream, extra_lds);        // 128 x 128
+        else launch_cfg<2, 2, 1, 2, EPI_RESSKIP>(r, stream, extra_lds);                    // 64 x 128
     } else if ((long long)a.max_rows * a.batch <= 8192 && a.cin % 8 == 0 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 &&
                (uintptr_t)a.x % 16 == 0 && env_int("MBX_NO_SMALL", 0) == 0) {
         // mel-rate sub-nets at small batch: latency bound, split-K 32x32 tiles
