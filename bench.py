@@ -169,6 +169,7 @@ def run_streaming(args, eng, dims, cfg, n_streams, chunk, rank, world, dist, tor
     host-inclusive tick latency of the Python driver (numpy staging + H2D + D2H) is reported next to it."""
     from mbexwn_vocoder_amd.streaming import StreamingSynthesizer, pack_state, stream_margins
     left, right, lead = stream_margins(dims, cfg)
+    left = -(-left // 8) * 8            # window starts are aligned to 8 frames (see streaming.py: bit-exact pairing)
     win = left + chunk + right
     rng = np.random.default_rng(7 + rank)
     mel_h, noise_h = synthetic_batch(rng, n_streams, win, dims.steps_per_frame)
@@ -304,6 +305,7 @@ def main():
     eng.profile_enable(False)
 
     if rank == 0:
+        winograd = os.environ.get("MBX_WINOGRAD", "1") != "0" and dims.wn_kernel_size == 3
         C, L, ks = dims.wn_channels, dims.wn_layers, dims.wn_kernel_size
         rows = batch * frames * dims.steps_per_frame
         gate_flop = 2.0 * rows * (ks * C) * (2 * C)                   # algorithmic FLOPs of one launch
@@ -329,11 +331,18 @@ def main():
             "config": {"workload": f"{args.workload}: MW-{voice[:2]}-FD canonical (C={C}, L={L}), batch {batch} x "
                                    f"{frames / 80:g} s per GPU, 80x{frames} synthetic mel, seeded synthetic weights",
                        "batch_per_gpu": batch, "frames": frames, "parallelism": f"utterance-sharded x{world}"},
-            "roofline": {"bound": "mfma", "kernel": "conv1d_mfma_dma_kernel<EPI_GATE> (dilated conv k=3 C->2C + cond + tanh*sigmoid)",
+            "roofline": {"bound": "mfma",
+                         "kernel": "wn_gate_winograd_kernel (dilated conv k=3 C->2C in Winograd F(2,3) form + cond + tanh*sigmoid)"
+                         if winograd else "conv1d_mfma_dma_kernel<EPI_GATE> (dilated conv k=3 C->2C + cond + tanh*sigmoid)",
                          "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": pmc_traffic(args.workload),
                          "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
-                         "flop_per_launch": gate_flop, "avg_launch_ms": gate_avg_s * 1e3, "launches_timed": gate_n,
+                         "flop_per_launch": gate_flop,
+                         "note": "achieved = algorithmic FLOPs of the direct convolution (2*rows*3C*2C) / launch time; the "
+                                 "Winograd form executes 2/3 of them on the matrix cores (MfmaUtil in profiles/)"
+                         if winograd else "achieved = 2*rows*3C*2C / launch time",
+                         "mfma_flop_executed_per_launch": gate_flop * (2.0 / 3.0 if winograd else 1.0),
+                         "avg_launch_ms": gate_avg_s * 1e3, "launches_timed": gate_n,
                          "res_skip_avg_launch_ms": rs_ms / max(rs_n, 1)},
         }
         if not args.no_cpu_baseline:

@@ -70,6 +70,7 @@ struct mbx_handle {
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_f0 = nullptr, ev_cond = nullptr, ev_vtf = nullptr;
     bool overlap = false;
+    bool use_winograd = false;   // Winograd F(2,3) gate kernel when the transformed weights were supplied
     // bench-only kernel timing (mbx_profile_*)
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool[2];   // 0: gate, 1: res_skip
@@ -490,6 +491,10 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
     // measured on MI355X: the fork/join costs more than it hides (config 2: 1.57 ms with, 1.54 ms without), so the
     // launch sequence stays on the caller's stream unless MBX_OVERLAP is set
     hd->overlap = getenv("MBX_OVERLAP") != nullptr;
+    {
+        const char *wv = getenv("MBX_WINOGRAD");
+        hd->use_winograd = wv ? atoi(wv) != 0 : true;   // default on (MBX_WINOGRAD=0 selects the direct form)
+    }
     for (int i = 0; i < 2; ++i) {
         e = hipStreamCreateWithFlags(&hd->side[i], hipStreamNonBlocking);
         if (e != hipSuccess) return bail(fail(MBX_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)));
@@ -608,7 +613,14 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         g.zeros = hd->zeros;
         {
             ScopedEvents ev(hd, 0, stream);
-            mbx::launch_conv1d(g, mbx::EPI_GATE, stream);
+            bool done = false;
+            const DevTensor *wino = hd->use_winograd ? find(hd, "wn.conv1D_" + ls + ".wino") : nullptr;
+            if (wino) {
+                mbx::ConvArgs gw = g;
+                gw.w = wino->ptr;
+                done = mbx::launch_wn_gate_winograd(gw, stream);
+            }
+            if (!done) mbx::launch_conv1d(g, mbx::EPI_GATE, stream);
         }
         const bool last = (l == L - 1);
         mbx::ConvArgs r = conv_args(w.a, nsteps * C, C, n_frames, c.steps_per_frame, (int)nsteps, B,

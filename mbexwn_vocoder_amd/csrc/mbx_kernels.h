@@ -55,6 +55,8 @@ struct ConvArgs {
 };
 
 void launch_conv1d(const ConvArgs &a, int epilogue, hipStream_t stream);
+// Winograd F(2,3) form of the WaveNet gate layer (wn_winograd.hip); a.w = host-transformed weights (4, cin, 2C)
+bool launch_wn_gate_winograd(const ConvArgs &a, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // element-wise / bandwidth-type stages (elementwise.hip)

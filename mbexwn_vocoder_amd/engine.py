@@ -223,6 +223,12 @@ def tensor_table(config, raw_weights, wavetables):
     _, syn = tb.pqmf_filters(int(mbc["subbands"]), int(mbc["taps"]), float(mbc["cutoff_ratio"]), float(mbc["beta"]),
                              mbc.get("max_band", None))
     out["table.pqmf_syn"] = syn
+    # Winograd F(2,3) combinations of the three taps of every dilated WaveNet convolution (wn_winograd.hip):
+    # W0, (W0+W1+W2)/2, (W0-W1+W2)/2, W2 -- formed in float64, stored float32
+    if dims.wn_kernel_size == 3:
+        for ll in range(dims.wn_layers):
+            w = out[f"wn.conv1D_{ll}.w"].astype(np.float64)
+            out[f"wn.conv1D_{ll}.wino"] = np.stack((w[0], (w[0] + w[1] + w[2]) / 2, (w[0] - w[1] + w[2]) / 2, w[2]))
     out["table.hann"] = tb.hann_periodic_f32(dims.stft_win)
     out["table.inv_win"] = tb.inverse_stft_window_f32(dims.stft_win, dims.hop_size)
     out["table.wavetables"] = np.ascontiguousarray(wavetables.tables, dtype=np.float32)

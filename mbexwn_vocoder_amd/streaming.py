@@ -77,6 +77,12 @@ class StreamingSynthesizer:
         self.dims = engine.dims
         self.chunk = int(chunk_frames)
         self.left, self.right, self.lead = stream_margins(engine.dims, engine.config)
+        # The Winograd form of the dilated convolution pairs outputs t and t+d inside blocks of 2d steps counted from
+        # the first row of the item; a window that starts on a multiple of 2*d_max steps pairs exactly like the offline
+        # run, which keeps the streamed audio bit-identical (any other start is equal up to float32 rounding only).
+        import math
+        d_max = max(engine.dims.wn_dilation(ll) for ll in range(engine.dims.wn_layers))
+        self.align = (2 * d_max) // math.gcd(2 * d_max, engine.dims.steps_per_frame)
         self.streams = {}
 
     @property
@@ -116,7 +122,7 @@ class StreamingSynthesizer:
         windows = []
         for sid, st, nn in todo:
             have = st.mel.shape[0]
-            ws = max(0, st.emitted - self.left)
+            ws = max(0, ((st.emitted - self.left) // self.align) * self.align)
             we = have if st.closed and st.emitted + nn + self.right >= have else st.emitted + nn + self.right
             we = min(we, have)
             windows.append((ws, we))
