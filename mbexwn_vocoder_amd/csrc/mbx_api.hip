@@ -615,7 +615,8 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
             ScopedEvents ev(hd, 0, stream);
             bool done = false;
             const DevTensor *wino = hd->use_winograd ? find(hd, "wn.conv1D_" + ls + ".wino") : nullptr;
-            if (wino) {
+            if (wino && wino->ndim == 3 && wino->shape[0] == (C + 31) / 32 && wino->shape[1] == (C + 15) / 16 &&
+                wino->shape[2] == 4096) {
                 mbx::ConvArgs gw = g;
                 gw.w = wino->ptr;
                 done = mbx::launch_wn_gate_winograd(gw, stream);

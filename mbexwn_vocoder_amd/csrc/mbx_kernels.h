@@ -55,7 +55,7 @@ struct ConvArgs {
 };
 
 void launch_conv1d(const ConvArgs &a, int epilogue, hipStream_t stream);
-// Winograd F(2,3) form of the WaveNet gate layer (wn_winograd.hip); a.w = host-transformed weights (4, cin, 2C)
+// Winograd F(2,3) form of the WaveNet gate layer (wn_winograd.hip); a.w = host-packed weights (ceil(C/32), ceil(C/16), 4096)
 bool launch_wn_gate_winograd(const ConvArgs &a, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------

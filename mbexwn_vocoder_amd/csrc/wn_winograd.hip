@@ -14,8 +14,11 @@
 // Pair P of the block: q = P / d, r = P % d, t = m0 + 2 d q + r (d is a power of two <= 16).
 // Per K slice of 16 channels the block stages, through LDS-DMA (see lds_dma16 in conv_mfma.hip):
 //   A: activation rows [m0-32, m0+288) x 16 channels, chunk (row, c) at position 4*row + (c ^ ((row>>2)&3))
-//   B: 4 weight combinations x 16 channels x 64 columns (32 tanh | 32 sigmoid), k-major
+//   B: 4 weight combinations x 16 channels x 64 columns (32 tanh | 32 sigmoid), pre-packed on the host in MFMA operand
+//      order [product j][channel half cc][tanh|sigmoid][lane][4 k steps] so that one ds_read_b128 per lane yields the
+//      weight operands of four consecutive MFMAs (engine.pack_winograd_weights)
 // Two LDS stages (72 KB per block, 2 blocks per CU); accumulators: 4 products x (tanh, sigmoid) x 16 = 128 VGPRs.
+#include <cstdlib>
 #include "mbx_kernels.h"
 
 namespace mbx {
@@ -29,7 +32,7 @@ constexpr int WG_BK = 16;
 constexpr int WG_A_FLOATS = WG_AROWS * WG_BK;          // 5120
 constexpr int WG_B_FLOATS = 4 * WG_BK * 64;            // 4096
 constexpr int WG_A_INST = WG_AROWS * 4 / 64 / 4;       // 5 LDS-DMA instructions per wave (A)
-constexpr int WG_B_INST = 4 * WG_BK * 16 / 64 / 4;     // 4 per wave (B)
+constexpr int WG_B_INST = WG_B_FLOATS / 4 / 64 / 4;        // 4 per wave (B)
 
 __device__ __forceinline__ void wg_lds_dma16(const float *src, unsigned lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(src) : "memory", "m0");
@@ -79,19 +82,8 @@ __global__ __launch_bounds__(256, 2) void wn_gate_winograd_kernel(ConvArgs p, in
         a_off[i] = max(src, 0) * p.ldx;
         if (src >= 0 && src < rows) a_ok |= 1u << i;
     }
-    long long b_off[WG_B_INST];
-    int b_k[WG_B_INST];
-    unsigned b_ok = 0;
-#pragma unroll
-    for (int i = 0; i < WG_B_INST; ++i) {
-        const int pos = (wave + 4 * i) * 64 + lane;          // 0..1023 = (j, k, column quad)
-        const int j = pos >> 8, k = (pos >> 4) & 15, c = (pos & 15) * 4;
-        const int ch = n0 + (c & 31);
-        const int gcol = (c < 32 ? 0 : C) + min(ch, C - 4);
-        b_k[i] = k;
-        b_off[i] = ((long long)j * p.cin + k) * p.cout + gcol;
-        if (ch < C) b_ok |= 1u << i;
-    }
+    // weights: the packed image of (column tile nt, slice kt) is copied verbatim, 16 KB = 4 x 1 KB per wave
+    const float *wsrc = p.w + (long long)nt * nk * WG_B_FLOATS + (wave * 64 + lane) * 4;
     auto issue = [&](int kt, int buf) {
         const int ci0 = kt * WG_BK;
         const unsigned adst = lds_base + 4u * (unsigned)(buf * WG_A_FLOATS);
@@ -103,9 +95,26 @@ __global__ __launch_bounds__(256, 2) void wn_gate_winograd_kernel(ConvArgs p, in
             wg_lds_dma16(ok ? xb + a_off[i] + ci : p.zeros, adst + 1024u * (unsigned)(wave + 4 * i));
         }
 #pragma unroll
-        for (int i = 0; i < WG_B_INST; ++i) {
-            const bool ok = ((b_ok >> i) & 1u) & (ci0 + b_k[i] < p.cin);
-            wg_lds_dma16(ok ? p.w + b_off[i] + (long long)ci0 * p.cout : p.zeros, bdst + 1024u * (unsigned)(wave + 4 * i));
+        for (int i = 0; i < WG_B_INST; ++i)
+            wg_lds_dma16(wsrc + (long long)kt * WG_B_FLOATS + i * 1024, bdst + 1024u * (unsigned)(wave + 4 * i));
+    };
+
+    // conditioning rows of this block (<= 32 rows x (32 tanh | 32 sigmoid) columns) go to a free A stage during the last
+    // slice, so that the epilogue reads them from LDS: row index = cond row - t2base, rows clamped to the last one
+    const int cond_up = p.cond_up;
+    const int n2 = rows / cond_up;
+    const int t2base = m0 / cond_up;
+    const float *cbase = p.cond + (long long)b * p.cond_bstride;
+    auto issue_cond = [&](int buf) {
+        const unsigned cdst = lds_base + 4u * (unsigned)(buf * WG_A_FLOATS);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pos = (wave + 4 * i) * 64 + lane;
+            const int crow = pos >> 4, cq = pos & 15;
+            const int chn = n0 + 4 * (cq & 7);
+            const int t = min(t2base + crow, n2 - 1);
+            wg_lds_dma16(chn < C ? cbase + (long long)t * (2 * C) + (cq >> 3) * C + chn : p.zeros,
+                         cdst + 1024u * (unsigned)(wave + 4 * i));
         }
     };
 
@@ -120,70 +129,97 @@ __global__ __launch_bounds__(256, 2) void wn_gate_winograd_kernel(ConvArgs p, in
     // pair of this lane (A operand row): P = 32*wave + lrow -> t = m0 + 2 d (P >> log2d) + (P & (d-1))
     const int pair = 32 * wave + lrow;
     const int trel = WG_HALO + ((pair >> log2d) << (log2d + 1)) + (pair & (d - 1));   // LDS row of h[t]
-    int arow[4];        // LDS rows of h[t-d], h[t], h[t+d], h[t+2d]
-    arow[0] = trel - d;
-    arow[1] = trel;
-    arow[2] = trel + d;
-    arow[3] = trel + 2 * d;
+    int aoff[4][2];     // LDS float offsets of h[t-d], h[t], h[t+d], h[t+2d] for the two channel halves of a slice
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = trel + (q - 1) * d;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) aoff[q][cc] = row * WG_BK + 4 * ((2 * cc + lk) ^ ((row >> 2) & 3));
+    }
+
+    // Operand groups: (slice, channel half cc, product j) = 8 MFMAs.  The operands of group n+1 are requested from LDS
+    // before the MFMAs of group n issue; the last group of a slice first passes the barrier that publishes the next slice.
+    float4 X[2][4];
+    float4 Bv[2][2];
+    auto load_x = [&](int buf, int cc, float4 (&x)[4]) {
+        const float *ab = lds + buf * WG_A_FLOATS;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[q] = *reinterpret_cast<const float4 *>(ab + aoff[q][cc]);
+    };
+    auto load_b = [&](int buf, int cc, int j, float4 (&bw)[2]) {
+        const float *bb = lds + 2 * WG_A_FLOATS + buf * WG_B_FLOATS + lane * 4;
+        bw[0] = *reinterpret_cast<const float4 *>(bb + ((j * 2 + cc) * 2 + 0) * 256);
+        bw[1] = *reinterpret_cast<const float4 *>(bb + ((j * 2 + cc) * 2 + 1) * 256);
+    };
 
     issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (nk > 1 && !(p.ablate & 1)) issue(1, 1);
+    load_x(0, 0, X[0]);
+    load_b(0, 0, 0, Bv[0]);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
-        const float *ab = lds + buf * WG_A_FLOATS;
-        const float *bb = lds + 2 * WG_A_FLOATS + buf * WG_B_FLOATS + lrow;
 #pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
-            float4 x[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                x[q] = *reinterpret_cast<const float4 *>(ab + arow[q] * WG_BK + 4 * ((2 * cc + lk) ^ ((arow[q] >> 2) & 3)));
-            float u[4][4];     // [product][k step]
-            u[0][0] = x[0].x - x[2].x; u[0][1] = x[0].y - x[2].y; u[0][2] = x[0].z - x[2].z; u[0][3] = x[0].w - x[2].w;
-            u[1][0] = x[1].x + x[2].x; u[1][1] = x[1].y + x[2].y; u[1][2] = x[1].z + x[2].z; u[1][3] = x[1].w + x[2].w;
-            u[2][0] = x[2].x - x[1].x; u[2][1] = x[2].y - x[1].y; u[2][2] = x[2].z - x[1].z; u[2][3] = x[2].w - x[1].w;
-            u[3][0] = x[1].x - x[3].x; u[3][1] = x[1].y - x[3].y; u[3][2] = x[1].z - x[3].z; u[3][3] = x[1].w - x[3].w;
-            // weight operands of step st+1 are requested before the 8 MFMAs of step st issue
-            float bv[2][4][2];
-            {
-                const int k = 8 * cc + 4 * lk;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    bv[0][j][0] = bb[(j * WG_BK + k) * 64];
-                    bv[0][j][1] = bb[(j * WG_BK + k) * 64 + 32];
+        for (int gi = 0; gi < 8; ++gi) {
+            const int cc = gi >> 2, j = gi & 3;
+            if (gi < 7) {
+                load_b(buf, (gi + 1) >> 2, (gi + 1) & 3, Bv[(gi + 1) & 1]);
+                if (gi == 3) load_x(buf, 1, X[1]);
+            } else if (kt + 1 < nk) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!(p.ablate & 2)) __syncthreads();
+                if (kt + 2 < nk) {
+                    if (!(p.ablate & 1)) issue(kt + 2, buf);
+                } else {
+                    issue_cond(buf);
                 }
+                load_b(buf ^ 1, 0, 0, Bv[0]);
+                load_x(buf ^ 1, 0, X[0]);
             }
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                const int cur = st & 1, nxt = cur ^ 1;
-                if (st + 1 < 4) {
-                    const int k = 8 * cc + 4 * lk + st + 1;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        bv[nxt][j][0] = bb[(j * WG_BK + k) * 64];
-                        bv[nxt][j][1] = bb[(j * WG_BK + k) * 64 + 32];
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[j][st], bv[cur][j][0], acc[j][0], 0, 0, 0);
-                    acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[j][st], bv[cur][j][1], acc[j][1], 0, 0, 0);
-                }
-                if (st + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the requests ahead of this group's MFMAs
+            const float4(&x)[4] = X[cc];
+            float4 u;
+            if (j == 0) u = make_float4(x[0].x - x[2].x, x[0].y - x[2].y, x[0].z - x[2].z, x[0].w - x[2].w);
+            else if (j == 1) u = make_float4(x[1].x + x[2].x, x[1].y + x[2].y, x[1].z + x[2].z, x[1].w + x[2].w);
+            else if (j == 2) u = make_float4(x[2].x - x[1].x, x[2].y - x[1].y, x[2].z - x[1].z, x[2].w - x[1].w);
+            else u = make_float4(x[1].x - x[3].x, x[1].y - x[3].y, x[1].z - x[3].z, x[1].w - x[3].w);
+            const float4(&bw)[2] = Bv[gi & 1];
+            acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.x, bw[0].x, acc[j][0], 0, 0, 0);
+            acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.x, bw[1].x, acc[j][1], 0, 0, 0);
+            acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.y, bw[0].y, acc[j][0], 0, 0, 0);
+            acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.y, bw[1].y, acc[j][1], 0, 0, 0);
+            acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.z, bw[0].z, acc[j][0], 0, 0, 0);
+            acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.z, bw[1].z, acc[j][1], 0, 0, 0);
+            acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.w, bw[0].w, acc[j][0], 0, 0, 0);
+            acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.w, bw[1].w, acc[j][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
     // ---- epilogue: combine the four products, add bias + conditioning, gate, store both outputs of the pair
+    const int cbuf = nk & 1;                       // stage that held slice nk-2 (the conditioning tile now)
+    float *lerp_lds = lds + cbuf * WG_A_FLOATS + 2048;
+    if (nk < 2) issue_cond(cbuf);
+    if (tid < cond_up) {
+        lerp_lds[tid] = p.lerp_w0[tid];
+        lerp_lds[64 + tid] = p.lerp_w1[tid];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     const int ch = n0 + lrow;
     if (ch >= C) return;
+    if (p.ablate & 4) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc += acc[0][0][r] + acc[1][0][r] + acc[2][0][r] + acc[3][0][r] + acc[0][1][r] + acc[1][1][r] + acc[2][1][r] + acc[3][1][r];
+        if (sacc == 1.2345f) p.out[0] = sacc;
+        return;
+    }
     const float bt = p.bias ? p.bias[ch] : 0.f;
     const float bsg = p.bias ? p.bias[C + ch] : 0.f;
-    const float *cb = p.cond + (long long)b * p.cond_bstride + ch;
-    const int n2 = rows / p.cond_up;
+    const float *cl = lds + cbuf * WG_A_FLOATS + lrow;
+    const float inv_up = 1.0f / (float)cond_up;
     float *ob = p.out + (long long)b * p.out_bstride + ch;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -197,28 +233,33 @@ __global__ __launch_bounds__(256, 2) void wn_gate_winograd_kernel(ConvArgs p, in
                                            : (acc[1][0][r] - acc[2][0][r]) - acc[3][0][r];
                 const float ys = half == 0 ? (acc[0][1][r] + acc[1][1][r]) + acc[2][1][r]
                                            : (acc[1][1][r] - acc[2][1][r]) - acc[3][1][r];
-                const int t2 = row / p.cond_up, u = row - t2 * p.cond_up;
-                const int t3 = min(t2 + 1, n2 - 1);
-                const float w0 = p.lerp_w0[u], w1 = p.lerp_w1[u];
-                const float *c0 = cb + t2 * (2 * C);
-                const float *c1 = cb + t3 * (2 * C);
-                const float zt = (yt + bt) + (c0[0] * w0 + c1[0] * w1);
-                const float zs = (ys + bsg) + (c0[C] * w0 + c1[C] * w1);
+                int t2 = (int)((float)row * inv_up);                       // row / cond_up (rows < 2^24)
+                int u = row - t2 * cond_up;
+                if (u < 0) { --t2; u += cond_up; }
+                if (u >= cond_up) { ++t2; u -= cond_up; }
+                const float w0 = lerp_lds[u], w1 = lerp_lds[64 + u];
+                const float *c0 = cl + (t2 - t2base) * 64;
+                const float zt = (yt + bt) + (c0[0] * w0 + c0[64] * w1);
+                const float zs = (ys + bsg) + (c0[32] * w0 + c0[96] * w1);
                 ob[row * p.ldo] = wg_gate_act(zt, zs);
             }
         }
     }
 }
 
-// a.w must point at the host-transformed weights (4, cin, 2C); returns false if the layer does not fit the kernel
+// a.w must point at the host-packed Winograd weights (ceil(C/32), ceil(C/16), 4096); returns false if the layer does not fit the kernel
 bool launch_wn_gate_winograd(const ConvArgs &a, hipStream_t stream) {
     int log2d = 0;
     while ((1 << log2d) < a.dil) ++log2d;
     const bool ok = a.ks == 3 && (1 << log2d) == a.dil && a.dil <= 16 && a.pad_l == a.dil && a.pad_mode == 0 &&
                     a.cin % 4 == 0 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 && a.channels % 4 == 0 &&
-                    a.cout == 2 * a.channels && (uintptr_t)a.x % 16 == 0 && (uintptr_t)a.w % 16 == 0 && a.zeros;
+                    a.cout == 2 * a.channels && (uintptr_t)a.x % 16 == 0 && (uintptr_t)a.w % 16 == 0 && a.zeros &&
+                    a.cond && (uintptr_t)a.cond % 16 == 0 && a.cond_bstride % 4 == 0 && a.cond_up <= 64 &&
+                    WG_ROWS / a.cond_up + 2 <= 32 && a.max_rows < (1 << 24);
     if (!ok) return false;
     ConvArgs r = a;
+    static const int ablate = getenv("MBX_WG_ABLATE") ? atoi(getenv("MBX_WG_ABLATE")) : 0;   // timing experiments only
+    r.ablate = ablate;
     r.n_tiles = (a.channels + 31) / 32;
     r.m_tiles_per_item = (a.max_rows + WG_ROWS - 1) / WG_ROWS;
     r.m_tiles_total = r.m_tiles_per_item * a.batch;

@@ -214,6 +214,27 @@ def make_config(config, wavetables):
     return cc, dims
 
 
+def pack_winograd_weights(w):
+    """Winograd F(2,3) combinations of the three taps (3, C, 2C) of a dilated WaveNet convolution, packed for
+    wn_gate_winograd_kernel (csrc/wn_winograd.hip).
+
+    Combinations W0, (W0+W1+W2)/2, (W0-W1+W2)/2, W2 are formed in float64 and stored float32.  Layout
+    (ceil(C/32) column tiles, ceil(C/16) channel slices, 4096): the 16 KB image of one (tile, slice) is what the kernel
+    copies verbatim into LDS, ordered [product j][channel half cc][tanh|sigmoid h][lane = 32*lk + n][k step st] with
+    input channel 16*slice + 8*cc + 4*lk + st and output column h*C + 32*tile + n; out-of-range entries are zero.
+    """
+    w = np.asarray(w, dtype=np.float64)
+    C = w.shape[1]
+    assert w.shape == (3, C, 2 * C)
+    wj = np.stack((w[0], (w[0] + w[1] + w[2]) / 2, (w[0] - w[1] + w[2]) / 2, w[2]))
+    nt, nk = (C + 31) // 32, (C + 15) // 16
+    wp = np.zeros((4, nk * 16, 2, nt * 32))
+    wp[:, :C, 0, :C] = wj[:, :, :C]
+    wp[:, :C, 1, :C] = wj[:, :, C:]
+    wp = wp.reshape(4, nk, 2, 2, 4, 2, nt, 32)                    # j, slice, cc, lk, st, h, tile, n
+    return np.ascontiguousarray(wp.transpose(6, 1, 0, 2, 5, 3, 7, 4).reshape(nt, nk, 4096), dtype=np.float32)
+
+
 def tensor_table(config, raw_weights, wavetables):
     """name -> float32 array of everything mbx_create needs: folded weights + constant tables."""
     dims = ModelDims(config)
@@ -223,12 +244,9 @@ def tensor_table(config, raw_weights, wavetables):
     _, syn = tb.pqmf_filters(int(mbc["subbands"]), int(mbc["taps"]), float(mbc["cutoff_ratio"]), float(mbc["beta"]),
                              mbc.get("max_band", None))
     out["table.pqmf_syn"] = syn
-    # Winograd F(2,3) combinations of the three taps of every dilated WaveNet convolution (wn_winograd.hip):
-    # W0, (W0+W1+W2)/2, (W0-W1+W2)/2, W2 -- formed in float64, stored float32
     if dims.wn_kernel_size == 3:
         for ll in range(dims.wn_layers):
-            w = out[f"wn.conv1D_{ll}.w"].astype(np.float64)
-            out[f"wn.conv1D_{ll}.wino"] = np.stack((w[0], (w[0] + w[1] + w[2]) / 2, (w[0] - w[1] + w[2]) / 2, w[2]))
+            out[f"wn.conv1D_{ll}.wino"] = pack_winograd_weights(out[f"wn.conv1D_{ll}.w"])
     out["table.hann"] = tb.hann_periodic_f32(dims.stft_win)
     out["table.inv_win"] = tb.inverse_stft_window_f32(dims.stft_win, dims.hop_size)
     out["table.wavetables"] = np.ascontiguousarray(wavetables.tables, dtype=np.float32)
