@@ -619,7 +619,10 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                 wino->shape[2] == 4096) {
                 mbx::ConvArgs gw = g;
                 gw.w = wino->ptr;
-                done = mbx::launch_wn_gate_winograd(gw, stream);
+                const DevTensor *wino2 = find(hd, "wn.conv1D_" + ls + ".wino_split");
+                const bool ok2 = wino2 && wino2->ndim == 3 && wino2->shape[0] == wino->shape[0] &&
+                                 wino2->shape[1] == wino->shape[1] && wino2->shape[2] == 4096;
+                done = mbx::launch_wn_gate_winograd(gw, ok2 ? wino2->ptr : nullptr, stream);
             }
             if (!done) mbx::launch_conv1d(g, mbx::EPI_GATE, stream);
         }

@@ -56,7 +56,7 @@ struct ConvArgs {
 
 void launch_conv1d(const ConvArgs &a, int epilogue, hipStream_t stream);
 // Winograd F(2,3) form of the WaveNet gate layer (wn_winograd.hip); a.w = host-packed weights (ceil(C/32), ceil(C/16), 4096)
-bool launch_wn_gate_winograd(const ConvArgs &a, hipStream_t stream);
+bool launch_wn_gate_winograd(const ConvArgs &a, const float *w_split, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // element-wise / bandwidth-type stages (elementwise.hip)

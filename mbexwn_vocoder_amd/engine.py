@@ -214,7 +214,7 @@ def make_config(config, wavetables):
     return cc, dims
 
 
-def pack_winograd_weights(w):
+def pack_winograd_weights(w, split=False):
     """Winograd F(2,3) combinations of the three taps (3, C, 2C) of a dilated WaveNet convolution, packed for
     wn_gate_winograd_kernel (csrc/wn_winograd.hip).
 
@@ -222,6 +222,8 @@ def pack_winograd_weights(w):
     (ceil(C/32) column tiles, ceil(C/16) channel slices, 4096): the 16 KB image of one (tile, slice) is what the kernel
     copies verbatim into LDS, ordered [product j][channel half cc][tanh|sigmoid h][lane = 32*lk + n][k step st] with
     input channel 16*slice + 8*cc + 4*lk + st and output column h*C + 32*tile + n; out-of-range entries are zero.
+    split=True is the image for the half-size block shape: column half h holds tile channels 16h..16h+15 as
+    [16 tanh | 16 sigmoid], i.e. lane column n -> output column (n // 16)*C + 32*tile + 16*h + n % 16.
     """
     w = np.asarray(w, dtype=np.float64)
     C = w.shape[1]
@@ -231,6 +233,8 @@ def pack_winograd_weights(w):
     wp = np.zeros((4, nk * 16, 2, nt * 32))
     wp[:, :C, 0, :C] = wj[:, :, :C]
     wp[:, :C, 1, :C] = wj[:, :, C:]
+    if split:
+        wp = wp.reshape(4, nk * 16, 2, nt, 2, 16).transpose(0, 1, 4, 3, 2, 5).reshape(4, nk * 16, 2, nt * 32)
     wp = wp.reshape(4, nk, 2, 2, 4, 2, nt, 32)                    # j, slice, cc, lk, st, h, tile, n
     return np.ascontiguousarray(wp.transpose(6, 1, 0, 2, 5, 3, 7, 4).reshape(nt, nk, 4096), dtype=np.float32)
 
@@ -247,6 +251,7 @@ def tensor_table(config, raw_weights, wavetables):
     if dims.wn_kernel_size == 3:
         for ll in range(dims.wn_layers):
             out[f"wn.conv1D_{ll}.wino"] = pack_winograd_weights(out[f"wn.conv1D_{ll}.w"])
+            out[f"wn.conv1D_{ll}.wino_split"] = pack_winograd_weights(out[f"wn.conv1D_{ll}.w"], split=True)
     out["table.hann"] = tb.hann_periodic_f32(dims.stft_win)
     out["table.inv_win"] = tb.inverse_stft_window_f32(dims.stft_win, dims.hop_size)
     out["table.wavetables"] = np.ascontiguousarray(wavetables.tables, dtype=np.float32)
