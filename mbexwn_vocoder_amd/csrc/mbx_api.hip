@@ -639,7 +639,18 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         r.last_layer = last;
         {
             ScopedEvents ev(hd, 1, stream);
-            mbx::launch_conv1d(r, mbx::EPI_RESSKIP, stream);
+            // LDS-DMA kernel with host-packed weights (MBX_RS_PACKED=0: generic conv kernel)
+            static const int rs_env = getenv("MBX_RS_PACKED") ? atoi(getenv("MBX_RS_PACKED")) : 1;
+            const DevTensor *pk = find(hd, "wn.res_skip_" + ls + ".packed");
+            const int cout_l = last ? C : 2 * C;
+            bool done = false;
+            if (pk && pk->ndim == 3 && pk->shape[0] == (cout_l + 127) / 128 && pk->shape[1] == (C + 15) / 16 &&
+                pk->shape[2] == 2048 && rs_env != 0) {
+                mbx::ConvArgs rp = r;
+                rp.w = pk->ptr;
+                done = mbx::launch_wn_resskip(rp, stream);
+            }
+            if (!done) mbx::launch_conv1d(r, mbx::EPI_RESSKIP, stream);
         }
     }
     {

@@ -1,0 +1,208 @@
+// WaveNet residual/skip layer: r = a W + b (1x1, C -> 2C; last layer C -> C), h += r[:, :C], skip (+)= r[:, C:].
+//
+// Same layer as conv1d_mfma_kernel<EPI_RESSKIP> (reference MBExWN_NVoc/vocoder/model/custom_AE_layers.py:322-336:
+// res_skip = res_skip_l(acts); x = x + res_skip[:C]; skip_out (+)= res_skip[C:]), restructured like the Winograd gate
+// kernel (wn_winograd.hip) for large row counts:
+//   block = 2 x 2 waves, (64 MT) rows x 128 columns, wave tile (32 MT) x 64; MT = 2 (128-row blocks, 3 per CU) for
+//   large launches, MT = 1 (64-row blocks, finer granularity) for small ones
+//   A: gate output rows [m0, m0+64 MT) x 16 channels per slice through LDS-DMA, chunk (row, c) at 4*row + (c ^ ((row>>2)&3))
+//   B: 16 channels x 128 columns per slice, pre-packed on the host in MFMA operand order
+//      [channel half cc][column tile jn][lane][4 k steps] (engine.pack_resskip_weights): one ds_read_b128 per lane
+//      = the weight operands of four consecutive MFMAs
+//   two LDS stages (32 / 24 KB per block); operand groups of 8 MFMAs, the operands of group n+1 are requested from
+//   LDS before the MFMAs of group n issue.
+// The accumulators start from (old value + bias), so the epilogue is a plain store (same arithmetic as the
+// acc_preloaded path of conv1d_mfma_kernel).
+#include <cstdlib>
+#include "mbx_kernels.h"
+
+namespace mbx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int RS_BK = 16;
+constexpr int RS_B_FLOATS = RS_BK * 128;     // 2048
+
+__device__ __forceinline__ void rs_lds_dma16(const float *src, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(src) : "memory", "m0");
+}
+
+template <int MT>
+__global__ __launch_bounds__(256, MT == 2 ? 3 : 4) void wn_resskip_kernel(ConvArgs p) {
+    constexpr int ROWS = 64 * MT;
+    constexpr int RS_A_FLOATS = ROWS * RS_BK;
+    constexpr int A_INST = ROWS / 64;          // LDS-DMA instructions per wave (A)
+    constexpr int NG = 2 * MT;                 // operand groups (8 MFMAs each) per slice
+    typedef __attribute__((address_space(3))) float lds_float;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (RS_A_FLOATS + RS_B_FLOATS)];   // A0 A1 B0 B1
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float *)lds);
+
+    // XCD-aware decode (see decode_tile in conv_mfma.hip)
+    const int id = blockIdx.x;
+    const int l = id >> 3;
+    const int g = (l / p.n_tiles) * 8 + (id & 7);
+    const int nt = l % p.n_tiles;
+    if (g >= p.m_tiles_total) return;
+    const int b = g / p.m_tiles_per_item;
+    const int mt = g - b * p.m_tiles_per_item;
+    const int rows = p.n_frames ? p.n_frames[b] * p.rows_per_frame : p.max_rows;
+    const int m0 = mt * ROWS;
+    if (m0 >= rows) return;
+    const int C = p.channels;
+    const int n0 = nt * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int lrow = lane & 31, lk = lane >> 5;
+    const float *xb = p.x + (long long)b * p.x_bstride;
+    const int nk = (p.cin + RS_BK - 1) / RS_BK;
+
+    // ---- per-lane DMA sources
+    int a_off[A_INST], a_ch[A_INST];
+    unsigned a_ok = 0;
+#pragma unroll
+    for (int i = 0; i < A_INST; ++i) {
+        const int pos = (wave + 4 * i) * 64 + lane;
+        const int row = pos >> 2;
+        a_ch[i] = 4 * ((pos & 3) ^ ((row >> 2) & 3));
+        a_off[i] = min(m0 + row, rows - 1) * p.ldx;
+        if (m0 + row < rows) a_ok |= 1u << i;
+    }
+    const float *wsrc = p.w + (long long)nt * nk * RS_B_FLOATS + (wave * 64 + lane) * 4;
+    auto issue = [&](int kt, int buf) {
+        const int ci0 = kt * RS_BK;
+        const unsigned adst = lds_base + 4u * (unsigned)(buf * RS_A_FLOATS);
+        const unsigned bdst = lds_base + 4u * (unsigned)(2 * RS_A_FLOATS + buf * RS_B_FLOATS);
+#pragma unroll
+        for (int i = 0; i < A_INST; ++i) {
+            const int ci = ci0 + a_ch[i];
+            const bool ok = ((a_ok >> i) & 1u) & (ci < p.cin);
+            rs_lds_dma16(ok ? xb + a_off[i] + ci : p.zeros, adst + 1024u * (unsigned)(wave + 4 * i));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            rs_lds_dma16(wsrc + (long long)kt * RS_B_FLOATS + i * 1024, bdst + 1024u * (unsigned)(wave + 4 * i));
+    };
+    issue(0, 0);
+
+    // ---- accumulators start from old value + bias (h columns always accumulate, skip columns unless skip_init)
+    f32x16 acc[MT][2];
+    float *dst[2];
+    bool col_ok[2];
+    {
+        // unconditional loads from clamped addresses (no branch, all 64 requests in flight), selected afterwards
+        int rowc[MT][16];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                rowc[i][r] = min(m0 + 32 * MT * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk, rows - 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + 64 * wn + 32 * j + lrow;
+            col_ok[j] = col < p.cout;
+            const int colc = min(col, p.cout - 1);
+            const bool to_h = (!p.last_layer) && colc < C;
+            const int oc = to_h ? colc : (p.last_layer ? colc : colc - C);
+            dst[j] = (to_h ? p.h : p.skip) + (long long)b * p.hs_bstride + oc;
+            const bool accumulate = (to_h || !p.skip_init) && col_ok[j];
+            const float bias = (p.bias && col_ok[j]) ? p.bias[colc] : 0.f;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float old = dst[j][(long long)rowc[i][r] * C];
+                    acc[i][j][r] = (accumulate ? old : 0.f) + bias;
+                }
+        }
+    }
+
+    int aoff[MT][2];    // LDS float offsets of this lane's A row of row tile i for the two channel halves of a slice
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int row = 32 * MT * wm + 32 * i + lrow;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) aoff[i][cc] = row * RS_BK + 4 * ((2 * cc + lk) ^ ((row >> 2) & 3));
+    }
+    float4 Av[2];
+    float4 Bv[2][2];
+    auto load_a = [&](int buf, int cc, int i, float4 &a) {
+        a = *reinterpret_cast<const float4 *>(lds + buf * RS_A_FLOATS + aoff[i][cc]);
+    };
+    auto load_b = [&](int buf, int cc, float4 (&bw)[2]) {
+        const float *bb = lds + 2 * RS_A_FLOATS + buf * RS_B_FLOATS + lane * 4;
+        bw[0] = *reinterpret_cast<const float4 *>(bb + (cc * 4 + 2 * wn + 0) * 256);
+        bw[1] = *reinterpret_cast<const float4 *>(bb + (cc * 4 + 2 * wn + 1) * 256);
+    };
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (nk > 1) issue(1, 1);
+    load_a(0, 0, 0, Av[0]);
+    load_b(0, 0, Bv[0]);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            const int cc = gi / MT, i = gi % MT;
+            if (gi < NG - 1) {
+                load_a(buf, (gi + 1) / MT, (gi + 1) % MT, Av[(gi + 1) & 1]);
+                if (gi == MT - 1) load_b(buf, 1, Bv[1]);
+            } else if (kt + 1 < nk) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (kt + 2 < nk) issue(kt + 2, buf);
+                load_a(buf ^ 1, 0, 0, Av[0]);
+                load_b(buf ^ 1, 0, Bv[0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the requests ahead of this group's MFMAs
+            const float4 a = Av[gi & 1];
+            const float4(&bw)[2] = Bv[cc];
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bw[0].x, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bw[1].x, acc[i][1], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bw[0].y, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bw[1].y, acc[i][1], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bw[0].z, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bw[1].z, acc[i][1], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bw[0].w, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bw[1].w, acc[i][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- epilogue: the accumulators are the new values
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (!col_ok[j]) continue;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 32 * MT * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (row < rows) dst[j][(long long)row * C] = acc[i][j][r];
+            }
+    }
+}
+
+// a.w must point at the host-packed weights (ceil(cout/128), ceil(C/16), 2048); returns false if the layer does not fit
+bool launch_wn_resskip(const ConvArgs &a, hipStream_t stream) {
+    const bool ok = a.ks == 1 && a.cin == a.channels && a.cin % 4 == 0 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 &&
+                    (uintptr_t)a.x % 16 == 0 && (uintptr_t)a.w % 16 == 0 && a.zeros && a.h && a.skip &&
+                    a.cout == (a.last_layer ? a.channels : 2 * a.channels);
+    if (!ok) return false;
+    ConvArgs r = a;
+    static const int small_env = getenv("MBX_RS_SMALL") ? atoi(getenv("MBX_RS_SMALL")) : -1;   // -1 auto, 0 never, 1 always
+    r.n_tiles = (a.cout + 127) / 128;
+    // 64-row blocks while the 128-row grid is less than three rounds of the 768 resident blocks (3 per CU x 256 CUs)
+    const long long big_blocks = (long long)((a.max_rows + 127) / 128) * a.batch * r.n_tiles;
+    const bool small = small_env < 0 ? big_blocks < 3 * 768 : small_env != 0;
+    const int tile_rows = small ? 64 : 128;
+    r.m_tiles_per_item = (a.max_rows + tile_rows - 1) / tile_rows;
+    r.m_tiles_total = r.m_tiles_per_item * a.batch;
+    const long long blocks = 8LL * ((r.m_tiles_total + 7) / 8) * r.n_tiles;
+    if (small) hipLaunchKernelGGL(wn_resskip_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, r);
+    else hipLaunchKernelGGL(wn_resskip_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, r);
+    return true;
+}
+
+}  // namespace mbx

@@ -239,6 +239,23 @@ def pack_winograd_weights(w, split=False):
     return np.ascontiguousarray(wp.transpose(6, 1, 0, 2, 5, 3, 7, 4).reshape(nt, nk, 4096), dtype=np.float32)
 
 
+def pack_resskip_weights(w):
+    """Weights (1, C, cout) of a WaveNet res/skip 1x1 convolution packed for wn_resskip_kernel (csrc/wn_resskip.hip).
+
+    Layout (ceil(cout/128) column tiles, ceil(C/16) channel slices, 2048): the 8 KB image of one (tile, slice), ordered
+    [channel half cc][column sub-tile jn][lane = 32*lk + n][k step st] with input channel 16*slice + 8*cc + 4*lk + st
+    and output column 128*tile + 32*jn + n; out-of-range entries are zero.
+    """
+    w = np.asarray(w, dtype=np.float32)
+    assert w.ndim == 3 and w.shape[0] == 1
+    C, cout = w.shape[1], w.shape[2]
+    nct, nk = (cout + 127) // 128, (C + 15) // 16
+    wp = np.zeros((nk * 16, nct * 128), dtype=np.float32)
+    wp[:C, :cout] = w[0]
+    wp = wp.reshape(nk, 2, 2, 4, nct, 4, 32)                      # slice, cc, lk, st, tile, jn, n
+    return np.ascontiguousarray(wp.transpose(4, 0, 1, 5, 2, 6, 3).reshape(nct, nk, 2048))
+
+
 def tensor_table(config, raw_weights, wavetables):
     """name -> float32 array of everything mbx_create needs: folded weights + constant tables."""
     dims = ModelDims(config)
@@ -248,6 +265,8 @@ def tensor_table(config, raw_weights, wavetables):
     _, syn = tb.pqmf_filters(int(mbc["subbands"]), int(mbc["taps"]), float(mbc["cutoff_ratio"]), float(mbc["beta"]),
                              mbc.get("max_band", None))
     out["table.pqmf_syn"] = syn
+    for ll in range(dims.wn_layers):
+        out[f"wn.res_skip_{ll}.packed"] = pack_resskip_weights(out[f"wn.res_skip_{ll}.w"])
     if dims.wn_kernel_size == 3:
         for ll in range(dims.wn_layers):
             out[f"wn.conv1D_{ll}.wino"] = pack_winograd_weights(out[f"wn.conv1D_{ll}.w"])
