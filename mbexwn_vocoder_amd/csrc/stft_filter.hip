@@ -13,33 +13,68 @@
 // so the head and the tail of the output are under-normalised; that taper is reproduced because the
 // same frames are summed.
 //
-// One 256-thread block per (item, frame): three radix-2 Stockham FFTs of fft_size points in LDS
-// (twiddles in LDS).  The three FFTs are ~0.1 % of the forward FLOPs; the stage is latency-type.
+// One 256-thread block per (item, frame).  The three transforms are real, so each runs as a complex transform of
+// fft_size/2 points (even samples in the real part, odd samples in the imaginary part, one butterfly pass to
+// separate / merge the halves): Stockham autosort in LDS, radix-4 passes (one butterfly per thread and pass for
+// fft_size = 2048) plus one radix-2 pass when log2(fft_size/2) is odd; twiddles exp(-2 pi i m / fft_size) in LDS.
 #include "mbx_kernels.h"
 
 namespace mbx {
 
 constexpr int FFT_THREADS = 256;
 
-// Stockham autosort radix-2; n complex points ping-pong between a and b, returns the buffer holding the result
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+// exp(-+ 2 pi i idx / (2 nc)) from the half-circle table tw[0..nc), idx < 2 nc
 template <bool INVERSE>
-__device__ float2 *fft_lds(float2 *a, float2 *b, const float2 *tw, int n, int tid) {
+__device__ __forceinline__ float2 twiddle(const float2 *tw, int idx, int nc) {
+    float2 w = tw[idx & (nc - 1)];
+    if (idx >= nc) w = make_float2(-w.x, -w.y);
+    if (INVERSE) w.y = -w.y;
+    return w;
+}
+
+// nc complex points ping-pong between a and b; returns the buffer holding the (un-normalised) result
+template <bool INVERSE>
+__device__ float2 *fft_lds(float2 *a, float2 *b, const float2 *tw, int nc, int tid) {
     float2 *in = a, *out = b;
-    const int half = n >> 1;
-    for (int ns = 1; ns < n; ns <<= 1) {
-        const int tstep = half / ns;
+    int ns = 1;
+    const int quarter = nc >> 2;
+    for (; ns * 4 <= nc; ns <<= 2) {
+        const int step = nc / (2 * ns);
+        for (int j = tid; j < quarter; j += FFT_THREADS) {
+            const int k = j & (ns - 1);
+            const float2 u0 = in[j];
+            float2 u1 = in[j + quarter], u2 = in[j + 2 * quarter], u3 = in[j + 3 * quarter];
+            if (ns > 1) {
+                u1 = cmul(u1, twiddle<INVERSE>(tw, k * step, nc));
+                u2 = cmul(u2, twiddle<INVERSE>(tw, 2 * k * step, nc));
+                u3 = cmul(u3, twiddle<INVERSE>(tw, 3 * k * step, nc));
+            }
+            const float2 v0 = cadd(u0, u2), v1 = csub(u0, u2), v2 = cadd(u1, u3), t = csub(u1, u3);
+            const float2 v3 = INVERSE ? make_float2(-t.y, t.x) : make_float2(t.y, -t.x);    // t * (+-i)
+            const int j0 = ((j - k) << 2) + k;
+            out[j0] = cadd(v0, v2);
+            out[j0 + ns] = cadd(v1, v3);
+            out[j0 + 2 * ns] = csub(v0, v2);
+            out[j0 + 3 * ns] = csub(v1, v3);
+        }
+        __syncthreads();
+        float2 *tmp = in;
+        in = out;
+        out = tmp;
+    }
+    if (ns < nc) {      // ns * 2 == nc: one radix-2 pass
+        const int half = nc >> 1;
         for (int j = tid; j < half; j += FFT_THREADS) {
             const int k = j & (ns - 1);
-            float2 w = tw[k * tstep];
-            if (INVERSE) w.y = -w.y;
             const float2 v0 = in[j];
-            const float2 v1 = in[j + half];
-            float2 t;
-            t.x = v1.x * w.x - v1.y * w.y;
-            t.y = v1.x * w.y + v1.y * w.x;
+            const float2 t = cmul(in[j + half], twiddle<INVERSE>(tw, k * (nc / ns), nc));
             const int j0 = ((j - k) << 1) + k;
-            out[j0] = make_float2(v0.x + t.x, v0.y + t.y);
-            out[j0 + ns] = make_float2(v0.x - t.x, v0.y - t.y);
+            out[j0] = cadd(v0, t);
+            out[j0 + ns] = csub(v0, t);
         }
         __syncthreads();
         float2 *tmp = in;
@@ -47,6 +82,16 @@ __device__ float2 *fft_lds(float2 *a, float2 *b, const float2 *tw, int n, int ti
         out = tmp;
     }
     return in;
+}
+
+// bin k (0 <= k <= nc) of the real transform of x from Z = FFT_nc(x[2m] + i x[2m+1])
+__device__ __forceinline__ float2 real_bin(const float2 *z, const float2 *tw, int k, int nc) {
+    const float2 zk = z[k & (nc - 1)];
+    const float2 zr = z[(nc - k) & (nc - 1)];
+    const float2 xe = make_float2(0.5f * (zk.x + zr.x), 0.5f * (zk.y - zr.y));       // (Z[k] + conj Z[nc-k]) / 2
+    const float2 xo = make_float2(0.5f * (zk.y + zr.y), -0.5f * (zk.x - zr.x));      // (Z[k] - conj Z[nc-k]) / 2i
+    const float2 w = k < nc ? tw[k] : make_float2(-1.f, 0.f);
+    return cadd(xe, cmul(w, xo));
 }
 
 constexpr int MAX_BINS_PER_THREAD = 5;   // fft_size/2 + 1 <= 4*256 + 1
@@ -57,34 +102,39 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_filter_kernel(StftConsts c, 
                                                                   const int *n_frames, int max_frames,
                                                                   float *frames) {
     extern __shared__ float2 smem2[];
-    const int n = c.fft_size, half = n >> 1;
+    const int n = c.fft_size, nc = n >> 1;
     float2 *bufa = smem2;
-    float2 *bufb = smem2 + n;
-    float2 *tw = smem2 + 2 * n;            // n/2 twiddles
+    float2 *bufb = smem2 + nc;
+    float2 *tw = smem2 + 2 * nc;           // nc twiddles exp(-2 pi i m / n)
     const int b = blockIdx.y, t = blockIdx.x;
     const int T = n_frames ? n_frames[b] : max_frames;
     if (t >= T) return;
     const int tid = threadIdx.x;
-    for (int i = tid; i < half; i += FFT_THREADS) tw[i] = reinterpret_cast<const float2 *>(c.twiddle)[i];
+    for (int i = tid; i < nc; i += FFT_THREADS) tw[i] = reinterpret_cast<const float2 *>(c.twiddle)[i];
 
     // ---- 1. windowed excitation frame (zero padded signal: win/2 in front, win/2+hop+1 behind)
     const float *eb = exc + (long long)b * exc_bstride;
     const int n_sig = T * c.hop;
-    for (int i = tid; i < n; i += FFT_THREADS) {
-        float v = 0.f;
-        if (i < c.win) {
-            const int s = t * c.hop + i - c.win / 2;
-            if (s >= 0 && s < n_sig) v = eb[s] * c.hann[i];
+    for (int m = tid; m < nc; m += FFT_THREADS) {
+        float v[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = 2 * m + q;
+            v[q] = 0.f;
+            if (i < c.win) {
+                const int s = t * c.hop + i - c.win / 2;
+                if (s >= 0 && s < n_sig) v[q] = eb[s] * c.hann[i];
+            }
         }
-        bufa[i] = make_float2(v, 0.f);
+        bufa[m] = make_float2(v[0], v[1]);
     }
     __syncthreads();
-    float2 *res = fft_lds<false>(bufa, bufb, tw, n, tid);
+    float2 *res = fft_lds<false>(bufa, bufb, tw, nc, tid);
     float2 xk[MAX_BINS_PER_THREAD];
 #pragma unroll
     for (int i = 0; i < MAX_BINS_PER_THREAD; ++i) {
         const int k = tid + i * FFT_THREADS;
-        xk[i] = (k <= half) ? res[k] : make_float2(0.f, 0.f);
+        xk[i] = (k <= nc) ? real_bin(res, tw, k, nc) : make_float2(0.f, 0.f);
     }
     __syncthreads();
 
@@ -92,50 +142,69 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_filter_kernel(StftConsts c, 
     const float *cb = ceps + (long long)b * ceps_bstride + (long long)t * c.n_ceps;
     const float *lw = nullptr;
     if (c.n_ceps_windows > 0 && index) lw = c.ceps_windows + (long long)index[(long long)b * max_frames + t] * c.n_ceps;
-    for (int i = tid; i < n; i += FFT_THREADS) {
-        float v = 0.f;
-        if (i >= 1 && i < c.n_ceps) v = lw ? cb[i] * lw[i] : cb[i];
-        bufa[i] = make_float2(v, 0.f);
+    for (int m = tid; m < nc; m += FFT_THREADS) {
+        float v[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = 2 * m + q;
+            v[q] = 0.f;
+            if (i >= 1 && i < c.n_ceps) v[q] = lw ? cb[i] * lw[i] : cb[i];
+        }
+        bufa[m] = make_float2(v[0], v[1]);
     }
     __syncthreads();
-    res = fft_lds<false>(bufa, bufb, tw, n, tid);
-    float2 *dst = (res == bufa) ? bufb : bufa;
-    // ---- 3. H = exp(R * tanh(Re S) + j Im S) ; Y = X * H ; Hermitian extension for the inverse transform
+    res = fft_lds<false>(bufa, bufb, tw, nc, tid);
+    // ---- 3. H = exp(R * tanh(Re S) + j Im S) ; Y = X * H
 #pragma unroll
     for (int i = 0; i < MAX_BINS_PER_THREAD; ++i) {
         const int k = tid + i * FFT_THREADS;
-        if (k <= half) {
-            const float2 s = res[k];
+        if (k <= nc) {
+            const float2 s = real_bin(res, tw, k, nc);
             const float re = (c.max_log_range > 0.f) ? c.max_log_range * tanhf(s.x) : s.x;
             const float mag = expf(re);
             float sn, cs;
             sincosf(s.y, &sn, &cs);
-            const float2 h = make_float2(mag * cs, mag * sn);
-            float2 yv;
-            yv.x = xk[i].x * h.x - xk[i].y * h.y;
-            yv.y = xk[i].x * h.y + xk[i].y * h.x;
-            if (k == 0 || k == half) {
-                dst[k] = make_float2(yv.x, 0.f);          // a real inverse transform ignores these imaginary parts
-            } else {
-                dst[k] = yv;
-                dst[n - k] = make_float2(yv.x, -yv.y);
-            }
+            xk[i] = cmul(xk[i], make_float2(mag * cs, mag * sn));
         }
     }
     __syncthreads();
-    float2 *other = (dst == bufa) ? bufb : bufa;
-    res = fft_lds<true>(dst, other, tw, n, tid);
-    // ---- 4. first win samples x synthesis window
+    // Y[0..nc) to LDS; a real inverse transform ignores Im Y[0] and Im Y[nc], so Re Y[nc] travels in Im of entry 0
+    float2 *ybuf = res, *zbuf = (res == bufa) ? bufb : bufa;
+#pragma unroll
+    for (int i = 0; i < MAX_BINS_PER_THREAD; ++i) {
+        const int k = tid + i * FFT_THREADS;
+        if (k == 0) ybuf[0].x = xk[i].x;
+        else if (k < nc) ybuf[k] = xk[i];
+        else if (k == nc) ybuf[0].y = xk[i].x;
+    }
+    __syncthreads();
+    // ---- 4. merge: Z[k] = Ye[k] + i Yo[k], Ye = (Y[k] + conj Y[nc-k]) / 2, Yo = (Y[k] - conj Y[nc-k]) / 2 * conj W^k
+    for (int k = tid; k < nc; k += FFT_THREADS) {
+        const float2 y0 = ybuf[0];
+        const float2 yk = k == 0 ? make_float2(y0.x, 0.f) : ybuf[k];
+        const float2 yr = k == 0 ? make_float2(y0.y, 0.f) : ybuf[nc - k];
+        const float2 ye = make_float2(0.5f * (yk.x + yr.x), 0.5f * (yk.y - yr.y));
+        const float2 d = make_float2(0.5f * (yk.x - yr.x), 0.5f * (yk.y + yr.y));
+        const float2 w = tw[k];
+        const float2 yo = cmul(d, make_float2(w.x, -w.y));
+        zbuf[k] = make_float2(ye.x - yo.y, ye.y + yo.x);
+    }
+    __syncthreads();
+    res = fft_lds<true>(zbuf, ybuf, tw, nc, tid);
+    // ---- 5. first win samples x synthesis window
     float *fb = frames + ((long long)b * max_frames + t) * c.win;
-    const float scale = 1.0f / (float)n;
-    for (int i = tid; i < c.win; i += FFT_THREADS) fb[i] = (res[i].x * scale) * c.inv_win[i];
+    const float scale = 1.0f / (float)nc;
+    for (int i = tid; i < c.win; i += FFT_THREADS) {
+        const float2 z = res[i >> 1];
+        fb[i] = (((i & 1) ? z.y : z.x) * scale) * c.inv_win[i];
+    }
 }
 
 void launch_stft_filter(const StftConsts &c, const float *exc, long long exc_bstride, const float *ceps,
                         long long ceps_bstride, const int *index, const int *n_frames, int max_frames, int batch,
                         float *frames, hipStream_t stream) {
     if (max_frames <= 0 || batch <= 0) return;
-    const size_t smem = sizeof(float2) * (size_t)(2 * c.fft_size + c.fft_size / 2);
+    const size_t smem = sizeof(float2) * (size_t)(3 * (c.fft_size / 2));
     hipLaunchKernelGGL(stft_filter_kernel, dim3(max_frames, batch), dim3(FFT_THREADS), smem, stream, c, exc,
                        exc_bstride, ceps, ceps_bstride, index, n_frames, max_frames, frames);
 }
