@@ -654,15 +654,25 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         }
     }
     {
-        mbx::ConvArgs a = conv_args(w.skip, nsteps * C, C, n_frames, c.steps_per_frame, (int)nsteps, B,
-                                    find(hd, "wn.end.w"), find(hd, "wn.end.b"), 1, C, c.wn_out_channels, 1, 0,
-                                    MBX_PAD_ZERO, w.wn_out, nsteps * c.wn_out_channels, c.wn_out_channels);
-        mbx::launch_conv1d(a, mbx::EPI_LINEAR, stream);
-        // post-net 1x1 (reference custom_pulsed_generator.py:490-493,913-914)
-        mbx::ConvArgs pn = conv_args(w.wn_out, nsteps * c.wn_out_channels, c.wn_out_channels, n_frames,
-                                     c.steps_per_frame, (int)nsteps, B, find(hd, "post.w"), find(hd, "post.b"), 1,
-                                     c.wn_out_channels, M, 1, 0, MBX_PAD_ZERO, w.sub, nsteps * M, M);
-        mbx::launch_conv1d(pn, mbx::EPI_LINEAR, stream);
+        const DevTensor *we = find(hd, "wn.end.w"), *be = find(hd, "wn.end.b"), *wpn = find(hd, "post.w"),
+                        *bpn = find(hd, "post.b");
+        static const int tail_env = getenv("MBX_WN_TAIL") ? atoi(getenv("MBX_WN_TAIL")) : 1;
+        const DevTensor *wep = find(hd, "wn.end.packed");
+        const bool fused = tail_env && wep && wep->count == (long long)((C + 7) / 8) * 256 &&
+            mbx::launch_wn_tail(w.skip, nsteps * C, n_frames, c.steps_per_frame, (int)nsteps, B, C, wep->ptr,
+                                be ? be->ptr : nullptr, c.wn_out_channels, wpn->ptr, bpn ? bpn->ptr : nullptr, M,
+                                w.wn_out, nsteps * c.wn_out_channels, w.sub, nsteps * M, stream);
+        if (!fused) {
+            mbx::ConvArgs a = conv_args(w.skip, nsteps * C, C, n_frames, c.steps_per_frame, (int)nsteps, B, we, be, 1, C,
+                                        c.wn_out_channels, 1, 0, MBX_PAD_ZERO, w.wn_out, nsteps * c.wn_out_channels,
+                                        c.wn_out_channels);
+            mbx::launch_conv1d(a, mbx::EPI_LINEAR, stream);
+            // post-net 1x1 (reference custom_pulsed_generator.py:490-493,913-914)
+            mbx::ConvArgs pn = conv_args(w.wn_out, nsteps * c.wn_out_channels, c.wn_out_channels, n_frames,
+                                         c.steps_per_frame, (int)nsteps, B, wpn, bpn, 1, c.wn_out_channels, M, 1, 0,
+                                         MBX_PAD_ZERO, w.sub, nsteps * M, M);
+            mbx::launch_conv1d(pn, mbx::EPI_LINEAR, stream);
+        }
     }
     // ---- PQMF synthesis (reference :920-921)
     mbx::launch_pqmf(w.sub, nsteps * M, n_frames, c.steps_per_frame, (int)nsteps, B, M, hd->poly, hd->poly_ndm,

@@ -59,6 +59,12 @@ void launch_conv1d(const ConvArgs &a, int epilogue, hipStream_t stream);
 bool launch_wn_gate_winograd(const ConvArgs &a, const float *w_split, hipStream_t stream);
 // WaveNet residual/skip layer for large row counts (wn_resskip.hip); a.w = host-packed weights (ceil(cout/128), ceil(C/16), 2048)
 bool launch_wn_resskip(const ConvArgs &a, hipStream_t stream);
+// WaveNet end convolution + post-net in one pass over the skip tensor (wn_tail.hip); w_end_packed = host-packed
+// weights (ceil(C/8), 2, 32, 4); false: shapes do not fit
+bool launch_wn_tail(const float *skip, long long skip_bstride, const int *n_frames, int rows_per_frame, int max_rows,
+                    int batch, int C, const float *w_end_packed, const float *b_end, int n_out, const float *w_post,
+                    const float *b_post, int M, float *y, long long y_bstride, float *sub, long long sub_bstride,
+                    hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // element-wise / bandwidth-type stages (elementwise.hip)

@@ -256,6 +256,19 @@ def pack_resskip_weights(w):
     return np.ascontiguousarray(wp.transpose(4, 0, 1, 5, 2, 6, 3).reshape(nct, nk, 2048))
 
 
+def pack_end_weights(w):
+    """Weights (1, C, n_out <= 32) of the WaveNet end convolution packed for wn_tail_kernel (csrc/wn_tail.hip):
+    (ceil(C/8), 2, 32, 4) = [channel group c][lane half lk][column n][k step st] with input channel 8c + 4lk + st,
+    zero padded to 32 columns and to a multiple of 8 channels."""
+    w = np.asarray(w, dtype=np.float32)
+    assert w.ndim == 3 and w.shape[0] == 1 and w.shape[2] <= 32
+    C, n_out = w.shape[1], w.shape[2]
+    nc8 = (C + 7) // 8
+    wp = np.zeros((nc8 * 8, 32), dtype=np.float32)
+    wp[:C, :n_out] = w[0]
+    return np.ascontiguousarray(wp.reshape(nc8, 2, 4, 32).transpose(0, 1, 3, 2))
+
+
 def tensor_table(config, raw_weights, wavetables):
     """name -> float32 array of everything mbx_create needs: folded weights + constant tables."""
     dims = ModelDims(config)
@@ -265,6 +278,8 @@ def tensor_table(config, raw_weights, wavetables):
     _, syn = tb.pqmf_filters(int(mbc["subbands"]), int(mbc["taps"]), float(mbc["cutoff_ratio"]), float(mbc["beta"]),
                              mbc.get("max_band", None))
     out["table.pqmf_syn"] = syn
+    if out["wn.end.w"].shape[0] == 1 and out["wn.end.w"].shape[2] <= 32:
+        out["wn.end.packed"] = pack_end_weights(out["wn.end.w"])
     for ll in range(dims.wn_layers):
         out[f"wn.res_skip_{ll}.packed"] = pack_resskip_weights(out[f"wn.res_skip_{ll}.w"])
     if dims.wn_kernel_size == 3:
