@@ -576,13 +576,11 @@ __global__ __launch_bounds__(256) void conv1d_mfma_dma_kernel(ConvArgs p) {
 // the MFMA registers: the tile is too small to amortise an LDS stage.  Lane (row r, half h) loads A[r][8g+4h..+3]
 // as one float4 and feeds it to four MFMA steps; the B lane (col c, half h) loads W[8g+4h+s][c] for the same steps.
 // Needs cin % 8 == 0 and 16-byte aligned rows (checked by the launcher).
-__global__ __launch_bounds__(256) void conv1d_small_kernel(ConvArgs p) {
-    __shared__ float red[3][16][64];
-    const int b = blockIdx.z;
+__device__ __forceinline__ void conv1d_small_tile(const ConvArgs &p, int bx, int by, int b, float (*red)[16][64]) {
     const int rows = p.n_frames ? p.n_frames[b] * p.rows_per_frame : p.max_rows;
-    const int m0 = blockIdx.x * 32;
+    const int m0 = bx * 32;
     if (m0 >= rows) return;
-    const int n0 = blockIdx.y * 32;
+    const int n0 = by * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 31, lk = lane >> 5;
     const float *xb = p.x + (long long)b * p.x_bstride;
@@ -666,6 +664,30 @@ __global__ __launch_bounds__(256) void conv1d_small_kernel(ConvArgs p) {
     }
 }
 
+__global__ __launch_bounds__(256) void conv1d_small_kernel(ConvArgs p) {
+    __shared__ float red[3][16][64];
+    conv1d_small_tile(p, blockIdx.x, blockIdx.y, blockIdx.z, red);
+}
+
+// Up to three independent small convolutions in one launch (the n-th layers of the F0-net, the VTF-net and the
+// conditioning convolution all read the mel input): at a few hundred rows a launch is latency-bound, so sharing it
+// costs nothing and removes launches from the critical path.  Blocks [start[k], start[k+1]) belong to convolution k.
+struct SmallConvGroup {
+    ConvArgs c[3];
+    int start[4];
+    int gx[3], gy[3];
+};
+
+__global__ __launch_bounds__(256) void conv1d_small_group_kernel(SmallConvGroup g) {
+    __shared__ float red[3][16][64];
+    const int id = blockIdx.x;
+    const int k = (id >= g.start[1]) + (id >= g.start[2]);
+    const int local = id - g.start[k];
+    const int bx = local % g.gx[k];
+    const int t = local / g.gx[k];
+    conv1d_small_tile(g.c[k], bx, t % g.gy[k], t / g.gy[k], red);
+}
+
 static int env_int(const char *name, int dflt) {
     const char *v = getenv(name);
     return v ? atoi(v) : dflt;
@@ -712,6 +734,53 @@ static bool launch_dma(const ConvArgs &a, hipStream_t stream) {
     return true;
 }
 
+static bool small_conv_eligible(const ConvArgs &a) {
+    static const int no_small = env_int("MBX_NO_SMALL", 0);
+    return (long long)a.max_rows * a.batch <= 8192 && a.cin % 8 == 0 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 &&
+           (uintptr_t)a.x % 16 == 0 && no_small == 0;
+}
+
+void launch_conv1d_group(const ConvArgs *convs, int n, hipStream_t stream) {
+    static const int no_group = env_int("MBX_NO_GROUP", 0);
+    int small[3], n_small = 0;
+    for (int i = 0; i < n && i < 3; ++i)
+        if (convs[i].max_rows > 0 && convs[i].batch > 0 && small_conv_eligible(convs[i])) small[n_small++] = i;
+    if (n > 3 || n_small < 2 || no_group) {
+        for (int i = 0; i < n; ++i) launch_conv1d(convs[i], EPI_LINEAR, stream);
+        return;
+    }
+    // longest chain (largest K) first, so that its blocks are resident from the start
+    for (int i = 0; i < n_small; ++i)
+        for (int j = i + 1; j < n_small; ++j)
+            if (convs[small[j]].ks * convs[small[j]].cin > convs[small[i]].ks * convs[small[i]].cin) {
+                const int t = small[i];
+                small[i] = small[j];
+                small[j] = t;
+            }
+    SmallConvGroup g;
+    int total = 0;
+    for (int k = 0; k < 3; ++k) {
+        g.start[k] = total;
+        if (k < n_small) {
+            g.c[k] = convs[small[k]];
+            g.gx[k] = (g.c[k].max_rows + 31) / 32;
+            g.gy[k] = (g.c[k].cout + 31) / 32;
+            total += g.gx[k] * g.gy[k] * g.c[k].batch;
+        } else {
+            g.c[k] = convs[small[0]];
+            g.gx[k] = g.gy[k] = 1;
+        }
+    }
+    g.start[3] = total;
+    for (int k = n_small; k < 3; ++k) g.start[k] = 0x7fffffff;
+    hipLaunchKernelGGL(conv1d_small_group_kernel, dim3((unsigned)total), dim3(256), 0, stream, g);
+    for (int i = 0; i < n; ++i) {
+        bool in_group = false;
+        for (int k = 0; k < n_small; ++k) in_group |= small[k] == i;
+        if (!in_group) launch_conv1d(convs[i], EPI_LINEAR, stream);
+    }
+}
+
 void launch_conv1d(const ConvArgs &a, int epilogue, hipStream_t stream) {
     if (a.max_rows <= 0 || a.batch <= 0) return;
     // Tile shapes of the two WaveNet GEMMs.  Defaults = the fastest measured on MI355X (profiles/README.md):
@@ -747,8 +816,7 @@ void launch_conv1d(const ConvArgs &a, int epilogue, hipStream_t stream) {
         r.acc_preloaded = env_int("MBX_RS_PRELOAD", 1);
         if (rs_cfg == 0) launch_cfg<2, 2, 2, 2, EPI_RESSKIP>(r, stream, extra_lds);        // 128 x 128
         else launch_cfg<2, 2, 1, 2, EPI_RESSKIP>(r, stream, extra_lds);                    // 64 x 128
-    } else if ((long long)a.max_rows * a.batch <= 8192 && a.cin % 8 == 0 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 &&
-               (uintptr_t)a.x % 16 == 0 && env_int("MBX_NO_SMALL", 0) == 0) {
+    } else if (small_conv_eligible(a)) {
         // mel-rate sub-nets at small batch: latency bound, split-K 32x32 tiles
         dim3 grid((a.max_rows + 31) / 32, (a.cout + 31) / 32, a.batch);
         hipLaunchKernelGGL(conv1d_small_kernel, grid, dim3(256), 0, stream, a);

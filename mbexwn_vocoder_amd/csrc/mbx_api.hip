@@ -65,11 +65,6 @@ struct mbx_handle {
     // derived
     int f0_time_factor = 1, vtf_time_factor = 1;
     long long subnet_buf_per_frame = 0;   // floats per frame of one ping-pong buffer
-    // fork/join inside a forward: the conditioning conv and the VTF-net (+ lifter selection) do not depend on the
-    // F0 -> wavetable -> WaveNet chain, so they run on two side streams and fill otherwise idle CUs
-    hipStream_t side[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_f0 = nullptr, ev_cond = nullptr, ev_vtf = nullptr;
-    bool overlap = false;
     bool use_winograd = false;   // Winograd F(2,3) gate kernel when the transformed weights were supplied
     // bench-only kernel timing (mbx_profile_*)
     bool profiling = false;
@@ -127,7 +122,7 @@ Workspace carve(const mbx_handle *hd, char *base, int B, int T) {
     const int chunks = (int)((npulse + c.phase_chunk - 1) / c.phase_chunk) + 1;
     w.sub0 = take(BT * hd->subnet_buf_per_frame);
     w.sub1 = take(BT * hd->subnet_buf_per_frame);
-    w.sub2 = take(BT * hd->subnet_buf_per_frame);   // VTF-net ping-pong (runs concurrently with the F0-net)
+    w.sub2 = take(BT * hd->subnet_buf_per_frame);   // VTF-net ping-pong (its convolutions share launches with the F0-net's)
     w.sub3 = take(BT * hd->subnet_buf_per_frame);
     w.f0 = take(B * npulse);
     w.cum = take(B * npulse);
@@ -175,92 +170,119 @@ mbx::ConvArgs conv_args(const float *x, long long x_bstride, int ldx, const int 
 
 // Executes a sub-net op list (reference custom_pulsed_generator.py:38-148 flattened by the host).
 // in (B, T, cin) -> final (B, T*factor, cout); optional affine y*scale+offset applied after the last op.
-mbx_status run_subnet(mbx_handle *hd, const mbx_subnet_op *ops, int n_ops, const float *in, int cin,
-                      const int *n_frames, int B, int T, float *buf0, float *buf1, float *final_out,
-                      bool affine, float scale, float offset, hipStream_t stream) {
-    const float *cur = in;
-    int chan = cin, rpf = 1;
-    long long cur_bstride = (long long)T * cin;
-    bool affine_done = !affine;
-    int pp = 0;
-    // index of the last op that launches a kernel writing a new buffer
-    int last_writer = -1;
-    for (int i = 0; i < n_ops; ++i)
-        if (ops[i].kind == MBX_OP_CONV || ops[i].kind == MBX_OP_LIN) last_writer = i;
-    for (int i = 0; i < n_ops; ++i) {
-        const mbx_subnet_op &op = ops[i];
-        if (op.kind == MBX_OP_CONV) {
-            const DevTensor *w = find(hd, std::string(op.name) + ".w");
-            const DevTensor *bias = find(hd, std::string(op.name) + ".b");
-            if (!w || !bias) return fail(MBX_ERR_INVALID_ARGUMENT, std::string("missing tensor ") + op.name + ".w/.b");
-            float *out = (i == last_writer) ? final_out : (pp ? buf1 : buf0);
-            pp ^= 1;
-            const long long out_bstride = (long long)T * rpf * op.cout;
-            mbx::ConvArgs a = conv_args(cur, cur_bstride, chan, n_frames, rpf, T * rpf, B, w, bias, op.ks, op.cin,
-                                        op.cout, 1, op.pad_l, op.pad_mode, out, out_bstride, op.cout);
-            if (i + 1 < n_ops && ops[i + 1].kind == MBX_OP_PRELU && op.up == 1) {
-                const DevTensor *al = find(hd, std::string(ops[i + 1].name) + ".alpha");
-                if (!al) return fail(MBX_ERR_INVALID_ARGUMENT, std::string("missing tensor ") + ops[i + 1].name + ".alpha");
-                a.alpha = al->ptr;
-                ++i;
-            } else if (i + 1 < n_ops && ops[i + 1].kind == MBX_OP_LEAKY) {
-                a.use_leaky = 1;
-                a.leaky = ops[i + 1].alpha;
-                ++i;
-            }
-            mbx::launch_conv1d(a, mbx::EPI_LINEAR, stream);
-            cur = out;
-            chan = op.cout / op.up;
-            rpf *= op.up;
-            cur_bstride = out_bstride;
-        } else if (op.kind == MBX_OP_LIN) {
-            auto it = hd->lerp.find(op.up);
-            if (it == hd->lerp.end()) return fail(MBX_ERR_INVALID_ARGUMENT, "interpolation table missing");
-            float *out = (i == last_writer) ? final_out : (pp ? buf1 : buf0);
-            pp ^= 1;
-            int act = MBX_ACT_LINEAR;
-            float sc = 1.f, of = 0.f;
-            int consumed = 0;
-            if (i + 1 < n_ops && ops[i + 1].kind == MBX_OP_ACT) {
-                act = ops[i + 1].act;
-                consumed = 1;
-            }
-            if (i + consumed == n_ops - 1 && !affine_done) {
-                sc = scale;
-                of = offset;
-                affine_done = true;
-            }
-            const long long out_bstride = (long long)T * rpf * op.up * chan;
-            mbx::launch_lin_interp(cur, cur_bstride, n_frames, rpf, T * rpf, B, chan, op.up, it->second.first,
-                                   it->second.second, act, sc, of, out, out_bstride, stream);
-            i += consumed;
-            cur = out;
-            rpf *= op.up;
-            cur_bstride = out_bstride;
-        } else if (op.kind == MBX_OP_PRELU || op.kind == MBX_OP_LEAKY) {
-            const DevTensor *al = op.kind == MBX_OP_PRELU ? find(hd, std::string(op.name) + ".alpha") : nullptr;
-            if (op.kind == MBX_OP_PRELU && !al) return fail(MBX_ERR_INVALID_ARGUMENT, "missing PReLU slopes");
-            mbx::launch_prelu(const_cast<float *>(cur), cur_bstride, n_frames, rpf, T * rpf, B, chan,
-                              al ? al->ptr : nullptr, op.alpha, stream);
-        } else if (op.kind == MBX_OP_ACT) {
-            float sc = 1.f, of = 0.f;
-            if (i == n_ops - 1 && !affine_done) {
-                sc = scale;
-                of = offset;
-                affine_done = true;
-            }
-            mbx::launch_activation(cur, cur_bstride, n_frames, rpf, T * rpf, B, chan, op.act, sc, of,
-                                   const_cast<float *>(cur), cur_bstride, stream);
-        } else {
-            return fail(MBX_ERR_INVALID_ARGUMENT, "unknown sub-net op kind");
-        }
+// Resumable: next_conv() launches the element-wise ops up to the next convolution and hands that convolution back
+// un-launched, so that the caller can put the convolutions of independent sub-nets into one launch
+// (launch_conv1d_group); the caller launches it before calling next_conv() again.
+struct SubnetRun {
+    mbx_handle *hd;
+    const mbx_subnet_op *ops;
+    int n_ops;
+    const int *n_frames;
+    int B, T;
+    float *buf0, *buf1, *final_out;
+    float scale, offset;
+    hipStream_t stream;
+    const float *cur;
+    int chan, rpf = 1, pp = 0, last_writer = -1, i = 0;
+    long long cur_bstride;
+    bool affine_done, finished = false;
+    mbx_status status = MBX_OK;
+
+    SubnetRun(mbx_handle *hd_, const mbx_subnet_op *ops_, int n_ops_, const float *in, int cin, const int *n_frames_,
+              int B_, int T_, float *buf0_, float *buf1_, float *final_out_, bool affine, float scale_, float offset_,
+              hipStream_t stream_)
+        : hd(hd_), ops(ops_), n_ops(n_ops_), n_frames(n_frames_), B(B_), T(T_), buf0(buf0_), buf1(buf1_),
+          final_out(final_out_), scale(scale_), offset(offset_), stream(stream_), cur(in), chan(cin),
+          cur_bstride((long long)T_ * cin), affine_done(!affine) {
+        // index of the last op that launches a kernel writing a new buffer
+        for (int k = 0; k < n_ops; ++k)
+            if (ops[k].kind == MBX_OP_CONV || ops[k].kind == MBX_OP_LIN) last_writer = k;
     }
-    if (!affine_done)
-        mbx::launch_activation(cur, cur_bstride, n_frames, rpf, T * rpf, B, chan, MBX_ACT_LINEAR, scale, offset,
-                               const_cast<float *>(cur), cur_bstride, stream);
-    if (cur != final_out) return fail(MBX_ERR_INVALID_ARGUMENT, "sub-net without a convolution");
-    return MBX_OK;
-}
+    bool stop(mbx_status st) {
+        status = st;
+        finished = true;
+        return false;
+    }
+    bool next_conv(mbx::ConvArgs &pending) {
+        if (finished) return false;
+        for (; i < n_ops; ++i) {
+            const mbx_subnet_op &op = ops[i];
+            if (op.kind == MBX_OP_CONV) {
+                const DevTensor *w = find(hd, std::string(op.name) + ".w");
+                const DevTensor *bias = find(hd, std::string(op.name) + ".b");
+                if (!w || !bias) return stop(fail(MBX_ERR_INVALID_ARGUMENT, std::string("missing tensor ") + op.name + ".w/.b"));
+                float *out = (i == last_writer) ? final_out : (pp ? buf1 : buf0);
+                pp ^= 1;
+                const long long out_bstride = (long long)T * rpf * op.cout;
+                mbx::ConvArgs a = conv_args(cur, cur_bstride, chan, n_frames, rpf, T * rpf, B, w, bias, op.ks, op.cin,
+                                            op.cout, 1, op.pad_l, op.pad_mode, out, out_bstride, op.cout);
+                if (i + 1 < n_ops && ops[i + 1].kind == MBX_OP_PRELU && op.up == 1) {
+                    const DevTensor *al = find(hd, std::string(ops[i + 1].name) + ".alpha");
+                    if (!al) return stop(fail(MBX_ERR_INVALID_ARGUMENT, std::string("missing tensor ") + ops[i + 1].name + ".alpha"));
+                    a.alpha = al->ptr;
+                    ++i;
+                } else if (i + 1 < n_ops && ops[i + 1].kind == MBX_OP_LEAKY) {
+                    a.use_leaky = 1;
+                    a.leaky = ops[i + 1].alpha;
+                    ++i;
+                }
+                cur = out;
+                chan = op.cout / op.up;
+                rpf *= op.up;
+                cur_bstride = out_bstride;
+                ++i;
+                pending = a;
+                return true;
+            } else if (op.kind == MBX_OP_LIN) {
+                auto it = hd->lerp.find(op.up);
+                if (it == hd->lerp.end()) return stop(fail(MBX_ERR_INVALID_ARGUMENT, "interpolation table missing"));
+                float *out = (i == last_writer) ? final_out : (pp ? buf1 : buf0);
+                pp ^= 1;
+                int act = MBX_ACT_LINEAR;
+                float sc = 1.f, of = 0.f;
+                int consumed = 0;
+                if (i + 1 < n_ops && ops[i + 1].kind == MBX_OP_ACT) {
+                    act = ops[i + 1].act;
+                    consumed = 1;
+                }
+                if (i + consumed == n_ops - 1 && !affine_done) {
+                    sc = scale;
+                    of = offset;
+                    affine_done = true;
+                }
+                const long long out_bstride = (long long)T * rpf * op.up * chan;
+                mbx::launch_lin_interp(cur, cur_bstride, n_frames, rpf, T * rpf, B, chan, op.up, it->second.first,
+                                       it->second.second, act, sc, of, out, out_bstride, stream);
+                i += consumed;
+                cur = out;
+                rpf *= op.up;
+                cur_bstride = out_bstride;
+            } else if (op.kind == MBX_OP_PRELU || op.kind == MBX_OP_LEAKY) {
+                const DevTensor *al = op.kind == MBX_OP_PRELU ? find(hd, std::string(op.name) + ".alpha") : nullptr;
+                if (op.kind == MBX_OP_PRELU && !al) return stop(fail(MBX_ERR_INVALID_ARGUMENT, "missing PReLU slopes"));
+                mbx::launch_prelu(const_cast<float *>(cur), cur_bstride, n_frames, rpf, T * rpf, B, chan,
+                                  al ? al->ptr : nullptr, op.alpha, stream);
+            } else if (op.kind == MBX_OP_ACT) {
+                float sc = 1.f, of = 0.f;
+                if (i == n_ops - 1 && !affine_done) {
+                    sc = scale;
+                    of = offset;
+                    affine_done = true;
+                }
+                mbx::launch_activation(cur, cur_bstride, n_frames, rpf, T * rpf, B, chan, op.act, sc, of,
+                                       const_cast<float *>(cur), cur_bstride, stream);
+            } else {
+                return stop(fail(MBX_ERR_INVALID_ARGUMENT, "unknown sub-net op kind"));
+            }
+        }
+        if (!affine_done)
+            mbx::launch_activation(cur, cur_bstride, n_frames, rpf, T * rpf, B, chan, MBX_ACT_LINEAR, scale, offset,
+                                   const_cast<float *>(cur), cur_bstride, stream);
+        if (cur != final_out) return stop(fail(MBX_ERR_INVALID_ARGUMENT, "sub-net without a convolution"));
+        finished = true;
+        return false;
+    }
+};
 
 // brackets one launch with events when profiling is on
 struct ScopedEvents {
@@ -488,21 +510,9 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
     if (hd->vtf_time_factor != 1 || vtf_out != c.n_ceps)
         return bail(fail(MBX_ERR_INVALID_ARGUMENT, "VTF sub-net must end with n_ceps channels at the mel frame rate"));
     hd->subnet_buf_per_frame = std::max(pf0, pvtf);
-    // measured on MI355X: the fork/join costs more than it hides (config 2: 1.57 ms with, 1.54 ms without), so the
-    // launch sequence stays on the caller's stream unless MBX_OVERLAP is set
-    hd->overlap = getenv("MBX_OVERLAP") != nullptr;
     {
         const char *wv = getenv("MBX_WINOGRAD");
         hd->use_winograd = wv ? atoi(wv) != 0 : true;   // default on (MBX_WINOGRAD=0 selects the direct form)
-    }
-    for (int i = 0; i < 2; ++i) {
-        e = hipStreamCreateWithFlags(&hd->side[i], hipStreamNonBlocking);
-        if (e != hipSuccess) return bail(fail(MBX_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)));
-    }
-    hipEvent_t *evs[4] = {&hd->ev_fork, &hd->ev_f0, &hd->ev_cond, &hd->ev_vtf};
-    for (auto ev : evs) {
-        e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
-        if (e != hipSuccess) return bail(fail(MBX_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)));
     }
     *out = hd;
     return MBX_OK;
@@ -511,10 +521,6 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
 mbx_status mbx_destroy(mbx_handle *handle) {
     if (!handle) return MBX_OK;
     if (handle->arena) (void)hipFree(handle->arena);
-    for (auto st : handle->side)
-        if (st) (void)hipStreamDestroy(st);
-    for (auto ev : {handle->ev_fork, handle->ev_f0, handle->ev_cond, handle->ev_vtf})
-        if (ev) (void)hipEventDestroy(ev);
     for (auto &pool : handle->ev_pool)
         for (auto &pr : pool) {
             (void)hipEventDestroy(pr.first);
@@ -548,46 +554,44 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     const DevTensor *cw = find(hd, "wn.cond.w"), *cbias = find(hd, "wn.cond.b");
     const int cond_cout = 2 * C * c.cond_conv_upsampling;
     mbx::StftConsts sc = stft_consts(hd);
-    const bool fork = hd->overlap;
-    hipStream_t s_cond = fork ? hd->side[0] : stream;
-    hipStream_t s_vtf = fork ? hd->side[1] : stream;
-    if (fork) {
-        HIP_TRY(hipEventRecord(hd->ev_fork, stream));
-        HIP_TRY(hipStreamWaitEvent(s_cond, hd->ev_fork, 0));
-        HIP_TRY(hipStreamWaitEvent(s_vtf, hd->ev_fork, 0));
-    }
-    // ---- side stream 1: conditioning conv (reference custom_AE_layers.py:214-227,287)
+    // ---- conditioning conv (reference custom_AE_layers.py:214-227,287), VTF-net -> cepstrum (reference
+    // custom_pulsed_generator.py:793-800) and F0-net (reference :773-791) are independent chains on the mel input:
+    // the n-th convolution of each goes into one launch (launch_conv1d_group; matters at small batch, where the
+    // mel-rate convolutions are latency-bound)
     {
-        mbx::ConvArgs a = conv_args(mel, (long long)T * c.mel_channels, c.mel_channels, n_frames, 1, T, B, cw, cbias,
-                                    c.cond_kernel_size, c.mel_channels, cond_cout, 1, (c.cond_kernel_size - 1) / 2,
-                                    MBX_PAD_ZERO, w.cond, (long long)T * cond_cout, cond_cout);
-        mbx::launch_conv1d(a, mbx::EPI_LINEAR, s_cond);
-        if (fork) HIP_TRY(hipEventRecord(hd->ev_cond, s_cond));
+        mbx::ConvArgs cond_conv = conv_args(mel, (long long)T * c.mel_channels, c.mel_channels, n_frames, 1, T, B, cw,
+                                            cbias, c.cond_kernel_size, c.mel_channels, cond_cout, 1,
+                                            (c.cond_kernel_size - 1) / 2, MBX_PAD_ZERO, w.cond, (long long)T * cond_cout,
+                                            cond_cout);
+        SubnetRun vtf(hd, c.vtf_ops, c.n_vtf_ops, mel, c.mel_channels, n_frames, B, T, w.sub2, w.sub3, w.ceps, false, 1.f,
+                      0.f, stream);
+        SubnetRun f0(hd, c.f0_ops, c.n_f0_ops, mel, c.mel_channels, n_frames, B, T, w.sub0, w.sub1, w.f0, true,
+                     c.f0_max - c.f0_min, c.f0_min, stream);
+        if (f0_in) f0.finished = true;
+        bool cond_pending = true;
+        for (;;) {
+            mbx::ConvArgs group[3];
+            int n = 0;
+            if (f0.next_conv(group[n])) ++n;
+            if (vtf.next_conv(group[n])) ++n;
+            if (cond_pending) {
+                group[n++] = cond_conv;
+                cond_pending = false;
+            }
+            if (!n) break;
+            mbx::launch_conv1d_group(group, n, stream);
+        }
+        if (vtf.status != MBX_OK) return vtf.status;
+        if (f0.status != MBX_OK) return f0.status;
     }
-    // ---- side stream 2: VTF-net -> cepstrum (reference custom_pulsed_generator.py:793-800)
-    mbx_status st = run_subnet(hd, c.vtf_ops, c.n_vtf_ops, mel, c.mel_channels, n_frames, B, T, w.sub2, w.sub3, w.ceps,
-                               false, 1.f, 0.f, s_vtf);
-    if (st != MBX_OK) return st;
-    // ---- F0 (reference custom_pulsed_generator.py:773-791)
-    if (f0_in) {   // externally supplied contour (reference wavegen_1d.py:546-550)
+    if (f0_in)   // externally supplied contour (reference wavegen_1d.py:546-550)
         mbx::launch_activation(f0_in, npulse, n_frames, c.pulse_per_frame, (int)npulse, B, 1, MBX_ACT_LINEAR, transposition,
                                0.f, w.f0, npulse, stream);
-    } else {
-        st = run_subnet(hd, c.f0_ops, c.n_f0_ops, mel, c.mel_channels, n_frames, B, T, w.sub0, w.sub1, w.f0, true,
-                        c.f0_max - c.f0_min, c.f0_min, stream);
-        if (st != MBX_OK) return st;
-        if (transposition != 1.f)
-            mbx::launch_activation(w.f0, npulse, n_frames, c.pulse_per_frame, (int)npulse, B, 1, MBX_ACT_LINEAR,
-                                   transposition, 0.f, w.f0, npulse, stream);
-    }
-    if (c.n_ceps_windows) {   // lifter selection needs F0 only (reference :507-525)
-        if (fork) {
-            HIP_TRY(hipEventRecord(hd->ev_f0, stream));
-            HIP_TRY(hipStreamWaitEvent(s_vtf, hd->ev_f0, 0));
-        }
-        mbx::launch_ceps_index(sc, w.f0, npulse, n_frames, T, B, w.ceps_index, s_vtf);
-    }
-    if (fork) HIP_TRY(hipEventRecord(hd->ev_vtf, s_vtf));
+    else if (transposition != 1.f)
+        mbx::launch_activation(w.f0, npulse, n_frames, c.pulse_per_frame, (int)npulse, B, 1, MBX_ACT_LINEAR,
+                               transposition, 0.f, w.f0, npulse, stream);
+    if (c.n_ceps_windows)   // lifter selection needs F0 only (reference :507-525)
+        mbx::launch_ceps_index(sc, w.f0, npulse, n_frames, T, B, w.ceps_index, stream);
     // ---- wavetable excitation (reference :889)
     mbx::launch_wavetable(wavetable_consts(hd), w.f0, npulse, n_frames, c.pulse_per_frame, (int)npulse, B, w.pulse,
                           nullptr, w.cum, w.chunk_last, st_in, st_out, stream);
@@ -595,7 +599,6 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     mbx::launch_wn_start(w.pulse, npulse, c.noise_sigma != 0.f ? noise : nullptr, nsteps, c.noise_sigma, n_frames,
                          c.steps_per_frame, (int)nsteps, B, c.pulse_channels, find(hd, "wn.start.w")->ptr,
                          find(hd, "wn.start.b")->ptr, C, w.h, nsteps * C, stream);
-    if (fork) HIP_TRY(hipStreamWaitEvent(stream, hd->ev_cond, 0));
     auto lerp = hd->lerp[c.cond_lin_upsampling];
     for (int l = 0; l < L; ++l) {
         const std::string ls = std::to_string(l);
@@ -677,8 +680,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     // ---- PQMF synthesis (reference :920-921)
     mbx::launch_pqmf(w.sub, nsteps * M, n_frames, c.steps_per_frame, (int)nsteps, B, M, hd->poly, hd->poly_ndm,
                      hd->poly_dm_min, w.exc, (long long)T * c.hop_size, stream);
-    // ---- STFT-domain filtering with the spectral envelope (reference :681-724, 801-855); joins side stream 2
-    if (fork) HIP_TRY(hipStreamWaitEvent(stream, hd->ev_vtf, 0));
+    // ---- STFT-domain filtering with the spectral envelope (reference :681-724, 801-855)
     mbx::launch_stft_filter(sc, w.exc, (long long)T * c.hop_size, w.ceps, (long long)T * c.n_ceps,
                             c.n_ceps_windows ? w.ceps_index : nullptr, n_frames, T, B, w.frames, stream);
     mbx::launch_overlap_add(sc, w.frames, n_frames, T, B, audio, (long long)T * c.hop_size, stream);

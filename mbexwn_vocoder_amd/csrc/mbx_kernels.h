@@ -55,6 +55,8 @@ struct ConvArgs {
 };
 
 void launch_conv1d(const ConvArgs &a, int epilogue, hipStream_t stream);
+// n <= 3 independent EPI_LINEAR convolutions; the small (mel-rate, small batch) ones share one launch
+void launch_conv1d_group(const ConvArgs *convs, int n, hipStream_t stream);
 // Winograd F(2,3) form of the WaveNet gate layer (wn_winograd.hip); a.w = host-packed weights (ceil(C/32), ceil(C/16), 4096)
 bool launch_wn_gate_winograd(const ConvArgs &a, const float *w_split, hipStream_t stream);
 // WaveNet residual/skip layer for large row counts (wn_resskip.hip); a.w = host-packed weights (ceil(cout/128), ceil(C/16), 2048)
