@@ -22,7 +22,7 @@
 //   B: 4 weight combinations x 16 channels x 64 columns, pre-packed on the host in MFMA operand order
 //      [product j][channel half cc][column half h][lane][4 k steps] so that one ds_read_b128 per lane yields the weight
 //      operands of four consecutive MFMAs (engine.pack_winograd_weights; h = tanh|sigmoid for NS = 1, h = wn for NS = 2)
-// Two LDS stages (72 / 56 KB per block, 2 blocks per CU).
+// Two LDS stages (72 KB per block, 2 blocks per CU / 52 KB, 3 per CU).
 #include <cstdlib>
 #include "mbx_kernels.h"
 
@@ -30,7 +30,6 @@ namespace mbx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int WG_HALO = 32;        // staged rows in front of m0 (>= max dilation)
 constexpr int WG_BK = 16;
 constexpr int WG_B_FLOATS = 4 * WG_BK * 64;            // 4096
 constexpr int WG_B_INST = WG_B_FLOATS / 4 / 64 / 4;    // 4 LDS-DMA instructions per wave (B)
@@ -59,12 +58,14 @@ __device__ __forceinline__ float4 wg_input_comb(int j, const float4 (&x)[4]) {
 }
 
 template <int NS>
-__global__ __launch_bounds__(256, 2) void wn_gate_winograd_kernel(ConvArgs p, int log2d) {
+__global__ __launch_bounds__(256, NS == 1 ? 2 : 3) void wn_gate_winograd_kernel(ConvArgs p, int log2d) {
     constexpr int MW = 4 / NS;                 // wave rows
     constexpr int ROWS = 64 * MW;              // output rows per block
-    constexpr int AROWS = ROWS + 64;           // staged rows per slice
+    constexpr int HALO = NS == 1 ? 32 : 16;    // staged rows in front of / behind the block (>= max dilation)
+    constexpr int AROWS = ROWS + 2 * HALO;     // staged rows per slice (NS = 2: 160 rows, 52 KB per block, 3 per CU)
     constexpr int A_FLOATS = AROWS * WG_BK;
-    constexpr int A_INST = AROWS / 64;         // LDS-DMA instructions per wave (A)
+    constexpr int A_CHUNKS = AROWS / 16;       // 1 KB LDS-DMA instructions per slice (A), dealt round-robin to the waves
+    constexpr int A_INST = (A_CHUNKS + 3) / 4;
     constexpr int NT = 2 / NS;                 // accumulator column tiles per product
     constexpr int NG = 8 / NS;                 // operand groups (8 MFMAs each) per slice
     typedef __attribute__((address_space(3))) float lds_float;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void wn_gate_winograd_kernel(ConvArgs p, in
     for (int i = 0; i < A_INST; ++i) {
         const int pos = (wave + 4 * i) * 64 + lane;
         const int row = pos >> 2;
-        const int src = m0 - WG_HALO + row;
+        const int src = m0 - HALO + row;
         a_ch[i] = 4 * ((pos & 3) ^ ((row >> 2) & 3));
         a_off[i] = max(src, 0) * p.ldx;
         if (src >= 0 && src < rows) a_ok |= 1u << i;
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(256, 2) void wn_gate_winograd_kernel(ConvArgs p, in
         const unsigned bdst = lds_base + 4u * (unsigned)(2 * A_FLOATS + buf * WG_B_FLOATS);
 #pragma unroll
         for (int i = 0; i < A_INST; ++i) {
+            if (A_CHUNKS % 4 != 0 && wave + 4 * i >= A_CHUNKS) continue;      // wave-uniform
             const int ci = ci0 + a_ch[i];
             const bool ok = ((a_ok >> i) & 1u) & (ci < p.cin);
             wg_lds_dma16(ok ? xb + a_off[i] + ci : p.zeros, adst + 1024u * (unsigned)(wave + 4 * i));
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void wn_gate_winograd_kernel(ConvArgs p, in
 
     // pair of this lane (A operand row): P = 32*wm + lrow -> t = m0 + 2 d (P >> log2d) + (P & (d-1))
     const int pair = 32 * wm + lrow;
-    const int trel = WG_HALO + ((pair >> log2d) << (log2d + 1)) + (pair & (d - 1));   // LDS row of h[t]
+    const int trel = HALO + ((pair >> log2d) << (log2d + 1)) + (pair & (d - 1));   // LDS row of h[t]
     int aoff[4][2];     // LDS float offsets of h[t-d], h[t], h[t+d], h[t+2d] for the two channel halves of a slice
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void wn_gate_winograd_kernel(ConvArgs p, in
 bool launch_wn_gate_winograd(const ConvArgs &a, const float *w_split, hipStream_t stream) {
     int log2d = 0;
     while ((1 << log2d) < a.dil) ++log2d;
-    const bool ok = a.ks == 3 && (1 << log2d) == a.dil && a.dil <= 16 && a.pad_l == a.dil && a.pad_mode == 0 &&
+    const bool ok = a.ks == 3 && (1 << log2d) == a.dil && a.dil <= 16 /* = HALO of the small shape */ && a.pad_l == a.dil && a.pad_mode == 0 &&
                     a.cin % 4 == 0 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 && a.channels % 4 == 0 &&
                     a.cout == 2 * a.channels && (uintptr_t)a.x % 16 == 0 && (uintptr_t)a.w % 16 == 0 && a.zeros &&
                     a.cond && (uintptr_t)a.cond % 16 == 0 && a.cond_bstride % 4 == 0 && a.cond_up <= 64 &&
