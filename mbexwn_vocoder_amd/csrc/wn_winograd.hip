@@ -318,9 +318,9 @@ bool launch_wn_gate_winograd(const ConvArgs &a, const float *w_split, hipStream_
     static const int split_env = getenv("MBX_WG_SPLIT") ? atoi(getenv("MBX_WG_SPLIT")) : -1; // -1 auto, 0 never, 1 always
     r.ablate = ablate;
     r.n_tiles = (a.channels + 31) / 32;
-    // half-size tiles while the full-size grid is less than three rounds of the 512 resident blocks (2 per CU x 256 CUs)
+    // half-size tiles while the full-size grid is less than four rounds of the 512 resident blocks (2 per CU x 256 CUs)
     const long long full_blocks = (long long)((a.max_rows + 255) / 256) * a.batch * r.n_tiles;
-    const bool split = w_split && (uintptr_t)w_split % 16 == 0 && (split_env < 0 ? full_blocks < 3 * 512 : split_env != 0);
+    const bool split = w_split && (uintptr_t)w_split % 16 == 0 && (split_env < 0 ? full_blocks < 4 * 512 : split_env != 0);
     const int tile_rows = split ? 128 : 256;
     r.m_tiles_per_item = (a.max_rows + tile_rows - 1) / tile_rows;
     r.m_tiles_total = r.m_tiles_per_item * a.batch;
