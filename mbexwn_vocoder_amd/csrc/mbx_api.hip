@@ -65,6 +65,7 @@ struct mbx_handle {
     // derived
     int f0_time_factor = 1, vtf_time_factor = 1;
     long long subnet_buf_per_frame = 0;   // floats per frame of one ping-pong buffer
+    bool fold_skip = false;      // skip path folded into the end convolution (needs the *.fold tensors)
     bool use_winograd = false;   // Winograd F(2,3) gate kernel when the transformed weights were supplied
     // bench-only kernel timing (mbx_profile_*)
     bool profiling = false;
@@ -511,6 +512,18 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
         return bail(fail(MBX_ERR_INVALID_ARGUMENT, "VTF sub-net must end with n_ceps channels at the mel frame rate"));
     hd->subnet_buf_per_frame = std::max(pf0, pvtf);
     {
+        // skip path folded into the end convolution when the host supplied the folded tensors (MBX_FOLD_SKIP=0: keep
+        // the skip tensor, e.g. to look at the "wn_skip" stage)
+        const char *fv = getenv("MBX_FOLD_SKIP");
+        bool have = (!fv || atoi(fv) != 0) && c.wn_out_channels <= 32 && M <= 16;
+        const long long nct = (C + c.wn_out_channels + 127) / 128, nk = (C + 15) / 16;
+        for (int l = 0; l + 1 < c.wn_layers && have; ++l)
+            have = expect("wn.res_skip_" + std::to_string(l) + ".fold", nct * nk * 2048) &&
+                   expect("wn.res_skip_" + std::to_string(l) + ".fold_b", C + c.wn_out_channels);
+        have = have && expect("wn.tail.fold", (long long)((C + 7) / 8) * 256) && expect("wn.tail.fold_b", c.wn_out_channels);
+        hd->fold_skip = have;
+    }
+    {
         const char *wv = getenv("MBX_WINOGRAD");
         hd->use_winograd = wv ? atoi(wv) != 0 : true;   // default on (MBX_WINOGRAD=0 selects the direct form)
     }
@@ -600,6 +613,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                          c.steps_per_frame, (int)nsteps, B, c.pulse_channels, find(hd, "wn.start.w")->ptr,
                          find(hd, "wn.start.b")->ptr, C, w.h, nsteps * C, stream);
     auto lerp = hd->lerp[c.cond_lin_upsampling];
+    const bool fold = hd->fold_skip;
     for (int l = 0; l < L; ++l) {
         const std::string ls = std::to_string(l);
         const int d = c.wn_dilations[l];
@@ -630,6 +644,25 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
             if (!done) mbx::launch_conv1d(g, mbx::EPI_GATE, stream);
         }
         const bool last = (l == L - 1);
+        if (fold) {
+            // skip path folded into the end convolution: layers 0..L-2 update h and add a W_skip W_end to the n_out-wide
+            // output accumulator; the last layer's contribution is added by the tail kernel below
+            if (!last) {
+                const DevTensor *fw = find(hd, "wn.res_skip_" + ls + ".fold"), *fb = find(hd, "wn.res_skip_" + ls + ".fold_b");
+                mbx::ConvArgs r = conv_args(w.a, nsteps * C, C, n_frames, c.steps_per_frame, (int)nsteps, B, fw, fb, 1, C,
+                                            C + c.wn_out_channels, 1, 0, MBX_PAD_ZERO, nullptr, 0, 0);
+                r.channels = C;
+                r.zeros = hd->zeros;
+                r.h = w.h;
+                r.skip = w.wn_out;
+                r.skip_ld = c.wn_out_channels;
+                r.hs_bstride = nsteps * C;
+                r.skip_init = (l == 0);
+                ScopedEvents ev(hd, 1, stream);
+                if (!mbx::launch_wn_resskip(r, stream)) return fail(MBX_ERR_INVALID_ARGUMENT, "folded res/skip layer does not fit its kernel");
+            }
+            continue;
+        }
         mbx::ConvArgs r = conv_args(w.a, nsteps * C, C, n_frames, c.steps_per_frame, (int)nsteps, B,
                                     find(hd, "wn.res_skip_" + ls + ".w"), find(hd, "wn.res_skip_" + ls + ".b"), 1, C,
                                     last ? C : 2 * C, 1, 0, MBX_PAD_ZERO, nullptr, 0, 0);
@@ -660,11 +693,18 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         const DevTensor *we = find(hd, "wn.end.w"), *be = find(hd, "wn.end.b"), *wpn = find(hd, "post.w"),
                         *bpn = find(hd, "post.b");
         static const int tail_env = getenv("MBX_WN_TAIL") ? atoi(getenv("MBX_WN_TAIL")) : 1;
+        if (fold) {
+            const DevTensor *tw = find(hd, "wn.tail.fold"), *tb = find(hd, "wn.tail.fold_b");
+            if (!mbx::launch_wn_tail(w.a, nsteps * C, n_frames, c.steps_per_frame, (int)nsteps, B, C, tw->ptr, tb->ptr,
+                                     c.wn_out_channels, wpn->ptr, bpn ? bpn->ptr : nullptr, M, L > 1 ? w.wn_out : nullptr,
+                                     w.wn_out, nsteps * c.wn_out_channels, w.sub, nsteps * M, stream))
+                return fail(MBX_ERR_INVALID_ARGUMENT, "folded WaveNet tail does not fit its kernel");
+        }
         const DevTensor *wep = find(hd, "wn.end.packed");
-        const bool fused = tail_env && wep && wep->count == (long long)((C + 7) / 8) * 256 &&
+        const bool fused = fold || (tail_env && wep && wep->count == (long long)((C + 7) / 8) * 256 &&
             mbx::launch_wn_tail(w.skip, nsteps * C, n_frames, c.steps_per_frame, (int)nsteps, B, C, wep->ptr,
-                                be ? be->ptr : nullptr, c.wn_out_channels, wpn->ptr, bpn ? bpn->ptr : nullptr, M,
-                                w.wn_out, nsteps * c.wn_out_channels, w.sub, nsteps * M, stream);
+                                be ? be->ptr : nullptr, c.wn_out_channels, wpn->ptr, bpn ? bpn->ptr : nullptr, M, nullptr,
+                                w.wn_out, nsteps * c.wn_out_channels, w.sub, nsteps * M, stream));
         if (!fused) {
             mbx::ConvArgs a = conv_args(w.skip, nsteps * C, C, n_frames, c.steps_per_frame, (int)nsteps, B, we, be, 1, C,
                                         c.wn_out_channels, 1, 0, MBX_PAD_ZERO, w.wn_out, nsteps * c.wn_out_channels,
@@ -692,7 +732,8 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     sg["pulse"] = {w.pulse, npulse, npulse};
     sg["cond"] = {w.cond, (long long)T * cond_cout, (long long)T * cond_cout};
     sg["wn_hidden"] = {w.h, nsteps * C, nsteps * C};
-    sg["wn_skip"] = {w.skip, nsteps * C, nsteps * C};
+    if (!hd->fold_skip) sg["wn_skip"] = {w.skip, nsteps * C, nsteps * C};
+    else sg.erase("wn_skip");
     sg["wn_out"] = {w.wn_out, nsteps * c.wn_out_channels, nsteps * c.wn_out_channels};
     sg["subbands"] = {w.sub, nsteps * M, nsteps * M};
     sg["excitation"] = {w.exc, (long long)T * c.hop_size, (long long)T * c.hop_size};

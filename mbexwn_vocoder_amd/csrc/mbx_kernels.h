@@ -44,7 +44,8 @@ struct ConvArgs {
     int channels;             // C (gate: cout == 2C, out has C columns; res/skip: split point)
     // EPI_RESSKIP extras
     float *h;                 // (batch, rows, C) updated in place
-    float *skip;              // (batch, rows, C)
+    float *skip;              // (batch, rows, skip_ld)
+    int skip_ld;              // floats between rows of skip (0: C)
     long long hs_bstride;
     int skip_init;            // 1: skip = s (first layer)  0: skip += s
     int last_layer;           // 1: cout == C, everything goes to skip
@@ -65,8 +66,8 @@ bool launch_wn_resskip(const ConvArgs &a, hipStream_t stream);
 // weights (ceil(C/8), 2, 32, 4); false: shapes do not fit
 bool launch_wn_tail(const float *skip, long long skip_bstride, const int *n_frames, int rows_per_frame, int max_rows,
                     int batch, int C, const float *w_end_packed, const float *b_end, int n_out, const float *w_post,
-                    const float *b_post, int M, float *y, long long y_bstride, float *sub, long long sub_bstride,
-                    hipStream_t stream);
+                    const float *b_post, int M, const float *y_acc, float *y, long long y_bstride, float *sub,
+                    long long sub_bstride, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // element-wise / bandwidth-type stages (elementwise.hip)

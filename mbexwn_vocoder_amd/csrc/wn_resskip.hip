@@ -1,4 +1,6 @@
 // WaveNet residual/skip layer: r = a W + b (1x1, C -> 2C; last layer C -> C), h += r[:, :C], skip (+)= r[:, C:].
+// With the skip path folded into the end convolution (engine.fold_skip_weights) the skip half of W is the C x n_out
+// product W_skip W_end and "skip" is the n_out-wide WaveNet output accumulator (row stride skip_ld).
 //
 // Same layer as conv1d_mfma_kernel<EPI_RESSKIP> (reference MBExWN_NVoc/vocoder/model/custom_AE_layers.py:322-336:
 // res_skip = res_skip_l(acts); x = x + res_skip[:C]; skip_out (+)= res_skip[C:]), restructured like the Winograd gate
@@ -88,7 +90,10 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 4) void wn_resskip_kernel(ConvAr
     // ---- accumulators start from old value + bias (h columns always accumulate, skip columns unless skip_init)
     f32x16 acc[MT][2];
     float *dst[2];
+    int ld[2];
     bool col_ok[2];
+    const int skip_ld = p.skip_ld ? p.skip_ld : C;
+    const long long skip_bstride = p.skip_ld ? (long long)p.max_rows * p.skip_ld : p.hs_bstride;
     {
         // unconditional loads from clamped addresses (no branch, all 64 requests in flight), selected afterwards
         int rowc[MT][16];
@@ -104,14 +109,15 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 4) void wn_resskip_kernel(ConvAr
             const int colc = min(col, p.cout - 1);
             const bool to_h = (!p.last_layer) && colc < C;
             const int oc = to_h ? colc : (p.last_layer ? colc : colc - C);
-            dst[j] = (to_h ? p.h : p.skip) + (long long)b * p.hs_bstride + oc;
+            dst[j] = to_h ? p.h + (long long)b * p.hs_bstride + oc : p.skip + (long long)b * skip_bstride + oc;
+            ld[j] = to_h ? C : skip_ld;
             const bool accumulate = (to_h || !p.skip_init) && col_ok[j];
             const float bias = (p.bias && col_ok[j]) ? p.bias[colc] : 0.f;
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float old = dst[j][(long long)rowc[i][r] * C];
+                    const float old = dst[j][(long long)rowc[i][r] * ld[j]];
                     acc[i][j][r] = (accumulate ? old : 0.f) + bias;
                 }
         }
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 4) void wn_resskip_kernel(ConvAr
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + 32 * MT * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (row < rows) dst[j][(long long)row * C] = acc[i][j][r];
+                if (row < rows) dst[j][(long long)row * ld[j]] = acc[i][j][r];
             }
     }
 }
@@ -187,8 +193,8 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 4) void wn_resskip_kernel(ConvAr
 // a.w must point at the host-packed weights (ceil(cout/128), ceil(C/16), 2048); returns false if the layer does not fit
 bool launch_wn_resskip(const ConvArgs &a, hipStream_t stream) {
     const bool ok = a.ks == 1 && a.cin == a.channels && a.cin % 4 == 0 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 &&
-                    (uintptr_t)a.x % 16 == 0 && (uintptr_t)a.w % 16 == 0 && a.zeros && a.h && a.skip &&
-                    a.cout == (a.last_layer ? a.channels : 2 * a.channels);
+                    (uintptr_t)a.x % 16 == 0 && (uintptr_t)a.w % 16 == 0 && a.zeros && a.h && a.skip && a.cout > 0 &&
+                    (a.skip_ld ? a.cout <= a.channels + a.skip_ld : a.cout == (a.last_layer ? a.channels : 2 * a.channels));
     if (!ok) return false;
     ConvArgs r = a;
     static const int small_env = getenv("MBX_RS_SMALL") ? atoi(getenv("MBX_RS_SMALL")) : -1;   // -1 auto, 0 never, 1 always

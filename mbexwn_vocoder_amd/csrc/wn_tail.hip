@@ -1,5 +1,8 @@
-// WaveNet output stage: y = skip W_end + b_end (1x1, C -> n_out <= 32) followed by the post-net s = y W_post + b_post
-// (1x1, n_out -> M <= 16), one kernel, one pass over the skip tensor.
+// WaveNet output stage: y = (y_acc +) x W + b (1x1, C -> n_out <= 32) followed by the post-net s = y W_post + b_post
+// (1x1, n_out -> M <= 16), one kernel, one pass over x.  Two uses:
+//   x = skip sum, W = W_end                        (end convolution after un-folded res/skip layers)
+//   x = gate output of the last layer, W = W_skip W_end, y_acc = contributions of the earlier layers
+//                                                  (skip path folded into the end convolution, engine.fold_skip_weights)
 //
 // Same arithmetic as the two EPI_LINEAR launches of conv1d_mfma_kernel it replaces (reference
 // MBExWN_NVoc/vocoder/model/custom_AE_layers.py:338-341 `end` convolution of the WaveNet,
@@ -21,8 +24,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void wn_tail_kernel(const float *skip, long long skip_bstride, const int *n_frames,
                                                       int rows_per_frame, int max_rows, int C, const float *w_end_packed,
                                                       const float *b_end, int n_out, const float *w_post,
-                                                      const float *b_post, int M, float *y, long long y_bstride,
-                                                      float *sub, long long sub_bstride) {
+                                                      const float *b_post, int M, const float *y_acc, float *y,
+                                                      long long y_bstride, float *sub, long long sub_bstride) {
     __shared__ float tile[4 * 32 * 33];
     __shared__ float wp[32 * 16 + 16];            // n_out * M post weights, then M post biases
     const int b = blockIdx.y;
@@ -60,12 +63,13 @@ __global__ __launch_bounds__(256) void wn_tail_kernel(const float *skip, long lo
     {
         const int rr = tid >> 3, nb = (tid & 7) * 4;
         float *yb = y + (long long)b * y_bstride + (long long)(m0 + rr) * n_out;
+        const float *ya = y_acc ? y_acc + (long long)b * y_bstride + (long long)min(m0 + rr, rows - 1) * n_out : nullptr;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int n = nb + q;
             const int o = rr * 33 + n;
             const float v = ((tile[o] + tile[32 * 33 + o]) + (tile[2 * 32 * 33 + o] + tile[3 * 32 * 33 + o])) +
-                            ((b_end && n < n_out) ? b_end[n] : 0.f);
+                            ((b_end && n < n_out) ? b_end[n] : 0.f) + ((ya && n < n_out) ? ya[n] : 0.f);
             tile[o] = v;
             if (n < n_out && m0 + rr < rows) yb[n] = v;
         }
@@ -93,15 +97,15 @@ __global__ __launch_bounds__(256) void wn_tail_kernel(const float *skip, long lo
 // returns false if the shapes do not fit (caller falls back to two generic convolutions)
 bool launch_wn_tail(const float *skip, long long skip_bstride, const int *n_frames, int rows_per_frame, int max_rows,
                     int batch, int C, const float *w_end_packed, const float *b_end, int n_out, const float *w_post,
-                    const float *b_post, int M, float *y, long long y_bstride, float *sub, long long sub_bstride,
-                    hipStream_t stream) {
+                    const float *b_post, int M, const float *y_acc, float *y, long long y_bstride, float *sub,
+                    long long sub_bstride, hipStream_t stream) {
     if (n_out > 32 || M > 16 || C % 4 != 0 || skip_bstride % 4 != 0 || (uintptr_t)skip % 16 != 0 ||
         (uintptr_t)w_end_packed % 16 != 0)
         return false;
     if (max_rows <= 0 || batch <= 0) return true;
     hipLaunchKernelGGL(wn_tail_kernel, dim3((max_rows + 31) / 32, batch), dim3(256), 0, stream, skip, skip_bstride,
-                       n_frames, rows_per_frame, max_rows, C, w_end_packed, b_end, n_out, w_post, b_post, M, y, y_bstride,
-                       sub, sub_bstride);
+                       n_frames, rows_per_frame, max_rows, C, w_end_packed, b_end, n_out, w_post, b_post, M, y_acc, y,
+                       y_bstride, sub, sub_bstride);
     return true;
 }
 

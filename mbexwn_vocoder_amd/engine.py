@@ -269,6 +269,48 @@ def pack_end_weights(w):
     return np.ascontiguousarray(wp.reshape(nc8, 2, 4, 32).transpose(0, 1, 3, 2))
 
 
+def fold_skip_weights(folded, n_layers, channels):
+    """Fold the skip path of the WaveNet into its end convolution (both are linear, reference
+    MBExWN_NVoc/vocoder/model/custom_AE_layers.py:322-341: output += res_skip[:, C:]; ...; self.end(output)):
+
+        end(sum_l (a_l Ws_l + bs_l)) = sum_l a_l (Ws_l We) + (sum_l bs_l We + be)
+
+    so layer l < L-1 needs the C x (C + n_out) matrix [Wr_l | Ws_l We] instead of C x 2C, the last layer C x n_out
+    instead of C x C, and the (rows, C) skip tensor never exists.  Products are formed in float64.  Returns the extra
+    tensors {name: array} (packed for wn_resskip_kernel / wn_tail_kernel) or {} if the layout does not allow it.
+    """
+    we = np.asarray(folded["wn.end.w"], dtype=np.float64)
+    if we.shape[0] != 1 or we.shape[2] > 32:
+        return {}
+    C, n_out = channels, we.shape[2]
+    we = we[0]
+    const = np.asarray(folded["wn.end.b"], dtype=np.float64).copy()
+    out = {}
+    biases = []
+    for ll in range(n_layers):
+        w = np.asarray(folded[f"wn.res_skip_{ll}.w"], dtype=np.float64)
+        b = np.asarray(folded[f"wn.res_skip_{ll}.b"], dtype=np.float64)
+        if w.shape[0] != 1:
+            return {}
+        last = ll == n_layers - 1
+        ws, bs = (w[0], b) if last else (w[0][:, C:], b[C:])
+        proj = ws @ we
+        const += bs @ we
+        if last:
+            out["wn.tail.fold"] = pack_end_weights(proj[None])
+        else:
+            out[f"wn.res_skip_{ll}.fold"] = pack_resskip_weights(np.concatenate((w[0][:, :C], proj), axis=1)[None])
+            biases.append(np.concatenate((b[:C], np.zeros(n_out))))
+    if biases:
+        biases[0][C:] = const                 # layer 0 initialises the accumulator
+        for ll, bb in enumerate(biases):
+            out[f"wn.res_skip_{ll}.fold_b"] = bb
+        out["wn.tail.fold_b"] = np.zeros(n_out)
+    else:
+        out["wn.tail.fold_b"] = const
+    return out
+
+
 def tensor_table(config, raw_weights, wavetables):
     """name -> float32 array of everything mbx_create needs: folded weights + constant tables."""
     dims = ModelDims(config)
@@ -280,6 +322,7 @@ def tensor_table(config, raw_weights, wavetables):
     out["table.pqmf_syn"] = syn
     if out["wn.end.w"].shape[0] == 1 and out["wn.end.w"].shape[2] <= 32:
         out["wn.end.packed"] = pack_end_weights(out["wn.end.w"])
+        out.update(fold_skip_weights(out, dims.wn_layers, dims.wn_channels))
     for ll in range(dims.wn_layers):
         out[f"wn.res_skip_{ll}.packed"] = pack_resskip_weights(out[f"wn.res_skip_{ll}.w"])
     if dims.wn_kernel_size == 3:
