@@ -94,14 +94,11 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 4) void wn_resskip_kernel(ConvAr
     bool col_ok[2];
     const int skip_ld = p.skip_ld ? p.skip_ld : C;
     const long long skip_bstride = p.skip_ld ? (long long)p.max_rows * p.skip_ld : p.hs_bstride;
+    const int lane_row = m0 + 32 * MT * wm + 4 * lk;      // row of register r of row tile i: lane_row + 32 i + (r & 3) + 8 (r >> 2)
+    int off_last[2];                                      // element offset of the last valid row (clamp target)
     {
-        // unconditional loads from clamped addresses (no branch, all 64 requests in flight), selected afterwards
-        int rowc[MT][16];
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                rowc[i][r] = min(m0 + 32 * MT * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk, rows - 1);
+        // unconditional loads from clamped addresses (no branch, all requests in flight), selected afterwards;
+        // element offsets in 32 bits with full-rate 24-bit multiplies (the launcher bounds rows * row stride)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + 64 * wn + 32 * j + lrow;
@@ -111,13 +108,17 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 4) void wn_resskip_kernel(ConvAr
             const int oc = to_h ? colc : (p.last_layer ? colc : colc - C);
             dst[j] = to_h ? p.h + (long long)b * p.hs_bstride + oc : p.skip + (long long)b * skip_bstride + oc;
             ld[j] = to_h ? C : skip_ld;
+            off_last[j] = (rows - 1) * ld[j];
+            const int off0 = lane_row * ld[j];
             const bool accumulate = (to_h || !p.skip_init) && col_ok[j];
             const float bias = (p.bias && col_ok[j]) ? p.bias[colc] : 0.f;
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float old = dst[j][(long long)rowc[i][r] * ld[j]];
+                    const int k = 32 * i + (r & 3) + 8 * (r >> 2);
+                    const int off = lane_row + k < rows ? off0 + (int)__umul24(k, ld[j]) : off_last[j];
+                    const float old = dst[j][off];
                     acc[i][j][r] = (accumulate ? old : 0.f) + bias;
                 }
         }
@@ -176,7 +177,10 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 4) void wn_resskip_kernel(ConvAr
         }
     }
 
-    // ---- epilogue: the accumulators are the new values
+    // ---- epilogue: the accumulators are the new values (offsets recomputed: keeping 64 of them live through the
+    // K loop would cost occupancy, so the compiler is kept from reusing the ones of the prologue)
+    int lane_row_e = lane_row;
+    asm volatile("" : "+v"(lane_row_e));
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         if (!col_ok[j]) continue;
@@ -184,8 +188,8 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 4) void wn_resskip_kernel(ConvAr
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + 32 * MT * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (row < rows) dst[j][(long long)row * ld[j]] = acc[i][j][r];
+                const int k = 32 * i + (r & 3) + 8 * (r >> 2);
+                if (lane_row_e + k < rows) dst[j][lane_row_e * ld[j] + (int)__umul24(k, ld[j])] = acc[i][j][r];
             }
     }
 }
@@ -194,6 +198,7 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 4) void wn_resskip_kernel(ConvAr
 bool launch_wn_resskip(const ConvArgs &a, hipStream_t stream) {
     const bool ok = a.ks == 1 && a.cin == a.channels && a.cin % 4 == 0 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 &&
                     (uintptr_t)a.x % 16 == 0 && (uintptr_t)a.w % 16 == 0 && a.zeros && a.h && a.skip && a.cout > 0 &&
+                    (long long)a.max_rows * a.channels < (1LL << 31) &&
                     (a.skip_ld ? a.cout <= a.channels + a.skip_ld : a.cout == (a.last_layer ? a.channels : 2 * a.channels));
     if (!ok) return false;
     ConvArgs r = a;
