@@ -66,7 +66,8 @@ struct mbx_handle {
     int f0_time_factor = 1, vtf_time_factor = 1;
     long long subnet_buf_per_frame = 0;   // floats per frame of one ping-pong buffer
     bool fold_skip = false;      // skip path folded into the end convolution (needs the *.fold tensors)
-    bool use_winograd = false;   // Winograd F(2,3) gate kernel when the transformed weights were supplied
+    bool winograd4_always = false;   // MBX_WINOGRAD=44: F(4,3) at every size (tests)
+    int winograd = 0;            // gate layer form: 0 direct, 2 Winograd F(2,3), 4 Winograd F(4,3) (needs the packed weights)
     // bench-only kernel timing (mbx_profile_*)
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool[2];   // 0: gate, 1: res_skip
@@ -525,7 +526,11 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
     }
     {
         const char *wv = getenv("MBX_WINOGRAD");
-        hd->use_winograd = wv ? atoi(wv) != 0 : true;   // default on (MBX_WINOGRAD=0 selects the direct form)
+        hd->winograd = wv ? atoi(wv) : 4;   // default F(4,3) / F(2,3) by size; MBX_WINOGRAD=2: F(2,3) only, 0: direct form
+        if (hd->winograd == 44) {
+            hd->winograd = 4;
+            hd->winograd4_always = true;
+        }
     }
     *out = hd;
     return MBX_OK;
@@ -631,7 +636,19 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         {
             ScopedEvents ev(hd, 0, stream);
             bool done = false;
-            const DevTensor *wino = hd->use_winograd ? find(hd, "wn.conv1D_" + ls + ".wino") : nullptr;
+            // F(4,3) for large launches (>= four rounds of 256-row blocks); F(2,3) below that (its half-size blocks keep a
+            // small grid balanced) and for streams: a window is bit-identical to the offline result only if both run the
+            // same form with the same group alignment (streaming.py), and F(2,3) needs the shorter alignment
+            const long long full_blocks = ((nsteps + 255) / 256) * B * ((C + 31) / 32);
+            const bool use4 = hd->winograd == 4 && !st_in && !st_out && (hd->winograd4_always || full_blocks >= 4 * 512);
+            const DevTensor *wino4 = use4 ? find(hd, "wn.conv1D_" + ls + ".wino4") : nullptr;
+            if (wino4 && wino4->ndim == 3 && wino4->shape[0] == (C + 31) / 32 && wino4->shape[1] == (C + 7) / 8 &&
+                wino4->shape[2] == 3072) {
+                mbx::ConvArgs gw = g;
+                gw.w = wino4->ptr;
+                done = mbx::launch_wn_gate_winograd4(gw, stream);
+            }
+            const DevTensor *wino = (!done && hd->winograd) ? find(hd, "wn.conv1D_" + ls + ".wino") : nullptr;
             if (wino && wino->ndim == 3 && wino->shape[0] == (C + 31) / 32 && wino->shape[1] == (C + 15) / 16 &&
                 wino->shape[2] == 4096) {
                 mbx::ConvArgs gw = g;

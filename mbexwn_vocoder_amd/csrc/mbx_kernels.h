@@ -60,6 +60,8 @@ void launch_conv1d(const ConvArgs &a, int epilogue, hipStream_t stream);
 void launch_conv1d_group(const ConvArgs *convs, int n, hipStream_t stream);
 // Winograd F(2,3) form of the WaveNet gate layer (wn_winograd.hip); a.w = host-packed weights (ceil(C/32), ceil(C/16), 4096)
 bool launch_wn_gate_winograd(const ConvArgs &a, const float *w_split, hipStream_t stream);
+// Winograd F(4,3) form (wn_winograd4.hip); a.w = host-packed weights (ceil(C/32), ceil(C/8), 3072)
+bool launch_wn_gate_winograd4(const ConvArgs &a, hipStream_t stream);
 // WaveNet residual/skip layer for large row counts (wn_resskip.hip); a.w = host-packed weights (ceil(cout/128), ceil(C/16), 2048)
 bool launch_wn_resskip(const ConvArgs &a, hipStream_t stream);
 // WaveNet end convolution + post-net in one pass over the skip tensor (wn_tail.hip); w_end_packed = host-packed

@@ -239,6 +239,31 @@ def pack_winograd_weights(w, split=False):
     return np.ascontiguousarray(wp.transpose(6, 1, 0, 2, 5, 3, 7, 4).reshape(nt, nk, 4096), dtype=np.float32)
 
 
+_WINOGRAD43_G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+                          [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=np.float64)
+
+
+def pack_winograd4_weights(w):
+    """Winograd F(4,3) combinations U = G W of the three taps (3, C, 2C) of a dilated WaveNet convolution, packed for
+    wn_gate_winograd4_kernel (csrc/wn_winograd4.hip); formed in float64, stored float32.
+
+    Layout (ceil(C/32) column tiles, ceil(C/8) channel slices, 3072): the 12 KB image of one (tile, slice) is copied
+    verbatim into LDS, ordered [product j][wave column wn][lane = 32*lk + n][k step st] with input channel
+    8*slice + 4*lk + st and output column (n // 16)*C + 32*tile + 16*wn + n % 16; out-of-range entries are zero.
+    """
+    w = np.asarray(w, dtype=np.float64)
+    C = w.shape[1]
+    assert w.shape == (3, C, 2 * C)
+    u = np.einsum("ij,jcn->icn", _WINOGRAD43_G, w)
+    nt, nk = (C + 31) // 32, (C + 7) // 8
+    wp = np.zeros((6, nk * 8, 2, nt * 32))
+    wp[:, :C, 0, :C] = u[:, :, :C]
+    wp[:, :C, 1, :C] = u[:, :, C:]
+    wp = wp.reshape(6, nk * 8, 2, nt, 2, 16).transpose(0, 1, 4, 3, 2, 5).reshape(6, nk * 8, 2, nt * 32)
+    wp = wp.reshape(6, nk, 2, 4, 2, nt, 32)                       # j, slice, lk, st, wn, tile, n
+    return np.ascontiguousarray(wp.transpose(5, 1, 0, 4, 2, 6, 3).reshape(nt, nk, 3072), dtype=np.float32)
+
+
 def pack_resskip_weights(w):
     """Weights (1, C, cout) of a WaveNet res/skip 1x1 convolution packed for wn_resskip_kernel (csrc/wn_resskip.hip).
 
@@ -329,6 +354,7 @@ def tensor_table(config, raw_weights, wavetables):
         for ll in range(dims.wn_layers):
             out[f"wn.conv1D_{ll}.wino"] = pack_winograd_weights(out[f"wn.conv1D_{ll}.w"])
             out[f"wn.conv1D_{ll}.wino_split"] = pack_winograd_weights(out[f"wn.conv1D_{ll}.w"], split=True)
+            out[f"wn.conv1D_{ll}.wino4"] = pack_winograd4_weights(out[f"wn.conv1D_{ll}.w"])
     out["table.hann"] = tb.hann_periodic_f32(dims.stft_win)
     out["table.inv_win"] = tb.inverse_stft_window_f32(dims.stft_win, dims.hop_size)
     out["table.wavetables"] = np.ascontiguousarray(wavetables.tables, dtype=np.float32)

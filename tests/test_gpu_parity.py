@@ -226,6 +226,49 @@ def test_forward_matches_reference_goldens(torch, golden_dir, case):
     assert cond.shape[1] == frames * 2 * 2 * eng.dims.wn_channels
 
 
+@pytest.mark.parametrize("form", ["0", "2", "44"])
+@pytest.mark.parametrize("key,spec,batch,frames", [("canon", CANON, 2, 40), ("voice", VOICE, 1, 17)])
+def test_gate_layer_forms_match_oracle(torch, monkeypatch, form, key, spec, batch, frames):
+    """The dilated convolution has three float32 implementations (direct, Winograd F(2,3), Winograd F(4,3); the engine
+    picks by launch size): each one is forced here (MBX_WINOGRAD is read by mbx_create) and held to the same tolerance,
+    including a ragged batch."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    monkeypatch.setenv("MBX_WINOGRAD", form)
+    cfg, raw, wt = build_case(*spec)
+    eng = MBExWNEngine(cfg, raw, wt)
+    om = get_engine(key, *spec)[1]
+    mel, noise = synthetic_inputs(5, batch, frames)
+    got = eng.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
+    ref = om.forward(mel, noise)
+    assert _maxdiff(got, ref) <= _tol(ref, E2E_TOL)
+    if batch > 1:
+        lengths = [frames, frames // 3]
+        nf = torch.as_tensor(lengths, dtype=torch.int32).cuda()
+        rag = eng.forward(dev(torch, mel), n_frames=nf, noise=dev(torch, noise)).cpu().numpy()
+        ll = lengths[1]
+        single = eng.forward(dev(torch, mel[1:2, :ll]), noise=dev(torch, noise[1:2, :ll * 20])).cpu().numpy()
+        assert np.array_equal(rag[1, :ll * 300], single[0])
+        assert np.all(rag[1, ll * 300:] == 0.0)
+
+
+def test_full_size_gate_forms_agree(torch, monkeypatch):
+    """BASELINE config 3 size (16 x 10 s): the launch is large enough for the F(4,3) kernel by default; its result
+    must agree with the F(2,3) form of the same engine to float32 rounding (size-independent property: two
+    algebraically identical evaluations)."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    cfg, raw, wt = build_case(*CANON)
+    mel, noise = synthetic_inputs(21, 16, 800)
+    outs = {}
+    for form in ("4", "2"):
+        monkeypatch.setenv("MBX_WINOGRAD", form)
+        eng = MBExWNEngine(cfg, raw, wt)
+        outs[form] = eng.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
+        del eng
+    assert np.all(np.isfinite(outs["4"]))
+    assert _maxdiff(outs["4"], outs["2"]) <= 2e-5 * max(1.0, float(np.abs(outs["2"]).max()))
+    assert not np.array_equal(outs["4"], outs["2"])       # the default really took the other kernel
+
+
 def test_padded_batch_equals_one_at_a_time(torch):
     """Every boundary op honours the item's own length: a ragged batch gives the per-utterance results
     (the reference processes one utterance at a time, bin/resynth_mel.py:74)."""
