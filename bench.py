@@ -305,7 +305,11 @@ def main():
     eng.profile_enable(False)
 
     if rank == 0:
-        winograd = os.environ.get("MBX_WINOGRAD", "1") != "0" and dims.wn_kernel_size == 3
+        form = eng.gate_form(batch, frames)
+        executed = {"direct": 1.0, "winograd_f23": 2.0 / 3.0, "winograd_f43": 0.5}[form]
+        kernel = {"direct": "conv1d_mfma_dma_kernel<EPI_GATE> (dilated conv k=3 C->2C + cond + tanh*sigmoid)",
+                  "winograd_f23": "wn_gate_winograd_kernel (dilated conv k=3 C->2C in Winograd F(2,3) form + cond + tanh*sigmoid)",
+                  "winograd_f43": "wn_gate_winograd4_kernel (dilated conv k=3 C->2C in Winograd F(4,3) form + cond + tanh*sigmoid)"}[form]
         C, L, ks = dims.wn_channels, dims.wn_layers, dims.wn_kernel_size
         rows = batch * frames * dims.steps_per_frame
         gate_flop = 2.0 * rows * (ks * C) * (2 * C)                   # algorithmic FLOPs of one launch
@@ -332,16 +336,16 @@ def main():
                                    f"{frames / 80:g} s per GPU, 80x{frames} synthetic mel, seeded synthetic weights",
                        "batch_per_gpu": batch, "frames": frames, "parallelism": f"utterance-sharded x{world}"},
             "roofline": {"bound": "mfma",
-                         "kernel": "wn_gate_winograd_kernel (dilated conv k=3 C->2C in Winograd F(2,3) form + cond + tanh*sigmoid)"
-                         if winograd else "conv1d_mfma_dma_kernel<EPI_GATE> (dilated conv k=3 C->2C + cond + tanh*sigmoid)",
+                         "kernel": kernel,
                          "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": pmc_traffic(args.workload),
                          "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
                          "flop_per_launch": gate_flop,
-                         "note": "achieved = algorithmic FLOPs of the direct convolution (2*rows*3C*2C) / launch time; the "
-                                 "Winograd form executes 2/3 of them on the matrix cores (MfmaUtil in profiles/)"
-                         if winograd else "achieved = 2*rows*3C*2C / launch time",
-                         "mfma_flop_executed_per_launch": gate_flop * (2.0 / 3.0 if winograd else 1.0),
+                         "note": "achieved = algorithmic FLOPs of the direct convolution (2*rows*3C*2C) / launch time; a "
+                                 "Winograd form executes 2/3 (F(2,3)) or 1/2 (F(4,3)) of them on the matrix cores, so "
+                                 "frac can exceed 1; frac_executed = executed FLOPs / launch time / peak (MfmaUtil in profiles/)",
+                         "mfma_flop_executed_per_launch": gate_flop * executed,
+                         "frac_executed": achieved * executed / FP32_MATRIX_PEAK_TFLOPS,
                          "avg_launch_ms": gate_avg_s * 1e3, "launches_timed": gate_n,
                          "res_skip_avg_launch_ms": rs_ms / max(rs_n, 1)},
         }

@@ -161,7 +161,9 @@ mbx_status mbx_forward_ex(mbx_handle *handle, const float *mel, const int32_t *n
 
 /* Intermediate tensors of the most recent mbx_forward (pointers into its workspace), for stage parity
  * tests.  Names: "f0" "pulse" "cond" "wn_hidden" "wn_skip" "wn_out" "subbands" "excitation" "cepstrum"
- * "ceps_index" "frames".  `count` = floats (int32 for ceps_index) per batch item, `stride` = item stride. */
+ * "ceps_index" "frames".  `count` = floats (int32 for ceps_index) per batch item, `stride` = item stride.
+ * "wn_skip" (the C-wide skip sum) only exists when the skip path is not folded into the end convolution
+ * (environment MBX_FOLD_SKIP=0 at mbx_create, or a handle created without the *.fold tensors). */
 mbx_status mbx_stage(const mbx_handle *handle, const char *name, const void **device_ptr, int64_t *count,
                      int64_t *stride);
 

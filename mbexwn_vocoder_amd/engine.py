@@ -497,6 +497,19 @@ class MBExWNEngine:
         _check(self._lib.mbx_profile_read(self._handle, kernel.encode(), ctypes.byref(ms), ctypes.byref(cnt)))
         return ms.value, cnt.value
 
+    def gate_form(self, batch, max_frames):
+        """Which implementation of the dilated convolution a forward of this size runs (mirror of the policy in
+        csrc/mbx_api.hip: MBX_WINOGRAD, read by mbx_create, default 4; F(4,3) from four rounds of 256-row blocks on):
+        "direct", "winograd_f23" or "winograd_f43"."""
+        mode = int(os.environ.get("MBX_WINOGRAD", "4"))
+        if mode == 0 or self.dims.wn_kernel_size != 3:
+            return "direct"
+        rows = max_frames * self.dims.steps_per_frame
+        full_blocks = ((rows + 255) // 256) * batch * ((self.dims.wn_channels + 31) // 32)
+        if mode == 44 or (mode == 4 and full_blocks >= 4 * 512):
+            return "winograd_f43"
+        return "winograd_f23"
+
     def stage(self, name):
         """Intermediate tensor of the last forward (copy), shaped (B, count); see mbx_stage."""
         torch = self._torch

@@ -19,7 +19,7 @@ summary = {}
 
 
 def short(name):
-    if "wn_gate_winograd_kernel" in name or ("conv1d_mfma_dma_kernel" in name and ", 1>" in name):
+    if "wn_gate_winograd" in name or ("conv1d_mfma_dma_kernel" in name and ", 1>" in name):
         return "gate"
     if "wn_resskip_kernel" in name or ("conv1d_mfma_kernel" in name and ", 2, true" in name):
         return "res_skip"
