@@ -11,7 +11,7 @@
 //   B: 16 channels x 128 columns per slice, pre-packed on the host in MFMA operand order
 //      [channel half cc][column tile jn][lane][4 k steps] (engine.pack_resskip_weights): one ds_read_b128 per lane
 //      = the weight operands of four consecutive MFMAs
-//   two LDS stages (32 / 24 KB per block); operand groups of 8 MFMAs, the operands of group n+1 are requested from
+//   three (large shape) or two LDS stages of 16 / 12 KB; operand groups of 8 MFMAs, the operands of group n+1 are requested from
 //   LDS before the MFMAs of group n issue.
 // The accumulators start from (old value + bias), so the epilogue is a plain store (same arithmetic as the
 // acc_preloaded path of conv1d_mfma_kernel).
@@ -29,14 +29,16 @@ __device__ __forceinline__ void rs_lds_dma16(const float *src, unsigned lds_byte
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(src) : "memory", "m0");
 }
 
-template <int MT>
+template <int MT, int NST>
 __global__ __launch_bounds__(256, MT == 2 ? 3 : 4) void wn_resskip_kernel(ConvArgs p) {
     constexpr int ROWS = 64 * MT;
     constexpr int RS_A_FLOATS = ROWS * RS_BK;
     constexpr int A_INST = ROWS / 64;          // LDS-DMA instructions per wave (A)
     constexpr int NG = 2 * MT;                 // operand groups (8 MFMAs each) per slice
     typedef __attribute__((address_space(3))) float lds_float;
-    __shared__ __attribute__((aligned(16))) float lds[2 * (RS_A_FLOATS + RS_B_FLOATS)];   // A0 A1 B0 B1
+    constexpr int STAGE = RS_A_FLOATS + RS_B_FLOATS;
+    constexpr int N_DMA = A_INST + 2;          // LDS-DMA instructions per wave and slice
+    __shared__ __attribute__((aligned(16))) float lds[NST * STAGE];   // stage s: A at s*STAGE, B behind it
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float *)lds);
 
     // XCD-aware decode (see decode_tile in conv_mfma.hip)
@@ -73,8 +75,8 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 4) void wn_resskip_kernel(ConvAr
     const float *wsrc = p.w + (long long)nt * nk * RS_B_FLOATS + (wave * 64 + lane) * 4;
     auto issue = [&](int kt, int buf) {
         const int ci0 = kt * RS_BK;
-        const unsigned adst = lds_base + 4u * (unsigned)(buf * RS_A_FLOATS);
-        const unsigned bdst = lds_base + 4u * (unsigned)(2 * RS_A_FLOATS + buf * RS_B_FLOATS);
+        const unsigned adst = lds_base + 4u * (unsigned)(buf * STAGE);
+        const unsigned bdst = adst + 4u * (unsigned)RS_A_FLOATS;
 #pragma unroll
         for (int i = 0; i < A_INST; ++i) {
             const int ci = ci0 + a_ch[i];
@@ -134,21 +136,33 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 4) void wn_resskip_kernel(ConvAr
     float4 Av[2];
     float4 Bv[2][2];
     auto load_a = [&](int buf, int cc, int i, float4 &a) {
-        a = *reinterpret_cast<const float4 *>(lds + buf * RS_A_FLOATS + aoff[i][cc]);
+        a = *reinterpret_cast<const float4 *>(lds + buf * STAGE + aoff[i][cc]);
     };
     auto load_b = [&](int buf, int cc, float4 (&bw)[2]) {
-        const float *bb = lds + 2 * RS_A_FLOATS + buf * RS_B_FLOATS + lane * 4;
+        const float *bb = lds + buf * STAGE + RS_A_FLOATS + lane * 4;
         bw[0] = *reinterpret_cast<const float4 *>(bb + (cc * 4 + 2 * wn + 0) * 256);
         bw[1] = *reinterpret_cast<const float4 *>(bb + (cc * 4 + 2 * wn + 1) * 256);
     };
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // NST stages: slices 1 .. NST-1 are requested behind slice 0 and the accumulator pre-loads; a slice has landed
+    // when at most the (NST-2) slices requested after it are still outstanding (N_DMA instructions each)
     if (nk > 1) issue(1, 1);
+    if (NST == 3 && nk > 2) issue(2, 2);
+    if (NST == 3 && nk > 2) {
+        if (N_DMA == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (NST == 2 && nk > 1) {
+        if (N_DMA == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
     load_a(0, 0, 0, Av[0]);
     load_b(0, 0, Bv[0]);
+    int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+        const int nbuf = buf == NST - 1 ? 0 : buf + 1;
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
             const int cc = gi / MT, i = gi % MT;
@@ -156,11 +170,17 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 4) void wn_resskip_kernel(ConvAr
                 load_a(buf, (gi + 1) / MT, (gi + 1) % MT, Av[(gi + 1) & 1]);
                 if (gi == MT - 1) load_b(buf, 1, Bv[1]);
             } else if (kt + 1 < nk) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // slice kt+1 must have landed (with three stages slice kt+2 may still be in flight)
+                if (NST == 3 && kt + 2 < nk) {
+                    if (N_DMA == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 __syncthreads();
-                if (kt + 2 < nk) issue(kt + 2, buf);
-                load_a(buf ^ 1, 0, 0, Av[0]);
-                load_b(buf ^ 1, 0, Bv[0]);
+                if (kt + NST < nk) issue(kt + NST, buf);
+                load_a(nbuf, 0, 0, Av[0]);
+                load_b(nbuf, 0, Bv[0]);
             }
             __builtin_amdgcn_sched_barrier(0);      // keep the requests ahead of this group's MFMAs
             const float4 a = Av[gi & 1];
@@ -175,6 +195,7 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 4) void wn_resskip_kernel(ConvAr
             acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bw[1].w, acc[i][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        buf = nbuf;
     }
 
     // ---- epilogue: the accumulators are the new values (offsets recomputed: keeping 64 of them live through the
@@ -211,8 +232,12 @@ bool launch_wn_resskip(const ConvArgs &a, hipStream_t stream) {
     r.m_tiles_per_item = (a.max_rows + tile_rows - 1) / tile_rows;
     r.m_tiles_total = r.m_tiles_per_item * a.batch;
     const long long blocks = 8LL * ((r.m_tiles_total + 7) / 8) * r.n_tiles;
-    if (small) hipLaunchKernelGGL(wn_resskip_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, r);
-    else hipLaunchKernelGGL(wn_resskip_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, r);
+    static const int nst_env = getenv("MBX_RS_STAGES") ? atoi(getenv("MBX_RS_STAGES")) : 0;    // tuning experiments
+    const int nst = nst_env ? nst_env : (small ? 2 : 3);     // measured: 3 stages -4% at batch 16, nothing at batch 1
+    if (small && nst == 3) hipLaunchKernelGGL((wn_resskip_kernel<1, 3>), dim3((unsigned)blocks), dim3(256), 0, stream, r);
+    else if (small) hipLaunchKernelGGL((wn_resskip_kernel<1, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, r);
+    else if (nst == 3) hipLaunchKernelGGL((wn_resskip_kernel<2, 3>), dim3((unsigned)blocks), dim3(256), 0, stream, r);
+    else hipLaunchKernelGGL((wn_resskip_kernel<2, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, r);
     return true;
 }
 
