@@ -1,0 +1,158 @@
+"""Host-side weight images consumed by the HIP kernels (engine.pack_*, engine.fold_skip_weights): every image is
+unpacked here with the index formula of the kernel that reads it and fed through a float64 numpy restatement of that
+kernel's arithmetic, which must reproduce the plain convolution."""
+import numpy as np
+import pytest
+
+from mbexwn_vocoder_amd import engine
+
+
+def _direct_dilated(x, w, d):
+    """y[t] = x[t-d] W0 + x[t] W1 + x[t+d] W2 with zero padding; x (T, C), w (3, C, N)."""
+    T = x.shape[0]
+    xp = np.concatenate((np.zeros((d, x.shape[1])), x, np.zeros((d, x.shape[1]))))
+    return xp[0:T] @ w[0] + xp[d:d + T] @ w[1] + xp[2 * d:2 * d + T] @ w[2]
+
+
+def _unpack_gate(packed, C, n_prod, bk, split):
+    """(tiles, slices, n_prod*bk*64) image -> U (n_prod, C, 2C) with the lane/step index map of the gate kernels."""
+    nt, nk, _ = packed.shape
+    steps = 4
+    halves = bk // 8 if bk == 16 else 1          # channel halves cc per slice (F(2,3): 2, F(4,3): 1)
+    img = packed.reshape(nt, nk, n_prod, halves, 2, 64, steps)      # tile, slice, j, cc, h|wn, lane, st
+    U = np.zeros((n_prod, C, 2 * C))
+    for tile in range(nt):
+        for kt in range(nk):
+            for cc in range(halves):
+                for hh in range(2):
+                    for lane in range(64):
+                        lk, n = lane >> 5, lane & 31
+                        if split:
+                            ch = 32 * tile + 16 * hh + n % 16
+                            col = (n // 16) * C + ch
+                        else:
+                            ch = 32 * tile + n
+                            col = hh * C + ch
+                        for st in range(steps):
+                            k = bk * kt + 8 * cc + 4 * lk + st
+                            if k < C and ch < C:
+                                U[:, k, col] = img[tile, kt, :, cc, hh, lane, st]
+    return U
+
+
+@pytest.mark.parametrize("C", [32, 40])
+@pytest.mark.parametrize("split", [False, True])
+def test_winograd_f23_image_reproduces_the_convolution(C, split):
+    rng = np.random.default_rng(C + split)
+    w = rng.normal(size=(3, C, 2 * C))
+    U = _unpack_gate(engine.pack_winograd_weights(w, split=split).astype(np.float64), C, 4, 16, split)
+    x = rng.normal(size=(64, C))
+    for d in (1, 2, 8):
+        ref = _direct_dilated(x, w, d)
+        xp = np.concatenate((np.zeros((d, C)), x, np.zeros((2 * d, C))))
+        got = np.zeros_like(ref)
+        for t0 in range(0, 64, 2 * d):
+            for r in range(d):
+                t = t0 + r
+                x0, x1, x2, x3 = (xp[t + i * d] for i in range(4))           # h[t-d], h[t], h[t+d], h[t+2d]
+                m1, m2, m3, m4 = (x0 - x2) @ U[0], (x1 + x2) @ U[1], (x2 - x1) @ U[2], (x1 - x3) @ U[3]
+                got[t], got[t + d] = m1 + m2 + m3, m2 - m3 - m4
+        assert np.max(np.abs(got - ref)) < 2e-6 * np.max(np.abs(ref))     # float32 storage of the combinations
+
+
+@pytest.mark.parametrize("C", [32, 40])
+def test_winograd_f43_image_reproduces_the_convolution(C):
+    rng = np.random.default_rng(C)
+    w = rng.normal(size=(3, C, 2 * C))
+    U = _unpack_gate(engine.pack_winograd4_weights(w).astype(np.float64), C, 6, 8, True)
+    x = rng.normal(size=(128, C))
+    for d in (1, 4, 16):
+        ref = _direct_dilated(x, w, d)
+        xp = np.concatenate((np.zeros((d, C)), x, np.zeros((4 * d, C))))
+        got = np.zeros_like(ref)
+        for t0 in range(0, 128, 4 * d):
+            for r in range(d):
+                t = t0 + r
+                x0, x1, x2, x3, x4, x5 = (xp[t + i * d] for i in range(6))   # h[t-d] .. h[t+4d]
+                v = [4 * x0 - 5 * x2 + x4, -4 * x1 - 4 * x2 + x3 + x4, 4 * x1 - 4 * x2 - x3 + x4,
+                     -2 * x1 - x2 + 2 * x3 + x4, 2 * x1 - x2 - 2 * x3 + x4, 4 * x1 - 5 * x3 + x5]
+                m = [v[j] @ U[j] for j in range(6)]
+                got[t] = m[0] + m[1] + m[2] + m[3] + m[4]
+                got[t + d] = m[1] - m[2] + 2 * (m[3] - m[4])
+                got[t + 2 * d] = m[1] + m[2] + 4 * (m[3] + m[4])
+                got[t + 3 * d] = m[1] - m[2] + 8 * (m[3] - m[4]) + m[5]
+        assert np.max(np.abs(got - ref)) < 1e-5 * np.max(np.abs(ref))
+
+
+def _unpack_resskip(packed, C, cout):
+    nct, nk, _ = packed.shape
+    img = packed.reshape(nct, nk, 2, 4, 64, 4)                      # tile, slice, cc, jn, lane, st
+    W = np.zeros((C, cout))
+    for tile in range(nct):
+        for kt in range(nk):
+            for cc in range(2):
+                for jn in range(4):
+                    for lane in range(64):
+                        lk, n = lane >> 5, lane & 31
+                        col = 128 * tile + 32 * jn + n
+                        for st in range(4):
+                            k = 16 * kt + 8 * cc + 4 * lk + st
+                            if k < C and col < cout:
+                                W[k, col] = img[tile, kt, cc, jn, lane, st]
+                            else:
+                                assert img[tile, kt, cc, jn, lane, st] == 0.0
+    return W
+
+
+def test_resskip_and_end_images_are_permutations_of_the_weights():
+    rng = np.random.default_rng(3)
+    C, cout = 40, 70
+    w = rng.normal(size=(1, C, cout)).astype(np.float32)
+    assert np.array_equal(_unpack_resskip(engine.pack_resskip_weights(w), C, cout), w[0].astype(np.float64))
+    we = rng.normal(size=(1, 44, 30)).astype(np.float32)
+    img = engine.pack_end_weights(we)                                 # [c][lk][n][st], channel 8c + 4lk + st
+    assert img.shape == (6, 2, 32, 4)
+    for c in range(6):
+        for lk in range(2):
+            for st in range(4):
+                k = 8 * c + 4 * lk + st
+                row = we[0, k] if k < 44 else np.zeros(30, np.float32)
+                assert np.array_equal(img[c, lk, :30, st], row) and np.all(img[c, lk, 30:, st] == 0)
+
+
+@pytest.mark.parametrize("layers", [1, 3])
+def test_folded_skip_path_is_the_same_linear_map(layers):
+    """end(sum_l (a_l Ws_l + bs_l)) == sum_l a_l (Ws_l We) + const, with the images the kernels read."""
+    rng = np.random.default_rng(layers)
+    C, n_out, T = 24, 30, 50
+    folded = {"wn.end.w": rng.normal(size=(1, C, n_out)), "wn.end.b": rng.normal(size=n_out)}
+    for ll in range(layers):
+        cout = C if ll == layers - 1 else 2 * C
+        folded[f"wn.res_skip_{ll}.w"] = rng.normal(size=(1, C, cout))
+        folded[f"wn.res_skip_{ll}.b"] = rng.normal(size=cout)
+    acts = [rng.normal(size=(T, C)) for _ in range(layers)]
+    # un-folded graph (reference custom_AE_layers.py:322-341)
+    skip = np.zeros((T, C))
+    res_ref = []
+    for ll in range(layers):
+        r = acts[ll] @ folded[f"wn.res_skip_{ll}.w"][0] + folded[f"wn.res_skip_{ll}.b"]
+        if ll < layers - 1:
+            res_ref.append(r[:, :C])
+            skip += r[:, C:]
+        else:
+            skip += r
+    ref = skip @ folded["wn.end.w"][0] + folded["wn.end.b"]
+    # folded graph as the kernels run it
+    extra = engine.fold_skip_weights(folded, layers, C)
+    y = np.zeros((T, n_out))
+    for ll in range(layers - 1):
+        W = _unpack_resskip(extra[f"wn.res_skip_{ll}.fold"].astype(np.float64), C, C + n_out)
+        r = acts[ll] @ W + extra[f"wn.res_skip_{ll}.fold_b"]
+        assert np.max(np.abs(r[:, :C] - res_ref[ll])) < 1e-5            # residual half untouched
+        y = (0 if ll == 0 else y) + r[:, C:]
+    tail = extra["wn.tail.fold"].astype(np.float64)                      # [c][lk][n][st]
+    P = np.zeros((C, n_out))
+    for k in range(C):
+        P[k] = tail[k // 8, (k % 8) // 4, :n_out, k % 4]
+    y = y + acts[-1] @ P + extra["wn.tail.fold_b"]
+    assert np.max(np.abs(y - ref)) < 1e-5 * np.max(np.abs(ref))
