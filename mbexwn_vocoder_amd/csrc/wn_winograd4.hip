@@ -14,10 +14,14 @@
 // channels (wave column wn owns 16 of them as one 32-wide MFMA tile [16 tanh | 16 sigmoid]); 6 accumulator tiles per
 // wave.  Group Q of the block: q = Q / d, r = Q % d, t = m0 + 4 d q + r (d a power of two <= 16).
 // Per K slice of 8 channels the block stages, through LDS-DMA (see lds_dma16 in conv_mfma.hip):
-//   A: activation rows [m0-16, m0+272) x 8 channels, 16-byte chunk (row, c) at position 2*row + (c ^ ((row>>3)&1))
+//   A: activation rows [m0-16, m0+272) x 8 channels in read order: row = m0 - d + d*m + b (b < d) lives in 32-byte cell
+//      p = (m & 3)*80 + (m >> 2)*d + b, its 16-byte chunk c at 2*p + (c ^ ((p>>3)&1)).  The six rows a lane reads are then
+//      cells (q & 3)*80 + Q + (q >> 2)*d: consecutive lanes read consecutive cells, bank-conflict free for every
+//      dilation (the natural row order costs 4-way conflicts at d = 1, 2).  An LDS-DMA lane writes a fixed cell, so
+//      the layout is realised by the source row each lane fetches.
 //   B: 6 weight combinations x 8 channels x 64 columns, pre-packed on the host in MFMA operand order
 //      [product j][wave column wn][lane][4 k steps]: one ds_read_b128 per lane = the weight operands of four MFMAs
-// Three LDS stages (63 KB per block, 2 blocks per CU): the slice needed next has landed two slices of compute ago.
+// Three LDS stages (66 KB per block, 2 blocks per CU): the slice needed next has landed two slices of compute ago.
 #include <cstdlib>
 #include <type_traits>
 #include "mbx_kernels.h"
@@ -28,12 +32,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int W4_ROWS = 256;
 constexpr int W4_HALO = 16;
-constexpr int W4_AROWS = W4_ROWS + 2 * W4_HALO;       // 288
+constexpr int W4_AROWS = W4_ROWS + 2 * W4_HALO;       // 288 rows can be needed
+constexpr int W4_PHASE = W4_ROWS / 4 + W4_HALO;        // 80 cells per phase (m & 3)
+constexpr int W4_CELLS = 4 * W4_PHASE;                 // 320 cells of 8 channels
 constexpr int W4_BK = 8;
-constexpr int W4_A_FLOATS = W4_AROWS * W4_BK;          // 2304
+constexpr int W4_A_FLOATS = W4_CELLS * W4_BK;          // 2560
 constexpr int W4_B_FLOATS = 6 * W4_BK * 64;            // 3072
-constexpr int W4_STAGE = W4_A_FLOATS + W4_B_FLOATS;    // 5376 floats = 21 KB
-constexpr int W4_A_CHUNKS = W4_AROWS * 2 / 64;         // 9 x 1 KB LDS-DMA instructions per slice (A)
+constexpr int W4_STAGE = W4_A_FLOATS + W4_B_FLOATS;    // 5632 floats = 22 KB
+constexpr int W4_A_CHUNKS = W4_CELLS * 2 / 64;         // 10 x 1 KB LDS-DMA instructions per slice (A)
 constexpr int W4_B_INST = W4_B_FLOATS / 4 / 64 / 4;    // 3 per wave (B)
 
 __device__ __forceinline__ void w4_lds_dma16(const float *src, unsigned lds_byte_addr) {
@@ -102,14 +108,17 @@ __global__ __launch_bounds__(256, 2) void wn_gate_winograd4_kernel(ConvArgs p, i
     unsigned a_ok = 0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        // chunks 0..7 are dealt round-robin; the 9th chunk is written by all four waves (same data), which keeps the
+        // chunks 0..7 are dealt round-robin, chunks 8 and 9 are each written by two waves (same data), which keeps the
         // number of outstanding LDS-DMA instructions per slice the same for every wave (s_waitcnt vmcnt below)
-        const int pos = (i < 2 ? wave + 4 * i : W4_A_CHUNKS - 1) * 64 + lane;
-        const int row = pos >> 1;
+        const int pos = (i < 2 ? wave + 4 * i : 8 + (wave & 1)) * 64 + lane;
+        const int cell = pos >> 1;
+        const int phase = cell / W4_PHASE, sidx = cell - phase * W4_PHASE;
+        const int m = 4 * (sidx >> log2d) + phase;
+        const int row = (m << log2d) + (sidx & (d - 1)) + W4_HALO - d;       // staged row index, m0 - 16 + row = source
         const int src = m0 - W4_HALO + row;
-        a_ch[i] = 4 * ((pos & 1) ^ ((row >> 3) & 1));
+        a_ch[i] = 4 * ((pos & 1) ^ ((cell >> 3) & 1));
         a_off[i] = min(max(src, 0), rows - 1) * p.ldx;
-        if (src >= 0 && src < rows) a_ok |= 1u << i;
+        if (row < W4_AROWS && src >= 0 && src < rows) a_ok |= 1u << i;
     }
     const float *wsrc = p.w + (long long)nt * nk * W4_B_FLOATS + (wave * 64 + lane) * 4;
     auto issue = [&](int kt, int stage) {
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void wn_gate_winograd4_kernel(ConvArgs p, i
             const int ci = ci0 + a_ch[i];
             const bool ok = ((a_ok >> i) & 1u) & (ci < p.cin);
             w4_lds_dma16(ok ? xb + a_off[i] + ci : p.zeros,
-                         adst + 1024u * (unsigned)(i < 2 ? wave + 4 * i : W4_A_CHUNKS - 1));
+                         adst + 1024u * (unsigned)(i < 2 ? wave + 4 * i : 8 + (wave & 1)));
         }
 #pragma unroll
         for (int i = 0; i < W4_B_INST; ++i)
@@ -153,12 +162,11 @@ __global__ __launch_bounds__(256, 2) void wn_gate_winograd4_kernel(ConvArgs p, i
 
     // group of this lane (A operand row): Q = 32*wm + lrow -> t = m0 + 4 d (Q >> log2d) + (Q & (d-1))
     const int grp = 32 * wm + lrow;
-    const int trel = W4_HALO + ((grp >> log2d) << (log2d + 2)) + (grp & (d - 1));    // LDS row of h[t]
     int aoff[6];        // LDS float offsets (inside a stage) of h[t-d] .. h[t+4d], this lane's 4 channels
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
-        const int row = trel + (q - 1) * d;
-        aoff[q] = 4 * (2 * row + (lk ^ ((row >> 3) & 1)));
+        const int cell = (q & 3) * W4_PHASE + grp + ((q >> 2) << log2d);
+        aoff[q] = 4 * (2 * cell + (lk ^ ((cell >> 3) & 1)));
     }
     float4 X0[6], X1[6];
     float4 B0[2], B1[2];
