@@ -169,16 +169,20 @@ class MELInverter(object):
         self.preprocess_config = hparams["preprocess_config"]
 
         weights_npz = os.path.join(model_dir, "weights.npz")
-        if not os.path.exists(weights_npz):
-            if os.path.exists(os.path.join(model_dir, "weights.tf.index")):
-                raise NotImplementedError(
-                    "this model directory holds a TensorFlow checkpoint (weights.tf); the TF-checkpoint reader is "
-                    "the next widening step (SURVEY.md section 8(f) rank 1). Convert the variables to weights.npz "
-                    "(names: <layer>.v/.g/.bias, <act>.alpha; see mbexwn_vocoder_amd/weights.py).")
-            raise FileNotFoundError(f"error::no weights found under {model_dir} (expected weights.npz)")
-        if verbose:
-            print(f"restore from {weights_npz}", file=sys.stderr)
-        self.model = MBExWNEngine(hparams, load_weights(weights_npz))
+        weights_tf = os.path.join(model_dir, "weights.tf")            # reference mel_inverter.py:206
+        if os.path.exists(weights_npz):
+            if verbose:
+                print(f"restore from {weights_npz}", file=sys.stderr)
+            raw = load_weights(weights_npz)
+        elif os.path.exists(weights_tf + ".index"):
+            # the pretrained models of the reference ship as TensorFlow checkpoints; read without TensorFlow
+            from .tf_checkpoint import load_reference_checkpoint
+            if verbose:
+                print(f"restore from {weights_tf}", file=sys.stderr)
+            raw = load_reference_checkpoint(weights_tf, hparams)
+        else:
+            raise FileNotFoundError(f"error::no weights found under {model_dir} (expected weights.npz or weights.tf.index)")
+        self.model = MBExWNEngine(hparams, raw)
 
         self.mel_channels = self.preprocess_config["mel_channels"]
         self.hop_size = self.preprocess_config["hop_size"]
@@ -204,13 +208,19 @@ class MELInverter(object):
         return
 
 
-def create_synthetic_model_dir(path, voice_type="SPEECH", seed=1234, **config_overrides):
-    """Write a model directory (config.yaml + weights.npz) with the canonical architecture and seeded synthetic
-    weights -- the stand-in for the pretrained model zip that is not part of the reference tree."""
+def create_synthetic_model_dir(path, voice_type="SPEECH", seed=1234, weights_format="npz", **config_overrides):
+    """Write a model directory (config.yaml + weights.npz, or weights.tf.* in the TensorFlow checkpoint format of the
+    reference's model zips) with the canonical architecture and seeded synthetic weights -- the stand-in for the
+    pretrained model zip that is not part of the reference tree."""
     from .config import canonical_config, dump_config
     from .weights import save_weights, synthetic_weights
     os.makedirs(path, exist_ok=True)
     cfg = canonical_config(voice_type, **config_overrides)
     dump_config(os.path.join(path, "config.yaml"), cfg)
-    save_weights(os.path.join(path, "weights.npz"), synthetic_weights(cfg, seed=seed))
+    raw = synthetic_weights(cfg, seed=seed)
+    if weights_format == "tf":
+        from .tf_checkpoint import to_reference_variables, write_checkpoint
+        write_checkpoint(os.path.join(path, "weights.tf"), to_reference_variables(raw))
+    else:
+        save_weights(os.path.join(path, "weights.npz"), raw)
     return path

@@ -54,6 +54,18 @@ def test_mel_inverter_end_to_end(model_dir):
     assert np.array_equal(a1, a2) and not np.array_equal(a1, audio)
 
 
+def test_tf_checkpoint_model_dir_gives_the_same_audio(model_dir, tmp_path):
+    """A model directory in the layout of the reference's model zips (config.yaml + weights.tf.index/.data-*) is read
+    without TensorFlow (tf_checkpoint.py) and synthesises exactly what the weights.npz directory does."""
+    from mbexwn_vocoder_amd.mel_inverter import MELInverter, create_synthetic_model_dir
+    tf_dir = create_synthetic_model_dir(str(tmp_path / "speech_small_tf"), "SPEECH", weights_format="tf", **SMALL)
+    assert os.path.exists(os.path.join(tf_dir, "weights.tf.index")) and not os.path.exists(os.path.join(tf_dir, "weights.npz"))
+    inv_npz, inv_tf = MELInverter(model_dir), MELInverter(tf_dir)
+    mell = inv_npz.scale_mel(mell_dict(11))
+    noise = np.random.default_rng(1).normal(size=(1, 11 * 20)).astype(np.float32)
+    assert np.array_equal(inv_tf.synth_from_mel(mell, noise=noise), inv_npz.synth_from_mel(mell, noise=noise))
+
+
 def test_cli_round_trip(model_dir, tmp_path):
     from mbexwn_vocoder_amd.fileio import save_var
     from scipy.io import wavfile

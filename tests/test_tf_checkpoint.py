@@ -1,0 +1,90 @@
+"""TF-checkpoint reader (mbexwn_vocoder_amd/tf_checkpoint.py): building blocks against known answers, tables with
+several prefix-compressed blocks, and a full round trip of a model's variables under the reference's variable names.
+No TensorFlow-written file exists in this environment, so compatibility rests on the published formats the module
+restates (its docstring says so)."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from mbexwn_vocoder_amd import tf_checkpoint as tfc
+from mbexwn_vocoder_amd.config import canonical_config
+from mbexwn_vocoder_amd.weights import layer_table, synthetic_weights
+
+
+def test_crc32c_known_answers():
+    assert tfc.crc32c(b"123456789") == 0xE3069283                  # Castagnoli check value
+    assert tfc.crc32c(b"\x00" * 32) == 0x8A9136AA                   # RFC 3720 B.4
+    assert tfc.crc32c(b"\xff" * 32) == 0x62A8AB43
+    assert tfc.mask_crc(0) == 0xA282EAD8
+
+
+def test_varint_and_message_round_trip():
+    for value in (0, 1, 127, 128, 300, 2 ** 32 + 5, 2 ** 63 - 1):
+        buf = tfc.write_varint(value)
+        assert tfc.read_varint(buf, 0) == (value, len(buf))
+    entry = tfc.encode_bundle_entry(1, (3, 80, 128), 0, 4096, 3 * 80 * 128 * 4, 0xDEADBEEF)
+    got = tfc.parse_bundle_entry(entry)
+    assert got["dtype"] == 1 and got["shape"] == (3, 80, 128) and got["offset"] == 4096
+    assert got["size"] == 3 * 80 * 128 * 4 and got["crc32c"] == 0xDEADBEEF and not got["sliced"]
+
+
+def test_snappy_decoder():
+    # literal "abcd", copy (1-byte offset form) of 8 bytes from offset 4 -> "abcdabcdabcd"; then a 2-byte-offset copy
+    stream = bytes([16]) + bytes([3 << 2]) + b"abcd" + bytes([((8 - 4) << 2) | 1, 4]) + bytes([((4 - 1) << 2) | 2, 12, 0])
+    assert tfc.snappy_decompress(stream) == b"abcdabcdabcdabcd"
+    with pytest.raises(ValueError):
+        tfc.snappy_decompress(bytes([5]) + bytes([3 << 2]) + b"abcd")
+
+
+def test_table_with_many_blocks_and_shared_prefixes(tmp_path):
+    items = [(f"model/layer_{ii:03d}/kernel/.ATTRIBUTES/VARIABLE_VALUE".encode(), os.urandom(ii % 7 + 1))
+             for ii in range(300)] + [(b"", b"header")]
+    path = str(tmp_path / "t.index")
+    tfc.write_table(path, items, block_entries=17)
+    assert tfc.read_table(path) == sorted(items)
+    raw = bytearray(open(path, "rb").read())
+    raw[10] ^= 0xFF                                                  # corrupt a data block
+    open(path, "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="checksum"):
+        tfc.read_table(path)
+    with pytest.raises(ValueError, match="magic"):
+        open(path, "wb").write(b"\x00" * 100)
+        tfc.read_table(path)
+
+
+_reference_names = tfc.to_reference_variables
+
+
+def test_checkpoint_round_trip_restores_the_engine_weights(tmp_path):
+    cfg = canonical_config("SPEECH", **{"mbexwn_config:pp_mod_subnet:n_channels": 32})
+    raw = synthetic_weights(cfg, seed=5)
+    prefix = str(tmp_path / "weights.tf")
+    named = _reference_names(raw)
+    named["save_counter"] = np.asarray(3, dtype=np.int64)             # a variable the engine does not know
+    tfc.write_checkpoint(prefix, named)
+    reader = tfc.CheckpointReader(prefix)
+    assert tfc.OBJECT_GRAPH_KEY in reader.entries and len(reader.variables()) == len(named)
+    key = reader.variables()["mb_ex_wn/PulsPar_Layer_0/kernel"]
+    assert np.array_equal(reader.get_tensor(key, verify=True), raw["PulsPar_Layer_0.v"])
+    got = tfc.load_reference_checkpoint(prefix, cfg)
+    assert sorted(got) == sorted(raw)
+    for name in raw:
+        assert got[name].dtype == np.float32 and np.array_equal(got[name], raw[name]), name
+    convs, prelus = layer_table(cfg)
+    assert len(got) == 3 * len(convs) + len(prelus)
+
+
+def test_checkpoint_mismatch_is_reported(tmp_path):
+    cfg = canonical_config("SPEECH", **{"mbexwn_config:pp_mod_subnet:n_channels": 32})
+    raw = synthetic_weights(cfg, seed=5)
+    named = _reference_names(raw)
+    del named["mb_ex_wn/PS_Layer_final_base/g"]
+    named["mb_ex_wn/PulsPar_Layer_0/kernel"] = named["mb_ex_wn/PulsPar_Layer_0/kernel"][:, :, :5]
+    prefix = str(tmp_path / "weights.tf")
+    tfc.write_checkpoint(prefix, named)
+    with pytest.raises(ValueError, match="missing PS_Layer_final.g|PulsPar_Layer_0.v has shape"):
+        tfc.load_reference_checkpoint(prefix, cfg)
+    with pytest.raises(FileNotFoundError):
+        tfc.CheckpointReader(str(tmp_path / "nothing.tf"))
