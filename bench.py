@@ -306,10 +306,11 @@ def main():
 
     if rank == 0:
         form = eng.gate_form(batch, frames)
-        executed = {"direct": 1.0, "winograd_f23": 2.0 / 3.0, "winograd_f43": 0.5}[form]
+        executed = {"direct": 1.0, "winograd_f23": 2.0 / 3.0, "winograd_f43": 0.5, "winograd_f43_small": 0.5}[form]
         kernel = {"direct": "conv1d_mfma_dma_kernel<EPI_GATE> (dilated conv k=3 C->2C + cond + tanh*sigmoid)",
                   "winograd_f23": "wn_gate_winograd_kernel (dilated conv k=3 C->2C in Winograd F(2,3) form + cond + tanh*sigmoid)",
-                  "winograd_f43": "wn_gate_winograd4_kernel (dilated conv k=3 C->2C in Winograd F(4,3) form + cond + tanh*sigmoid)"}[form]
+                  "winograd_f43": "wn_gate_winograd4_kernel (dilated conv k=3 C->2C in Winograd F(4,3) form + cond + tanh*sigmoid)",
+                  "winograd_f43_small": "wn_gate_winograd4k_kernel (same, 128-row blocks whose waves split the input channels)"}[form]
         C, L, ks = dims.wn_channels, dims.wn_layers, dims.wn_kernel_size
         rows = batch * frames * dims.steps_per_frame
         gate_flop = 2.0 * rows * (ks * C) * (2 * C)                   # algorithmic FLOPs of one launch

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libmbexwn_hip.so")
-SOURCES = ["conv_mfma.hip", "wn_winograd.hip", "wn_winograd4.hip", "wn_resskip.hip", "wn_tail.hip", "elementwise.hip", "wavetable.hip", "pqmf.hip", "stft_filter.hip", "mbx_api.hip"]
+SOURCES = ["conv_mfma.hip", "wn_winograd.hip", "wn_winograd4.hip", "wn_winograd4k.hip", "wn_resskip.hip", "wn_tail.hip", "elementwise.hip", "wavetable.hip", "pqmf.hip", "stft_filter.hip", "mbx_api.hip"]
 HEADERS = ["mbx_kernels.h", os.path.join("..", "..", "include", "mbexwn.h")]
 
 

@@ -636,17 +636,20 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         {
             ScopedEvents ev(hd, 0, stream);
             bool done = false;
-            // F(4,3) for large launches (>= four rounds of 256-row blocks); F(2,3) below that (its half-size blocks keep a
-            // small grid balanced) and for streams: a window is bit-identical to the offline result only if both run the
-            // same form with the same group alignment (streaming.py), and F(2,3) needs the shorter alignment
+            // F(4,3): 256-row blocks for large launches (>= four rounds of blocks), 128-row blocks whose waves split the
+            // input channels below that (finer granularity of the last round).  Streams run F(2,3): a window is
+            // bit-identical to an offline result only if both use one form with one group alignment (streaming.py),
+            // and F(2,3) needs the shorter alignment; MBX_WINOGRAD=2 makes offline runs use it as well.
             const long long full_blocks = ((nsteps + 255) / 256) * B * ((C + 31) / 32);
-            const bool use4 = hd->winograd == 4 && !st_in && !st_out && (hd->winograd4_always || full_blocks >= 4 * 512);
+            static const int w4k_env = getenv("MBX_W4K") ? atoi(getenv("MBX_W4K")) : 1;
+            const bool use4 = hd->winograd == 4 && !st_in && !st_out;
             const DevTensor *wino4 = use4 ? find(hd, "wn.conv1D_" + ls + ".wino4") : nullptr;
             if (wino4 && wino4->ndim == 3 && wino4->shape[0] == (C + 31) / 32 && wino4->shape[1] == (C + 7) / 8 &&
                 wino4->shape[2] == 3072) {
                 mbx::ConvArgs gw = g;
                 gw.w = wino4->ptr;
-                done = mbx::launch_wn_gate_winograd4(gw, stream);
+                if (hd->winograd4_always || full_blocks >= 4 * 512) done = mbx::launch_wn_gate_winograd4(gw, stream);
+                else if (w4k_env) done = mbx::launch_wn_gate_winograd4k(gw, stream);
             }
             const DevTensor *wino = (!done && hd->winograd) ? find(hd, "wn.conv1D_" + ls + ".wino") : nullptr;
             if (wino && wino->ndim == 3 && wino->shape[0] == (C + 31) / 32 && wino->shape[1] == (C + 15) / 16 &&

@@ -62,6 +62,8 @@ void launch_conv1d_group(const ConvArgs *convs, int n, hipStream_t stream);
 bool launch_wn_gate_winograd(const ConvArgs &a, const float *w_split, hipStream_t stream);
 // Winograd F(4,3) form (wn_winograd4.hip); a.w = host-packed weights (ceil(C/32), ceil(C/8), 3072)
 bool launch_wn_gate_winograd4(const ConvArgs &a, hipStream_t stream);
+// same weights, small launches: 128-row blocks whose waves split the input channels (wn_winograd4k.hip)
+bool launch_wn_gate_winograd4k(const ConvArgs &a, hipStream_t stream);
 // WaveNet residual/skip layer for large row counts (wn_resskip.hip); a.w = host-packed weights (ceil(cout/128), ceil(C/16), 2048)
 bool launch_wn_resskip(const ConvArgs &a, hipStream_t stream);
 // WaveNet end convolution + post-net in one pass over the skip tensor (wn_tail.hip); w_end_packed = host-packed

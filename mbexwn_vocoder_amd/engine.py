@@ -499,16 +499,19 @@ class MBExWNEngine:
 
     def gate_form(self, batch, max_frames):
         """Which implementation of the dilated convolution a forward of this size runs (mirror of the policy in
-        csrc/mbx_api.hip: MBX_WINOGRAD, read by mbx_create, default 4; F(4,3) from four rounds of 256-row blocks on):
-        "direct", "winograd_f23" or "winograd_f43"."""
+        csrc/mbx_api.hip: MBX_WINOGRAD, read by mbx_create, default 4 = F(4,3), with 256-row blocks from four rounds of
+        blocks on and 128-row channel-split blocks below; streams always run F(2,3)):
+        "direct", "winograd_f23", "winograd_f43" or "winograd_f43_small"."""
         mode = int(os.environ.get("MBX_WINOGRAD", "4"))
         if mode == 0 or self.dims.wn_kernel_size != 3:
             return "direct"
+        if mode not in (4, 44):
+            return "winograd_f23"
         rows = max_frames * self.dims.steps_per_frame
         full_blocks = ((rows + 255) // 256) * batch * ((self.dims.wn_channels + 31) // 32)
-        if mode == 44 or (mode == 4 and full_blocks >= 4 * 512):
+        if mode == 44 or full_blocks >= 4 * 512:
             return "winograd_f43"
-        return "winograd_f23"
+        return "winograd_f43_small" if os.environ.get("MBX_W4K", "1") != "0" else "winograd_f23"
 
     def stage(self, name):
         """Intermediate tensor of the last forward (copy), shaped (B, count); see mbx_stage."""

@@ -48,8 +48,26 @@ def test_phase_state_carry_is_bit_exact(engine):
     assert np.all(pulse_win[:lo] == 0.0)
 
 
+@pytest.fixture(scope="module")
+def offline_f23_engine():
+    """Offline engine pinned to the convolution form the streams use (Winograd F(2,3); MBX_WINOGRAD is read by
+    mbx_create): bit-equality needs the same arithmetic on both sides, the default offline form is picked by size."""
+    import os
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    cfg, raw, wt = build_case("SPEECH", SMALL)
+    old = os.environ.get("MBX_WINOGRAD")
+    os.environ["MBX_WINOGRAD"] = "2"
+    try:
+        return MBExWNEngine(cfg, raw, wt)
+    finally:
+        if old is None:
+            del os.environ["MBX_WINOGRAD"]
+        else:
+            os.environ["MBX_WINOGRAD"] = old
+
+
 @pytest.mark.parametrize("chunk", [8, 5])
-def test_streaming_equals_offline(engine, chunk):
+def test_streaming_equals_offline(engine, offline_f23_engine, chunk):
     import torch
     from mbexwn_vocoder_amd.streaming import StreamingSynthesizer
     lengths = [97, 40, 8, 23]
@@ -58,7 +76,11 @@ def test_streaming_equals_offline(engine, chunk):
     offline, pending = {}, {}
     for sid, ll in enumerate(lengths):
         mel, noise = synthetic_inputs(100 + sid, 1, ll)
-        offline[sid] = engine.forward(torch.as_tensor(mel).cuda(), noise=torch.as_tensor(noise).cuda()).cpu().numpy()[0]
+        mel_d, noise_d = torch.as_tensor(mel).cuda(), torch.as_tensor(noise).cuda()
+        offline[sid] = offline_f23_engine.forward(mel_d, noise=noise_d).cpu().numpy()[0]
+        # the default offline form (picked by launch size) is the same function up to float32 rounding
+        default = engine.forward(mel_d, noise=noise_d).cpu().numpy()[0]
+        assert np.max(np.abs(default - offline[sid])) <= 2e-5 * max(1.0, np.abs(default).max())
         pending[sid] = (mel[0], noise[0], 0)
         syn.open(sid)
     got = {sid: [] for sid in offline}
