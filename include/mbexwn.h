@@ -15,6 +15,14 @@
  *   - a handle owns the folded weights and the constant tables; one handle per device; a handle is
  *     not re-entrant; calls only enqueue work on the given stream and never synchronise
  *   - all tensors are float32, channels-last, row-major
+ *
+ * Environment switches read by mbx_create (the defaults are the measured best):
+ *   MBX_WINOGRAD=0|2|4   form of the dilated convolution: direct / Winograd F(2,3) only / F(4,3) with the block shape
+ *                        picked by launch size (default 4; streams always run F(2,3))
+ *   MBX_FOLD_SKIP=0      keep the un-folded skip path (C -> 2C res/skip layers, stage "wn_skip")
+ * The optional operand-order images of the weights ("*.wino", "*.wino_split", "*.wino4", "*.packed", "*.fold",
+ * "wn.tail.fold", "wn.end.packed"; engine.tensor_table builds them) select the specialised kernels; a handle
+ * created from the plain folded weights alone runs the generic ones.
  */
 #ifndef MBEXWN_H
 #define MBEXWN_H
