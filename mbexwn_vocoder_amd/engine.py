@@ -372,7 +372,9 @@ def tensor_table(config, raw_weights, wavetables):
 class MBExWNEngine:
     """Device-resident MBExWN generator. One instance per GPU (one process per GPU)."""
 
-    def __init__(self, config, raw_weights, wavetables=None, device=None):
+    def __init__(self, config, raw_weights, wavetables=None, device=None, weight_images=True):
+        """``weight_images=False`` hands mbx_create only the folded weights and the tables (what a minimal binding of the
+        C ABI would do): the engine then runs its generic kernels instead of the specialised ones."""
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("MBExWNEngine needs an AMD GPU (no CPU fallback for the mel-inversion path)")
@@ -390,6 +392,9 @@ class MBExWNEngine:
             from .norm_mel import NormMel
             self.norm_mel = NormMel(config)
         self._tensors = tensor_table(config, raw_weights, wavetables)   # keep the host arrays alive
+        if not weight_images:
+            self._tensors = {kk: vv for kk, vv in self._tensors.items()
+                             if kk.startswith("table.") or kk.rsplit(".", 1)[-1] in ("w", "b", "alpha")}
         arr = (mbx_tensor * len(self._tensors))()
         for ii, (name, val) in enumerate(self._tensors.items()):
             arr[ii].name = name.encode()

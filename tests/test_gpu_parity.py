@@ -251,6 +251,21 @@ def test_gate_layer_forms_match_oracle(torch, monkeypatch, form, key, spec, batc
         assert np.all(rag[1, ll * 300:] == 0.0)
 
 
+def test_engine_without_weight_images_runs_the_generic_kernels(torch):
+    """A handle created from the folded weights and tables alone (no operand-order images) must give the same audio
+    through the generic convolution kernels (direct gate, C->2C res/skip with the skip tensor, separate end/post)."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    cfg, raw, wt = build_case(*CANON)
+    eng = MBExWNEngine(cfg, raw, wt, weight_images=False)
+    assert not any(kk.endswith((".wino", ".wino4", ".packed", ".fold")) for kk in eng._tensors)
+    om = get_engine("canon", *CANON)[1]
+    mel, noise = synthetic_inputs(9, 2, 25)
+    got = eng.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
+    ref = om.forward(mel, noise)
+    assert _maxdiff(got, ref) <= _tol(ref, E2E_TOL)
+    assert eng.stage("wn_skip").shape[-1] == 25 * 20 * eng.dims.wn_channels      # the skip tensor exists on this path
+
+
 def test_full_size_gate_forms_agree(torch, monkeypatch):
     """BASELINE config 3 size (16 x 10 s): the launch is large enough for the F(4,3) kernel by default; its result
     must agree with the F(2,3) form of the same engine to float32 rounding (size-independent property: two
