@@ -266,13 +266,14 @@ def test_engine_without_weight_images_runs_the_generic_kernels(torch):
     assert eng.stage("wn_skip").shape[-1] == 25 * 20 * eng.dims.wn_channels      # the skip tensor exists on this path
 
 
-def test_full_size_gate_forms_agree(torch, monkeypatch):
-    """BASELINE config 3 size (16 x 10 s): the launch is large enough for the F(4,3) kernel by default; its result
-    must agree with the F(2,3) form of the same engine to float32 rounding (size-independent property: two
-    algebraically identical evaluations)."""
+@pytest.mark.parametrize("batch", [16, 1])
+def test_full_size_gate_forms_agree(torch, monkeypatch, batch):
+    """BASELINE config 3 / config 2 sizes (16 x 10 s, 1 x 10 s): the default picks the F(4,3) kernel with 256-row
+    blocks / with channel-split 128-row blocks; its result must agree with the F(2,3) form of the same engine to
+    float32 rounding (size-independent property: two algebraically identical evaluations)."""
     from mbexwn_vocoder_amd.engine import MBExWNEngine
     cfg, raw, wt = build_case(*CANON)
-    mel, noise = synthetic_inputs(21, 16, 800)
+    mel, noise = synthetic_inputs(21, batch, 800)
     outs = {}
     for form in ("4", "2"):
         monkeypatch.setenv("MBX_WINOGRAD", form)
@@ -299,9 +300,12 @@ def test_padded_batch_equals_one_at_a_time(torch):
         assert np.all(batch_out[ii, ll * 300:] == 0.0)
 
 
-def test_deterministic(torch):
+@pytest.mark.parametrize("batch,frames", [(2, 30), (1, 800), (16, 800)])
+def test_deterministic(torch, batch, frames):
+    """Same input, same bits -- also at the BASELINE sizes, where the large-launch kernels (F(4,3) with its three-stage
+    ring, channel-split blocks meeting through LDS) run: a missing barrier or wait shows up as run-to-run noise."""
     eng = get_engine("canon", *CANON)[0]
-    mel, noise = synthetic_inputs(3, 2, 30)
+    mel, noise = synthetic_inputs(3, batch, frames)
     a = eng.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
     b = eng.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
     assert np.array_equal(a, b)
