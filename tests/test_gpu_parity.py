@@ -251,6 +251,27 @@ def test_gate_layer_forms_match_oracle(torch, monkeypatch, form, key, spec, batc
         assert np.all(rag[1, ll * 300:] == 0.0)
 
 
+@pytest.mark.parametrize("overrides", [
+    {"mbexwn_config:pp_mod_subnet:n_channels": 36, "mbexwn_config:pp_mod_subnet:n_layers": 3},      # C not a multiple of 8
+    {"mbexwn_config:pp_mod_subnet:n_channels": 24, "mbexwn_config:pp_mod_subnet:n_layers": 7,
+     "mbexwn_config:pp_mod_subnet:max_log2_dilation_rate": 3},                                         # dilation cycle 1..8,1..4
+    {"mbexwn_config:pp_mod_subnet:n_channels": 64, "mbexwn_config:pp_mod_subnet:n_layers": 1},       # one layer: tail only
+], ids=["C36_L3", "C24_L7_cycle", "C64_L1"])
+def test_other_wavenet_geometries(torch, overrides):
+    """Every size is configuration driven: partial channel tiles and slices, repeating dilation cycles, a single layer
+    (the folded skip path then consists of the tail kernel alone)."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    cfg, raw, wt = build_case("SPEECH", overrides)
+    eng, om = MBExWNEngine(cfg, raw, wt), orc.OracleModel(cfg, raw, wt)
+    for batch, frames in ((2, 21), (1, 3)):
+        mel, noise = synthetic_inputs(batch + frames, batch, frames)
+        got = eng.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
+        ref = om.forward(mel, noise)
+        assert _maxdiff(got, ref) <= _tol(ref, E2E_TOL)
+    with pytest.raises(ValueError, match="multiple of 4"):
+        MBExWNEngine(*build_case("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 34}))
+
+
 def test_engine_without_weight_images_runs_the_generic_kernels(torch):
     """A handle created from the folded weights and tables alone (no operand-order images) must give the same audio
     through the generic convolution kernels (direct gate, C->2C res/skip with the skip tensor, separate end/post)."""
