@@ -52,6 +52,7 @@ struct ConvArgs {
     int acc_preloaded;        // set by the launcher: accumulators start from bias + old value, epilogue only stores
     int remap, n_tiles, m_tiles_per_item, m_tiles_total;   // XCD-aware 1-D grid (set by the launcher)
     const float *zeros;       // >= 16 bytes of zeros in global memory (LDS-DMA source of padding lanes)
+    int fast_dma;             // set by the launcher: 32-bit source offsets are safe (LDS-DMA with a uniform base)
     int ablate;               // timing experiments only: bit0 no global loads, bit1 no LDS stores, bit2 no barrier, bit3 no epilogue
 };
 

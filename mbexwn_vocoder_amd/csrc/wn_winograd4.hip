@@ -46,6 +46,12 @@ __device__ __forceinline__ void w4_lds_dma16(const float *src, unsigned lds_byte
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(src) : "memory", "m0");
 }
 
+// same with a wave-uniform base address and a per-lane 32-bit byte offset (no per-lane 64-bit address arithmetic)
+__device__ __forceinline__ void w4_lds_dma16_s(const float *sbase, unsigned voff_bytes, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte_addr), "v"(voff_bytes), "s"(sbase)
+                 : "memory", "m0");
+}
+
 __device__ __forceinline__ float w4_gate_act(float zt, float zs) {
     const float e2 = __expf(2.0f * zt);
     const float e1 = __expf(-zs);
@@ -105,6 +111,7 @@ __global__ __launch_bounds__(256, 2) void wn_gate_winograd4_kernel(ConvArgs p, i
 
     // ---- per-lane DMA sources (fixed for the whole kernel except the channel offset)
     int a_off[3], a_ch[3];
+    unsigned a_voff[3];
     unsigned a_ok = 0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -119,12 +126,28 @@ __global__ __launch_bounds__(256, 2) void wn_gate_winograd4_kernel(ConvArgs p, i
         a_ch[i] = 4 * ((pos & 1) ^ ((cell >> 3) & 1));
         a_off[i] = min(max(src, 0), rows - 1) * p.ldx;
         if (row < W4_AROWS && src >= 0 && src < rows) a_ok |= 1u << i;
+        a_voff[i] = 4u * (unsigned)(a_off[i] + a_ch[i]);
     }
     const float *wsrc = p.w + (long long)nt * nk * W4_B_FLOATS + (wave * 64 + lane) * 4;
+    // interior blocks (every staged row exists, whole slices): uniform base + per-lane byte offset, no selects
+    const bool fast = p.fast_dma && m0 >= W4_HALO && m0 + W4_ROWS + W4_HALO <= rows && p.cin % W4_BK == 0;
+    const float *wtile = p.w + (long long)nt * nk * W4_B_FLOATS;
+    const unsigned b_voff = 16u * (unsigned)lane;
     auto issue = [&](int kt, int stage) {
         const int ci0 = kt * W4_BK;
         const unsigned adst = lds_base + 4u * (unsigned)(stage * W4_STAGE);
         const unsigned bdst = adst + 4u * (unsigned)W4_A_FLOATS;
+        if (fast) {
+            const float *abase = xb + ci0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                w4_lds_dma16_s(abase, a_voff[i], adst + 1024u * (unsigned)(i < 2 ? wave + 4 * i : 8 + (wave & 1)));
+            const float *bbase = wtile + (long long)kt * W4_B_FLOATS + wave * 256;
+#pragma unroll
+            for (int i = 0; i < W4_B_INST; ++i)
+                w4_lds_dma16_s(bbase + i * 1024, b_voff, bdst + 1024u * (unsigned)(wave + 4 * i));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int ci = ci0 + a_ch[i];
@@ -331,6 +354,8 @@ bool launch_wn_gate_winograd4(const ConvArgs &a, hipStream_t stream) {
                     W4_ROWS / a.cond_up + 2 <= 32 && a.max_rows < (1 << 24);
     if (!ok) return false;
     ConvArgs r = a;
+    static const int fast_env = getenv("MBX_W4_FAST_DMA") ? atoi(getenv("MBX_W4_FAST_DMA")) : 1;
+    r.fast_dma = fast_env && (long long)a.max_rows * a.ldx * 4 < (1LL << 32);
     static const int ablate = getenv("MBX_WG_ABLATE") ? atoi(getenv("MBX_WG_ABLATE")) : 0;   // timing experiments only
     r.ablate = ablate;
     r.n_tiles = (a.channels + 31) / 32;
