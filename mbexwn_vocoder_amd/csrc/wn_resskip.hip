@@ -29,6 +29,12 @@ __device__ __forceinline__ void rs_lds_dma16(const float *src, unsigned lds_byte
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(src) : "memory", "m0");
 }
 
+// same with a wave-uniform base address and a per-lane 32-bit byte offset
+__device__ __forceinline__ void rs_lds_dma16_s(const float *sbase, unsigned voff_bytes, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte_addr), "v"(voff_bytes), "s"(sbase)
+                 : "memory", "m0");
+}
+
 template <int MT, int NST>
 __global__ __launch_bounds__(256, MT == 2 ? 3 : 4) void wn_resskip_kernel(ConvArgs p) {
     constexpr int ROWS = 64 * MT;
@@ -63,6 +69,7 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 4) void wn_resskip_kernel(ConvAr
 
     // ---- per-lane DMA sources
     int a_off[A_INST], a_ch[A_INST];
+    unsigned a_voff[A_INST];
     unsigned a_ok = 0;
 #pragma unroll
     for (int i = 0; i < A_INST; ++i) {
@@ -71,12 +78,26 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 4) void wn_resskip_kernel(ConvAr
         a_ch[i] = 4 * ((pos & 3) ^ ((row >> 2) & 3));
         a_off[i] = min(m0 + row, rows - 1) * p.ldx;
         if (m0 + row < rows) a_ok |= 1u << i;
+        a_voff[i] = 4u * (unsigned)(a_off[i] + a_ch[i]);
     }
+    // full blocks and whole slices: uniform base + per-lane byte offset, no selects
+    const bool fast = p.fast_dma && m0 + ROWS <= rows && p.cin % RS_BK == 0;
+    const float *wtile = p.w + (long long)nt * nk * RS_B_FLOATS + wave * 256;
+    const unsigned b_voff = 16u * (unsigned)lane;
     const float *wsrc = p.w + (long long)nt * nk * RS_B_FLOATS + (wave * 64 + lane) * 4;
     auto issue = [&](int kt, int buf) {
         const int ci0 = kt * RS_BK;
         const unsigned adst = lds_base + 4u * (unsigned)(buf * STAGE);
         const unsigned bdst = adst + 4u * (unsigned)RS_A_FLOATS;
+        if (fast) {
+            const float *abase = xb + ci0;
+#pragma unroll
+            for (int i = 0; i < A_INST; ++i) rs_lds_dma16_s(abase, a_voff[i], adst + 1024u * (unsigned)(wave + 4 * i));
+            const float *bbase = wtile + (long long)kt * RS_B_FLOATS;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) rs_lds_dma16_s(bbase + i * 1024, b_voff, bdst + 1024u * (unsigned)(wave + 4 * i));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < A_INST; ++i) {
             const int ci = ci0 + a_ch[i];
@@ -223,6 +244,8 @@ bool launch_wn_resskip(const ConvArgs &a, hipStream_t stream) {
                     (a.skip_ld ? a.cout <= a.channels + a.skip_ld : a.cout == (a.last_layer ? a.channels : 2 * a.channels));
     if (!ok) return false;
     ConvArgs r = a;
+    static const int fast_env = getenv("MBX_W4_FAST_DMA") ? atoi(getenv("MBX_W4_FAST_DMA")) : 1;
+    r.fast_dma = fast_env && (long long)a.max_rows * a.ldx * 4 < (1LL << 32);
     static const int small_env = getenv("MBX_RS_SMALL") ? atoi(getenv("MBX_RS_SMALL")) : -1;   // -1 auto, 0 never, 1 always
     r.n_tiles = (a.cout + 127) / 128;
     // 64-row blocks while the 128-row grid is less than three rounds of the 768 resident blocks (3 per CU x 256 CUs)

@@ -32,6 +32,12 @@ __device__ __forceinline__ void k4_lds_dma16(const float *src, unsigned lds_byte
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(src) : "memory", "m0");
 }
 
+// same with a wave-uniform base address and a per-lane 32-bit byte offset
+__device__ __forceinline__ void k4_lds_dma16_s(const float *sbase, unsigned voff_bytes, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte_addr), "v"(voff_bytes), "s"(sbase)
+                 : "memory", "m0");
+}
+
 __device__ __forceinline__ float k4_gate_act(float zt, float zs) {
     const float e2 = __expf(2.0f * zt);
     const float e1 = __expf(-zs);
@@ -92,6 +98,7 @@ __global__ __launch_bounds__(256, 2) void wn_gate_winograd4k_kernel(ConvArgs p, 
 
     // ---- per-lane LDS-DMA sources: 12 A instructions per stage (2 sub-tiles x 6), 3 per wave
     int a_off[3], a_ch[3], a_sub[3], a_inst[3];
+    unsigned a_voff[3];
     unsigned a_ok = 0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -107,11 +114,30 @@ __global__ __launch_bounds__(256, 2) void wn_gate_winograd4k_kernel(ConvArgs p, 
         a_ch[i] = 8 * a_sub[i] + 4 * ((pos & 1) ^ ((cell >> 3) & 1));
         a_off[i] = min(max(src, 0), rows - 1) * p.ldx;
         if (row < K4_AROWS && src >= 0 && src < rows) a_ok |= 1u << i;
+        a_voff[i] = 4u * (unsigned)(a_off[i] + a_ch[i]);
     }
+    // interior blocks (every staged row exists, whole double slices): uniform base + per-lane byte offset, no selects
+    const bool fast = p.fast_dma && m0 >= K4_HALO && m0 + K4_ROWS + K4_HALO <= rows && p.cin % 16 == 0;
+    const float *wtile = p.w + (long long)nt * nk8 * K4_SUB_B;
+    const unsigned b_voff = 16u * (unsigned)lane;
     // 24 B instructions per stage (2 sub-tiles x 12), 6 per wave
     const float *wbase = p.w + (long long)nt * nk8 * K4_SUB_B + lane * 4;
     auto issue = [&](int ds, int stage) {
         const unsigned sdst = lds_base + 4u * (unsigned)(stage * K4_STAGE);
+        if (fast) {
+            const float *abase = xb + 16 * ds;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                k4_lds_dma16_s(abase, a_voff[i], sdst + 4u * (unsigned)(a_sub[i] * K4_SUB) + 1024u * (unsigned)a_inst[i]);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int ii = wave + 4 * i;                          // 0..23
+                const int sub = ii / 12, k = ii - 12 * sub;
+                k4_lds_dma16_s(wtile + (long long)(2 * ds + sub) * K4_SUB_B + k * 256, b_voff,
+                               sdst + 4u * (unsigned)(sub * K4_SUB + K4_SUB_A) + 1024u * (unsigned)k);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int ci = 16 * ds + a_ch[i];
@@ -314,6 +340,8 @@ bool launch_wn_gate_winograd4k(const ConvArgs &a, hipStream_t stream) {
                     K4_ROWS / a.cond_up + 2 <= 16 && a.max_rows < (1 << 24);
     if (!ok) return false;
     ConvArgs r = a;
+    static const int fast_env = getenv("MBX_W4_FAST_DMA") ? atoi(getenv("MBX_W4_FAST_DMA")) : 1;
+    r.fast_dma = fast_env && (long long)a.max_rows * a.ldx * 4 < (1LL << 32);
     static const int ablate = getenv("MBX_WG_ABLATE") ? atoi(getenv("MBX_WG_ABLATE")) : 0;   // timing experiments only
     r.ablate = ablate;
     r.n_tiles = (a.channels + 31) / 32;
