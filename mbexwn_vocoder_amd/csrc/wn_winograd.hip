@@ -38,6 +38,12 @@ __device__ __forceinline__ void wg_lds_dma16(const float *src, unsigned lds_byte
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(src) : "memory", "m0");
 }
 
+// same with a wave-uniform base address and a per-lane 32-bit byte offset
+__device__ __forceinline__ void wg_lds_dma16_s(const float *sbase, unsigned voff_bytes, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte_addr), "v"(voff_bytes), "s"(sbase)
+                 : "memory", "m0");
+}
+
 __device__ __forceinline__ float wg_gate_act(float zt, float zs) {
     const float e2 = __expf(2.0f * zt);
     const float e1 = __expf(-zs);
@@ -95,6 +101,7 @@ __global__ __launch_bounds__(256, NS == 1 ? 2 : 3) void wn_gate_winograd_kernel(
 
     // ---- per-lane DMA sources (fixed for the whole kernel except the channel offset)
     int a_off[A_INST], a_ch[A_INST];
+    unsigned a_voff[A_INST];
     unsigned a_ok = 0;
 #pragma unroll
     for (int i = 0; i < A_INST; ++i) {
@@ -104,13 +111,31 @@ __global__ __launch_bounds__(256, NS == 1 ? 2 : 3) void wn_gate_winograd_kernel(
         a_ch[i] = 4 * ((pos & 3) ^ ((row >> 2) & 3));
         a_off[i] = max(src, 0) * p.ldx;
         if (src >= 0 && src < rows) a_ok |= 1u << i;
+        a_voff[i] = 4u * (unsigned)(min(max(src, 0), rows - 1) * p.ldx + a_ch[i]);
     }
+    // interior blocks (every staged row exists, whole slices): uniform base + per-lane byte offset, no selects
+    const bool fast = p.fast_dma && m0 >= HALO && m0 + ROWS + HALO <= rows && p.cin % WG_BK == 0;
+    const float *wtile = p.w + (long long)nt * nk * WG_B_FLOATS + wave * 256;
+    const unsigned b_voff = 16u * (unsigned)lane;
     // weights: the packed image of (column tile nt, slice kt) is copied verbatim, 16 KB = 4 x 1 KB per wave
     const float *wsrc = p.w + (long long)nt * nk * WG_B_FLOATS + (wave * 64 + lane) * 4;
     auto issue = [&](int kt, int buf) {
         const int ci0 = kt * WG_BK;
         const unsigned adst = lds_base + 4u * (unsigned)(buf * A_FLOATS);
         const unsigned bdst = lds_base + 4u * (unsigned)(2 * A_FLOATS + buf * WG_B_FLOATS);
+        if (fast) {
+            const float *abase = xb + ci0;
+#pragma unroll
+            for (int i = 0; i < A_INST; ++i) {
+                if (A_CHUNKS % 4 != 0 && wave + 4 * i >= A_CHUNKS) continue;  // wave-uniform
+                wg_lds_dma16_s(abase, a_voff[i], adst + 1024u * (unsigned)(wave + 4 * i));
+            }
+            const float *bbase = wtile + (long long)kt * WG_B_FLOATS;
+#pragma unroll
+            for (int i = 0; i < WG_B_INST; ++i)
+                wg_lds_dma16_s(bbase + i * 1024, b_voff, bdst + 1024u * (unsigned)(wave + 4 * i));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < A_INST; ++i) {
             if (A_CHUNKS % 4 != 0 && wave + 4 * i >= A_CHUNKS) continue;      // wave-uniform
@@ -314,6 +339,8 @@ bool launch_wn_gate_winograd(const ConvArgs &a, const float *w_split, hipStream_
                     256 / a.cond_up + 2 <= 32 && a.max_rows < (1 << 24);
     if (!ok) return false;
     ConvArgs r = a;
+    static const int fast_env = getenv("MBX_W4_FAST_DMA") ? atoi(getenv("MBX_W4_FAST_DMA")) : 1;
+    r.fast_dma = fast_env && (long long)a.max_rows * a.ldx * 4 < (1LL << 32);
     static const int ablate = getenv("MBX_WG_ABLATE") ? atoi(getenv("MBX_WG_ABLATE")) : 0;   // timing experiments only
     static const int split_env = getenv("MBX_WG_SPLIT") ? atoi(getenv("MBX_WG_SPLIT")) : -1; // -1 auto, 0 never, 1 always
     r.ablate = ablate;
