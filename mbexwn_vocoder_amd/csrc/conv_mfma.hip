@@ -87,10 +87,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x16 (&acc)[T
     const int C = p.channels;
     const int ecol = lane & 31;
     auto col_base = [&](int tn) { return (EPI == EPI_GATE) ? tn * (BN / 2) + wc * 32 : (wc * TN + tn) * 32; };
-    if (p.ablate & 8) {
-        if (acc[0][0][0] == 123.456f) p.out[0] = acc[0][TN - 1][3];
-        return;
-    }
     if (EPI == EPI_GATE) {
         const int ch = n0 + wc * 32 + ecol;   // gate channel of this lane
         if (ch < C) {
@@ -361,7 +357,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs p) {
     const int lrow = lane & 31, lk = lane >> 5;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk && !(p.ablate & 1)) load_slice(kt + 1);
+        if (kt + 1 < nk) load_slice(kt + 1);
         const float *a = As + buf * BK * LDA + lk * LDA + wr * TM * 32 + lrow;
         const float *bs = Bs + buf * BK * LDB + lk * LDB + lrow;
         // software pipeline over the k-steps of the slice: the LDS reads of k-step kk+2 are issued before the
@@ -389,8 +385,8 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs p) {
             if (kk + 2 < BK) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);   // DS reads of k-step kk+2
             __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);                    // MFMAs of k-step kk
         }
-        if (kt + 1 < nk && !(p.ablate & 2)) store_slice(buf ^ 1);
-        if (!(p.ablate & 4)) __syncthreads();
+        if (kt + 1 < nk) store_slice(buf ^ 1);
+        __syncthreads();
     }
 
     conv_epilogue<WM, WN, TM, TN, EPI>(p, acc, b, rows, m0, n0, wr, wc, lane);
@@ -722,13 +718,6 @@ static bool launch_dma(const ConvArgs &a, hipStream_t stream) {
     r.n_tiles = (ncols + bn_eff - 1) / bn_eff;
     r.m_tiles_per_item = (a.max_rows + BM - 1) / BM;
     r.m_tiles_total = r.m_tiles_per_item * a.batch;
-    static const int no_remap = env_int("MBX_NO_REMAP", 0);
-    if (no_remap) {
-        r.remap = 0;
-        dim3 grid(r.m_tiles_per_item, r.n_tiles, a.batch);
-        hipLaunchKernelGGL((conv1d_mfma_dma_kernel<WM, WN, TM, TN, EPI>), grid, dim3(256), 0, stream, r);
-        return true;
-    }
     const long long blocks = 8LL * ((r.m_tiles_total + 7) / 8) * r.n_tiles;
     hipLaunchKernelGGL((conv1d_mfma_dma_kernel<WM, WN, TM, TN, EPI>), dim3((unsigned)blocks), dim3(256), 0, stream, r);
     return true;
@@ -783,39 +772,18 @@ void launch_conv1d_group(const ConvArgs *convs, int n, hipStream_t stream) {
 
 void launch_conv1d(const ConvArgs &a, int epilogue, hipStream_t stream) {
     if (a.max_rows <= 0 || a.batch <= 0) return;
-    // Tile shapes of the two WaveNet GEMMs.  Defaults = the fastest measured on MI355X (profiles/README.md):
-    //   gate     : LDS-DMA kernel, 64 rows x 64 gate channels (MBX_GATE_CFG=10)
-    //   res/skip : register-staged kernel, 64 x 128 (MBX_RS_CFG=1)
-    // The environment knobs exist for the tuning experiments only.
-    static const int gate_cfg = env_int("MBX_GATE_CFG", 10);
-    static const int rs_cfg = env_int("MBX_RS_CFG", 1);
-    static const int extra_lds = env_int("MBX_EXTRA_LDS", 0);
-    static const int ablate = env_int("MBX_ABLATE", 0);   // timing experiments only (results are wrong when set)
-    if (ablate && (epilogue == EPI_GATE || epilogue == EPI_RESSKIP)) {
-        ConvArgs b = a;
-        b.ablate = ablate;
-        if (epilogue == EPI_GATE) launch_cfg<2, 2, 1, 2, EPI_GATE>(b, stream, extra_lds);
-        else launch_cfg<2, 2, 1, 2, EPI_RESSKIP>(b, stream, extra_lds);
-        return;
-    }
+    // Generic forms of the two WaveNet GEMMs (the engine normally runs the specialised kernels of wn_winograd*.hip and
+    // wn_resskip.hip; these serve handles created without the packed weight images and shapes those kernels reject).
+    // Tile shapes = the fastest measured on MI355X among the variants tried (profiles/README.md):
+    //   gate     : LDS-DMA kernel, 64 rows x 64 gate channels; register-staged 64 x 64 when the layout is not 16-byte regular
+    //   res/skip : register-staged kernel, 64 x 128, accumulators pre-loaded with the old values
     if (epilogue == EPI_GATE) {
-        bool done = false;
-        if (gate_cfg == 10) done = launch_dma<2, 2, 1, 2, EPI_GATE>(a, stream);            // 64 x 64 gate channels
-        else if (gate_cfg == 11) done = launch_dma<2, 2, 2, 2, EPI_GATE>(a, stream);       // 128 x 64
-        else if (gate_cfg == 12) done = launch_dma<4, 1, 1, 2, EPI_GATE>(a, stream);       // 128 x 32
-        if (done) return;
-        if (gate_cfg == 0) launch_cfg<2, 2, 2, 2, EPI_GATE>(a, stream, extra_lds);         // 128 x 64, register staged
-        else if (gate_cfg == 2) launch_cfg<4, 1, 1, 2, EPI_GATE>(a, stream, extra_lds);    // 128 x 32
-        else launch_cfg<2, 2, 1, 2, EPI_GATE>(a, stream, extra_lds);                       // 64 x 64 (also the non-VEC fallback)
+        if (launch_dma<2, 2, 1, 2, EPI_GATE>(a, stream)) return;
+        launch_cfg<2, 2, 1, 2, EPI_GATE>(a, stream);
     } else if (epilogue == EPI_RESSKIP) {
-        bool done = false;
-        if (rs_cfg == 10) done = launch_dma<2, 2, 1, 2, EPI_RESSKIP>(a, stream);
-        else if (rs_cfg == 11) done = launch_dma<2, 2, 2, 2, EPI_RESSKIP>(a, stream);
-        if (done) return;
         ConvArgs r = a;
-        r.acc_preloaded = env_int("MBX_RS_PRELOAD", 1);
-        if (rs_cfg == 0) launch_cfg<2, 2, 2, 2, EPI_RESSKIP>(r, stream, extra_lds);        // 128 x 128
-        else launch_cfg<2, 2, 1, 2, EPI_RESSKIP>(r, stream, extra_lds);                    // 64 x 128
+        r.acc_preloaded = 1;
+        launch_cfg<2, 2, 1, 2, EPI_RESSKIP>(r, stream);
     } else if (small_conv_eligible(a)) {
         // mel-rate sub-nets at small batch: latency bound, split-K 32x32 tiles
         dim3 grid((a.max_rows + 31) / 32, (a.cout + 31) / 32, a.batch);

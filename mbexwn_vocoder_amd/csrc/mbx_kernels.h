@@ -53,7 +53,8 @@ struct ConvArgs {
     int remap, n_tiles, m_tiles_per_item, m_tiles_total;   // XCD-aware 1-D grid (set by the launcher)
     const float *zeros;       // >= 16 bytes of zeros in global memory (LDS-DMA source of padding lanes)
     int fast_dma;             // set by the launcher: 32-bit source offsets are safe (LDS-DMA with a uniform base)
-    int ablate;               // timing experiments only: bit0 no global loads, bit1 no LDS stores, bit2 no barrier, bit3 no epilogue
+    int ablate;               // timing experiments of the Winograd kernels only (MBX_WG_ABLATE): bit0 no LDS-DMA after the
+                              // first slices, bit1 no barrier, bit2 no epilogue -- results are wrong when set
 };
 
 void launch_conv1d(const ConvArgs &a, int epilogue, hipStream_t stream);
