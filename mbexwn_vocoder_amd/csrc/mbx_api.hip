@@ -608,8 +608,6 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     else if (transposition != 1.f)
         mbx::launch_activation(w.f0, npulse, n_frames, c.pulse_per_frame, (int)npulse, B, 1, MBX_ACT_LINEAR,
                                transposition, 0.f, w.f0, npulse, stream);
-    if (c.n_ceps_windows)   // lifter selection needs F0 only (reference :507-525)
-        mbx::launch_ceps_index(sc, w.f0, npulse, n_frames, T, B, w.ceps_index, stream);
     // ---- wavetable excitation (reference :889)
     mbx::launch_wavetable(wavetable_consts(hd), w.f0, npulse, n_frames, c.pulse_per_frame, (int)npulse, B, w.pulse,
                           nullptr, w.cum, w.chunk_last, st_in, st_out, stream);
@@ -741,8 +739,10 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     mbx::launch_pqmf(w.sub, nsteps * M, n_frames, c.steps_per_frame, (int)nsteps, B, M, hd->poly, hd->poly_ndm,
                      hd->poly_dm_min, w.exc, (long long)T * c.hop_size, stream);
     // ---- STFT-domain filtering with the spectral envelope (reference :681-724, 801-855)
-    mbx::launch_stft_filter(sc, w.exc, (long long)T * c.hop_size, w.ceps, (long long)T * c.n_ceps,
-                            c.n_ceps_windows ? w.ceps_index : nullptr, n_frames, T, B, w.frames, stream);
+    // (the lifter row of a frame is selected from the F0 contour inside the kernel, reference :507-525)
+    mbx::launch_stft_filter(sc, w.exc, (long long)T * c.hop_size, w.ceps, (long long)T * c.n_ceps, nullptr,
+                            c.n_ceps_windows ? w.f0 : nullptr, npulse, c.n_ceps_windows ? w.ceps_index : nullptr, n_frames,
+                            T, B, w.frames, stream);
     mbx::launch_overlap_add(sc, w.frames, n_frames, T, B, audio, (long long)T * c.hop_size, stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MBX_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
@@ -887,7 +887,8 @@ mbx_status mbx_stft_filter(mbx_handle *hd, const float *excitation, const float 
     mbx::StftConsts sc = stft_consts(hd);
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     mbx::launch_stft_filter(sc, excitation, (long long)frames * c.hop_size, cepstrum, (long long)frames * c.n_ceps,
-                            c.n_ceps_windows ? ceps_index : nullptr, nullptr, frames, batch, scratch, stream);
+                            c.n_ceps_windows ? ceps_index : nullptr, nullptr, 0, nullptr, nullptr, frames, batch, scratch,
+                            stream);
     mbx::launch_overlap_add(sc, scratch, nullptr, frames, batch, audio, (long long)frames * c.hop_size, stream);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MBX_OK : fail(MBX_ERR_HIP, hipGetErrorString(e));

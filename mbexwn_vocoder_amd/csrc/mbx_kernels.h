@@ -139,13 +139,10 @@ struct StftConsts {
     const float *f0_smooth;           // (2*hop+1)
     int pulse_per_frame;
 };
-// smoothed-F0 -> lifter row index (B, frames)
-void launch_ceps_index(const StftConsts &c, const float *f0, long long f0_bstride, const int *n_frames,
-                       int max_frames, int batch, int *index, hipStream_t stream);
-// per frame: window+FFT of the excitation, FFT of the liftered cepstrum, exp, multiply, inverse FFT, window
 void launch_stft_filter(const StftConsts &c, const float *exc, long long exc_bstride, const float *ceps,
-                        long long ceps_bstride, const int *index, const int *n_frames, int max_frames, int batch,
-                        float *frames, hipStream_t stream);
+                        long long ceps_bstride, const int *index, const float *f0, long long f0_bstride,
+                        int *index_out, const int *n_frames, int max_frames, int batch, float *frames,
+                        hipStream_t stream);
 // overlap-add of the windowed frames + slice -> audio (B, max_frames*hop), tail zeroed
 void launch_overlap_add(const StftConsts &c, const float *frames, const int *n_frames, int max_frames, int batch,
                         float *audio, long long audio_bstride, hipStream_t stream);

@@ -94,11 +94,32 @@ __device__ __forceinline__ float2 real_bin(const float2 *z, const float2 *tw, in
     return cadd(xe, cmul(w, xo));
 }
 
+// Cepstral lifter selection from the smoothed F0 contour, by one wavefront (lane = threadIdx.x & 63); every lane
+// returns the index.  reference custom_pulsed_generator.py:507-525 (601-tap Bartlett smoother on the edge-replicated
+// contour, log10, clip, nearest of the n_ceps_windows rows)
+__device__ __forceinline__ int ceps_index_of_frame(const StftConsts &c, const float *fb, int T, int t, int lane) {
+    const int n = T * c.pulse_per_frame;
+    const int taps = 2 * c.hop + 1, halfk = taps / 2;
+    float acc = 0.f;
+    for (int j = lane; j < taps; j += 64) {
+        int s = t * c.pulse_per_frame + j - halfk;          // edge-replicated contour
+        s = min(max(s, 0), n - 1);
+        acc += fb[s] * c.f0_smooth[j];
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    const float lo = c.ceps_log10f0[0], hi = c.ceps_log10f0[c.n_ceps_windows - 1];
+    float lg = (float)(1.0 / 2.302585092994046) * logf(acc);
+    lg = fminf(fmaxf(lg, lo), hi);
+    const float ratio = (lg - lo) / (hi - lo);
+    return (int)rintf(ratio * (float)(c.n_ceps_windows - 1));
+}
+
 constexpr int MAX_BINS_PER_THREAD = 5;   // fft_size/2 + 1 <= 4*256 + 1
 
 __global__ __launch_bounds__(FFT_THREADS) void stft_filter_kernel(StftConsts c, const float *exc,
                                                                   long long exc_bstride, const float *ceps,
                                                                   long long ceps_bstride, const int *index,
+                                                                  const float *f0, long long f0_bstride, int *index_out,
                                                                   const int *n_frames, int max_frames,
                                                                   float *frames) {
     extern __shared__ float2 smem2[];
@@ -111,6 +132,16 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_filter_kernel(StftConsts c, 
     if (t >= T) return;
     const int tid = threadIdx.x;
     for (int i = tid; i < nc; i += FFT_THREADS) tw[i] = reinterpret_cast<const float2 *>(c.twiddle)[i];
+    // lifter row of this frame: given, or selected here from the F0 contour by the first wavefront while the others
+    // stage the frame
+    __shared__ int s_index;
+    if (c.n_ceps_windows > 0 && !index && f0 && tid < 64) {
+        const int idx = ceps_index_of_frame(c, f0 + (long long)b * f0_bstride, T, t, tid);
+        if (tid == 0) {
+            s_index = idx;
+            if (index_out) index_out[(long long)b * max_frames + t] = idx;
+        }
+    }
 
     // ---- 1. windowed excitation frame (zero padded signal: win/2 in front, win/2+hop+1 behind)
     const float *eb = exc + (long long)b * exc_bstride;
@@ -142,6 +173,7 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_filter_kernel(StftConsts c, 
     const float *cb = ceps + (long long)b * ceps_bstride + (long long)t * c.n_ceps;
     const float *lw = nullptr;
     if (c.n_ceps_windows > 0 && index) lw = c.ceps_windows + (long long)index[(long long)b * max_frames + t] * c.n_ceps;
+    else if (c.n_ceps_windows > 0 && f0) lw = c.ceps_windows + (long long)s_index * c.n_ceps;   // written before the first barrier
     for (int m = tid; m < nc; m += FFT_THREADS) {
         float v[2];
 #pragma unroll
@@ -200,45 +232,16 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_filter_kernel(StftConsts c, 
     }
 }
 
+// index: lifter rows (B, max_frames) or null; with null and f0 != null the rows are selected inside the kernel from
+// the F0 contour (B, max_frames * pulse_per_frame) and written to index_out (may be null)
 void launch_stft_filter(const StftConsts &c, const float *exc, long long exc_bstride, const float *ceps,
-                        long long ceps_bstride, const int *index, const int *n_frames, int max_frames, int batch,
-                        float *frames, hipStream_t stream) {
+                        long long ceps_bstride, const int *index, const float *f0, long long f0_bstride,
+                        int *index_out, const int *n_frames, int max_frames, int batch, float *frames,
+                        hipStream_t stream) {
     if (max_frames <= 0 || batch <= 0) return;
     const size_t smem = sizeof(float2) * (size_t)(3 * (c.fft_size / 2));
     hipLaunchKernelGGL(stft_filter_kernel, dim3(max_frames, batch), dim3(FFT_THREADS), smem, stream, c, exc,
-                       exc_bstride, ceps, ceps_bstride, index, n_frames, max_frames, frames);
-}
-
-// Cepstral lifter selection from the smoothed F0 contour; one wavefront per (item, frame).
-__global__ __launch_bounds__(64) void ceps_index_kernel(StftConsts c, const float *f0, long long f0_bstride,
-                                                        const int *n_frames, int max_frames, int *index) {
-    const int b = blockIdx.y, t = blockIdx.x;
-    const int T = n_frames ? n_frames[b] : max_frames;
-    if (t >= T) return;
-    const int n = T * c.pulse_per_frame;
-    const int taps = 2 * c.hop + 1, halfk = taps / 2;
-    const float *fb = f0 + (long long)b * f0_bstride;
-    float acc = 0.f;
-    for (int j = threadIdx.x; j < taps; j += 64) {
-        int s = t * c.pulse_per_frame + j - halfk;          // edge-replicated contour
-        s = min(max(s, 0), n - 1);
-        acc += fb[s] * c.f0_smooth[j];
-    }
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-    if (threadIdx.x == 0) {
-        const float lo = c.ceps_log10f0[0], hi = c.ceps_log10f0[c.n_ceps_windows - 1];
-        float lg = (float)(1.0 / 2.302585092994046) * logf(acc);
-        lg = fminf(fmaxf(lg, lo), hi);
-        const float ratio = (lg - lo) / (hi - lo);
-        index[(long long)b * max_frames + t] = (int)rintf(ratio * (float)(c.n_ceps_windows - 1));
-    }
-}
-
-void launch_ceps_index(const StftConsts &c, const float *f0, long long f0_bstride, const int *n_frames,
-                       int max_frames, int batch, int *index, hipStream_t stream) {
-    if (max_frames <= 0 || batch <= 0) return;
-    hipLaunchKernelGGL(ceps_index_kernel, dim3(max_frames, batch), dim3(64), 0, stream, c, f0, f0_bstride, n_frames,
-                       max_frames, index);
+                       exc_bstride, ceps, ceps_bstride, index, f0, f0_bstride, index_out, n_frames, max_frames, frames);
 }
 
 // overlap-add in frame order + slice [win/2, win/2 + T*hop)
