@@ -531,9 +531,24 @@ class MBExWNEngine:
         flat = ws[offset: offset + B * stride.value * 4].view(dtype)
         return flat.view(B, stride.value)[:, :cnt.value].clone()
 
-    def infer(self, spect, sigma=None, synth_length=0, noise=None, **_):
+    def infer(self, spect, sigma=None, z_in=None, synth_length=0, F0=None, return_F0=False, return_components=False,
+              training=False, test_grad=None, noise=None, **_):
         """Keras-model look-alike of PaNWaveNet.infer (reference wavegen_1d.py:483-526):
-        spect numpy/torch (B,T,80) -> tensor with .numpy() of shape (B, synth_length)."""
+        spect numpy/torch (B,T,80) -> tensor with .numpy() of shape (B, synth_length).
+
+        ``sigma`` and ``z_in`` are accepted and unused, as in the reference.  ``F0`` (Hz at the pulse rate) replaces the
+        F0-net output (reference custom_pulsed_generator.py:773-791).  The training / gradient-test switches and the
+        component outputs of this call are outside the inference path: use :meth:`infer_components` for F0,
+        excitation and spectral envelope."""
+        if return_F0 or return_components or training or test_grad is not None:
+            raise NotImplementedError("infer(): return_F0 / return_components / training / test_grad are not part of the "
+                                      "mel-inversion path; infer_components() returns F0, excitation and envelope")
+        if F0 is not None:
+            gain = self.infer_components(spect, synth_length=synth_length, F0=F0, noise=noise)[3]
+            audio = self.last_audio
+            if gain is not None:                                     # reference wavegen_1d.py:506-507
+                audio = audio * self._torch.as_tensor(gain, device=self.device)
+            return _HostTensor(audio)
         torch = self._torch
         mel = torch.as_tensor(np.asarray(spect, dtype=np.float32) if not torch.is_tensor(spect) else spect)
         mel = mel.to(self.device, torch.float32)

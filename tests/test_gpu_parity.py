@@ -387,6 +387,23 @@ def test_infer_components_and_transposition(torch):
     assert _maxdiff(exc_e, exc_ref) <= _tol(exc_ref, E2E_TOL)
 
 
+def test_infer_accepts_the_reference_arguments(torch):
+    """PaNWaveNet.infer(spect, sigma, z_in, synth_length, F0, return_F0, ...) (reference wavegen_1d.py:483-484): sigma and
+    z_in are inert as in the reference, F0 replaces the F0-net, the training-side switches raise."""
+    eng, om = get_engine("small", *SMALL)[:2]
+    mel, noise = synthetic_inputs(31, 1, 9)
+    base = eng.infer(mel, synth_length=9 * 300, noise=noise).numpy()
+    assert np.array_equal(eng.infer(mel, sigma=0.1, z_in=None, synth_length=9 * 300, noise=noise).numpy(), base)
+    f0 = eng.stage("f0").cpu().numpy()
+    same = eng.infer(mel, synth_length=9 * 300, F0=f0, noise=noise).numpy()
+    assert _maxdiff(same, base) <= 1e-6 * max(1.0, np.abs(base).max())          # the net's own F0 fed back
+    other = eng.infer(mel, synth_length=9 * 300, F0=np.full_like(f0, 220.0), noise=noise).numpy()
+    assert other.shape == base.shape and not np.allclose(other, base)
+    for kwargs in ({"return_F0": True}, {"return_components": True}, {"training": True}):
+        with pytest.raises(NotImplementedError):
+            eng.infer(mel, **kwargs)
+
+
 def test_forward_is_graph_capturable(torch):
     """mbx_forward only enqueues kernels (no allocation, no synchronisation): it can be captured into a hipGraph."""
     eng = get_engine("small", *SMALL)[0]
