@@ -310,12 +310,15 @@ def test_padded_batch_equals_one_at_a_time(torch):
     """Every boundary op honours the item's own length: a ragged batch gives the per-utterance results
     (the reference processes one utterance at a time, bin/resynth_mel.py:74)."""
     eng = get_engine("small", *SMALL)[0]
-    lengths = [23, 7, 1, 16]
+    lengths = [23, 7, 0, 1, 16]                      # ragged, including an empty item
     T = max(lengths)
     mel, noise = synthetic_inputs(7, len(lengths), T)
     nf = torch.as_tensor(lengths, dtype=torch.int32).cuda()
     batch_out = eng.forward(dev(torch, mel), n_frames=nf, noise=dev(torch, noise)).cpu().numpy()
     for ii, ll in enumerate(lengths):
+        if ll == 0:
+            assert np.all(batch_out[ii] == 0.0)
+            continue
         single = eng.forward(dev(torch, mel[ii:ii + 1, :ll]), noise=dev(torch, noise[ii:ii + 1, :ll * 20])).cpu().numpy()
         assert np.array_equal(batch_out[ii, :ll * 300], single[0]), f"item {ii} differs from its single run"
         assert np.all(batch_out[ii, ll * 300:] == 0.0)
