@@ -354,6 +354,20 @@ def test_full_size_prefix_property(torch):
     assert _maxdiff(full[:40 * 300 - margin], ref[:40 * 300 - margin]) <= _tol(ref, E2E_TOL)
 
 
+def test_one_minute_utterance(torch):
+    """A 60 s utterance (4800 frames, 96 000 WaveNet steps, 1.44 M samples) in one call: finite, and its first seconds
+    equal the synthesis of the 5 s prefix up to float32 rounding (the long launch runs the large-launch kernels, the
+    prefix the small-launch ones)."""
+    eng = get_engine("canon", *CANON)[0]
+    mel, noise = synthetic_inputs(77, 1, 4800)
+    full = eng.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()[0]
+    assert full.shape == (4800 * 300,) and np.all(np.isfinite(full)) and np.abs(full).max() > 0.1
+    cut = 400
+    part = eng.forward(dev(torch, mel[:, :cut]), noise=dev(torch, noise[:, :cut * 20])).cpu().numpy()[0]
+    keep = (cut - 12) * 300
+    assert _maxdiff(full[:keep], part[:keep]) <= 2e-5 * max(1.0, np.abs(full).max())
+
+
 def test_error_paths(torch):
     eng = get_engine("small", *SMALL)[0]
     mel, noise = synthetic_inputs(1, 1, 4)
