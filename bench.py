@@ -5,14 +5,19 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path (mel -> 24 kHz audio) over one batch of synthetic mels that is already
-resident in HBM.  Workload at every N: BASELINE.json configs[1] -- MW-SP-FD (C=320), batch = 1, 10 s
-(80 x 800 mel) per GPU; utterances are independent, so N ranks run N utterances (weak scaling, no
-data-path collective; RCCL only carries the barrier and the max-over-ranks of the timing).
-Rank 0 prints ONE JSON line.
+resident in HBM.  Default workload at every N: BASELINE.json configs[2] -- MW-SI-FD (C=320), batch = 16 x 10 s
+(80 x 800 mels) per GPU, the largest single-GPU configuration; utterances are independent, so N ranks run N such
+batches (weak scaling, no data-path collective; RCCL only carries the barrier and the max-over-ranks of the timing).
+Started without a launcher and with --gpus N > 1 the script starts the N ranks itself (one process per GPU, RCCL).
+Rank 0 prints ONE JSON line: the default workload's throughput, max|delta| against the float64 oracle, the roofline
+of the dominant kernel and of the bandwidth-type stages, the CPU baseline (2 threads and all cores), and as secondary
+fields the step times of configs[1] (1 x 10 s) and configs[3] (256 utterances sharded over the ranks, strong scaling).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,22 +34,40 @@ WORKLOADS = {
     # BASELINE.json configs[3]: 256 variable-length utterances (U[2 s, 15 s]) sharded over the ranks (strong scaling)
     "config4_vo_256utt": ("VOICE", 256, None),
     # BASELINE.json configs[4]: 64 concurrent streams, one tick = 8 mel frames (100 ms; "80 ms" = 6.4 frames is not
-    # frame aligned) per stream with 10 frames of left context and 11 frames (137.5 ms) of look-ahead
+    # frame aligned) per stream
     "config5_sp_stream64": ("SPEECH", 64, -8),
 }
+DEFAULT_WORKLOAD = "config3_si_b16_10s"
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+HBM_PEAK_GBS = 8000.0             # same guide: HBM3E 8 TB/s (spec; 6.3 TB/s measured for a float4 copy)
+DELTA_FRAMES = 80                 # prefix of the benchmark input the oracle is run on for max|delta|
+DELTA_TOL = 1e-4                  # tolerance of max|delta|, relative to max(1, max|oracle audio|) (tests/test_gpu_parity.py)
+REJECTED_ENV = ("MBX_WG_ABLATE",)  # switches of timing experiments that produce wrong audio: never measured
+
+
+def mbx_env():
+    """Every MBX_* variable of the environment: they change which kernels run, so they belong to the measurement."""
+    return {kk: vv for kk, vv in sorted(os.environ.items()) if kk.startswith("MBX_")}
+
+
+_ENGINES = {}
 
 
 def build_engine(voice):
+    """(cfg, raw weights, wavetables, dims, engine) of the canonical model of a voice type; engines are shared
+    between voice types whose configuration is identical (SING == SPEECH: C = 320)."""
     from mbexwn_vocoder_amd.config import ModelDims, canonical_config
     from mbexwn_vocoder_amd.engine import MBExWNEngine
     from mbexwn_vocoder_amd.tables import WaveTables
     from mbexwn_vocoder_amd.weights import synthetic_weights
     cfg = canonical_config(voice)
-    dims = ModelDims(cfg)
-    raw = synthetic_weights(cfg, seed=1234)          # bias 0, PReLU alpha 0.2
-    wt = WaveTables(sample_rate=dims.pulse_rate, **cfg["mbexwn_config"]["wavetable_config"])
-    return cfg, raw, wt, dims, MBExWNEngine(cfg, raw, wt)
+    key = json.dumps(cfg, sort_keys=True, default=str)
+    if key not in _ENGINES:
+        dims = ModelDims(cfg)
+        raw = synthetic_weights(cfg, seed=1234)          # BASELINE.md section 3: bias 0, PReLU alpha 0.2
+        wt = WaveTables(sample_rate=dims.pulse_rate, **cfg["mbexwn_config"]["wavetable_config"])
+        _ENGINES[key] = (cfg, raw, wt, dims, MBExWNEngine(cfg, raw, wt))
+    return _ENGINES[key]
 
 
 def synthetic_batch(rng, batch, frames, steps_per_frame):
@@ -61,197 +84,316 @@ def pmc_traffic(workload):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
     if not files:
-        return None
+        return None, None
     try:
         with open(files[-1]) as fi:
             data = json.load(fi)
-        return data[workload]["gate"]["hbm_bytes_per_launch"]
+        return data[workload]["gate"]["hbm_bytes_per_launch"], os.path.basename(files[-1])
     except (KeyError, ValueError):
-        return None
+        return None, None
 
 
 def cpu_baseline(cfg, raw, wt, seconds=3.0):
-    """The oracle (numpy float32 port of the reference graph) timed on the host cores, on a bounded sample
-    (one 3 s utterance, the reference's own CPU-runnable case configs[0]); timing protocol of the reference
-    CLI (bin/resynth_mel.py:86-88): wall clock around the synthesis call only, one warm-up call."""
+    """The oracle (numpy float32 port of the reference graph) timed on the host cores on a bounded sample: one 3 s
+    utterance (the reference's own CPU-runnable case, configs[0]) at 2 threads -- the reference CLI's default
+    `-nt 2`, bin/resynth_mel.py:120 -- and at all cores.  Timing protocol of the reference CLI
+    (bin/resynth_mel.py:86-88): wall clock around the synthesis call only, one warm-up call first."""
     from oracle.mbexwn_oracle import OracleModel
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([pp.get("num_threads", 1) for pp in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
+    from threadpoolctl import threadpool_limits
     frames = int(round(seconds * 80))
     om = OracleModel(cfg, raw, wt, dtype=np.float32)
     rng = np.random.default_rng(42)
     mel, noise = synthetic_batch(rng, 1, frames, 20)
-    om.forward(mel[:, :16], noise[:, :320])         # warm-up (weight folding, BLAS thread start)
-    times = []
-    budget = time.time() + 20.0                     # bounded: at most ~20 s of CPU work
-    while len(times) < 15 and (len(times) < 3 or time.time() < budget):
-        t0 = time.time()
-        om.forward(mel, noise)
-        times.append(time.time() - t0)
-    best = float(np.median(times))
-    return {"value": frames * 300 / best, "unit": "audio samples/s", "cores": int(threads), "kind": "port",
-            "sample": f"1 utterance x {seconds:g} s (80x{frames} mel), numpy float32 oracle, median of {len(times)} runs after 1 warm-up",
-            "x_realtime": frames * 300 / best / 24000.0}
+    legs = {}
+    all_cores = os.cpu_count() or 1
+    for tag, threads in (("threads_2", 2), ("all_cores", all_cores)):
+        with threadpool_limits(limits=threads):
+            om.forward(mel[:, :16], noise[:, :320])         # warm-up (weight folding, BLAS thread start)
+            times = []
+            budget = time.time() + 12.0                     # bounded: ~12 s of CPU work per leg
+            while len(times) < 9 and (len(times) < 2 or time.time() < budget):
+                t0 = time.time()
+                om.forward(mel, noise)
+                times.append(time.time() - t0)
+        best = float(np.median(times))
+        legs[tag] = {"value": frames * 300 / best, "x_realtime": frames * 300 / best / 24000.0, "cores": threads,
+                     "runs": len(times)}
+    top = legs["all_cores"]
+    return {"value": top["value"], "unit": "audio samples/s", "cores": top["cores"], "kind": "port",
+            "sample": f"1 utterance x {seconds:g} s (80x{frames} mel), numpy float32 oracle, median of {top['runs']} runs "
+                      f"after 1 warm-up, time.time() around the synthesis call only (reference bin/resynth_mel.py:86-88)",
+            "x_realtime": top["x_realtime"], "threads_2": legs["threads_2"], "all_cores": legs["all_cores"],
+            "reference_claim": "README.md:222-223: about 2x real time on one laptop core (TF-CPU)"}
 
 
-def run_sharded(args, eng, dims, voice, n_utt, rank, world, dist, torch):
-    """config 4: every rank sees the same seeded list of utterance lengths, takes its LPT shard, runs padded
-    micro-batches (inputs staged in HBM before the timed region) and all-gathers the audio (RCCL) every step."""
-    from mbexwn_vocoder_amd.sharding import lpt_partition, plan_batches
+def max_abs_delta(eng, cfg, raw, wt, mel_h, noise_h, torch):
+    """Second half of BASELINE.json's metric: max|delta| of the HIP audio against the float64 oracle, on the first
+    DELTA_FRAMES frames of item 0 of the benchmark input (outside the timed region)."""
+    from oracle.mbexwn_oracle import OracleModel
+    nf = min(DELTA_FRAMES, mel_h.shape[1])
+    spf = noise_h.shape[1] // mel_h.shape[1]
+    mel, noise = mel_h[:1, :nf], noise_h[:1, :nf * spf]
+    got = eng.forward(torch.as_tensor(mel).cuda(), noise=torch.as_tensor(noise).cuda()).cpu().numpy()
+    ref = OracleModel(cfg, raw, wt).forward(mel, noise)
+    scale = max(1.0, float(np.max(np.abs(ref))))
+    delta = float(np.max(np.abs(got.astype(np.float64) - ref)))
+    return {"max_abs_delta": delta, "max_abs_delta_tolerance": DELTA_TOL * scale, "max_abs_ref": float(np.max(np.abs(ref))),
+            "max_abs_delta_ok": bool(delta <= DELTA_TOL * scale),
+            "max_abs_delta_sample": f"first {nf} frames ({nf / 80:g} s) of item 0 of the benchmark input, float32 HIP vs float64 "
+                                    "numpy oracle (oracle/mbexwn_oracle.py)"}
+
+
+class Fence:
+    def __init__(self, torch, dist):
+        self.torch, self.dist = torch, dist
+
+    def __call__(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, elapsed):
+        if self.dist is None:
+            return elapsed
+        tt = self.torch.tensor([elapsed], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+        return float(tt.item())
+
+
+def time_steps(step, steps, warmup, fence):
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize; max over ranks."""
+    for _ in range(warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    return fence.max_over_ranks(time.perf_counter() - t0)
+
+
+def run_batch(args, name, rank, world, fence, torch, profile):
+    """configs[0..2]: one padded batch per GPU.  Returns (result dict, context for the roofline / delta legs)."""
+    voice, batch, frames = WORKLOADS[name]
+    cfg, raw, wt, dims, eng = build_engine(voice)
+    rng = np.random.default_rng(42 + rank)
+    mel_h, noise_h = synthetic_batch(rng, batch, frames, dims.steps_per_frame)
+    mel, noise = torch.as_tensor(mel_h).cuda(), torch.as_tensor(noise_h).cuda()
+    out = torch.empty((batch, frames * dims.hop_size), dtype=torch.float32, device=mel.device)
+    elapsed = time_steps(lambda: eng.forward(mel, noise=noise, out=out), args.steps, args.warmup, fence)
+    samples = world * batch * frames * dims.hop_size * args.steps
+    res = {"workload": f"{name}: MW-{voice[:2]}-FD canonical (C={dims.wn_channels}, L={dims.wn_layers}), batch {batch} x "
+                       f"{frames / 80:g} s per GPU, 80x{frames} synthetic mel, seeded synthetic weights",
+           "batch_per_gpu": batch, "frames": frames, "value": samples / elapsed, "x_realtime": samples / elapsed / 24000.0,
+           "ms_per_step": elapsed / args.steps * 1e3, "steps": args.steps, "scaling": "weak",
+           "gate_form": eng.gate_form(batch, frames)}
+    ctx = None
+    if profile:
+        # per-stage device times from HIP events on the launch stream, in a separate pass so that the events do not sit
+        # inside the throughput measurement
+        eng.profile_enable(True)
+        for _ in range(max(3, min(args.steps, 10))):
+            eng.forward(mel, noise=noise, out=out)
+        torch.cuda.synchronize()
+        stages = {kk: eng.profile_read(kk) for kk in ("gate", "res_skip", "frontend", "wavetable", "start", "tail",
+                                                       "pqmf", "stft_filter", "overlap_add")}
+        eng.profile_enable(False)
+        ctx = {"stages": stages, "cfg": cfg, "raw": raw, "wt": wt, "dims": dims, "eng": eng, "mel_h": mel_h,
+               "noise_h": noise_h, "batch": batch, "frames": frames}
+    return res, ctx
+
+
+def roofline(ctx, workload):
+    """Dominant kernel (dilated conv + gate: 75 % of the WaveNet FLOPs) against the fp32 MFMA peak, and the
+    bandwidth-type stages against the HBM peak.  Algorithmic work per launch: DESIGN.md section 4."""
+    dims, eng, batch, frames, stages = ctx["dims"], ctx["eng"], ctx["batch"], ctx["frames"], ctx["stages"]
+    form = eng.gate_form(batch, frames)
+    executed = {"direct": 1.0, "winograd_f23": 2.0 / 3.0, "winograd_f43": 0.5, "winograd_f43_small": 0.5}[form]
+    kernel = {"direct": "conv1d_mfma_dma_kernel<EPI_GATE> (dilated conv k=3 C->2C + cond + tanh*sigmoid)",
+              "winograd_f23": "wn_gate_winograd_kernel (dilated conv k=3 C->2C in Winograd F(2,3) form + cond + tanh*sigmoid)",
+              "winograd_f43": "wn_gate_winograd4_kernel (dilated conv k=3 C->2C in Winograd F(4,3) form + cond + tanh*sigmoid)",
+              "winograd_f43_small": "wn_gate_winograd4k_kernel (same, 128-row blocks whose waves split the input channels)"}[form]
+    C, ks, L = dims.wn_channels, dims.wn_kernel_size, dims.wn_layers
+    rows = batch * frames * dims.steps_per_frame
+    gate_ms, gate_n = stages["gate"]
+    gate_s = gate_ms / max(gate_n, 1) * 1e-3
+    flop_alg = 2.0 * rows * (ks * C) * (2 * C)               # direct convolution: the algorithmic FLOPs of one launch
+    flop_exec = flop_alg * executed                           # what the matrix cores execute in this form
+    rs_ms, rs_n = stages["res_skip"]
+    rs_flop = 2.0 * rows * C * (C + dims.wn_out_channels)     # folded res/skip layer
+    traffic, traffic_src = pmc_traffic(workload)
+    T, B = frames, batch
+    n_out, M, hop, ppf = dims.wn_out_channels, dims.subbands, dims.hop_size, dims.pulse_per_frame
+    spf, nceps, win = dims.steps_per_frame, dims.n_ceps, dims.stft_win
+    stage_bytes = {            # algorithmic bytes of one launch (inputs read once + outputs written once)
+        "start": B * T * (ppf * 4 + spf * 4 + spf * C * 4),                       # pulse + noise -> h
+        "tail": B * T * spf * (C * 4 + 2 * n_out * 4 + M * 4),                    # a + output accumulator r/w -> sub-bands
+        "pqmf": B * T * (spf * M * 4 + hop * 4),                                   # sub-bands -> excitation
+        "stft_filter": B * T * (hop * 4 + nceps * 4 + ppf * 4 + win * 4),          # excitation + cepstrum + f0 -> frames
+        "overlap_add": B * T * (win * 4 + hop * 4),                                # frames -> audio
+        "wavetable": B * T * (ppf * 4 * 2),                                        # f0 -> pulse (phase + lookup)
+    }
+    stage_list = []
+    for name, nbytes in stage_bytes.items():
+        ms, cnt = stages[name]
+        avg_s = ms / max(cnt, 1) * 1e-3
+        gbs = nbytes / avg_s / 1e9 if avg_s > 0 else None
+        stage_list.append({"stage": name, "bound": "hbm", "avg_launch_ms": avg_s * 1e3, "bytes": nbytes,
+                           "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": gbs / HBM_PEAK_GBS if gbs else None})
+    fe_ms, fe_n = stages["frontend"]
+    return {"bound": "mfma", "kernel": kernel,
+            "achieved": flop_exec / gate_s / 1e12, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": flop_exec / gate_s / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
+            "achieved_algorithmic": flop_alg / gate_s / 1e12,
+            "frac_algorithmic": flop_alg / gate_s / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
+            "flop_per_launch": flop_alg, "mfma_flop_executed_per_launch": flop_exec,
+            "note": "achieved / frac = FLOPs the matrix cores execute (Winograd F(4,3): 1/2, F(2,3): 2/3 of the direct "
+                    "convolution's 2*rows*3C*2C) / launch time: <= 1, comparable with MfmaUtil in profiles/; "
+                    "*_algorithmic = the direct convolution's FLOPs / launch time (can exceed 1)",
+            "avg_launch_ms": gate_s * 1e3, "launches_timed": gate_n, "launches_per_step": L,
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
+            "traffic_source": traffic_src,
+            "res_skip": {"avg_launch_ms": rs_ms / max(rs_n, 1), "flop_per_launch": rs_flop,
+                         "achieved": rs_flop / (rs_ms / max(rs_n, 1) * 1e-3) / 1e12 if rs_ms else None,
+                         "frac": rs_flop / (rs_ms / max(rs_n, 1) * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS if rs_ms else None,
+                         "unit": "TFLOP/s", "launches_per_step": L - 1},
+            "frontend_ms_per_step": fe_ms / max(fe_n, 1),
+            "stages": stage_list}
+
+
+def run_sharded(args, name, rank, world, dist, fence, torch, steps=None, warmup=None):
+    """configs[3]: every rank sees the same seeded list of utterance lengths, ShardedSynthesizer takes its LPT shard,
+    stages the padded micro-batches in HBM once, and every step runs them and all-gathers the audio (RCCL, device
+    tensors: no host copy between the forward pass and the collective)."""
+    from mbexwn_vocoder_amd.sharding import ShardedSynthesizer
+    voice, n_utt, _ = WORKLOADS[name]
+    cfg, raw, wt, dims, eng = build_engine(voice)
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     rng = np.random.default_rng(4242)
     lengths = [int(vv) for vv in rng.integers(160, 1201, size=n_utt)]          # 2 s .. 15 s in frames
-    shards = lpt_partition(lengths, world)
-    mine = shards[rank]
-    batches = []
-    for group in plan_batches(mine, lengths, max_batch=16, max_padded_frames=16 * 1200):
-        tmax = max(lengths[ii] for ii in group)
-        mel_h, noise_h = synthetic_batch(np.random.default_rng(1000 + group[0]), len(group), tmax, dims.steps_per_frame)
-        nfr = torch.as_tensor([lengths[ii] for ii in group], dtype=torch.int32).cuda()
-        batches.append((torch.as_tensor(mel_h).cuda(), nfr, torch.as_tensor(noise_h).cuda(),
-                        torch.empty((len(group), tmax * dims.hop_size), dtype=torch.float32, device="cuda"), group))
-    totals = [sum(lengths[ii] for ii in ss) * dims.hop_size for ss in shards]
-    flat = torch.zeros(max(totals), dtype=torch.float32, device="cuda")
-    parts = [torch.empty_like(flat) for _ in range(world)] if world > 1 else None
-
-    def step():
-        pos = 0
-        for mel, nfr, noise, out, group in batches:
-            eng.forward(mel, n_frames=nfr, noise=noise, out=out)
-            for jj, ii in enumerate(group):                                  # pack this rank's shard
-                nn = lengths[ii] * dims.hop_size
-                flat[pos:pos + nn] = out[jj, :nn]
-                pos += nn
-        if world > 1:
-            dist.all_gather(parts, flat)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    if rank == 0:
-        samples = sum(lengths) * dims.hop_size * args.steps
-        value = samples / elapsed
-        print(json.dumps({
-            "metric": "24 kHz audio samples/sec (whole job; x real-time = value / 24000)", "value": value,
-            "unit": "audio samples/s", "x_realtime": value / 24000.0, "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: MW-{voice[:2]}-FD canonical (C={dims.wn_channels}), {n_utt} utterances "
-                                   f"U[2 s,15 s] = {sum(lengths) / 80:.0f} s of audio, LPT-sharded over {world} ranks, padded "
-                                   f"micro-batches <= 16 items, result all_gather each step",
-                       "parallelism": f"utterance-sharded x{world}", "padding_overhead":
-                       sum(bb[0].shape[0] * bb[0].shape[1] for bb in batches) / max(1, sum(lengths[ii] for ii in mine))}}))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    syn = ShardedSynthesizer(lambda mel, nfr, noise: eng.forward(mel, n_frames=nfr, noise=noise),
+                             dims.hop_size, dims.steps_per_frame, rank=rank, world_size=world, max_batch=16,
+                             max_padded_frames=16 * 1200, device=torch.device("cuda", torch.cuda.current_device()))
+    from mbexwn_vocoder_amd.sharding import lpt_partition
+    mine = set(lpt_partition(lengths, world)[rank])
+    mels, noises = [], []
+    for ii, ll in enumerate(lengths):       # only this rank's utterances are generated; the others are placeholders
+        if ii in mine:
+            mm, nn = synthetic_batch(np.random.default_rng(1000 + ii), 1, ll, dims.steps_per_frame)
+            mels.append(mm[0])
+            noises.append(nn[0])
+        else:
+            mels.append(np.zeros((ll, 80), dtype=np.float32))
+            noises.append(np.zeros((ll * dims.steps_per_frame,), dtype=np.float32))
+    plan = syn.stage(mels, noises)
+    elapsed = time_steps(lambda: syn.run_staged(plan, gather="all"), steps, warmup, fence)
+    samples = sum(lengths) * dims.hop_size * steps
+    padded = sum(int(bb[1].shape[0]) * int(bb[1].shape[1]) for bb in plan["batches"])
+    return {"workload": f"{name}: MW-{voice[:2]}-FD canonical (C={dims.wn_channels}), {n_utt} utterances U[2 s,15 s] = "
+                        f"{sum(lengths) / 80:.0f} s of audio, LPT-sharded over {world} ranks (ShardedSynthesizer), padded "
+                        f"micro-batches <= 16 items, device-resident all_gather of the audio each step",
+            "value": samples / elapsed, "x_realtime": samples / elapsed / 24000.0, "ms_per_step": elapsed / steps * 1e3,
+            "steps": steps, "scaling": "strong", "parallelism": f"utterance-sharded x{world}",
+            "padding_overhead": padded / max(1, sum(lengths[ii] for ii in mine))}
 
 
-def run_streaming(args, eng, dims, cfg, n_streams, chunk, rank, world, dist, torch):
-    """config 5: steady-state tick of the streaming driver -- every stream advances by `chunk` frames; the engine
-    sees a batch of windows (left context + chunk + look-ahead) with the carried phase state.  `value` counts the
-    emitted audio only (the context frames are overhead of chunked operation), inputs resident in HBM; the
-    host-inclusive tick latency of the Python driver (numpy staging + H2D + D2H) is reported next to it."""
-    from mbexwn_vocoder_amd.streaming import StreamingSynthesizer, pack_state, stream_margins
-    left, right, lead = stream_margins(dims, cfg)
-    left = -(-left // 8) * 8            # window starts are aligned to 8 frames (see streaming.py: bit-exact pairing)
-    win = left + chunk + right
-    rng = np.random.default_rng(7 + rank)
-    mel_h, noise_h = synthetic_batch(rng, n_streams, win, dims.steps_per_frame)
-    mel, noise = torch.as_tensor(mel_h).cuda(), torch.as_tensor(noise_h).cuda()
-    st = np.stack([pack_state(0.1, 0.3, 137, lead * dims.pulse_per_frame, (lead + chunk) * dims.pulse_per_frame)
-                   for _ in range(n_streams)])
-    state = torch.as_tensor(st).cuda()
-    out = torch.empty((n_streams, win * dims.hop_size), dtype=torch.float32, device="cuda")
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        eng.forward(mel, noise=noise, out=out, stream_state=state)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.forward(mel, noise=noise, out=out, stream_state=state)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    # host-inclusive latency through the real driver
+def run_streaming(args, name, rank, world, fence, torch):
+    """configs[4]: steady-state tick of the streaming driver -- every stream advances by `chunk` frames.  `value`
+    counts the emitted audio only, inputs resident in HBM; the tick is timed on the device with HIP events (events on
+    the launch stream around each tick) and, separately, host-inclusive through the Python driver."""
+    from mbexwn_vocoder_amd.streaming import StreamingSynthesizer
+    voice, n_streams, chunk = WORKLOADS[name]
+    chunk = -chunk
+    cfg, raw, wt, dims, eng = build_engine(voice)
     syn = StreamingSynthesizer(eng, chunk_frames=chunk)
-    total = 40 * chunk + right
+    syn.time_device = True
+    lead_ticks = 4                                   # ticks before the steady state (growing left context)
+    n_ticks = lead_ticks + args.warmup + args.steps
+    total = (n_ticks + 1) * chunk + syn.right + 8
     for sid in range(n_streams):
         syn.open(sid)
-        mm, nn = synthetic_batch(np.random.default_rng(sid), 1, total, dims.steps_per_frame)
+        mm, nn = synthetic_batch(np.random.default_rng(1000 * rank + sid), 1, total, dims.steps_per_frame)
         syn.push(sid, mm[0], nn[0])
-    lat = []
-    for _ in range(40):
+    dev_ms, host_ms, frames = [], [], []
+    for tick in range(n_ticks):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         res = syn.tick()
         torch.cuda.synchronize()
-        if len(res) == n_streams:
-            lat.append(time.perf_counter() - t1)
-    if rank == 0:
-        samples = world * n_streams * chunk * dims.hop_size * args.steps
-        value = samples / elapsed
-        print(json.dumps({
-            "metric": "24 kHz audio samples/sec (whole job; x real-time = value / 24000)", "value": value,
-            "unit": "audio samples/s", "x_realtime": value / 24000.0, "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: MW-SP-FD canonical, {n_streams} streams per GPU, tick = {chunk} frames "
-                                   f"({chunk * 12.5:g} ms) per stream, window {left}+{chunk}+{right} frames, look-ahead "
-                                   f"{right * 12.5:g} ms, carried phase state (bit-exact with offline synthesis)",
-                       "tick_ms_device": elapsed / args.steps * 1e3,
-                       "tick_ms_host_inclusive_p50": float(np.percentile(lat, 50) * 1e3) if lat else None,
-                       "tick_ms_host_inclusive_p99": float(np.percentile(lat, 99) * 1e3) if lat else None,
-                       "recompute_overhead": win / chunk}}))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        assert len(res) == n_streams
+        if tick >= lead_ticks + args.warmup:
+            host_ms.append((time.perf_counter() - t1) * 1e3)
+            dev_ms.append(syn.last_tick_device_ms)
+            frames.append(syn.last_tick_frames)
+    fence()
+    elapsed = fence.max_over_ranks(float(np.sum(dev_ms)) * 1e-3)       # device time of the timed ticks
+    samples = world * n_streams * chunk * dims.hop_size * args.steps
+    return {"workload": f"{name}: MW-SP-FD canonical, {n_streams} streams per GPU, tick = {chunk} frames "
+                        f"({chunk * 12.5:g} ms) per stream, look-ahead {syn.right * 12.5:g} ms, carried phase state, "
+                        f"bit-equal to offline synthesis; value = emitted audio / device time of the ticks (HIP events "
+                        f"around the engine call of each tick), host-inclusive latency beside it",
+            "value": samples / elapsed, "x_realtime": samples / elapsed / 24000.0, "ms_per_step": elapsed / args.steps * 1e3,
+            "steps": args.steps, "scaling": "weak",
+            "tick_ms_device_p50": float(np.percentile(dev_ms, 50)), "tick_ms_device_p99": float(np.percentile(dev_ms, 99)),
+            "tick_ms_host_inclusive_p50": float(np.percentile(host_ms, 50)),
+            "tick_ms_host_inclusive_p99": float(np.percentile(host_ms, 99)),
+            "frames_computed_per_emitted_frame": float(np.mean(frames)) / (n_streams * chunk)}
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU, RCCL).  This parent never
+    touches the GPU -- torch.cuda.device_count() does not initialise it on this image -- and exits with the worst
+    child status."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible")
+    with socket.socket() as ss:
+        ss.bind(("127.0.0.1", 0))
+        port = ss.getsockname()[1]
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [pp.wait() for pp in procs]
+    raise SystemExit(max(abs(cc) for cc in codes))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="config2_sp_b1_10s", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary workloads (configs[1] and configs[3]) and the max|delta| leg: profiling runs")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even for one rank: exercises the N>1 code path on a 1-GPU box")
     args = ap.parse_args()
+    if args.gpus < 1 or args.steps < 1:
+        raise SystemExit("--gpus and --steps must be >= 1")
+    for kk in REJECTED_ENV:
+        if kk in os.environ:
+            raise SystemExit(f"{kk} is set: it selects a timing experiment that produces wrong audio; refusing to measure")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: local GPU {local_rank} does not exist ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.force_dist:
@@ -261,97 +403,43 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    fence = Fence(torch, dist)
 
     voice, batch, frames = WORKLOADS[args.workload]
-    cfg, raw, wt, dims, eng = build_engine(voice)
+    line = {"metric": "24 kHz audio samples/sec (whole job; x real-time = value / 24000) + max|delta| vs the CPU oracle"}
+    ctx = None
     if frames is None:
-        run_sharded(args, eng, dims, voice, batch, rank, world, dist, torch)
-        return
-    if frames < 0:
-        run_streaming(args, eng, dims, cfg, batch, -frames, rank, world, dist, torch)
-        return
-    rng = np.random.default_rng(42 + rank)
-    mel_h, noise_h = synthetic_batch(rng, batch, frames, dims.steps_per_frame)
-    mel = torch.as_tensor(mel_h).cuda()
-    noise = torch.as_tensor(noise_h).cuda()
-    out = torch.empty((batch, frames * dims.hop_size), dtype=torch.float32, device=mel.device)
+        main_res = run_sharded(args, args.workload, rank, world, dist, fence, torch)
+    elif frames < 0:
+        main_res = run_streaming(args, args.workload, rank, world, fence, torch)
+    else:
+        main_res, ctx = run_batch(args, args.workload, rank, world, fence, torch, profile=True)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        eng.forward(mel, noise=noise, out=out)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.forward(mel, noise=noise, out=out)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=mel.device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    # ---- dominant kernel: dilated conv + gate (75 % of the WaveNet FLOPs), timed with HIP events on the
-    #      launch stream in a separate pass so that the events do not sit inside the throughput measurement
-    eng.profile_enable(True)
-    for _ in range(max(3, min(args.steps, 10))):
-        eng.forward(mel, noise=noise, out=out)
-    torch.cuda.synchronize()
-    gate_ms, gate_n = eng.profile_read("gate")
-    rs_ms, rs_n = eng.profile_read("res_skip")
-    eng.profile_enable(False)
+    secondary = {}
+    if args.workload == DEFAULT_WORKLOAD and not args.no_secondary:
+        # configs[1] at the same step count; configs[3] with a bounded step count (one step = 2 181 s of audio)
+        res2, _ = run_batch(args, "config2_sp_b1_10s", rank, world, fence, torch, profile=False)
+        secondary["config2_sp_b1_10s"] = res2
+        secondary["config4_vo_256utt"] = run_sharded(args, "config4_vo_256utt", rank, world, dist, fence, torch,
+                                                     steps=min(args.steps, 3), warmup=1)
 
     if rank == 0:
-        form = eng.gate_form(batch, frames)
-        executed = {"direct": 1.0, "winograd_f23": 2.0 / 3.0, "winograd_f43": 0.5, "winograd_f43_small": 0.5}[form]
-        kernel = {"direct": "conv1d_mfma_dma_kernel<EPI_GATE> (dilated conv k=3 C->2C + cond + tanh*sigmoid)",
-                  "winograd_f23": "wn_gate_winograd_kernel (dilated conv k=3 C->2C in Winograd F(2,3) form + cond + tanh*sigmoid)",
-                  "winograd_f43": "wn_gate_winograd4_kernel (dilated conv k=3 C->2C in Winograd F(4,3) form + cond + tanh*sigmoid)",
-                  "winograd_f43_small": "wn_gate_winograd4k_kernel (same, 128-row blocks whose waves split the input channels)"}[form]
-        C, L, ks = dims.wn_channels, dims.wn_layers, dims.wn_kernel_size
-        rows = batch * frames * dims.steps_per_frame
-        gate_flop = 2.0 * rows * (ks * C) * (2 * C)                   # algorithmic FLOPs of one launch
-        gate_avg_s = gate_ms / max(gate_n, 1) * 1e-3
-        achieved = gate_flop / gate_avg_s / 1e12
-        samples = world * batch * frames * dims.hop_size * args.steps
-        value = samples / elapsed
-        line = {
-            "metric": "24 kHz audio samples/sec (whole job; x real-time = value / 24000)",
-            "value": value,
-            "unit": "audio samples/s",
-            "x_realtime": value / 24000.0,
-            "x_realtime_per_gpu": value / 24000.0 / world,
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"{args.workload}: MW-{voice[:2]}-FD canonical (C={C}, L={L}), batch {batch} x "
-                                   f"{frames / 80:g} s per GPU, 80x{frames} synthetic mel, seeded synthetic weights",
-                       "batch_per_gpu": batch, "frames": frames, "parallelism": f"utterance-sharded x{world}"},
-            "roofline": {"bound": "mfma",
-                         "kernel": kernel,
-                         "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": pmc_traffic(args.workload),
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
-                         "flop_per_launch": gate_flop,
-                         "note": "achieved = algorithmic FLOPs of the direct convolution (2*rows*3C*2C) / launch time; a "
-                                 "Winograd form executes 2/3 (F(2,3)) or 1/2 (F(4,3)) of them on the matrix cores, so "
-                                 "frac can exceed 1; frac_executed = executed FLOPs / launch time / peak (MfmaUtil in profiles/)",
-                         "mfma_flop_executed_per_launch": gate_flop * executed,
-                         "frac_executed": achieved * executed / FP32_MATRIX_PEAK_TFLOPS,
-                         "avg_launch_ms": gate_avg_s * 1e3, "launches_timed": gate_n,
-                         "res_skip_avg_launch_ms": rs_ms / max(rs_n, 1)},
-        }
+        line.update({
+            "value": main_res["value"], "unit": "audio samples/s", "x_realtime": main_res["x_realtime"],
+            "x_realtime_per_gpu": main_res["x_realtime"] / world, "n_gpus": world, "steps": main_res["steps"],
+            "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True,
+            "scaling": main_res["scaling"], "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {kk: vv for kk, vv in main_res.items() if kk not in ("value", "x_realtime", "ms_per_step", "steps", "scaling")},
+            "env": mbx_env()})
+        line["config"]["parallelism"] = main_res.get("parallelism", f"utterance-sharded x{world}")
+        if ctx is not None:
+            line["roofline"] = roofline(ctx, args.workload)
+            if not args.no_secondary:
+                line.update(max_abs_delta(ctx["eng"], ctx["cfg"], ctx["raw"], ctx["wt"], ctx["mel_h"], ctx["noise_h"], torch))
+        if secondary:
+            line["secondary"] = secondary
         if not args.no_cpu_baseline:
+            cfg, raw, wt = build_engine(voice)[:3]
             line["cpu_baseline"] = cpu_baseline(cfg, raw, wt)
         print(json.dumps(line))
     if dist is not None:

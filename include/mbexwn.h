@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MBX_ABI_VERSION 1
+#define MBX_ABI_VERSION 2
 #define MBX_MAX_SUBNET_OPS 32
 #define MBX_MAX_WN_LAYERS 64
 #define MBX_NAME_LEN 64
@@ -91,6 +91,18 @@ typedef struct {
     mbx_subnet_op f0_ops[MBX_MAX_SUBNET_OPS];
     int32_t n_vtf_ops;
     mbx_subnet_op vtf_ops[MBX_MAX_SUBNET_OPS];
+    /* optional RMS normalisation of the mel input and de-normalisation of the audio: NormMelComponents
+     * (reference wavegen_1d.py:578-769) as PaNWaveNet.infer applies it (:493-495, 506-507), smoothing variant.
+     * nm_iters == 0 => off.  Tables "table.nm_inv_enorm" (mel_channels), "table.nm_gwin" (stft_win),
+     * "table.nm_smooth_win" (nm_smooth_win). */
+    int32_t nm_iters;            /* normalize_rms_num_smooth_iters */
+    int32_t nm_smooth_win;       /* win_size * normalize_smooth_win_scale */
+    int32_t nm_use_compressor;   /* normalize_compressor_exp given */
+    int32_t nm_use_max_limit;    /* use_max_limit */
+    float nm_rms_norm_fact;      /* fft_size * win_size / 2 */
+    float nm_rms_floor;          /* 1 / max_norm_fact, 0 => none */
+    float nm_compressor_exp;
+    float nm_lin_amp_scale, nm_lin_amp_off, nm_mel_amp_scale;
 } mbx_config;
 
 /* A named HOST tensor handed over at creation (weights already weight-norm folded, tables).
@@ -175,10 +187,12 @@ mbx_status mbx_forward_ex(mbx_handle *handle, const float *mel, const int32_t *n
 mbx_status mbx_stage(const mbx_handle *handle, const char *name, const void **device_ptr, int64_t *count,
                      int64_t *stride);
 
-/* Kernel timing for bench.py: while enabled, mbx_forward brackets every launch of the two WaveNet GEMM
- * kernels with HIP events on the caller's stream (not capturable into a graph while enabled).
- * mbx_profile_read waits for the recorded events, returns the summed device time and the launch count of
- * kernel "gate" (dilated conv + gate) or "res_skip" since the last read, and recycles the events. */
+/* Kernel timing for bench.py: while enabled, mbx_forward brackets the launches of every stage of the sequence with
+ * HIP events on the caller's stream (not capturable into a graph while enabled).  mbx_profile_read waits for the
+ * recorded events, returns the summed device time and the number of bracketed launch groups of one stage since the
+ * last read, and recycles the events.  Stages: "gate" (dilated conv + gate, one per layer), "res_skip" (one per layer),
+ * "frontend" (F0-net, VTF-net, conditioning conv: the mel-rate launches), "wavetable" (phase + lookup), "start",
+ * "tail" (end conv + post-net), "pqmf", "stft_filter", "overlap_add", "norm_mel". */
 mbx_status mbx_profile_enable(mbx_handle *handle, int32_t enabled);
 mbx_status mbx_profile_read(mbx_handle *handle, const char *kernel, double *total_ms, int64_t *launches);
 
@@ -211,6 +225,13 @@ mbx_status mbx_wavetable(mbx_handle *handle, const float *f0, int32_t batch, int
 mbx_status mbx_stft_filter(mbx_handle *handle, const float *excitation, const float *cepstrum,
                            const int32_t *ceps_index, int32_t batch, int32_t frames, float *audio, float *scratch,
                            void *hip_stream);
+
+/* NormMelComponents.normalize_inputs_by_rms(None, mell, synth_length) (reference wavegen_1d.py:638-769), only for
+ * models with nm_iters > 0: mel (batch, frames, mel_channels) -> mel_out (same shape) and, if gain != NULL,
+ * gain (batch, frames*hop) = upsampled_rms (what mbx_forward multiplies onto the audio).  n_frames: device int32
+ * (batch) or NULL.  scratch >= 2*batch*frames floats. */
+mbx_status mbx_norm_mel(mbx_handle *handle, const float *mel, const int32_t *n_frames, int32_t batch, int32_t frames,
+                        float *mel_out, float *gain, float *scratch, void *hip_stream);
 
 #ifdef __cplusplus
 }

@@ -220,6 +220,7 @@ class ModelDims:
         self.sample_rate = int(pp["sample_rate"])
         self.hop_size = int(pp["hop_size"])
         self.mel_channels = int(pp["mel_channels"])
+        self.segment_length = int(pp.get("segment_length", 0))     # infer(synth_length=0) falls back to it (wavegen_1d.py:489)
         self.subbands = int(mb["multi_band_config"]["subbands"])
         self.pulse_rate_factor = int(mb.get("pulse_rate_factor", 2))
         self.pulse_rate = self.sample_rate / self.pulse_rate_factor
@@ -251,6 +252,18 @@ class ModelDims:
             raise NotImplementedError("n_ch_groups > 1 is not supported by the HIP path")
         if self.wn_activation != "gtu":
             raise NotImplementedError("only the gtu (tanh*sigmoid) gate is supported")
+        # keys of WaveNetAE.__init__ (reference custom_AE_layers.py:120-131) that change the arithmetic and are not built:
+        # silently ignoring them would load a valid model and produce wrong audio
+        if wn.get("use_equalized_lr", False):
+            raise NotImplementedError("pp_mod_subnet.use_equalized_lr (W = g v / sqrt(mean v^2), reference "
+                                      "conv_layers.py:151) is not supported")
+        if wn.get("pre_cond_layer_channels", None):
+            raise NotImplementedError("pp_mod_subnet.pre_cond_layer_channels is not supported")
+        if wn.get("disable_conditioning", False):
+            raise NotImplementedError("pp_mod_subnet.disable_conditioning is not supported")
+        if str(wn.get("padding", "SAME")).upper() != "SAME":
+            raise NotImplementedError("pp_mod_subnet.padding other than SAME is not supported")
+        self.wn_use_weight_norm = bool(wn.get("use_weight_norm", False))
         self.cond_lin_upsampling = int(wn.get("cond_lin_upsampling", 16))
         self.cond_kernel_size = int(wn.get("cond_kernel_size", 3))
         curr_rate = self.pulse_rate / self.pulse_channels
@@ -283,7 +296,7 @@ class ModelDims:
         if mb.get("pulse_channels_use_pqmf", False) or not mb.get("pp_mod_subnet_use_pqmf", True):
             raise NotImplementedError("pulse_channels_use_pqmf / no-PQMF variants are not supported")
         self.alpha = float(mb.get("alpha", 0.2))
-        # NormMelComponents (reference wavegen_1d.py:578-769, row A14) is host-side pre/post-processing: norm_mel.py
+        # NormMelComponents (reference wavegen_1d.py:578-769, row A14): device kernels csrc/norm_mel.hip, tables norm_mel.py
         self.normalize_rms_from_mell = bool(mb.get("normalize_rms_from_mell", False))
 
     def wn_dilation(self, index):

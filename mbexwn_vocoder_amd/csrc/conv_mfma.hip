@@ -684,11 +684,6 @@ __global__ __launch_bounds__(256) void conv1d_small_group_kernel(SmallConvGroup 
     conv1d_small_tile(g.c[k], bx, t % g.gy[k], t / g.gy[k], red);
 }
 
-static int env_int(const char *name, int dflt) {
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
 template <int WM, int WN, int TM, int TN, int EPI, int BK = 16>
 static void launch_cfg(const ConvArgs &a, hipStream_t stream, int extra_lds = 0) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -724,17 +719,17 @@ static bool launch_dma(const ConvArgs &a, hipStream_t stream) {
 }
 
 static bool small_conv_eligible(const ConvArgs &a) {
-    static const int no_small = env_int("MBX_NO_SMALL", 0);
-    return (long long)a.max_rows * a.batch <= 8192 && a.cin % 8 == 0 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 &&
-           (uintptr_t)a.x % 16 == 0 && no_small == 0;
+    // no row limit: the mel-rate convolutions then sum K in the same order at every launch size, which keeps a padded
+    // batch bit-identical to one-at-a-time runs (the F0 contour feeds the phase accumulator: rounding there is audible
+    // in the last bits everywhere downstream)
+    return a.cin % 8 == 0 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 && (uintptr_t)a.x % 16 == 0;
 }
 
 void launch_conv1d_group(const ConvArgs *convs, int n, hipStream_t stream) {
-    static const int no_group = env_int("MBX_NO_GROUP", 0);
     int small[3], n_small = 0;
     for (int i = 0; i < n && i < 3; ++i)
         if (convs[i].max_rows > 0 && convs[i].batch > 0 && small_conv_eligible(convs[i])) small[n_small++] = i;
-    if (n > 3 || n_small < 2 || no_group) {
+    if (n > 3 || n_small < 2) {
         for (int i = 0; i < n; ++i) launch_conv1d(convs[i], EPI_LINEAR, stream);
         return;
     }

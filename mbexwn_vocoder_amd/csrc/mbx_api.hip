@@ -48,7 +48,30 @@ struct StageRef {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Makes the handle's device current for the duration of a call and puts the caller's device back afterwards, so
+// that an engine can be created for / used from a thread whose current device is another one.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false, ok = true;
+    explicit DeviceGuard(int device) {
+        ok = hipGetDevice(&prev) == hipSuccess;
+        if (ok && prev != device) {
+            ok = hipSetDevice(device) == hipSuccess;
+            switched = ok;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
 }  // namespace
+
+// stages of the launch sequence that mbx_profile_read can report (names in kProfNames)
+enum { PROF_GATE = 0, PROF_RES_SKIP, PROF_FRONTEND, PROF_WAVETABLE, PROF_START, PROF_TAIL, PROF_PQMF, PROF_STFT_FILTER,
+       PROF_OVERLAP_ADD, PROF_NORM_MEL, PROF_KINDS };
+static const char *const kProfNames[PROF_KINDS] = {"gate", "res_skip", "frontend", "wavetable", "start", "tail", "pqmf",
+                                                   "stft_filter", "overlap_add", "norm_mel"};
 
 struct mbx_handle {
     mbx_config cfg;
@@ -68,10 +91,10 @@ struct mbx_handle {
     bool fold_skip = false;      // skip path folded into the end convolution (needs the *.fold tensors)
     bool winograd4_always = false;   // MBX_WINOGRAD=44: F(4,3) at every size (tests)
     int winograd = 0;            // gate layer form: 0 direct, 2 Winograd F(2,3), 4 Winograd F(4,3) (needs the packed weights)
-    // bench-only kernel timing (mbx_profile_*)
+    // bench-only kernel timing (mbx_profile_*): one event pool per stage of the launch sequence
     bool profiling = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool[2];   // 0: gate, 1: res_skip
-    size_t ev_used[2] = {0, 0};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool[PROF_KINDS];
+    size_t ev_used[PROF_KINDS] = {};
 };
 
 namespace {
@@ -105,7 +128,8 @@ mbx_status analyse_subnet(const mbx_subnet_op *ops, int n_ops, int cin, long lon
 }
 
 struct Workspace {
-    float *sub0, *sub1, *sub2, *sub3, *f0, *cum, *chunk_last, *pulse, *cond, *h, *a, *skip, *wn_out, *sub, *exc, *ceps, *frames;
+    float *mel_norm, *nm_a, *nm_b;
+    float *sub0, *sub1, *sub2, *sub3, *f0_wide, *f0, *cum, *chunk_last, *pulse, *cond, *h, *a, *skip, *wn_out, *sub, *exc, *ceps, *frames;
     int *ceps_index;
     size_t total;
 };
@@ -122,10 +146,17 @@ Workspace carve(const mbx_handle *hd, char *base, int B, int T) {
     const size_t BT = (size_t)B * T;
     const size_t npulse = (size_t)T * c.pulse_per_frame, nsteps = (size_t)T * c.steps_per_frame;
     const int chunks = (int)((npulse + c.phase_chunk - 1) / c.phase_chunk) + 1;
+    const bool nm = c.nm_iters > 0;
+    w.mel_norm = take(nm ? BT * c.mel_channels : 0);
+    w.nm_a = take(nm ? BT : 0);
+    w.nm_b = take(nm ? BT : 0);
     w.sub0 = take(BT * hd->subnet_buf_per_frame);
     w.sub1 = take(BT * hd->subnet_buf_per_frame);
     w.sub2 = take(BT * hd->subnet_buf_per_frame);   // VTF-net ping-pong (its convolutions share launches with the F0-net's)
     w.sub3 = take(BT * hd->subnet_buf_per_frame);
+    // an F0-net with a bare ["L", up] entry runs at a multiple of the pulse rate and is cut to it (reference
+    // custom_pulsed_generator.py:57-60, 787): the uncut contour lives here
+    w.f0_wide = take(hd->f0_time_factor > c.pulse_per_frame ? BT * hd->f0_time_factor : 0);
     w.f0 = take(B * npulse);
     w.cum = take(B * npulse);
     w.chunk_last = take((size_t)B * chunks);
@@ -324,6 +355,29 @@ mbx::WaveTableConsts wavetable_consts(const mbx_handle *hd) {
     return k;
 }
 
+mbx::NormMelConsts norm_mel_consts(const mbx_handle *hd) {
+    const mbx_config &c = hd->cfg;
+    mbx::NormMelConsts k;
+    k.iters = c.nm_iters;
+    k.mel_channels = c.mel_channels;
+    k.hop = c.hop_size;
+    k.win = c.stft_win;
+    k.smooth_win = c.nm_smooth_win;
+    k.cut = c.nm_smooth_win / 2 + 2 * c.hop_size - c.stft_win / 2;
+    k.rms_norm_fact = c.nm_rms_norm_fact;
+    k.rms_floor = c.nm_rms_floor;
+    k.compressor_exp = c.nm_compressor_exp;
+    k.lin_amp_scale = c.nm_lin_amp_scale;
+    k.lin_amp_off = c.nm_lin_amp_off;
+    k.mel_amp_scale = c.nm_mel_amp_scale;
+    k.use_compressor = c.nm_use_compressor;
+    k.use_max_limit = c.nm_use_max_limit;
+    k.inv_enorm = find(hd, "table.nm_inv_enorm")->ptr;
+    k.gwin = find(hd, "table.nm_gwin")->ptr;
+    k.smooth_win_table = find(hd, "table.nm_smooth_win")->ptr;
+    return k;
+}
+
 mbx::StftConsts stft_consts(const mbx_handle *hd) {
     const mbx_config &c = hd->cfg;
     mbx::StftConsts k;
@@ -379,11 +433,12 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
         mbx_destroy(hd);
         return st;
     };
-    hipError_t e = hipSetDevice(device);
-    if (e != hipSuccess) {
+    DeviceGuard guard(device);
+    if (!guard.ok) {
         delete hd;
-        return fail(MBX_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+        return fail(MBX_ERR_HIP, "hipSetDevice: cannot select device " + std::to_string(device));
     }
+    hipError_t e = hipSuccess;
 
     // interpolation factors in use
     std::vector<int> ups = {c.cond_lin_upsampling};
@@ -469,6 +524,13 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
     // required tensors
     std::vector<std::string> need = {"table.hann", "table.inv_win", "table.wavetables", "wn.start.w", "wn.start.b",
                                      "wn.cond.w", "wn.cond.b", "wn.end.w", "wn.end.b", "post.w", "post.b"};
+    if (c.nm_iters > 0) {
+        if (c.nm_smooth_win < c.hop_size || c.nm_smooth_win % 2 || !(c.nm_rms_norm_fact > 0.f))
+            return bail(fail(MBX_ERR_INVALID_ARGUMENT, "RMS normalisation: bad smoothing window / norm factor"));
+        need.push_back("table.nm_inv_enorm");
+        need.push_back("table.nm_gwin");
+        need.push_back("table.nm_smooth_win");
+    }
     if (c.n_ceps_windows) {
         need.push_back("table.ceps_windows");
         need.push_back("table.ceps_log10f0");
@@ -499,6 +561,9 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
     if (c.n_ceps_windows)
         ok = ok && expect("table.ceps_windows", (long long)c.n_ceps_windows * c.n_ceps) &&
              expect("table.f0_smooth", 2 * c.hop_size + 1);
+    if (c.nm_iters > 0)
+        ok = ok && expect("table.nm_inv_enorm", c.mel_channels) && expect("table.nm_gwin", c.stft_win) &&
+             expect("table.nm_smooth_win", c.nm_smooth_win);
     if (!ok) return bail(fail(MBX_ERR_INVALID_ARGUMENT, "a tensor has the wrong number of elements"));
 
     long long pf0 = 0, pvtf = 0;
@@ -507,8 +572,8 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
     if (st != MBX_OK) return bail(st);
     st = analyse_subnet(c.vtf_ops, c.n_vtf_ops, c.mel_channels, &pvtf, &hd->vtf_time_factor, &vtf_out);
     if (st != MBX_OK) return bail(st);
-    if (hd->f0_time_factor != c.pulse_per_frame || f0_out != 1)
-        return bail(fail(MBX_ERR_INVALID_ARGUMENT, "F0 sub-net must end with 1 channel at pulse_per_frame samples per frame"));
+    if (hd->f0_time_factor < c.pulse_per_frame || f0_out != 1)
+        return bail(fail(MBX_ERR_INVALID_ARGUMENT, "F0 sub-net must end with 1 channel at >= pulse_per_frame samples per frame"));
     if (hd->vtf_time_factor != 1 || vtf_out != c.n_ceps)
         return bail(fail(MBX_ERR_INVALID_ARGUMENT, "VTF sub-net must end with n_ceps channels at the mel frame rate"));
     hd->subnet_buf_per_frame = std::max(pf0, pvtf);
@@ -559,6 +624,8 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                                void *hip_stream, const float *f0_in = nullptr, float transposition = 1.f) {
     if (!hd || !mel || !audio || !workspace) return fail(MBX_ERR_INVALID_ARGUMENT, "null argument");
     if (batch <= 0 || max_frames <= 0) return fail(MBX_ERR_INVALID_ARGUMENT, "batch and max_frames must be positive");
+    DeviceGuard guard(hd->device);
+    if (!guard.ok) return fail(MBX_ERR_HIP, "cannot select the handle's device");
     const mbx_config &c = hd->cfg;
     if (c.noise_sigma != 0.f && !noise) return fail(MBX_ERR_INVALID_ARGUMENT, "noise is required when noise_sigma != 0");
     if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return fail(MBX_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
@@ -569,6 +636,18 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     const int C = c.wn_channels, L = c.wn_layers, M = c.subbands;
     const long long npulse = (long long)T * c.pulse_per_frame, nsteps = (long long)T * c.steps_per_frame;
 
+    // ---- optional RMS normalisation of the mel input (reference wavegen_1d.py:493-495, 638-769); the matching gain
+    // is multiplied onto the audio at the end (reference wavegen_1d.py:506-507)
+    const float *nm_gain_src = nullptr;
+    if (c.nm_iters > 0) {
+        if (st_in || st_out)
+            return fail(MBX_ERR_UNSUPPORTED, "streaming windows cannot carry the RMS normalisation (its smoothing "
+                                             "spans the utterance edges)");
+        ScopedEvents ev(hd, PROF_NORM_MEL, stream);
+        nm_gain_src = mbx::launch_norm_mel(norm_mel_consts(hd), mel, (long long)T * c.mel_channels, n_frames, T, B,
+                                           w.nm_a, w.nm_b, w.mel_norm, stream);
+        mel = w.mel_norm;
+    }
     const DevTensor *cw = find(hd, "wn.cond.w"), *cbias = find(hd, "wn.cond.b");
     const int cond_cout = 2 * C * c.cond_conv_upsampling;
     mbx::StftConsts sc = stft_consts(hd);
@@ -577,14 +656,16 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     // the n-th convolution of each goes into one launch (launch_conv1d_group; matters at small batch, where the
     // mel-rate convolutions are latency-bound)
     {
+        ScopedEvents ev(hd, PROF_FRONTEND, stream);
         mbx::ConvArgs cond_conv = conv_args(mel, (long long)T * c.mel_channels, c.mel_channels, n_frames, 1, T, B, cw,
                                             cbias, c.cond_kernel_size, c.mel_channels, cond_cout, 1,
                                             (c.cond_kernel_size - 1) / 2, MBX_PAD_ZERO, w.cond, (long long)T * cond_cout,
                                             cond_cout);
         SubnetRun vtf(hd, c.vtf_ops, c.n_vtf_ops, mel, c.mel_channels, n_frames, B, T, w.sub2, w.sub3, w.ceps, false, 1.f,
                       0.f, stream);
-        SubnetRun f0(hd, c.f0_ops, c.n_f0_ops, mel, c.mel_channels, n_frames, B, T, w.sub0, w.sub1, w.f0, true,
-                     c.f0_max - c.f0_min, c.f0_min, stream);
+        const bool f0_wide = hd->f0_time_factor > c.pulse_per_frame;
+        SubnetRun f0(hd, c.f0_ops, c.n_f0_ops, mel, c.mel_channels, n_frames, B, T, w.sub0, w.sub1,
+                     f0_wide ? w.f0_wide : w.f0, true, c.f0_max - c.f0_min, c.f0_min, stream);
         if (f0_in) f0.finished = true;
         bool cond_pending = true;
         for (;;) {
@@ -601,6 +682,9 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         }
         if (vtf.status != MBX_OK) return vtf.status;
         if (f0.status != MBX_OK) return f0.status;
+        if (f0_wide && !f0_in)   // pulse_frequency[:, :T * pulse_per_frame] (reference custom_pulsed_generator.py:787)
+            mbx::launch_activation(w.f0_wide, (long long)T * hd->f0_time_factor, n_frames, c.pulse_per_frame, (int)npulse,
+                                   B, 1, MBX_ACT_LINEAR, 1.f, 0.f, w.f0, npulse, stream);
     }
     if (f0_in)   // externally supplied contour (reference wavegen_1d.py:546-550)
         mbx::launch_activation(f0_in, npulse, n_frames, c.pulse_per_frame, (int)npulse, B, 1, MBX_ACT_LINEAR, transposition,
@@ -609,12 +693,18 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         mbx::launch_activation(w.f0, npulse, n_frames, c.pulse_per_frame, (int)npulse, B, 1, MBX_ACT_LINEAR,
                                transposition, 0.f, w.f0, npulse, stream);
     // ---- wavetable excitation (reference :889)
-    mbx::launch_wavetable(wavetable_consts(hd), w.f0, npulse, n_frames, c.pulse_per_frame, (int)npulse, B, w.pulse,
-                          nullptr, w.cum, w.chunk_last, st_in, st_out, stream);
+    {
+        ScopedEvents ev(hd, PROF_WAVETABLE, stream);
+        mbx::launch_wavetable(wavetable_consts(hd), w.f0, npulse, n_frames, c.pulse_per_frame, (int)npulse, B, w.pulse,
+                              nullptr, w.cum, w.chunk_last, st_in, st_out, stream);
+    }
     // ---- WaveNet (reference custom_AE_layers.py:273-346)
-    mbx::launch_wn_start(w.pulse, npulse, c.noise_sigma != 0.f ? noise : nullptr, nsteps, c.noise_sigma, n_frames,
-                         c.steps_per_frame, (int)nsteps, B, c.pulse_channels, find(hd, "wn.start.w")->ptr,
-                         find(hd, "wn.start.b")->ptr, C, w.h, nsteps * C, stream);
+    {
+        ScopedEvents ev(hd, PROF_START, stream);
+        mbx::launch_wn_start(w.pulse, npulse, c.noise_sigma != 0.f ? noise : nullptr, nsteps, c.noise_sigma, n_frames,
+                             c.steps_per_frame, (int)nsteps, B, c.pulse_channels, find(hd, "wn.start.w")->ptr,
+                             find(hd, "wn.start.b")->ptr, C, w.h, nsteps * C, stream);
+    }
     auto lerp = hd->lerp[c.cond_lin_upsampling];
     const bool fold = hd->fold_skip;
     for (int l = 0; l < L; ++l) {
@@ -632,14 +722,13 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         g.channels = C;
         g.zeros = hd->zeros;
         {
-            ScopedEvents ev(hd, 0, stream);
+            ScopedEvents ev(hd, PROF_GATE, stream);
             bool done = false;
             // F(4,3): 256-row blocks for large launches (>= four rounds of blocks), 128-row blocks whose waves split the
             // input channels below that (finer granularity of the last round).  Streams run F(2,3): a window is
             // bit-identical to an offline result only if both use one form with one group alignment (streaming.py),
             // and F(2,3) needs the shorter alignment; MBX_WINOGRAD=2 makes offline runs use it as well.
             const long long full_blocks = ((nsteps + 255) / 256) * B * ((C + 31) / 32);
-            static const int w4k_env = getenv("MBX_W4K") ? atoi(getenv("MBX_W4K")) : 1;
             const bool use4 = hd->winograd == 4 && !st_in && !st_out;
             const DevTensor *wino4 = use4 ? find(hd, "wn.conv1D_" + ls + ".wino4") : nullptr;
             if (wino4 && wino4->ndim == 3 && wino4->shape[0] == (C + 31) / 32 && wino4->shape[1] == (C + 7) / 8 &&
@@ -647,7 +736,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                 mbx::ConvArgs gw = g;
                 gw.w = wino4->ptr;
                 if (hd->winograd4_always || full_blocks >= 4 * 512) done = mbx::launch_wn_gate_winograd4(gw, stream);
-                else if (w4k_env) done = mbx::launch_wn_gate_winograd4k(gw, stream);
+                else done = mbx::launch_wn_gate_winograd4k(gw, stream);
             }
             const DevTensor *wino = (!done && hd->winograd) ? find(hd, "wn.conv1D_" + ls + ".wino") : nullptr;
             if (wino && wino->ndim == 3 && wino->shape[0] == (C + 31) / 32 && wino->shape[1] == (C + 15) / 16 &&
@@ -676,7 +765,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                 r.skip_ld = c.wn_out_channels;
                 r.hs_bstride = nsteps * C;
                 r.skip_init = (l == 0);
-                ScopedEvents ev(hd, 1, stream);
+                ScopedEvents ev(hd, PROF_RES_SKIP, stream);
                 if (!mbx::launch_wn_resskip(r, stream)) return fail(MBX_ERR_INVALID_ARGUMENT, "folded res/skip layer does not fit its kernel");
             }
             continue;
@@ -692,14 +781,13 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         r.skip_init = (l == 0);
         r.last_layer = last;
         {
-            ScopedEvents ev(hd, 1, stream);
-            // LDS-DMA kernel with host-packed weights (MBX_RS_PACKED=0: generic conv kernel)
-            static const int rs_env = getenv("MBX_RS_PACKED") ? atoi(getenv("MBX_RS_PACKED")) : 1;
+            ScopedEvents ev(hd, PROF_RES_SKIP, stream);
+            // LDS-DMA kernel with host-packed weights
             const DevTensor *pk = find(hd, "wn.res_skip_" + ls + ".packed");
             const int cout_l = last ? C : 2 * C;
             bool done = false;
             if (pk && pk->ndim == 3 && pk->shape[0] == (cout_l + 127) / 128 && pk->shape[1] == (C + 15) / 16 &&
-                pk->shape[2] == 2048 && rs_env != 0) {
+                pk->shape[2] == 2048) {
                 mbx::ConvArgs rp = r;
                 rp.w = pk->ptr;
                 done = mbx::launch_wn_resskip(rp, stream);
@@ -708,9 +796,9 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         }
     }
     {
+        ScopedEvents ev(hd, PROF_TAIL, stream);
         const DevTensor *we = find(hd, "wn.end.w"), *be = find(hd, "wn.end.b"), *wpn = find(hd, "post.w"),
                         *bpn = find(hd, "post.b");
-        static const int tail_env = getenv("MBX_WN_TAIL") ? atoi(getenv("MBX_WN_TAIL")) : 1;
         if (fold) {
             const DevTensor *tw = find(hd, "wn.tail.fold"), *tb = find(hd, "wn.tail.fold_b");
             if (!mbx::launch_wn_tail(w.a, nsteps * C, n_frames, c.steps_per_frame, (int)nsteps, B, C, tw->ptr, tb->ptr,
@@ -719,7 +807,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                 return fail(MBX_ERR_INVALID_ARGUMENT, "folded WaveNet tail does not fit its kernel");
         }
         const DevTensor *wep = find(hd, "wn.end.packed");
-        const bool fused = fold || (tail_env && wep && wep->count == (long long)((C + 7) / 8) * 256 &&
+        const bool fused = fold || (wep && wep->count == (long long)((C + 7) / 8) * 256 &&
             mbx::launch_wn_tail(w.skip, nsteps * C, n_frames, c.steps_per_frame, (int)nsteps, B, C, wep->ptr,
                                 be ? be->ptr : nullptr, c.wn_out_channels, wpn->ptr, bpn ? bpn->ptr : nullptr, M, nullptr,
                                 w.wn_out, nsteps * c.wn_out_channels, w.sub, nsteps * M, stream));
@@ -736,18 +824,34 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         }
     }
     // ---- PQMF synthesis (reference :920-921)
-    mbx::launch_pqmf(w.sub, nsteps * M, n_frames, c.steps_per_frame, (int)nsteps, B, M, hd->poly, hd->poly_ndm,
-                     hd->poly_dm_min, w.exc, (long long)T * c.hop_size, stream);
+    {
+        ScopedEvents ev(hd, PROF_PQMF, stream);
+        mbx::launch_pqmf(w.sub, nsteps * M, n_frames, c.steps_per_frame, (int)nsteps, B, M, hd->poly, hd->poly_ndm,
+                         hd->poly_dm_min, w.exc, (long long)T * c.hop_size, stream);
+    }
     // ---- STFT-domain filtering with the spectral envelope (reference :681-724, 801-855)
     // (the lifter row of a frame is selected from the F0 contour inside the kernel, reference :507-525)
-    mbx::launch_stft_filter(sc, w.exc, (long long)T * c.hop_size, w.ceps, (long long)T * c.n_ceps, nullptr,
-                            c.n_ceps_windows ? w.f0 : nullptr, npulse, c.n_ceps_windows ? w.ceps_index : nullptr, n_frames,
-                            T, B, w.frames, stream);
-    mbx::launch_overlap_add(sc, w.frames, n_frames, T, B, audio, (long long)T * c.hop_size, stream);
+    {
+        ScopedEvents ev(hd, PROF_STFT_FILTER, stream);
+        mbx::launch_stft_filter(sc, w.exc, (long long)T * c.hop_size, w.ceps, (long long)T * c.n_ceps, nullptr,
+                                c.n_ceps_windows ? w.f0 : nullptr, npulse, c.n_ceps_windows ? w.ceps_index : nullptr,
+                                n_frames, T, B, w.frames, stream);
+    }
+    {
+        ScopedEvents ev(hd, PROF_OVERLAP_ADD, stream);
+        mbx::launch_overlap_add(sc, w.frames, n_frames, T, B, audio, (long long)T * c.hop_size, stream);
+    }
+    if (nm_gain_src) {
+        ScopedEvents ev(hd, PROF_NORM_MEL, stream);
+        mbx::launch_norm_mel_gain(norm_mel_consts(hd), nm_gain_src, n_frames, T, B, audio, (long long)T * c.hop_size,
+                                  false, stream);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MBX_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
 
     auto &sg = hd->stages;
+    if (nm_gain_src) sg["mel_norm"] = {w.mel_norm, (long long)T * c.mel_channels, (long long)T * c.mel_channels};
+    else sg.erase("mel_norm");
     sg["f0"] = {w.f0, npulse, npulse};
     sg["pulse"] = {w.pulse, npulse, npulse};
     sg["cond"] = {w.cond, (long long)T * cond_cout, (long long)T * cond_cout};
@@ -800,10 +904,10 @@ mbx_status mbx_profile_enable(mbx_handle *handle, int32_t enabled) {
 
 mbx_status mbx_profile_read(mbx_handle *handle, const char *kernel, double *total_ms, int64_t *launches) {
     if (!handle || !kernel || !total_ms || !launches) return fail(MBX_ERR_INVALID_ARGUMENT, "null argument");
-    int kind;
-    if (std::strcmp(kernel, "gate") == 0) kind = 0;
-    else if (std::strcmp(kernel, "res_skip") == 0) kind = 1;
-    else return fail(MBX_ERR_INVALID_ARGUMENT, "kernel must be gate or res_skip");
+    int kind = -1;
+    for (int k = 0; k < PROF_KINDS; ++k)
+        if (std::strcmp(kernel, kProfNames[k]) == 0) kind = k;
+    if (kind < 0) return fail(MBX_ERR_INVALID_ARGUMENT, std::string("unknown profile stage ") + kernel);
     double sum = 0.0;
     for (size_t i = 0; i < handle->ev_used[kind]; ++i) {
         auto &pr = handle->ev_pool[kind][i];
@@ -832,6 +936,7 @@ mbx_status mbx_stage(const mbx_handle *handle, const char *name, const void **de
 mbx_status mbx_pqmf_synthesis(mbx_handle *hd, const float *x, int32_t batch, int32_t n_steps, float *y,
                               void *hip_stream) {
     if (!hd || !x || !y || batch <= 0 || n_steps <= 0) return fail(MBX_ERR_INVALID_ARGUMENT, "bad argument");
+    DeviceGuard guard(hd->device);
     const int M = hd->cfg.subbands;
     mbx::launch_pqmf(x, (long long)n_steps * M, nullptr, 1, n_steps, batch, M, hd->poly, hd->poly_ndm,
                      hd->poly_dm_min, y, (long long)n_steps * M, static_cast<hipStream_t>(hip_stream));
@@ -845,6 +950,7 @@ mbx_status mbx_conv1d(mbx_handle *hd, const float *x, int32_t batch, int32_t n_r
     if (!hd || !x || !w || !y || batch <= 0 || n_rows <= 0 || cin <= 0 || cout <= 0 || ks <= 0 || dilation <= 0)
         return fail(MBX_ERR_INVALID_ARGUMENT, "bad argument");
     if (pad_mode < MBX_PAD_ZERO || pad_mode > MBX_PAD_EDGE) return fail(MBX_ERR_INVALID_ARGUMENT, "bad pad_mode");
+    DeviceGuard guard(hd->device);
     DevTensor wt, bt;
     wt.ptr = const_cast<float *>(w);
     bt.ptr = const_cast<float *>(b);
@@ -859,6 +965,7 @@ mbx_status mbx_conv1d(mbx_handle *hd, const float *x, int32_t batch, int32_t n_r
 mbx_status mbx_lin_interp(mbx_handle *hd, const float *x, int32_t batch, int32_t n_rows, int32_t channels, int32_t up,
                           float *y, void *hip_stream) {
     if (!hd || !x || !y || batch <= 0 || n_rows <= 0 || channels <= 0) return fail(MBX_ERR_INVALID_ARGUMENT, "bad argument");
+    DeviceGuard guard(hd->device);
     auto it = hd->lerp.find(up);
     if (it == hd->lerp.end()) return fail(MBX_ERR_INVALID_ARGUMENT, "interpolation factor not part of this model");
     mbx::launch_lin_interp(x, (long long)n_rows * channels, nullptr, 1, n_rows, batch, channels, up, it->second.first,
@@ -871,6 +978,7 @@ mbx_status mbx_lin_interp(mbx_handle *hd, const float *x, int32_t batch, int32_t
 mbx_status mbx_wavetable(mbx_handle *hd, const float *f0, int32_t batch, int32_t n, float *pulse, float *phase,
                          float *scratch, void *hip_stream) {
     if (!hd || !f0 || !pulse || !scratch || batch <= 0 || n <= 0) return fail(MBX_ERR_INVALID_ARGUMENT, "bad argument");
+    DeviceGuard guard(hd->device);
     float *cum = scratch;
     float *chunk_last = scratch + (size_t)batch * n;
     mbx::launch_wavetable(wavetable_consts(hd), f0, n, nullptr, 1, n, batch, pulse, phase, cum, chunk_last, nullptr,
@@ -879,10 +987,28 @@ mbx_status mbx_wavetable(mbx_handle *hd, const float *f0, int32_t batch, int32_t
     return e == hipSuccess ? MBX_OK : fail(MBX_ERR_HIP, hipGetErrorString(e));
 }
 
+mbx_status mbx_norm_mel(mbx_handle *hd, const float *mel, const int32_t *n_frames, int32_t batch, int32_t frames,
+                        float *mel_out, float *gain, float *scratch, void *hip_stream) {
+    if (!hd || !mel || !mel_out || !scratch || batch <= 0 || frames <= 0)
+        return fail(MBX_ERR_INVALID_ARGUMENT, "bad argument");
+    if (hd->cfg.nm_iters <= 0) return fail(MBX_ERR_INVALID_ARGUMENT, "this model has no RMS normalisation (nm_iters == 0)");
+    DeviceGuard guard(hd->device);
+    const mbx_config &c = hd->cfg;
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    mbx::NormMelConsts k = norm_mel_consts(hd);
+    const float *src = mbx::launch_norm_mel(k, mel, (long long)frames * c.mel_channels, n_frames, frames, batch, scratch,
+                                            scratch + (size_t)batch * frames, mel_out, stream);
+    if (gain)
+        mbx::launch_norm_mel_gain(k, src, n_frames, frames, batch, gain, (long long)frames * c.hop_size, true, stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MBX_OK : fail(MBX_ERR_HIP, hipGetErrorString(e));
+}
+
 mbx_status mbx_stft_filter(mbx_handle *hd, const float *excitation, const float *cepstrum, const int32_t *ceps_index,
                            int32_t batch, int32_t frames, float *audio, float *scratch, void *hip_stream) {
     if (!hd || !excitation || !cepstrum || !audio || !scratch || batch <= 0 || frames <= 0)
         return fail(MBX_ERR_INVALID_ARGUMENT, "bad argument");
+    DeviceGuard guard(hd->device);
     const mbx_config &c = hd->cfg;
     mbx::StftConsts sc = stft_consts(hd);
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);

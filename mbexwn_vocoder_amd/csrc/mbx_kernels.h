@@ -53,8 +53,6 @@ struct ConvArgs {
     int remap, n_tiles, m_tiles_per_item, m_tiles_total;   // XCD-aware 1-D grid (set by the launcher)
     const float *zeros;       // >= 16 bytes of zeros in global memory (LDS-DMA source of padding lanes)
     int fast_dma;             // set by the launcher: 32-bit source offsets are safe (LDS-DMA with a uniform base)
-    int ablate;               // timing experiments of the Winograd kernels only (MBX_WG_ABLATE): bit0 no LDS-DMA after the
-                              // first slices, bit1 no barrier, bit2 no epilogue -- results are wrong when set
 };
 
 void launch_conv1d(const ConvArgs &a, int epilogue, hipStream_t stream);
@@ -146,5 +144,24 @@ void launch_stft_filter(const StftConsts &c, const float *exc, long long exc_bst
 // overlap-add of the windowed frames + slice -> audio (B, max_frames*hop), tail zeroed
 void launch_overlap_add(const StftConsts &c, const float *frames, const int *n_frames, int max_frames, int batch,
                         float *audio, long long audio_bstride, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// optional RMS normalisation of the mel input / de-normalisation of the audio (norm_mel.hip)
+// ---------------------------------------------------------------------------------------------
+struct NormMelConsts {
+    int iters, mel_channels, hop, win, smooth_win, cut;    // cut = smooth_win/2 + 2 hop - win/2
+    float rms_norm_fact, rms_floor, compressor_exp, lin_amp_scale, lin_amp_off, mel_amp_scale;
+    int use_compressor, use_max_limit;
+    const float *inv_enorm;          // (mel_channels)
+    const float *gwin;               // (win) unit-sum analysis window
+    const float *smooth_win_table;   // (smooth_win)
+};
+// returns the (B, Tmax) buffer the output gain is built from (pass it to launch_norm_mel_gain)
+const float *launch_norm_mel(const NormMelConsts &c, const float *mell, long long mel_bstride, const int *n_frames,
+                             int max_frames, int batch, float *rms_a, float *rms_b, float *mell_out,
+                             hipStream_t stream);
+// audio *= gain (overwrite: audio = gain), gain = max(gain[win/2 + n], eps) of the last smoothing pass
+void launch_norm_mel_gain(const NormMelConsts &c, const float *r_last, const int *n_frames, int max_frames, int batch,
+                          float *audio, long long audio_bstride, bool overwrite, hipStream_t stream);
 
 }  // namespace mbx

@@ -244,23 +244,18 @@ bool launch_wn_resskip(const ConvArgs &a, hipStream_t stream) {
                     (a.skip_ld ? a.cout <= a.channels + a.skip_ld : a.cout == (a.last_layer ? a.channels : 2 * a.channels));
     if (!ok) return false;
     ConvArgs r = a;
-    static const int fast_env = getenv("MBX_W4_FAST_DMA") ? atoi(getenv("MBX_W4_FAST_DMA")) : 1;
-    r.fast_dma = fast_env && (long long)a.max_rows * a.ldx * 4 < (1LL << 32);
-    static const int small_env = getenv("MBX_RS_SMALL") ? atoi(getenv("MBX_RS_SMALL")) : -1;   // -1 auto, 0 never, 1 always
+    r.fast_dma = (long long)a.max_rows * a.ldx * 4 < (1LL << 32);
     r.n_tiles = (a.cout + 127) / 128;
     // 64-row blocks while the 128-row grid is less than three rounds of the 768 resident blocks (3 per CU x 256 CUs)
     const long long big_blocks = (long long)((a.max_rows + 127) / 128) * a.batch * r.n_tiles;
-    const bool small = small_env < 0 ? big_blocks < 3 * 768 : small_env != 0;
+    const bool small = big_blocks < 3 * 768;
     const int tile_rows = small ? 64 : 128;
     r.m_tiles_per_item = (a.max_rows + tile_rows - 1) / tile_rows;
     r.m_tiles_total = r.m_tiles_per_item * a.batch;
     const long long blocks = 8LL * ((r.m_tiles_total + 7) / 8) * r.n_tiles;
-    static const int nst_env = getenv("MBX_RS_STAGES") ? atoi(getenv("MBX_RS_STAGES")) : 0;    // tuning experiments
-    const int nst = nst_env ? nst_env : (small ? 2 : 3);     // measured: 3 stages -4% at batch 16, nothing at batch 1
-    if (small && nst == 3) hipLaunchKernelGGL((wn_resskip_kernel<1, 3>), dim3((unsigned)blocks), dim3(256), 0, stream, r);
-    else if (small) hipLaunchKernelGGL((wn_resskip_kernel<1, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, r);
-    else if (nst == 3) hipLaunchKernelGGL((wn_resskip_kernel<2, 3>), dim3((unsigned)blocks), dim3(256), 0, stream, r);
-    else hipLaunchKernelGGL((wn_resskip_kernel<2, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, r);
+    // stages: three for the large shape (measured -4 % at batch 16), two for the small one (no difference at batch 1)
+    if (small) hipLaunchKernelGGL((wn_resskip_kernel<1, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, r);
+    else hipLaunchKernelGGL((wn_resskip_kernel<2, 3>), dim3((unsigned)blocks), dim3(256), 0, stream, r);
     return true;
 }
 

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256, NS == 1 ? 2 : 3) void wn_gate_winograd_kernel(
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (nk > 1 && !(p.ablate & 1)) issue(1, 1);
+    if (nk > 1) issue(1, 1);
     load_x(0, 0, X[0]);
     load_b(0, 0, Bv[0]);
     for (int kt = 0; kt < nk; ++kt) {
@@ -224,9 +224,9 @@ __global__ __launch_bounds__(256, NS == 1 ? 2 : 3) void wn_gate_winograd_kernel(
                 if (gi == NG / 2 - 1) load_x(buf, 1, X[1]);
             } else if (kt + 1 < nk) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (!(p.ablate & 2)) __syncthreads();
+                __syncthreads();
                 if (kt + 2 < nk) {
-                    if (!(p.ablate & 1)) issue(kt + 2, buf);
+                    issue(kt + 2, buf);
                 } else {
                     issue_cond(buf);
                 }
@@ -261,15 +261,6 @@ __global__ __launch_bounds__(256, NS == 1 ? 2 : 3) void wn_gate_winograd_kernel(
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (p.ablate & 4) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) sacc += acc[j][0][r] + acc[j][NT - 1][r];
-        if (sacc == 1.2345f) p.out[0] = sacc;
-        return;
-    }
     const float inv_up = 1.0f / (float)cond_up;
     const float *cl = lds + cbuf * A_FLOATS;
     float *obase = p.out + (long long)b * p.out_bstride;
@@ -339,15 +330,11 @@ bool launch_wn_gate_winograd(const ConvArgs &a, const float *w_split, hipStream_
                     256 / a.cond_up + 2 <= 32 && a.max_rows < (1 << 24);
     if (!ok) return false;
     ConvArgs r = a;
-    static const int fast_env = getenv("MBX_W4_FAST_DMA") ? atoi(getenv("MBX_W4_FAST_DMA")) : 1;
-    r.fast_dma = fast_env && (long long)a.max_rows * a.ldx * 4 < (1LL << 32);
-    static const int ablate = getenv("MBX_WG_ABLATE") ? atoi(getenv("MBX_WG_ABLATE")) : 0;   // timing experiments only
-    static const int split_env = getenv("MBX_WG_SPLIT") ? atoi(getenv("MBX_WG_SPLIT")) : -1; // -1 auto, 0 never, 1 always
-    r.ablate = ablate;
+    r.fast_dma = (long long)a.max_rows * a.ldx * 4 < (1LL << 32);
     r.n_tiles = (a.channels + 31) / 32;
     // half-size tiles while the full-size grid is less than four rounds of the 512 resident blocks (2 per CU x 256 CUs)
     const long long full_blocks = (long long)((a.max_rows + 255) / 256) * a.batch * r.n_tiles;
-    const bool split = w_split && (uintptr_t)w_split % 16 == 0 && (split_env < 0 ? full_blocks < 4 * 512 : split_env != 0);
+    const bool split = w_split && (uintptr_t)w_split % 16 == 0 && full_blocks < 4 * 512;
     const int tile_rows = split ? 128 : 256;
     r.m_tiles_per_item = (a.max_rows + tile_rows - 1) / tile_rows;
     r.m_tiles_total = r.m_tiles_per_item * a.batch;

@@ -294,15 +294,6 @@ __global__ __launch_bounds__(256, 2) void wn_gate_winograd4_kernel(ConvArgs p, i
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (p.ablate & 4) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) sacc += acc[j][r];
-        if (sacc == 1.2345f) p.out[0] = sacc;
-        return;
-    }
     const float inv_up = 1.0f / (float)cond_up;
     const float *cl = lds + cstage * W4_STAGE;
     float *obase = p.out + (long long)b * p.out_bstride;
@@ -354,10 +345,7 @@ bool launch_wn_gate_winograd4(const ConvArgs &a, hipStream_t stream) {
                     W4_ROWS / a.cond_up + 2 <= 32 && a.max_rows < (1 << 24);
     if (!ok) return false;
     ConvArgs r = a;
-    static const int fast_env = getenv("MBX_W4_FAST_DMA") ? atoi(getenv("MBX_W4_FAST_DMA")) : 1;
-    r.fast_dma = fast_env && (long long)a.max_rows * a.ldx * 4 < (1LL << 32);
-    static const int ablate = getenv("MBX_WG_ABLATE") ? atoi(getenv("MBX_WG_ABLATE")) : 0;   // timing experiments only
-    r.ablate = ablate;
+    r.fast_dma = (long long)a.max_rows * a.ldx * 4 < (1LL << 32);
     r.n_tiles = (a.channels + 31) / 32;
     r.m_tiles_per_item = (a.max_rows + W4_ROWS - 1) / W4_ROWS;
     r.m_tiles_total = r.m_tiles_per_item * a.batch;

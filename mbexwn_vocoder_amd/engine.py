@@ -19,7 +19,7 @@ from .config import ModelDims
 from .subnet import build_subnet
 from .weights import fold_weights
 
-MBX_ABI_VERSION = 1
+MBX_ABI_VERSION = 2
 MBX_MAX_SUBNET_OPS = 32
 MBX_MAX_WN_LAYERS = 64
 MBX_NAME_LEN = 64
@@ -55,7 +55,12 @@ class mbx_config(ctypes.Structure):
                 ("wt_max_transposition", ctypes.c_float), ("wt_grid_norm", ctypes.c_float),
                 ("phase_chunk", ctypes.c_int32),
                 ("n_f0_ops", ctypes.c_int32), ("f0_ops", mbx_subnet_op * MBX_MAX_SUBNET_OPS),
-                ("n_vtf_ops", ctypes.c_int32), ("vtf_ops", mbx_subnet_op * MBX_MAX_SUBNET_OPS)]
+                ("n_vtf_ops", ctypes.c_int32), ("vtf_ops", mbx_subnet_op * MBX_MAX_SUBNET_OPS),
+                ("nm_iters", ctypes.c_int32), ("nm_smooth_win", ctypes.c_int32), ("nm_use_compressor", ctypes.c_int32),
+                ("nm_use_max_limit", ctypes.c_int32), ("nm_rms_norm_fact", ctypes.c_float),
+                ("nm_rms_floor", ctypes.c_float), ("nm_compressor_exp", ctypes.c_float),
+                ("nm_lin_amp_scale", ctypes.c_float), ("nm_lin_amp_off", ctypes.c_float),
+                ("nm_mel_amp_scale", ctypes.c_float)]
 
 
 class mbx_forward_options(ctypes.Structure):
@@ -119,13 +124,15 @@ def load_library():
     lib.mbx_wavetable.argtypes = [vp, fp, i32, i32, fp, fp, fp, vp]
     lib.mbx_stft_filter.restype = i32
     lib.mbx_stft_filter.argtypes = [vp, fp, fp, vp, i32, i32, fp, fp, vp]
+    lib.mbx_norm_mel.restype = i32
+    lib.mbx_norm_mel.argtypes = [vp, fp, vp, i32, i32, fp, fp, fp, vp]
     _lib = lib
     return lib
 
 
 EXPORTED_SYMBOLS = ["mbx_last_error", "mbx_create", "mbx_destroy", "mbx_workspace_size", "mbx_forward",
                     "mbx_forward_stream", "mbx_forward_ex", "mbx_stage",
-                    "mbx_profile_enable", "mbx_profile_read", "mbx_pqmf_synthesis", "mbx_conv1d", "mbx_lin_interp", "mbx_wavetable", "mbx_stft_filter"]
+                    "mbx_profile_enable", "mbx_profile_read", "mbx_pqmf_synthesis", "mbx_conv1d", "mbx_lin_interp", "mbx_wavetable", "mbx_stft_filter", "mbx_norm_mel"]
 
 
 def _check(status):
@@ -211,6 +218,19 @@ def make_config(config, wavetables):
     f0_ops, vtf_ops = subnet_ops(config)
     cc.n_f0_ops = _fill_ops(cc.f0_ops, f0_ops)
     cc.n_vtf_ops = _fill_ops(cc.vtf_ops, vtf_ops)
+    if mb.get("normalize_rms_from_mell", False):                     # row A14 (reference wavegen_1d.py:93-104)
+        from .norm_mel import NormMel
+        nm = NormMel(config)
+        if nm.win != dims.stft_win:
+            raise RuntimeError("normalize_rms_from_mell: preprocess win_size must equal the generator's STFT window")
+        cc.nm_iters, cc.nm_smooth_win = nm.iters, nm.smooth_win_size
+        cc.nm_use_compressor = int(nm.compressor_exp is not None)
+        cc.nm_use_max_limit = int(nm.use_max_limit)
+        cc.nm_rms_norm_fact = float(nm.rms_norm_fact)
+        cc.nm_rms_floor = float(1.0 / nm.max_norm_fact) if nm.max_norm_fact else 0.0
+        cc.nm_compressor_exp = float(nm.compressor_exp) if nm.compressor_exp is not None else 1.0
+        cc.nm_lin_amp_scale, cc.nm_lin_amp_off = float(nm.lin_amp_scale), float(nm.lin_amp_off)
+        cc.nm_mel_amp_scale = float(nm.mel_amp_scale)
     return cc, dims
 
 
@@ -363,6 +383,12 @@ def tensor_table(config, raw_weights, wavetables):
         out["table.ceps_windows"] = rows
         out["table.ceps_log10f0"] = logs
         out["table.f0_smooth"] = tb.f0_smoothing_kernel(dims.hop_size)
+    if mb.get("normalize_rms_from_mell", False):
+        from .norm_mel import NormMel
+        nm = NormMel(config)
+        out["table.nm_inv_enorm"] = nm.inv_enorm
+        out["table.nm_gwin"] = nm.gwin
+        out["table.nm_smooth_win"] = nm.smooth_syn_win
     return {kk: np.ascontiguousarray(vv, dtype=np.float32) for kk, vv in out.items()}
 
 
@@ -387,10 +413,7 @@ class MBExWNEngine:
         self.wavetables = wavetables
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         cconf, self.dims = make_config(config, wavetables)
-        self.norm_mel = None
-        if config["mbexwn_config"].get("normalize_rms_from_mell", False):
-            from .norm_mel import NormMel
-            self.norm_mel = NormMel(config)
+        self.normalizes_rms = cconf.nm_iters > 0            # row A14: done on the device inside mbx_forward
         self._tensors = tensor_table(config, raw_weights, wavetables)   # keep the host arrays alive
         if not weight_images:
             self._tensors = {kk: vv for kk, vv in self._tensors.items()
@@ -516,7 +539,7 @@ class MBExWNEngine:
         full_blocks = ((rows + 255) // 256) * batch * ((self.dims.wn_channels + 31) // 32)
         if mode == 44 or full_blocks >= 4 * 512:
             return "winograd_f43"
-        return "winograd_f43_small" if os.environ.get("MBX_W4K", "1") != "0" else "winograd_f23"
+        return "winograd_f43_small"
 
     def stage(self, name):
         """Intermediate tensor of the last forward (copy), shaped (B, count); see mbx_stage."""
@@ -531,69 +554,83 @@ class MBExWNEngine:
         flat = ws[offset: offset + B * stride.value * 4].view(dtype)
         return flat.view(B, stride.value)[:, :cnt.value].clone()
 
-    def infer(self, spect, sigma=None, z_in=None, synth_length=0, F0=None, return_F0=False, return_components=False,
-              training=False, test_grad=None, noise=None, **_):
-        """Keras-model look-alike of PaNWaveNet.infer (reference wavegen_1d.py:483-526):
-        spect numpy/torch (B,T,80) -> tensor with .numpy() of shape (B, synth_length).
-
-        ``sigma`` and ``z_in`` are accepted and unused, as in the reference.  ``F0`` (Hz at the pulse rate) replaces the
-        F0-net output (reference custom_pulsed_generator.py:773-791).  The training / gradient-test switches and the
-        component outputs of this call are outside the inference path: use :meth:`infer_components` for F0,
-        excitation and spectral envelope."""
-        if return_F0 or return_components or training or test_grad is not None:
-            raise NotImplementedError("infer(): return_F0 / return_components / training / test_grad are not part of the "
-                                      "mel-inversion path; infer_components() returns F0, excitation and envelope")
-        if F0 is not None:
-            gain = self.infer_components(spect, synth_length=synth_length, F0=F0, noise=noise)[3]
-            audio = self.last_audio
-            if gain is not None:                                     # reference wavegen_1d.py:506-507
-                audio = audio * self._torch.as_tensor(gain, device=self.device)
-            return _HostTensor(audio)
+    def _prepare(self, spect, synth_length, noise):
+        """Common front of infer / infer_components: device mel (last frame repeated when the mel is shorter than
+        synth_length, reference wavegen_1d.py:490-491, 537-538) and the noise draw."""
         torch = self._torch
         mel = torch.as_tensor(np.asarray(spect, dtype=np.float32) if not torch.is_tensor(spect) else spect)
         mel = mel.to(self.device, torch.float32)
-        hop = self.dims.hop_size
-        synth_length = int(synth_length) if synth_length else mel.shape[1] * hop
-        if mel.shape[1] * hop < synth_length:                        # reference wavegen_1d.py:490-491
+        if mel.shape[1] * self.dims.hop_size < synth_length:
             mel = torch.cat((mel, mel[:, -1:]), dim=1)
-        gain = None
-        if self.norm_mel is not None:                                # reference wavegen_1d.py:493-495 (row A14)
-            mel_n, gain = self.norm_mel.normalize(mel.cpu().numpy(), synth_length)
-            mel = torch.as_tensor(mel_n, device=self.device)
+        mel = mel.contiguous()
         if noise is None and self.dims.noise_sigma:
             # the reference draws tf.random.normal here (custom_pulsed_generator.py:905-906)
             noise = torch.randn((mel.shape[0], mel.shape[1] * self.dims.steps_per_frame), device=self.device,
                                 dtype=torch.float32)
         elif noise is not None:
-            noise = torch.as_tensor(noise).to(self.device, torch.float32)
-        audio = self.forward(mel, noise=noise)[:, :synth_length]
-        if gain is not None:                                         # reference wavegen_1d.py:506-507
-            audio = audio * torch.as_tensor(gain, device=self.device)
-        return _HostTensor(audio)
+            noise = torch.as_tensor(noise).to(self.device, torch.float32).contiguous()
+        return mel, noise
+
+    def _envelope(self, B, T):
+        """Spectral envelope (B, T, fft/2+1) complex64 of the last forward, rebuilt on the host from its cepstrum stage
+        (reference custom_pulsed_generator.py:801-855): lifter row, one-sided cepstrum -> rfft -> exp(R tanh(Re) + j Im)."""
+        ceps = self.stage("cepstrum").cpu().numpy().reshape(B, T, self.dims.n_ceps)
+        if "table.ceps_windows" in self._tensors:
+            idx = self.stage("ceps_index").cpu().numpy()
+            ceps = ceps * self._tensors["table.ceps_windows"][idx]
+        full = np.zeros((B, T, self.dims.fft_size), dtype=np.float32)
+        full[:, :, 1:self.dims.n_ceps] = ceps[:, :, 1:]
+        spec = np.fft.rfft(full, axis=-1)
+        rng = self.dims.filter_max_log_range
+        env = np.exp(rng * np.tanh(spec.real) + 1j * spec.imag) if rng else np.exp(spec)
+        return env.astype(np.complex64)
+
+    def infer(self, spect, sigma=None, z_in=None, synth_length=0, F0=None, return_F0=False, return_components=False,
+              training=False, test_grad=None, noise=None, **_):
+        """Keras-model look-alike of PaNWaveNet.infer (reference wavegen_1d.py:483-526):
+        spect numpy/torch (B,T,80) -> tensor with .numpy() of shape (B, synth_length).
+
+        As in the reference: ``sigma`` and ``z_in`` are unused; ``F0`` is only used by the training branch of
+        ``MBExWN.call`` (custom_pulsed_generator.py:640-663: at inference ``pulse_frequency_ = pulse_frequency``), so it is
+        ignored here -- :meth:`infer_components` is the F0-injection path; ``synth_length = 0`` means the model's
+        ``segment_length`` (wavegen_1d.py:489).  ``return_F0`` adds the parameter list
+        ``[["F0", .], ["PSig", excitation], ["PS", |envelope|]]`` (custom_pulsed_generator.py:756-767, every entry cut to
+        ``[:, :synth_length]`` as wavegen_1d.py:512-515 does), ``return_components`` returns the list of signals.
+        ``noise`` (B, T*steps_per_frame) is this build's explicit N(0,1) draw of the noise channel."""
+        if training or test_grad is not None:
+            raise NotImplementedError("infer(): training / test_grad belong to the training graph, not to the "
+                                      "mel-inversion path")
+        synth_length = int(synth_length) if synth_length else int(self.dims.segment_length)
+        mel, noise = self._prepare(spect, synth_length, noise)
+        # the optional RMS normalisation of the mel input and the matching output gain (reference
+        # wavegen_1d.py:493-495, 506-507, row A14) run inside mbx_forward
+        audio = self.forward(mel, noise=noise)
+        signals = [_HostTensor(audio[:, :synth_length])]
+        if not return_F0:
+            return signals if return_components else signals[0]
+        B, T = int(mel.shape[0]), int(mel.shape[1])
+        rate = int(self.dims.sample_rate // self.dims.pulse_rate)
+        f0 = self.stage("f0")[:, :audio.shape[1]:rate]               # the reference's own slice (:757)
+        params = [["F0", _HostTensor(f0[:, :synth_length])],
+                  ["PSig", _HostTensor(self.stage("excitation")[:, :audio.shape[1]][:, :synth_length])],
+                  ["PS", np.abs(self._envelope(B, T))[:, :synth_length]]]
+        return (signals, params) if return_components else (signals[0], params)
 
     def infer_components(self, spect, synth_length=0, F0=None, transposition_factor=None, noise=None):
         """PaNWaveNet.infer_components (reference wavegen_1d.py:528-557): returns
-        (F0 (B, T*pulse_per_frame), excitation (B, T*hop), spectral envelope complex (B, T, fft/2+1), upsampled_rms)
-        as numpy arrays; ``F0`` may be given (Hz at the pulse rate), ``transposition_factor`` scales it.
-        Additionally the transposed synthesis itself is available as ``self.last_audio`` (device tensor)."""
+        (F0 (B, T*pulse_per_frame), excitation (B, T*hop), spectral envelope complex (B, T, fft/2+1), upsampled_rms or
+        None) as numpy arrays; ``F0`` may be given (Hz at the pulse rate), ``transposition_factor`` scales it.  As in the
+        reference, ``synth_length`` is replaced by ``F0.shape[1]`` when a contour is given and only decides whether the
+        last mel frame is repeated and how long ``upsampled_rms`` is.
+        Additionally the (transposed) synthesis itself is available as ``self.last_audio`` (device tensor)."""
         torch = self._torch
-        mel = torch.as_tensor(np.asarray(spect, dtype=np.float32) if not torch.is_tensor(spect) else spect)
-        mel = mel.to(self.device, torch.float32).contiguous()
+        synth_length = int(synth_length) if F0 is None else int(np.asarray(F0).shape[1])
+        mel, noise = self._prepare(spect, synth_length, noise)
         hop, ppf = self.dims.hop_size, self.dims.pulse_per_frame
-        if F0 is not None:
-            synth_length = int(np.asarray(F0).shape[1]) * self.dims.f0_down_sampling_factor
-        synth_length = int(synth_length) if synth_length else mel.shape[1] * hop
-        if mel.shape[1] * hop < synth_length:
-            mel = torch.cat((mel, mel[:, -1:]), dim=1)
-        gain = None
-        if self.norm_mel is not None:
-            mel_n, gain = self.norm_mel.normalize(mel.cpu().numpy(), synth_length)
-            mel = torch.as_tensor(mel_n, device=self.device)
         B, T = int(mel.shape[0]), int(mel.shape[1])
-        if noise is None and self.dims.noise_sigma:
-            noise = torch.randn((B, T * self.dims.steps_per_frame), device=self.device, dtype=torch.float32)
-        elif noise is not None:
-            noise = torch.as_tensor(noise).to(self.device, torch.float32).contiguous()
+        gain = None
+        if self.normalizes_rms:                                      # 4th output: upsampled_rms (reference :539-542)
+            gain = self.norm_mel_stage(mel)[1][:, :synth_length].cpu().numpy()
         f0_dev = None
         if F0 is not None:
             f0_np = np.zeros((B, T * ppf), dtype=np.float32)
@@ -612,19 +649,10 @@ class MBExWNEngine:
                                         noise.data_ptr() if noise is not None else None, out.data_ptr(), ws.data_ptr(),
                                         need, ctypes.byref(opt), self._stream()))
         self._last_shape = (B, T)
-        self.last_audio = out[:, :synth_length]
+        self.last_audio = out
         f0 = self.stage("f0").cpu().numpy()
-        exc = self.stage("excitation").cpu().numpy()[:, :synth_length]
-        ceps = self.stage("cepstrum").cpu().numpy().reshape(B, T, self.dims.n_ceps)
-        if "table.ceps_windows" in self._tensors:
-            idx = self.stage("ceps_index").cpu().numpy()
-            ceps = ceps * self._tensors["table.ceps_windows"][idx]
-        full = np.zeros((B, T, self.dims.fft_size), dtype=np.float32)
-        full[:, :, 1:self.dims.n_ceps] = ceps[:, :, 1:]
-        spec = np.fft.rfft(full, axis=-1)
-        rng = self.dims.filter_max_log_range
-        env = np.exp(rng * np.tanh(spec.real) + 1j * spec.imag) if rng else np.exp(spec)
-        return f0, exc, env.astype(np.complex64), gain
+        exc = self.stage("excitation").cpu().numpy()
+        return f0, exc, self._envelope(B, T), gain
 
     # -- stage entry points (unit parity tests)
     def pqmf_synthesis(self, x):
@@ -665,6 +693,18 @@ class MBExWNEngine:
         _check(self._lib.mbx_wavetable(self._handle, f0.data_ptr(), B, N, pulse.data_ptr(), phase.data_ptr(),
                                        scratch.data_ptr(), self._stream()))
         return pulse, phase
+
+    def norm_mel_stage(self, mel, n_frames=None):
+        """NormMelComponents.normalize_inputs_by_rms on the device: mel (B,T,80) -> (mel' (B,T,80), gain (B,T*hop))."""
+        torch = self._torch
+        mel = mel.contiguous()
+        B, T = int(mel.shape[0]), int(mel.shape[1])
+        out = torch.empty_like(mel)
+        gain = torch.zeros((B, T * self.dims.hop_size), dtype=torch.float32, device=self.device)
+        scratch = torch.empty(2 * B * T, dtype=torch.float32, device=self.device)
+        _check(self._lib.mbx_norm_mel(self._handle, mel.data_ptr(), n_frames.data_ptr() if n_frames is not None else None,
+                                      B, T, out.data_ptr(), gain.data_ptr(), scratch.data_ptr(), self._stream()))
+        return out, gain
 
     def stft_filter(self, excitation, cepstrum, ceps_index=None):
         torch = self._torch

@@ -41,73 +41,127 @@ def plan_batches(indices, lengths, max_batch=16, max_padded_frames=16 * 1200):
     return batches
 
 
+class ShardResult:
+    """Audio of a sharded run, still where the forward pass left it (device tensors when the engine ran on a GPU).
+
+    ``parts[r]`` is rank r's shard: its utterances (LPT order) packed back to back in one flat float32 tensor
+    (``None`` for ranks whose shard this process does not hold)."""
+
+    def __init__(self, parts, shards, lengths, hop):
+        self.parts, self.shards, self.lengths, self.hop = parts, shards, lengths, hop
+
+    def item(self, index):
+        """Audio of utterance ``index`` as a view of the flat shard (tensor), or None if its shard is not held here."""
+        for rr, ss in enumerate(self.shards):
+            if index in ss:
+                if self.parts[rr] is None:
+                    return None
+                pos = sum(self.lengths[ii] for ii in ss[:ss.index(index)]) * self.hop
+                return self.parts[rr][pos:pos + self.lengths[index] * self.hop]
+        raise KeyError(index)
+
+    def to_list(self):
+        """List of numpy arrays in input order (None where the shard is not held): ONE device->host copy per shard."""
+        result = [None] * len(self.lengths)
+        for rr, ss in enumerate(self.shards):
+            if self.parts[rr] is None:
+                continue
+            data = self.parts[rr].detach().cpu().numpy()
+            pos = 0
+            for ii in ss:
+                nn = self.lengths[ii] * self.hop
+                result[ii] = data[pos:pos + nn].copy()
+                pos += nn
+        return result
+
+
 class ShardedSynthesizer:
     """Runs ``forward_fn`` over this rank's share of a list of utterances and gathers the audio.
 
-    forward_fn(mel (B,Tmax,C) float32 array, n_frames (B,) int32 array, noise (B,Tmax*spf) float32 array or None)
-        -> audio (B, Tmax*hop) array-like (torch tensor on the device or numpy)
+    forward_fn(mel (B,Tmax,C) float32, n_frames (B,) int32, noise (B,Tmax*spf) float32 or None) -> audio (B, Tmax*hop)
+
+    With ``device`` set (a torch device) the padded micro-batches are staged there once (:meth:`stage`), ``forward_fn``
+    receives and returns tensors on that device, the shard is packed on the device and handed to the collective as it
+    is -- RCCL over xGMI for CUDA tensors, no host copy between the forward pass and the gather.  Without ``device``
+    the arguments are numpy arrays (CPU test doubles) and the collective runs on CPU tensors (gloo).
     """
 
     def __init__(self, forward_fn, hop_size, steps_per_frame, rank=0, world_size=1, max_batch=16,
-                 max_padded_frames=16 * 1200):
+                 max_padded_frames=16 * 1200, device=None):
         self.forward_fn = forward_fn
         self.hop = int(hop_size)
         self.spf = int(steps_per_frame)
         self.rank, self.world = int(rank), int(world_size)
         self.max_batch, self.max_padded_frames = max_batch, max_padded_frames
+        self.device = device
 
-    def local_run(self, mels, noises=None):
-        """Process this rank's shard. Returns ({index: audio np.ndarray}, shard index list)."""
+    def stage(self, mels, noises=None):
+        """Partition, pad and (with a device) upload this rank's micro-batches.  Returns the plan for run_staged."""
+        import torch
         lengths = [int(mm.shape[0]) for mm in mels]
-        shard = lpt_partition(lengths, self.world)[self.rank]
-        out = {}
-        for batch in plan_batches(shard, lengths, self.max_batch, self.max_padded_frames):
-            tmax = max(lengths[ii] for ii in batch)
-            mel = np.zeros((len(batch), tmax, mels[batch[0]].shape[1]), dtype=np.float32)
-            noise = None if noises is None else np.zeros((len(batch), tmax * self.spf), dtype=np.float32)
-            nfr = np.asarray([lengths[ii] for ii in batch], dtype=np.int32)
-            for jj, ii in enumerate(batch):
+        shards = lpt_partition(lengths, self.world)
+        batches = []
+        for group in plan_batches(shards[self.rank], lengths, self.max_batch, self.max_padded_frames):
+            tmax = max(lengths[ii] for ii in group)
+            mel = np.zeros((len(group), tmax, mels[group[0]].shape[1]), dtype=np.float32)
+            noise = None if noises is None else np.zeros((len(group), tmax * self.spf), dtype=np.float32)
+            nfr = np.asarray([lengths[ii] for ii in group], dtype=np.int32)
+            for jj, ii in enumerate(group):
                 mel[jj, :lengths[ii]] = mels[ii]
                 if noises is not None:
                     noise[jj, :lengths[ii] * self.spf] = noises[ii]
-            audio = self.forward_fn(mel, nfr, noise)
-            audio = audio.detach().cpu().numpy() if hasattr(audio, "detach") else np.asarray(audio)
-            for jj, ii in enumerate(batch):
-                out[ii] = np.array(audio[jj, :lengths[ii] * self.hop], dtype=np.float32)
-        return out, shard
-
-    def run(self, mels, noises=None, gather="all", device=None):
-        """Returns the list of audio arrays in input order on every rank (gather="all"), on rank 0 only
-        (gather="rank0", other ranks get None) or only the local dict (gather=None)."""
-        local, shard = self.local_run(mels, noises)
-        if gather is None:
-            return local
-        if self.world == 1:
-            return [local[ii] for ii in range(len(mels))]
-        import torch
-        import torch.distributed as dist
-        lengths = [int(mm.shape[0]) for mm in mels]
-        shards = lpt_partition(lengths, self.world)
+            if self.device is not None:
+                mel, nfr = torch.as_tensor(mel, device=self.device), torch.as_tensor(nfr, device=self.device)
+                noise = None if noise is None else torch.as_tensor(noise, device=self.device)
+            batches.append((group, mel, nfr, noise))
         totals = [sum(lengths[ii] for ii in ss) * self.hop for ss in shards]
-        flat = np.concatenate([local[ii] for ii in shard]) if shard else np.zeros((0,), np.float32)
-        assert flat.shape[0] == totals[self.rank]
-        dev = device if device is not None else torch.device("cpu")
-        buf = torch.zeros(max(totals), dtype=torch.float32, device=dev)   # one padded shard per rank
-        buf[:flat.shape[0]] = torch.as_tensor(flat, device=dev)
-        if gather == "rank0":
-            parts = [torch.empty_like(buf) for _ in range(self.world)] if self.rank == 0 else None
-            dist.gather(buf, parts, dst=0)
-            if self.rank != 0:
-                return None
+        dev = self.device if self.device is not None else torch.device("cpu")
+        # one padded flat buffer per rank (all_gather needs equal sizes); reused by every run_staged of this plan
+        flat = torch.zeros(max(totals) if totals else 0, dtype=torch.float32, device=dev)
+        return {"lengths": lengths, "shards": shards, "batches": batches, "totals": totals, "flat": flat, "parts": None}
+
+    def run_staged(self, plan, gather="all"):
+        """Forward passes of this rank's micro-batches + the result gather; everything stays on the plan's device.
+        gather: "all" (every rank gets every shard), "rank0" (rank 0 only) or None (local shard only)."""
+        import torch
+        lengths, shards, flat = plan["lengths"], plan["shards"], plan["flat"]
+        where = {}
+        for group, mel, nfr, noise in plan["batches"]:
+            audio = self.forward_fn(mel, nfr, noise)
+            audio = audio if torch.is_tensor(audio) else torch.as_tensor(np.asarray(audio))
+            for jj, ii in enumerate(group):
+                where[ii] = (audio, jj)
+        pos = 0
+        for ii in shards[self.rank]:                       # pack in shard order (device-side copies, no sync)
+            audio, jj = where[ii]
+            nn = lengths[ii] * self.hop
+            flat[pos:pos + nn] = audio[jj, :nn]
+            pos += nn
+        assert pos == plan["totals"][self.rank]
+        parts = [None] * self.world
+        if self.world == 1 or gather is None:
+            parts[self.rank] = flat[:pos]
         else:
-            parts = [torch.empty_like(buf) for _ in range(self.world)]
-            dist.all_gather(parts, buf)
-        result = [None] * len(mels)
-        for rr, ss in enumerate(shards):
-            data = parts[rr].cpu().numpy()
-            pos = 0
-            for ii in ss:
-                nn = lengths[ii] * self.hop
-                result[ii] = data[pos:pos + nn].copy()
-                pos += nn
-        return result
+            import torch.distributed as dist
+            if plan["parts"] is None:
+                plan["parts"] = [torch.empty_like(flat) for _ in range(self.world)]
+            if gather == "rank0":
+                dist.gather(flat, plan["parts"] if self.rank == 0 else None, dst=0)
+                if self.rank == 0:
+                    parts = [pp[:tt] for pp, tt in zip(plan["parts"], plan["totals"])]
+            else:
+                dist.all_gather(plan["parts"], flat)
+                parts = [pp[:tt] for pp, tt in zip(plan["parts"], plan["totals"])]
+        return ShardResult(parts, shards, lengths, self.hop)
+
+    def run(self, mels, noises=None, gather="all"):
+        """Returns the list of audio arrays in input order on every rank (gather="all"), on rank 0 only
+        (gather="rank0", other ranks get None) or the local dict {index: audio} (gather=None)."""
+        plan = self.stage(mels, noises)
+        res = self.run_staged(plan, gather)
+        if gather is None:
+            listed = res.to_list()
+            return {ii: listed[ii] for ii in plan["shards"][self.rank]}
+        if gather == "rank0" and self.rank != 0:
+            return None
+        return res.to_list()

@@ -84,6 +84,9 @@ class StreamingSynthesizer:
         d_max = max(engine.dims.wn_dilation(ll) for ll in range(engine.dims.wn_layers))
         self.align = (2 * d_max) // math.gcd(2 * d_max, engine.dims.steps_per_frame)
         self.streams = {}
+        self.time_device = False          # bench: bracket the engine call of a tick with events on its stream
+        self.last_tick_device_ms = None
+        self.last_tick_frames = 0         # frames the engine computed in the last tick (all streams)
 
     @property
     def lookahead_ms(self):
@@ -147,9 +150,18 @@ class StreamingSynthesizer:
                                     (nxt - ws) * ppf if nxt < we else -1)
             next_state_frame.append(nxt)
         dev = self.engine.device
-        audio, state_out = self.engine.forward(torch.as_tensor(mel, device=dev), n_frames=torch.as_tensor(nfr, device=dev),
-                                               noise=torch.as_tensor(noise, device=dev) if self.dims.noise_sigma else None,
-                                               stream_state=torch.as_tensor(states, device=dev))
+        mel_d, nfr_d = torch.as_tensor(mel, device=dev), torch.as_tensor(nfr, device=dev)
+        noise_d = torch.as_tensor(noise, device=dev) if self.dims.noise_sigma else None
+        states_d = torch.as_tensor(states, device=dev)
+        self.last_tick_frames = int(nfr.sum())
+        if self.time_device:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        audio, state_out = self.engine.forward(mel_d, n_frames=nfr_d, noise=noise_d, stream_state=states_d)
+        if self.time_device:
+            ev1.record()
+            ev1.synchronize()
+            self.last_tick_device_ms = ev0.elapsed_time(ev1)
         audio = audio.cpu().numpy()
         state_out = state_out.cpu().numpy()
         result = {}

@@ -403,7 +403,11 @@ def write_checkpoint(prefix, variables):
 # ------------------------------------------------------------------------------------------------------
 # Keras names a variable <layer name>/<weight name>.  The reference wraps every convolution in
 # TF2C_Conv1DWeightNorm: the inner Conv1D carries the layer's name and owns `kernel` (the direction v) and `bias`, the
-# wrapper is called <name>_base and owns `g` (tf2_components/layers/conv_layers.py:52-112).  PReLU slopes are `alpha`.
+# wrapper is called <name>_base and owns `g` (tf2_components/layers/conv_layers.py:52-112).  The wrapper builds the inner
+# layer from inside its own build() (conv_layers.py:72-75, tf2c_base_layer.py:34-37), so depending on the Keras name
+# scope in force the inner variables appear as `<name>/kernel` or as `<name>_base/kernel` (and `g` as `<name>_base/g`
+# or `<name>/g`): both spellings are accepted.  PReLU slopes are `alpha`.  NOT verified against a TensorFlow-written
+# checkpoint (none exists in this environment): treat a model loaded this way as unverified until one has been tested.
 # Layer names: sub-nets custom_pulsed_generator.py:100-148, WaveNet custom_AE_layers.py:182-257, post-net :490-493.
 _WAVENET_LAYERS = {"start": "wn.start", "end": "wn.end", "cond_": "wn.cond"}
 
@@ -430,14 +434,13 @@ def map_reference_variables(named_arrays):
         parts = full_name.split(":")[0].split("/")
         leaf = parts[-1]
         target = None
-        if leaf in ("kernel", "bias") and len(parts) >= 2:
-            layer = _engine_layer_name(parts[-2])
+        owner = parts[-2] if len(parts) >= 2 else ""
+        if owner.endswith("_base"):
+            owner = owner[:-len("_base")]
+        if leaf in ("kernel", "bias", "g") and owner:
+            layer = _engine_layer_name(owner)
             if layer:
-                target = f"{layer}.{'v' if leaf == 'kernel' else 'bias'}"
-        elif leaf == "g" and len(parts) >= 2 and parts[-2].endswith("_base"):
-            layer = _engine_layer_name(parts[-2][:-len("_base")])
-            if layer:
-                target = f"{layer}.g"
+                target = layer + "." + ("v" if leaf == "kernel" else leaf)
         elif leaf == "alpha":
             for comp in reversed(parts[:-1]):
                 layer = _engine_layer_name(comp)
@@ -477,6 +480,14 @@ def to_reference_variables(raw, model_scope="mb_ex_wn"):
     return out
 
 
+def _uses_weight_norm(config, layer):
+    """WaveNet layers follow pp_mod_subnet.use_weight_norm (reference custom_AE_layers.py:123 default False); the
+    sub-nets and the post-net are always weight-normed (custom_pulsed_generator.py:100-148, 490-493)."""
+    if layer.startswith("wn."):
+        return bool(config["mbexwn_config"]["pp_mod_subnet"].get("use_weight_norm", False))
+    return True
+
+
 def load_reference_checkpoint(prefix, config=None):
     """Read ``prefix``(.index/.data-*) and return the engine's raw weight dict; with ``config`` the result is checked
     against weights.layer_table (missing tensors / wrong shapes raise)."""
@@ -492,7 +503,9 @@ def load_reference_checkpoint(prefix, config=None):
             for suffix, shape in ((".v", (ks, cin, cout)), (".g", (cout,)), (".bias", (cout,))):
                 got = weights.get(name + suffix)
                 if got is None:
-                    problems.append(f"missing {name}{suffix}")
+                    # a layer built with use_weight_norm=False has no g: its kernel is the weight (weights.fold_weights)
+                    if suffix != ".g" or _uses_weight_norm(config, name):
+                        problems.append(f"missing {name}{suffix}")
                 elif tuple(got.shape) != shape:
                     problems.append(f"{name}{suffix} has shape {tuple(got.shape)}, expected {shape}")
         for name, channels in prelus:

@@ -81,7 +81,10 @@ def fold_weights(raw):
     for key, val in raw.items():
         if key.endswith(".v"):
             name = key[:-2]
-            out[name + ".w"] = fold_weight_norm(val, raw[name + ".g"])
+            if name + ".g" in raw:
+                out[name + ".w"] = fold_weight_norm(val, raw[name + ".g"])
+            else:       # layer built with use_weight_norm=False: the kernel is the weight (reference conv_layers.py:157-165)
+                out[name + ".w"] = np.asarray(val, dtype=np.float32)
             out[name + ".b"] = np.asarray(raw[name + ".bias"], dtype=np.float32)
         elif key.endswith(".alpha"):
             out[key] = np.asarray(val, dtype=np.float32)

@@ -28,7 +28,18 @@ CASES = {
     # name: (voice type, config overrides, batch, frames)
     "small": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3}, 2, 23),
     "canon": ("SPEECH", {}, 1, 12),
+    # long enough for several 1000-sample phase chunks, the chunk-offset chain and F0-dependent lifter rows
+    "canon60": ("SPEECH", {}, 1, 60),
+    # MW-VO-FD geometry: C = 340 (340 % 32 != 0, 340 % 16 = 4: partial column tile, masked staging paths)
+    "voice": ("VOICE", {}, 2, 41),
+    # sub-net grammar variants (reference custom_pulsed_generator.py:57-60, 74-108): sub-pixel convolution with Keras SAME
+    # zero padding, "L<up>" interpolation behind a convolution, bare ["L", up] (total_ups not updated -> the F0-net runs
+    # at 5x the pulse rate and generate_f0 cuts it, :787)
+    "grammar": ("SPEECH", {"mbexwn_config:pp_subnet": [[5, 32, 2], [3, 64, "L2"], ["L", 5]],
+                           "mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3}, 2, 9),
 }
+# the long cases keep the small stage outputs only (the full conditioning / envelope tensors would be megabytes)
+LEAN = {"canon60", "voice", "grammar"}
 
 
 def assign_conv(layer, raw, name):
@@ -114,6 +125,12 @@ def main():
         bundle = {}
         for name, (voice, overrides, batch, frames) in CASES.items():
             res = run_case(voice, overrides, batch, frames, float_type)
+            if name in LEAN:
+                res["cond"] = np.asarray(res["cond"])[:, ::37]
+                for kk in ("envelope_re", "envelope_im", "wavetables"):
+                    res.pop(kk)
+                if tag == "f64":
+                    res = {kk: res[kk] for kk in ("mell", "noise", "f0", "excitation", "audio")}
             for kk, vv in res.items():
                 arr = np.asarray(vv)
                 if arr.dtype == np.float64 and tag == "f32":

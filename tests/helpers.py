@@ -11,7 +11,12 @@ from mbexwn_vocoder_amd.weights import synthetic_weights
 GOLDEN_CASES = {
     "small": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3}, 2, 23),
     "canon": ("SPEECH", {}, 1, 12),
+    "canon60": ("SPEECH", {}, 1, 60),
+    "voice": ("VOICE", {}, 2, 41),
+    "grammar": ("SPEECH", {"mbexwn_config:pp_subnet": [[5, 32, 2], [3, 64, "L2"], ["L", 5]],
+                           "mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3}, 2, 9),
 }
+LEAN_GOLDEN_CASES = {"canon60", "voice", "grammar"}     # cond subsampled [:, ::37], no envelope / wavetables (see the generator)
 
 
 @functools.lru_cache(maxsize=None)

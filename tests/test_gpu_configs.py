@@ -1,0 +1,255 @@
+"""The BASELINE configurations at their real geometry, through the C ABI (task 4):
+
+  config 4  MW-VO-FD (C = 340: 340 % 32 = 20 -> partial column tile, 340 % 16 = 4 -> the masked LDS-DMA staging paths):
+            ragged batch of 16, lengths U[160, 1200] frames, every convolution form
+  config 5  MW-SP-FD (C = 320) streaming: 64 concurrent streams, 8-frame ticks, bit-equal to offline synthesis
+  A2        sub-net grammar variants on the device: sub-pixel conv (Keras SAME zero padding), "L<up>", bare ["L", up]
+  A14       RMS normalisation on the device against the reference-generated goldens
+
+Tolerances as in tests/test_gpu_parity.py: end to end 1e-4 * max(1, max|ref|); bit exact where the arithmetic is the same.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import mbexwn_oracle as orc
+from helpers import GOLDEN_CASES, build_case, synthetic_inputs
+
+pytestmark = pytest.mark.gpu
+
+E2E_TOL = 1e-4
+
+
+def _tol(ref, rel=E2E_TOL):
+    return rel * max(1.0, float(np.max(np.abs(ref))))
+
+
+def _maxdiff(a, b):
+    return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as _torch
+    assert _torch.cuda.is_available(), "GPU tests need an MI355X"
+    return _torch
+
+
+def dev(torch, arr, dtype=None):
+    return torch.as_tensor(np.ascontiguousarray(arr), dtype=dtype or torch.float32).cuda()
+
+
+# ------------------------------------------------------------------------------------------------
+# config 4: VOICE geometry, ragged batch of 16
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def voice_case():
+    cfg, raw, wt = build_case("VOICE", {})
+    rng = np.random.default_rng(44)
+    lengths = [int(vv) for vv in rng.integers(160, 1201, size=16)]
+    lengths[3], lengths[11] = 160, 163                       # two short items for the oracle
+    lengths[7] = 1200                                        # and the longest possible one
+    mel, noise = synthetic_inputs(404, 16, max(lengths))
+    return cfg, raw, wt, lengths, mel, noise
+
+
+@pytest.mark.parametrize("form", ["default", "0", "2", "44"])
+def test_voice_ragged_batch_of_16(torch, monkeypatch, voice_case, form):
+    """Every item of the ragged batch equals its one-at-a-time run: bit for bit when the convolution form is pinned
+    (MBX_WINOGRAD = 0 direct, 2 Winograd F(2,3), 44 Winograd F(4,3) at every size); with the default policy the batch
+    runs the large-launch F(4,3) kernel and a single item the channel-split one (two K halves summed), which agree to
+    float32 rounding: 4e-5 relative to the peak (measured 2.1e-5; each is within 1e-4 of the float64 oracle).
+    The two shortest items are held to the float64 oracle, the longest to the prefix property."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    cfg, raw, wt, lengths, mel, noise = voice_case
+    if form != "default":
+        monkeypatch.setenv("MBX_WINOGRAD", form)
+    else:
+        monkeypatch.delenv("MBX_WINOGRAD", raising=False)
+    eng = MBExWNEngine(cfg, raw, wt)
+    assert eng.dims.wn_channels == 340
+    nf = torch.as_tensor(lengths, dtype=torch.int32).cuda()
+    batch = eng.forward(dev(torch, mel), n_frames=nf, noise=dev(torch, noise)).cpu().numpy()
+    assert np.all(np.isfinite(batch))
+    scale = max(1.0, float(np.abs(batch).max()))
+    for ii, ll in enumerate(lengths):
+        single = eng.forward(dev(torch, mel[ii:ii + 1, :ll]), noise=dev(torch, noise[ii:ii + 1, :ll * 20])).cpu().numpy()[0]
+        if form == "default":
+            assert _maxdiff(batch[ii, :ll * 300], single) <= 4e-5 * scale, f"item {ii}"
+        else:
+            assert np.array_equal(batch[ii, :ll * 300], single), f"item {ii} (form {form}) differs from its single run"
+        assert np.all(batch[ii, ll * 300:] == 0.0)
+    om = orc.OracleModel(cfg, raw, wt)
+    for ii in (3, 11):
+        ll = lengths[ii]
+        ref = om.forward(mel[ii:ii + 1, :ll], noise[ii:ii + 1, :ll * 20])[0]
+        assert _maxdiff(batch[ii, :ll * 300], ref) <= _tol(ref), f"item {ii} vs oracle"
+    # prefix property on the longest item: the first 300 frames do not depend on what follows (finite receptive
+    # field + causal phase), up to the rounding of the launch-size dependent kernel choice
+    cut, margin = 300, 12
+    part = eng.forward(dev(torch, mel[7:8, :cut]), noise=dev(torch, noise[7:8, :cut * 20])).cpu().numpy()[0]
+    keep = (cut - margin) * 300
+    assert _maxdiff(batch[7, :keep], part[:keep]) <= 4e-5 * scale
+
+
+def test_voice_reference_golden(torch, golden_dir):
+    """C = 340, 2 x 41 frames, against the float32 run of the reference's own MBExWN.call."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    gold = np.load(os.path.join(golden_dir, "reference_forward_f32.npz"))
+    voice, overrides, batch, frames = GOLDEN_CASES["voice"]
+    eng = MBExWNEngine(*build_case(voice, overrides))
+    got = eng.forward(dev(torch, gold["voice/mell"]), noise=dev(torch, gold["voice/noise"])).cpu().numpy()
+    assert _maxdiff(got, gold["voice/audio"]) <= _tol(gold["voice/audio"])
+    assert _maxdiff(eng.stage("f0").cpu().numpy(), gold["voice/f0"]) <= 1e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# config 5: canonical model, 64 streams
+# ------------------------------------------------------------------------------------------------
+def test_canonical_streaming_64_streams_bit_equal(torch, monkeypatch):
+    """What `bench.py --workload config5_sp_stream64` times: 64 concurrent streams of the canonical C = 320 model,
+    8-frame ticks.  The concatenated stream output must be bit-equal to the offline synthesis of the same utterance
+    with the same convolution form (streams run Winograd F(2,3); MBX_WINOGRAD=2 pins the offline engine to it)."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    from mbexwn_vocoder_amd.streaming import StreamingSynthesizer
+    monkeypatch.setenv("MBX_WINOGRAD", "2")
+    cfg, raw, wt = build_case("SPEECH", {})
+    eng = MBExWNEngine(cfg, raw, wt)
+    n_streams, chunk = 64, 8
+    rng = np.random.default_rng(5)
+    lengths = [int(vv) for vv in rng.integers(50, 75, size=n_streams)]      # >= 5 ticks each, ragged ends
+    syn = StreamingSynthesizer(eng, chunk_frames=chunk)
+    utts = []
+    for sid, ll in enumerate(lengths):
+        mm, nn = synthetic_inputs(900 + sid, 1, ll)
+        utts.append((mm[0], nn[0]))
+        syn.open(sid)
+    got = {sid: [] for sid in range(n_streams)}
+    pos = [0] * n_streams
+    ticks = 0
+    while not all(syn.finished(sid) for sid in range(n_streams)):
+        for sid, ll in enumerate(lengths):                 # packets of 8 frames arrive, the last one closes the stream
+            if pos[sid] < ll:
+                nn = min(chunk, ll - pos[sid])
+                syn.push(sid, utts[sid][0][pos[sid]:pos[sid] + nn], utts[sid][1][pos[sid] * 20:(pos[sid] + nn) * 20],
+                         last=pos[sid] + nn >= ll)
+                pos[sid] += nn
+        for sid, audio in syn.tick().items():
+            got[sid].append(audio)
+        ticks += 1
+        assert ticks < 200
+    assert ticks >= 5
+    for sid in range(0, n_streams, 1):
+        ll = lengths[sid]
+        offline = eng.forward(dev(torch, utts[sid][0][None]), noise=dev(torch, utts[sid][1][None])).cpu().numpy()[0]
+        stream = np.concatenate(got[sid])
+        assert stream.shape == (ll * 300,)
+        assert np.array_equal(stream, offline), f"stream {sid} is not bit-equal to the offline synthesis"
+
+
+# ------------------------------------------------------------------------------------------------
+# A2: sub-net grammar variants
+# ------------------------------------------------------------------------------------------------
+def test_subnet_grammar_variants_end_to_end(torch, golden_dir):
+    """pp_subnet = [[5,32,2], [3,64,"L2"], ["L",5]] (reference custom_pulsed_generator.py:57-60, 74-108): sub-pixel
+    convolution with SAME zero padding, interpolation behind a convolution, bare interpolation whose factor the
+    reference forgets in total_ups -- the F0-net then runs at 5x the pulse rate and generate_f0 cuts it (:787).
+    Held to the oracle, to a ragged batch, and to the float32 run of the reference's own code."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    voice, overrides, batch, frames = GOLDEN_CASES["grammar"]
+    cfg, raw, wt = build_case(voice, overrides)
+    eng, om = MBExWNEngine(cfg, raw, wt), orc.OracleModel(cfg, raw, wt)
+    mel, noise = synthetic_inputs(12, 3, 21)
+    got = eng.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
+    ref, st = om.forward(mel, noise, return_stages=True)
+    assert _maxdiff(eng.stage("f0").cpu().numpy(), st["f0"]) <= 1e-3
+    assert _maxdiff(got, ref) <= _tol(ref)
+    lengths = [21, 4, 13]
+    nf = torch.as_tensor(lengths, dtype=torch.int32).cuda()
+    rag = eng.forward(dev(torch, mel), n_frames=nf, noise=dev(torch, noise)).cpu().numpy()
+    for ii, ll in enumerate(lengths):
+        single = eng.forward(dev(torch, mel[ii:ii + 1, :ll]), noise=dev(torch, noise[ii:ii + 1, :ll * 20])).cpu().numpy()[0]
+        assert np.array_equal(rag[ii, :ll * 300], single)
+    gold = np.load(os.path.join(golden_dir, "reference_forward_f32.npz"))
+    out = eng.forward(dev(torch, gold["grammar/mell"]), noise=dev(torch, gold["grammar/noise"])).cpu().numpy()
+    assert _maxdiff(eng.stage("f0").cpu().numpy(), gold["grammar/f0"]) <= 1e-3
+    assert _maxdiff(out, gold["grammar/audio"]) <= _tol(gold["grammar/audio"])
+
+
+def test_long_canonical_reference_golden(torch, golden_dir):
+    """60 frames of the canonical model against the float32 run of the reference: six 1000-sample phase chunks (bit
+    exact phase from the reference's own F0), the chunk-offset chain, F0-dependent lifter rows."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    gold = np.load(os.path.join(golden_dir, "reference_forward_f32.npz"))
+    voice, overrides, batch, frames = GOLDEN_CASES["canon60"]
+    eng = MBExWNEngine(*build_case(voice, overrides))
+    got = eng.forward(dev(torch, gold["canon60/mell"]), noise=dev(torch, gold["canon60/noise"])).cpu().numpy()
+    assert _maxdiff(got, gold["canon60/audio"]) <= _tol(gold["canon60/audio"])
+    assert _maxdiff(eng.stage("excitation").cpu().numpy(), gold["canon60/excitation"]) <= _tol(gold["canon60/excitation"])
+    pulse, phase = eng.wavetable(dev(torch, gold["canon60/f0"]))
+    assert np.array_equal(phase.cpu().numpy(), gold["canon60/phase"])
+    assert _maxdiff(pulse.cpu().numpy(), gold["canon60/pulse"]) <= 2e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# A14: RMS normalisation on the device
+# ------------------------------------------------------------------------------------------------
+NORM_CASES = {
+    "iters1": {"normalize_rms_num_smooth_iters": 1},
+    "iters2_comp": {"normalize_rms_num_smooth_iters": 2, "normalize_compressor_exp": 0.8, "max_norm_fact": 200.0},
+    "scaled_win": {"normalize_rms_num_smooth_iters": 1, "normalize_smooth_win_scale": 2,
+                   "normalize_smooth_with_squared_win": False, "lin_amp_scale": 1.5, "mel_amp_scale": 0.5},
+}
+
+
+def _norm_engine(extra):
+    from mbexwn_vocoder_amd.config import canonical_config
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    from mbexwn_vocoder_amd.tables import WaveTables
+    from mbexwn_vocoder_amd.weights import synthetic_weights
+    from mbexwn_vocoder_amd.config import ModelDims
+    cfg = canonical_config("SPEECH", **{"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3})
+    cfg["mbexwn_config"].update(normalize_rms_from_mell=True, **extra)
+    raw = synthetic_weights(cfg, seed=1234, bias_std=0.05, alpha_jitter=0.05)
+    wt = WaveTables(sample_rate=ModelDims(cfg).pulse_rate, **cfg["mbexwn_config"]["wavetable_config"])
+    return cfg, raw, wt, MBExWNEngine(cfg, raw, wt)
+
+
+@pytest.mark.parametrize("case", sorted(NORM_CASES))
+def test_norm_mel_device_vs_reference_goldens(torch, golden_dir, case):
+    """mbx_norm_mel (NormMelComponents.normalize_inputs_by_rms on the device) against the float32 run of the
+    reference's own class (tests/golden/make_reference_normmel.py): normalised log-mel and up-sampled gain."""
+    gold = np.load(os.path.join(golden_dir, "reference_normmel.npz"))
+    cfg, raw, wt, eng = _norm_engine(NORM_CASES[case])
+    mell = gold[f"f32/{case}/mell"]
+    out, gain = eng.norm_mel_stage(dev(torch, mell))
+    np.testing.assert_allclose(out.cpu().numpy(), gold[f"f32/{case}/mell_norm"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(gain.cpu().numpy(), gold[f"f32/{case}/gain"], rtol=2e-5, atol=0)
+    # ragged: the smoothing uses the item's own edges
+    nf = torch.as_tensor([17, 9], dtype=torch.int32).cuda()
+    out_r, gain_r = eng.norm_mel_stage(dev(torch, mell), n_frames=nf)
+    out_s, gain_s = eng.norm_mel_stage(dev(torch, mell[1:2, :9]))
+    assert np.array_equal(out_r.cpu().numpy()[1, :9], out_s.cpu().numpy()[0])
+    assert np.array_equal(gain_r.cpu().numpy()[1, :9 * 300], gain_s.cpu().numpy()[0])
+    assert np.array_equal(out_r.cpu().numpy()[0], out.cpu().numpy()[0])
+
+
+def test_norm_mel_inside_forward_matches_oracle(torch):
+    """A model with normalize_rms_from_mell: mbx_forward normalises the mel on the device, synthesises and multiplies
+    the gain onto the audio (reference wavegen_1d.py:493-507) -- no host round trip; vs the float64 oracle."""
+    cfg, raw, wt, eng = _norm_engine(NORM_CASES["iters2_comp"])
+    assert eng.normalizes_rms
+    om = orc.OracleModel(cfg, raw, wt)
+    mel, noise = synthetic_inputs(8, 2, 19)
+    got = eng.infer(mel, synth_length=19 * 300, noise=noise).numpy()
+    mel_n, gain = orc.normalize_inputs_by_rms(mel, cfg, 19 * 300)
+    ref = om.forward(mel_n.astype(np.float32), noise) * gain
+    assert _maxdiff(eng.stage("mel_norm").cpu().numpy().reshape(2, 19, 80), mel_n) <= 2e-5
+    assert _maxdiff(got, ref) <= _tol(ref)
+    f0, exc, env, rms = eng.infer_components(mel, synth_length=19 * 300, noise=noise)
+    np.testing.assert_allclose(rms, gain, rtol=2e-5)
+    with pytest.raises(NotImplementedError):                # streaming windows cannot carry the smoothing
+        from mbexwn_vocoder_amd.streaming import pack_state
+        st = torch.as_tensor(np.stack([pack_state() for _ in range(2)])).cuda()
+        eng.forward(dev(torch, mel), noise=dev(torch, noise), stream_state=st)

@@ -405,18 +405,37 @@ def test_infer_components_and_transposition(torch):
 
 
 def test_infer_accepts_the_reference_arguments(torch):
-    """PaNWaveNet.infer(spect, sigma, z_in, synth_length, F0, return_F0, ...) (reference wavegen_1d.py:483-484): sigma and
-    z_in are inert as in the reference, F0 replaces the F0-net, the training-side switches raise."""
+    """PaNWaveNet.infer(spect, sigma, z_in, synth_length, F0, return_F0, return_components, ...) (reference
+    wavegen_1d.py:483-526): sigma and z_in are inert; F0 is only used by the training branch of MBExWN.call
+    (custom_pulsed_generator.py:640-663), so at inference it changes nothing; synth_length = 0 means the model's
+    segment_length (:489); return_F0 / return_components add the parameter list / return the list of signals
+    (:512-526, custom_pulsed_generator.py:756-771); the training-side switches raise."""
     eng, om = get_engine("small", *SMALL)[:2]
     mel, noise = synthetic_inputs(31, 1, 9)
     base = eng.infer(mel, synth_length=9 * 300, noise=noise).numpy()
+    ref, st = om.forward(mel, noise, return_stages=True)
+    assert _maxdiff(base, ref) <= _tol(ref, E2E_TOL)
     assert np.array_equal(eng.infer(mel, sigma=0.1, z_in=None, synth_length=9 * 300, noise=noise).numpy(), base)
-    f0 = eng.stage("f0").cpu().numpy()
-    same = eng.infer(mel, synth_length=9 * 300, F0=f0, noise=noise).numpy()
-    assert _maxdiff(same, base) <= 1e-6 * max(1.0, np.abs(base).max())          # the net's own F0 fed back
-    other = eng.infer(mel, synth_length=9 * 300, F0=np.full_like(f0, 220.0), noise=noise).numpy()
-    assert other.shape == base.shape and not np.allclose(other, base)
-    for kwargs in ({"return_F0": True}, {"return_components": True}, {"training": True}):
+    f0_net = eng.stage("f0").cpu().numpy()
+    ignored = eng.infer(mel, synth_length=9 * 300, F0=np.full_like(f0_net, 220.0), noise=noise).numpy()
+    assert np.array_equal(ignored, base)                       # as in the reference: F0 is a training-only input
+    # synth_length: shorter cuts, 0 = segment_length (24000 > 9 frames: the last mel frame is repeated once, :490-491)
+    assert np.array_equal(eng.infer(mel, synth_length=1000, noise=noise).numpy(), base[:, :1000])
+    noise10 = np.concatenate((noise, noise[:, -20:]), axis=1)
+    seg = eng.infer(mel, noise=noise10).numpy()
+    mel10 = np.concatenate((mel, mel[:, -1:]), axis=1)
+    assert seg.shape == (1, 10 * 300) and _maxdiff(seg, om.forward(mel10, noise10)) <= _tol(ref, E2E_TOL)
+    # return_F0 / return_components
+    sig, params = eng.infer(mel, synth_length=9 * 300, noise=noise, return_F0=True)
+    assert np.array_equal(sig.numpy(), base) and [pp[0] for pp in params] == ["F0", "PSig", "PS"]
+    assert _maxdiff(params[0][1].numpy(), st["f0"][:, ::3]) <= 1e-3            # the reference's own slice [:, :len:3]
+    assert _maxdiff(params[1][1].numpy(), st["excitation"]) <= _tol(st["excitation"], E2E_TOL)
+    assert params[2][1].shape == (1, 9, 1025) and _maxdiff(params[2][1], np.abs(st["envelope"])) <= _tol(np.abs(st["envelope"]), 2e-4)
+    sigs = eng.infer(mel, synth_length=9 * 300, noise=noise, return_components=True)
+    assert isinstance(sigs, list) and len(sigs) == 1 and np.array_equal(sigs[0].numpy(), base)
+    sigs, params = eng.infer(mel, synth_length=9 * 300, noise=noise, return_components=True, return_F0=True)
+    assert isinstance(sigs, list) and len(params) == 3
+    for kwargs in ({"training": True}, {"test_grad": 1}):
         with pytest.raises(NotImplementedError):
             eng.infer(mel, **kwargs)
 

@@ -88,3 +88,52 @@ def test_checkpoint_mismatch_is_reported(tmp_path):
         tfc.load_reference_checkpoint(prefix, cfg)
     with pytest.raises(FileNotFoundError):
         tfc.CheckpointReader(str(tmp_path / "nothing.tf"))
+
+
+def test_both_keras_name_scopes_of_the_wrapped_convolution_load(tmp_path):
+    """TF2C_Conv1DWeightNorm builds its inner Conv1D from inside its own build() (reference conv_layers.py:72-75), so
+    the inner kernel / bias can appear under `<layer>/...` or under `<layer>_base/...`: both spellings must map."""
+    cfg = canonical_config("SPEECH", **{"mbexwn_config:pp_mod_subnet:n_channels": 32})
+    raw = synthetic_weights(cfg, seed=7)
+    named = {}
+    for name, arr in _reference_names(raw).items():
+        scope, leaf = name.rsplit("/", 1)
+        if leaf in ("kernel", "bias") and not scope.endswith("_base"):
+            name = f"{scope}_base/{leaf}"                            # the alternative spelling
+        named[name] = arr
+    assert any(kk.endswith("start_base/kernel") for kk in named)
+    prefix = str(tmp_path / "weights.tf")
+    tfc.write_checkpoint(prefix, named)
+    got = tfc.load_reference_checkpoint(prefix, cfg)
+    assert sorted(got) == sorted(raw)
+    for name in raw:
+        assert np.array_equal(got[name], raw[name]), name
+
+
+def test_wavenet_without_weight_norm_loads_and_folds(tmp_path):
+    """pp_mod_subnet.use_weight_norm = False (the WaveNetAE default, reference custom_AE_layers.py:123): those layers
+    have no `g`; the kernel is the weight."""
+    from mbexwn_vocoder_amd.weights import fold_weights
+    cfg = canonical_config("SPEECH", **{"mbexwn_config:pp_mod_subnet:n_channels": 32,
+                                        "mbexwn_config:pp_mod_subnet:use_weight_norm": False})
+    raw = {kk: vv for kk, vv in synthetic_weights(cfg, seed=9).items() if not (kk.startswith("wn.") and kk.endswith(".g"))}
+    prefix = str(tmp_path / "weights.tf")
+    tfc.write_checkpoint(prefix, _reference_names(raw))
+    got = tfc.load_reference_checkpoint(prefix, cfg)
+    assert sorted(got) == sorted(raw) and "wn.start.g" not in got and "PS_Layer_0.g" in got
+    folded = fold_weights(got)
+    assert np.array_equal(folded["wn.conv1D_0.w"], raw["wn.conv1D_0.v"])
+    # with weight norm configured the missing g is an error
+    cfg_wn = canonical_config("SPEECH", **{"mbexwn_config:pp_mod_subnet:n_channels": 32})
+    with pytest.raises(ValueError, match="missing wn"):
+        tfc.load_reference_checkpoint(prefix, cfg_wn)
+
+
+def test_unbuilt_wavenet_options_raise():
+    """Keys of WaveNetAE.__init__ that change the arithmetic and are not built must not be ignored silently."""
+    from mbexwn_vocoder_amd.config import ModelDims
+    for key, value in (("use_equalized_lr", True), ("pre_cond_layer_channels", [64]), ("disable_conditioning", True),
+                       ("padding", "VALID"), ("n_ch_groups", 2)):
+        cfg = canonical_config("SPEECH", **{f"mbexwn_config:pp_mod_subnet:{key}": value})
+        with pytest.raises(NotImplementedError):
+            ModelDims(cfg)
