@@ -735,8 +735,15 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                 wino4->shape[2] == 3072) {
                 mbx::ConvArgs gw = g;
                 gw.w = wino4->ptr;
-                if (hd->winograd4_always || full_blocks >= 4 * 512) done = mbx::launch_wn_gate_winograd4(gw, stream);
-                else done = mbx::launch_wn_gate_winograd4k(gw, stream);
+                const DevTensor *wino4w = find(hd, "wn.conv1D_" + ls + ".wino4w");
+                const bool okw = wino4w && wino4w->ndim == 3 && wino4w->shape[0] == wino4->shape[0] &&
+                                 wino4w->shape[1] == wino4->shape[1] && wino4w->shape[2] == 3072;
+                if (hd->winograd4_always || full_blocks >= 4 * 512) {
+                    if (okw) {
+                        gw.w = wino4w->ptr;
+                        done = mbx::launch_wn_gate_winograd4w(gw, stream);
+                    } else done = mbx::launch_wn_gate_winograd4(gw, stream);
+                } else done = mbx::launch_wn_gate_winograd4k(gw, stream);
             }
             const DevTensor *wino = (!done && hd->winograd) ? find(hd, "wn.conv1D_" + ls + ".wino") : nullptr;
             if (wino && wino->ndim == 3 && wino->shape[0] == (C + 31) / 32 && wino->shape[1] == (C + 15) / 16 &&

@@ -64,6 +64,8 @@ bool launch_wn_gate_winograd(const ConvArgs &a, const float *w_split, hipStream_
 bool launch_wn_gate_winograd4(const ConvArgs &a, hipStream_t stream);
 // same weights, small launches: 128-row blocks whose waves split the input channels (wn_winograd4k.hip)
 bool launch_wn_gate_winograd4k(const ConvArgs &a, hipStream_t stream);
+// F(4,3) on v_mfma_f32_16x16x4_f32, wave tile 16 groups x 64 columns (wn_winograd4w.hip); a.w = engine.pack_winograd4w_weights image
+bool launch_wn_gate_winograd4w(const ConvArgs &a, hipStream_t stream);
 // WaveNet residual/skip layer for large row counts (wn_resskip.hip); a.w = host-packed weights (ceil(cout/128), ceil(C/16), 2048)
 bool launch_wn_resskip(const ConvArgs &a, hipStream_t stream);
 // WaveNet end convolution + post-net in one pass over the skip tensor (wn_tail.hip); w_end_packed = host-packed

@@ -1,0 +1,381 @@
+// WaveNet dilated convolution (k = 3, dilation d) + conditioning + tanh*sigmoid in Winograd F(4,3) form, large launches.
+//
+// Layer: reference MBExWN_NVoc/vocoder/model/custom_AE_layers.py:305-321.  Four outputs y[t], y[t+d], y[t+2d], y[t+3d]
+// per group from six products: with x0..x5 = h[t-d] .. h[t+4d]
+//     v0 = 4 x0 - 5 x2 + x4          v1 = -4 x1 - 4 x2 + x3 + x4      v2 = 4 x1 - 4 x2 - x3 + x4
+//     v3 = -2 x1 - x2 + 2 x3 + x4    v4 = 2 x1 - x2 - 2 x3 + x4       v5 = 4 x1 - 5 x3 + x5
+//     m_j = v_j U_j,  U = G W  (G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]])
+//     y[t] = m0+m1+m2+m3+m4   y[t+d] = m1-m2+2(m3-m4)   y[t+2d] = m1+m2+4(m3+m4)   y[t+3d] = m1-m2+8(m3-m4)+m5
+// = 6 channel contractions per four outputs instead of 12.  Float32 on the exact fp32 MFMA; U is formed on the host in
+// float64 (engine.pack_winograd4w_weights).
+//
+// What shapes this kernel: on gfx950 the fp32 MFMA runs at the fp32 vector rate and every vector instruction a wave
+// issues takes matrix-pipe time away (measured, profiles/README.md: an LDS-read + MFMA loop holds 0.95 of the fp32
+// peak, 0.85 with three vector instructions per v_mfma_f32_32x32x2_f32).  The input combinations v_j are vector work
+// proportional to (rows x channels) of a wave's tile, the MFMA work to (rows x channels x columns): so a wave owns FEW
+// rows and MANY columns -- 16 groups (v_mfma_f32_16x16x4_f32) x all 64 weight columns of the block (4 column tiles:
+// [16 tanh | 16 sigmoid] of the even gate channels and of the odd ones) x 6 products = 24 accumulator tiles of 4
+// registers.  Per 8-channel slice a wave issues 48 MFMAs (1536 matrix-pipe cycles) beside 24 vector instructions.
+// Lane n of the column tiles holds tanh and sigmoid column of gate channels 2n and 2n+1: the epilogue needs no
+// cross-lane traffic, reads the conditioning as float2 and stores float2 (a wave instruction writes whole 128-byte rows).
+// The bias is the initial value of product 1's accumulators (m1 enters all four outputs with coefficient 1).
+//
+// Block = 4 waves, 256 consecutive output rows (64 groups; wave w owns groups 16 w .. 16 w + 15) x 32 gate channels.
+// (Measured and rejected, batch 16 x 10 s: a fifth wave that issues all LDS-DMA requests, 1.50 ms against 1.39 ms per
+// launch -- the requests then queue on one SIMD whose MFMA waves become the stragglers of every barrier; spreading a
+// slice's requests over three phases instead of issuing them behind the barrier, and s_setprio: no change.)
+// Group Q of the block: q = Q / d, r = Q % d, t = m0 + 4 d q + r (d a power of two <= 16).
+// Per K slice of 8 channels the block stages, through LDS-DMA:
+//   A: activation rows [m0-16, m0+272) x 8 channels in read order: row = m0 - d + d*m + b (b < d) lives in 32-byte cell
+//      p = (m & 3)*80 + (m >> 2)*d + b, its 16-byte chunk c at 2*p + (c ^ ((p>>3)&1)).  Lane (r = lane & 15, kq = lane >> 4)
+//      reads the 8 bytes of channels 2 kq, 2 kq + 1 of cell (q & 3)*80 + Q + (q >> 2)*d for each of its six rows q:
+//      consecutive lanes read consecutive cells, and with the chunk swizzle the 32 lanes of a ds_read_b64 half hit 64
+//      different banks at every dilation.  MFMA step m (0, 1) of a slice contracts channels {2 kq + m}.
+//   B: 6 products x 8 channels x 64 columns, packed on the host in MFMA operand order [product j][channel parity e]
+//      [lane][tanh step 0, tanh step 1, sigmoid step 0, sigmoid step 1]: one ds_read_b128 = the weight operands of four MFMAs
+// Three LDS stages (66 KB per block, 2 blocks per CU): the slice needed next has landed two slices of compute ago.
+// The slice loop is unrolled by three so that every LDS address is a loop-invariant register plus an immediate.
+#include <cstdlib>
+#include <type_traits>
+#include "mbx_kernels.h"
+
+namespace mbx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WW_ROWS = 256;
+constexpr int WW_HALO = 16;
+constexpr int WW_AROWS = WW_ROWS + 2 * WW_HALO;       // 288 rows can be needed
+constexpr int WW_PHASE = WW_ROWS / 4 + WW_HALO;        // 80 cells per phase (m & 3)
+constexpr int WW_CELLS = 4 * WW_PHASE;                 // 320 cells of 8 channels
+constexpr int WW_BK = 8;
+constexpr int WW_A_FLOATS = WW_CELLS * WW_BK;          // 2560
+constexpr int WW_B_FLOATS = 6 * WW_BK * 64;            // 3072
+constexpr int WW_STAGE = WW_A_FLOATS + WW_B_FLOATS;    // 5632 floats = 22 KB
+constexpr int WW_B_INST = WW_B_FLOATS / 4 / 64 / 4;    // 3 per wave (B)
+// epilogue tables (in the stage that holds the conditioning tile): float offsets inside that stage
+constexpr int WW_TABW = 2304;                          // (w0, w1) of block row lr: 256 x float2
+constexpr int WW_TABO = 2816;                          // float offset of the conditioning row of block row lr: 256 x int
+
+__device__ __forceinline__ void ww_lds_dma16(const float *src, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(src) : "memory", "m0");
+}
+
+// same with a wave-uniform base address and a per-lane 32-bit byte offset (no per-lane 64-bit address arithmetic)
+__device__ __forceinline__ void ww_lds_dma16_s(const float *sbase, unsigned voff_bytes, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte_addr), "v"(voff_bytes), "s"(sbase)
+                 : "memory", "m0");
+}
+
+// tanh(zt) * sigmoid(zs) = (t - 1) / ((t + 1)(1 + s)), t = e^(2 zt), s = e^(-zs): two exponentials and one reciprocal
+// (zt is clamped where tanh is 1 in float32, so t stays finite; s = inf gives 0, as it should)
+__device__ __forceinline__ float ww_gate_act(float zt, float zs) {
+    const float t = __builtin_amdgcn_exp2f(fminf(zt, 15.f) * 2.885390081777927f);
+    const float sg = __builtin_amdgcn_exp2f(zs * -1.4426950408889634f);
+    const float tp = t + 1.0f;
+    return (t - 1.0f) * __builtin_amdgcn_rcpf(fmaf(sg, tp, tp));
+}
+
+__device__ __forceinline__ float2 ww_fma(float s, float2 a, float2 b) { return make_float2(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y)); }
+__device__ __forceinline__ float2 ww_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 ww_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+#define WW_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+#define WW_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define WW_SG_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
+#define WW_SG_VALU(n) __builtin_amdgcn_sched_group_barrier(0x002, n, 0)
+
+__global__ __launch_bounds__(256, 2) void wn_gate_winograd4w_kernel(ConvArgs p, int log2d) {
+    typedef __attribute__((address_space(3))) float lds_float;
+    __shared__ __attribute__((aligned(16))) float lds[3 * WW_STAGE];          // stage s: A at s*STAGE, B behind it
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float *)lds);
+
+    // XCD-aware decode (see decode_tile in conv_mfma.hip)
+    const int id = blockIdx.x;
+    const int l = id >> 3;
+    const int g_ = (l / p.n_tiles) * 8 + (id & 7);
+    const int nt = l % p.n_tiles;
+    if (g_ >= p.m_tiles_total) return;
+    const int b = g_ / p.m_tiles_per_item;
+    const int mt = g_ - b * p.m_tiles_per_item;
+    const int rows = p.n_frames ? p.n_frames[b] * p.rows_per_frame : p.max_rows;
+    const int m0 = mt * WW_ROWS;
+    if (m0 >= rows) return;
+    const int C = p.channels;
+    const int n0 = nt * 32;
+    const int d = 1 << log2d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;
+    const float *xb = p.x + (long long)b * p.x_bstride;
+    const int nk = (p.cin + WW_BK - 1) / WW_BK;
+
+    // ---- per-lane DMA sources (fixed for the whole kernel except the channel offset): byte offset of (row, chunk) from
+    // the item's first element + validity bits (bit i: the row exists, bit 4 + i: the chunk is the upper half of the slice)
+    unsigned a_voff[3];
+    unsigned a_bits = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        // chunks 0..7 are dealt round-robin, chunks 8 and 9 are each written by two waves (same data), which keeps the
+        // number of outstanding LDS-DMA instructions per slice the same for every wave (s_waitcnt vmcnt below)
+        const int pos = (i < 2 ? wave + 4 * i : 8 + (wave & 1)) * 64 + lane;
+        const int cell = pos >> 1;
+        const int phase = cell / WW_PHASE, sidx = cell - phase * WW_PHASE;
+        const int m = 4 * (sidx >> log2d) + phase;
+        const int row = (m << log2d) + (sidx & (d - 1)) + WW_HALO - d;       // staged row index, m0 - 16 + row = source
+        const int src = m0 - WW_HALO + row;
+        const int hi = (pos & 1) ^ ((cell >> 3) & 1);
+        if (row < WW_AROWS && src >= 0 && src < rows) a_bits |= 1u << i;
+        a_bits |= (unsigned)hi << (4 + i);
+        a_voff[i] = 4u * (unsigned)(min(max(src, 0), rows - 1) * p.ldx + 4 * hi);
+    }
+    // interior blocks (every staged row exists, whole slices): uniform base + per-lane byte offset, no selects
+    const bool fast = p.fast_dma && m0 >= WW_HALO && m0 + WW_ROWS + WW_HALO <= rows && p.cin % WW_BK == 0;
+    const float *wtile = p.w + (long long)nt * nk * WW_B_FLOATS;
+    const unsigned b_voff = 16u * (unsigned)lane;
+    // LDS-DMA of slice kt into a stage: 3 A + 3 B instructions per wave
+    auto issue = [&](int kt, int stage) {
+        const int ci0 = kt * WW_BK;
+        const unsigned adst = lds_base + 4u * (unsigned)(stage * WW_STAGE);
+        const unsigned bdst = adst + 4u * (unsigned)WW_A_FLOATS;
+        const float *bbase = wtile + (long long)kt * WW_B_FLOATS + wave * 256;
+        if (fast) {
+            const float *abase = xb + ci0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                ww_lds_dma16_s(abase, a_voff[i], adst + 1024u * (unsigned)(i < 2 ? wave + 4 * i : 8 + (wave & 1)));
+                ww_lds_dma16_s(bbase + i * 1024, b_voff, bdst + 1024u * (unsigned)(wave + 4 * i));
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int ci = ci0 + 4 * (int)((a_bits >> (4 + i)) & 1u);
+            const bool ok = ((a_bits >> i) & 1u) & (ci < p.cin);
+            const float *src = reinterpret_cast<const float *>(reinterpret_cast<const char *>(xb + ci0) + a_voff[i]);
+            ww_lds_dma16(ok ? src : p.zeros, adst + 1024u * (unsigned)(i < 2 ? wave + 4 * i : 8 + (wave & 1)));
+            ww_lds_dma16(reinterpret_cast<const float *>(reinterpret_cast<const char *>(bbase + i * 1024) + b_voff),
+                         bdst + 1024u * (unsigned)(wave + 4 * i));
+        }
+    };
+    // conditioning rows of this block (<= 32 rows x (32 tanh | 32 sigmoid) columns) -> a free stage near the end
+    const int cond_up = p.cond_up;
+    const int n2 = rows / cond_up;
+    const int t2base = m0 / cond_up;
+    const float *cbase = p.cond + (long long)b * p.cond_bstride;
+    auto issue_cond = [&](int stage) {
+        const unsigned cdst = lds_base + 4u * (unsigned)(stage * WW_STAGE);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pos = (wave + 4 * i) * 64 + lane;
+            const int crow = pos >> 4, cq = pos & 15;
+            const int chn = n0 + 4 * (cq & 7);
+            const int t = min(t2base + crow, n2 - 1);
+            ww_lds_dma16(chn < C ? cbase + (long long)t * (2 * C) + (cq >> 3) * C + chn : p.zeros,
+                         cdst + 1024u * (unsigned)(wave + 4 * i));
+        }
+    };
+
+    // lane n of column tile (e, tanh | sigmoid) holds gate channel n0 + 2 n + e
+    const bool ch_ok = n0 + 2 * r16 < C;                 // C is even: both channels of the lane exist or neither
+    f32x4 acc[6][4];          // [product][column tile: 2 e + (0 tanh | 1 sigmoid)]
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            // m1 enters y[t] .. y[t+3d] with coefficient 1: its accumulators start from the bias
+            const float bv = (j == 1 && p.bias && ch_ok) ? p.bias[(c & 1) * C + n0 + 2 * r16 + (c >> 1)] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[j][c][r] = bv;
+        }
+
+    // A operand: group of this lane Q = 16*wave + r16 -> t = m0 + 4 d (Q >> log2d) + (Q & (d-1)); channels 2 kq, 2 kq + 1
+    const int grp = 16 * wave + r16;
+    const float *xptr[6];     // LDS addresses (stage 0) of h[t-d] .. h[t+4d]
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int cell = (q & 3) * WW_PHASE + grp + ((q >> 2) << log2d);
+        xptr[q] = lds + 8 * cell + 4 * ((kq >> 1) ^ ((cell >> 3) & 1)) + 2 * (kq & 1);
+    }
+    const float *bptr = lds + WW_A_FLOATS + lane * 4;
+
+    float2 x[6];              // raw activation rows of the slice whose combinations are being formed
+    float2 u[2];              // input combination of product j in u[j & 1]
+    float4 bw[2][2];          // weights of product j in bw[j & 1][channel half e]
+    float2 ca, cb;            // shared sub-expressions (-4 x2 + x4, -4 x1 + x3), then (x4 - x2, x3 - x1)
+
+    auto load_x = [&](auto sc) {
+        constexpr int S = decltype(sc)::value;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) x[q] = *reinterpret_cast<const float2 *>(xptr[q] + S * WW_STAGE);
+    };
+    auto load_b = [&](auto sc, auto jc) {
+        constexpr int S = decltype(sc)::value, J = decltype(jc)::value;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            bw[J & 1][e] = *reinterpret_cast<const float4 *>(bptr + S * WW_STAGE + (J * 2 + e) * 256);
+    };
+    // product j: 2 steps x 4 column tiles
+    auto mfma8 = [&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        f32x4 *ac = acc[J];
+        const float2 uu = u[J & 1];
+        const float4 b0 = bw[J & 1][0], b1 = bw[J & 1][1];
+        ac[0] = WW_MFMA(uu.x, b0.x, ac[0]);
+        ac[1] = WW_MFMA(uu.x, b0.z, ac[1]);
+        ac[2] = WW_MFMA(uu.x, b1.x, ac[2]);
+        ac[3] = WW_MFMA(uu.x, b1.z, ac[3]);
+        ac[0] = WW_MFMA(uu.y, b0.y, ac[0]);
+        ac[1] = WW_MFMA(uu.y, b0.w, ac[1]);
+        ac[2] = WW_MFMA(uu.y, b1.y, ac[2]);
+        ac[3] = WW_MFMA(uu.y, b1.w, ac[3]);
+    };
+    // input combination of product J from the rows in x (24 vector instructions per slice)
+    auto comb = [&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        if (J == 0) u[0] = ww_fma(4.f, x[0], ww_fma(-5.f, x[2], x[4]));
+        if (J == 1) {
+            ca = ww_fma(-4.f, x[2], x[4]);
+            cb = ww_fma(-4.f, x[1], x[3]);
+            u[1] = ww_add(ca, cb);
+        }
+        if (J == 2) u[0] = ww_sub(ca, cb);
+        if (J == 3) {
+            ca = ww_sub(x[4], x[2]);
+            cb = ww_sub(x[3], x[1]);
+            u[1] = ww_fma(2.f, cb, ca);
+        }
+        if (J == 4) u[0] = ww_fma(-2.f, cb, ca);
+        if (J == 5) u[1] = ww_fma(4.f, x[1], ww_fma(-5.f, x[3], x[5]));
+    };
+    // One slice = six phases of 8 MFMAs (one product each).  While product j is multiplied, the weights of product j+1
+    // are requested from LDS and its input combination is formed between the MFMAs.  The barrier that publishes slice
+    // kt+1 sits in front of the last product: every wave has requested all LDS operands of slice kt by then, so the
+    // stage is free for slice kt+3.  In: u[0], bw[0] of product 0 of this slice.  Out: those of the next slice.
+    // 6 LDS-DMA instructions per wave and slice, 2 for the conditioning tile.
+    auto phase = [&](auto sc, auto jc) {
+        constexpr int J = decltype(jc)::value;
+        load_b(sc, std::integral_constant<int, J + 1>());
+        WW_FENCE();
+        comb(std::integral_constant<int, J + 1>());
+        mfma8(jc);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { WW_SG_MFMA(1); WW_SG_VALU(1); }
+        WW_SG_MFMA(2);
+        WW_FENCE();
+    };
+    auto slice = [&](auto sc, int kt) {
+        constexpr int S = decltype(sc)::value;
+        std::integral_constant<int, (S + 1) % 3> ns;
+        phase(sc, std::integral_constant<int, 0>());
+        phase(sc, std::integral_constant<int, 1>());
+        phase(sc, std::integral_constant<int, 2>());
+        phase(sc, std::integral_constant<int, 3>());
+        phase(sc, std::integral_constant<int, 4>());
+        // ---- product 5 behind the barrier
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // slice kt+2 may still be in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 3 < nk) issue(kt + 3, S);
+        else if (kt + 3 == nk) issue_cond(S);
+        load_x(ns);
+        load_b(ns, std::integral_constant<int, 0>());
+        WW_FENCE();
+        mfma8(std::integral_constant<int, 5>());
+        WW_FENCE();
+        comb(std::integral_constant<int, 0>());
+        WW_FENCE();
+    };
+
+    // ---- prologue: three slices in flight, the first one landed (the launcher guarantees nk >= 4)
+    issue(0, 0);
+    issue(1, 1);
+    issue(2, 2);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __syncthreads();
+    load_x(std::integral_constant<int, 0>());
+    load_b(std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
+    comb(std::integral_constant<int, 0>());
+    {
+        int kt = 0;
+        for (; kt + 3 <= nk; kt += 3) {
+            slice(std::integral_constant<int, 0>(), kt);
+            slice(std::integral_constant<int, 1>(), kt + 1);
+            slice(std::integral_constant<int, 2>(), kt + 2);
+        }
+        if (kt < nk) {
+            slice(std::integral_constant<int, 0>(), kt);
+            if (kt + 1 < nk) slice(std::integral_constant<int, 1>(), kt + 1);
+        }
+    }
+
+    // ---- epilogue: combine the six products, add the conditioning, gate, store the four outputs of the group
+    // the conditioning tile sits in the stage that held slice nk-3 (issued when slice nk-3 was done)
+    const int cstage = (nk - 3) % 3;
+    float *cl = lds + cstage * WW_STAGE;
+    {
+        // block row lr = tid: conditioning row offset and interpolation weights
+        const int row = m0 + tid;
+        const int t2 = row / cond_up;
+        const int u = row - t2 * cond_up;
+        reinterpret_cast<float2 *>(cl + WW_TABW)[tid] = make_float2(p.lerp_w0[u], p.lerp_w1[u]);
+        reinterpret_cast<int *>(cl + WW_TABO)[tid] = (t2 - t2base) * 64;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float *obase = p.out + (long long)b * p.out_bstride + n0 + 2 * r16;
+    const float *clane = cl + 2 * r16;
+    // everything up to the store is unconditional (every table and conditioning address is valid), so the LDS reads of
+    // all rows can be in flight together; only the store is predicated
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int gi = 16 * wave + 4 * kq + v;                                   // group held by register v
+        const int lr0 = ((gi >> log2d) << (log2d + 2)) + (gi & (d - 1));         // its first row, relative to m0
+        float y[4][4];                                                           // [column tile][output]
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float s12 = acc[1][c][v] + acc[2][c][v], d12 = acc[1][c][v] - acc[2][c][v];
+            const float s34 = acc[3][c][v] + acc[4][c][v], d34 = acc[3][c][v] - acc[4][c][v];
+            y[c][0] = (acc[0][c][v] + s12) + s34;
+            y[c][1] = fmaf(2.f, d34, d12);
+            y[c][2] = fmaf(4.f, s34, s12);
+            y[c][3] = fmaf(8.f, d34, d12) + acc[5][c][v];
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int lr = lr0 + (o << log2d);
+            const int row = m0 + lr;
+            const float2 w = reinterpret_cast<const float2 *>(cl + WW_TABW)[lr];
+            const float *c0 = clane + reinterpret_cast<const int *>(cl + WW_TABO)[lr];
+            const float2 ct0 = *reinterpret_cast<const float2 *>(c0), ct1 = *reinterpret_cast<const float2 *>(c0 + 64);
+            const float2 cs0 = *reinterpret_cast<const float2 *>(c0 + 32), cs1 = *reinterpret_cast<const float2 *>(c0 + 96);
+            float2 res;
+            res.x = ww_gate_act(y[0][o] + (ct0.x * w.x + ct1.x * w.y), y[1][o] + (cs0.x * w.x + cs1.x * w.y));
+            res.y = ww_gate_act(y[2][o] + (ct0.y * w.x + ct1.y * w.y), y[3][o] + (cs0.y * w.x + cs1.y * w.y));
+            if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res;
+        }
+    }
+}
+
+// a.w must point at the host-packed F(4,3) weights (ceil(C/32), ceil(C/8), 3072) of engine.pack_winograd4w_weights;
+// returns false if the layer does not fit
+bool launch_wn_gate_winograd4w(const ConvArgs &a, hipStream_t stream) {
+    int log2d = 0;
+    while ((1 << log2d) < a.dil) ++log2d;
+    const bool ok = a.ks == 3 && (1 << log2d) == a.dil && a.dil <= WW_HALO && a.cin >= 4 * WW_BK && a.pad_l == a.dil && a.pad_mode == 0 &&
+                    a.cin % 4 == 0 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 && a.channels % 4 == 0 &&
+                    a.cout == 2 * a.channels && (uintptr_t)a.x % 16 == 0 && (uintptr_t)a.w % 16 == 0 && a.zeros &&
+                    a.cond && (uintptr_t)a.cond % 16 == 0 && a.cond_bstride % 4 == 0 && a.cond_up <= 64 &&
+                    WW_ROWS / a.cond_up + 2 <= 32 && a.max_rows < (1 << 24);
+    if (!ok) return false;
+    ConvArgs r = a;
+    r.fast_dma = (long long)a.max_rows * a.ldx * 4 < (1LL << 32);
+    r.n_tiles = (a.channels + 31) / 32;
+    r.m_tiles_per_item = (a.max_rows + WW_ROWS - 1) / WW_ROWS;
+    r.m_tiles_total = r.m_tiles_per_item * a.batch;
+    const long long blocks = 8LL * ((r.m_tiles_total + 7) / 8) * r.n_tiles;
+    hipLaunchKernelGGL(wn_gate_winograd4w_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, r, log2d);
+    return true;
+}
+
+}  // namespace mbx

@@ -284,6 +284,27 @@ def pack_winograd4_weights(w):
     return np.ascontiguousarray(wp.transpose(5, 1, 0, 4, 2, 6, 3).reshape(nt, nk, 3072), dtype=np.float32)
 
 
+def pack_winograd4w_weights(w):
+    """Winograd F(4,3) combinations U = G W of the three taps (3, C, 2C) of a dilated WaveNet convolution, packed for
+    wn_gate_winograd4w_kernel (csrc/wn_winograd4w.hip, v_mfma_f32_16x16x4_f32); formed in float64, stored float32.
+
+    Layout (ceil(C/32) column tiles, ceil(C/8) channel slices, 3072): the 12 KB image of one (tile, slice) is copied
+    verbatim into LDS, ordered [product j][channel parity e][lane = 16*kq + n][tanh step 0, tanh step 1, sigmoid step 0,
+    sigmoid step 1] with input channel 8*slice + 2*kq + step and output column (0 | C) + 32*tile + 2*n + e;
+    out-of-range entries are zero.
+    """
+    w = np.asarray(w, dtype=np.float64)
+    C = w.shape[1]
+    assert w.shape == (3, C, 2 * C)
+    u = np.einsum("ij,jcn->icn", _WINOGRAD43_G, w)
+    nt, nk = (C + 31) // 32, (C + 7) // 8
+    wp = np.zeros((6, nk * 8, 2, nt * 32))
+    wp[:, :C, 0, :C] = u[:, :, :C]
+    wp[:, :C, 1, :C] = u[:, :, C:]
+    wp = wp.reshape(6, nk, 4, 2, 2, nt, 16, 2)                    # j, slice, kq, step, tanh|sigmoid, tile, n, e
+    return np.ascontiguousarray(wp.transpose(5, 1, 0, 7, 2, 6, 4, 3).reshape(nt, nk, 3072), dtype=np.float32)
+
+
 def pack_resskip_weights(w):
     """Weights (1, C, cout) of a WaveNet res/skip 1x1 convolution packed for wn_resskip_kernel (csrc/wn_resskip.hip).
 
@@ -375,6 +396,7 @@ def tensor_table(config, raw_weights, wavetables):
             out[f"wn.conv1D_{ll}.wino"] = pack_winograd_weights(out[f"wn.conv1D_{ll}.w"])
             out[f"wn.conv1D_{ll}.wino_split"] = pack_winograd_weights(out[f"wn.conv1D_{ll}.w"], split=True)
             out[f"wn.conv1D_{ll}.wino4"] = pack_winograd4_weights(out[f"wn.conv1D_{ll}.w"])
+            out[f"wn.conv1D_{ll}.wino4w"] = pack_winograd4w_weights(out[f"wn.conv1D_{ll}.w"])
     out["table.hann"] = tb.hann_periodic_f32(dims.stft_win)
     out["table.inv_win"] = tb.inverse_stft_window_f32(dims.stft_win, dims.hop_size)
     out["table.wavetables"] = np.ascontiguousarray(wavetables.tables, dtype=np.float32)

@@ -84,6 +84,35 @@ def test_winograd_f43_image_reproduces_the_convolution(C):
         assert np.max(np.abs(got - ref)) < 1e-5 * np.max(np.abs(ref))
 
 
+def _unpack_gate_4w(packed, C):
+    """Image of engine.pack_winograd4w_weights -> U (6, C, 2C) with the lane/step map of wn_gate_winograd4w_kernel."""
+    nt, nk, _ = packed.shape
+    img = packed.reshape(nt, nk, 6, 2, 64, 2, 2)                    # tile, slice, j, e, lane, tanh|sigmoid, step
+    U = np.zeros((6, C, 2 * C))
+    for tile in range(nt):
+        for kt in range(nk):
+            for e in range(2):
+                for lane in range(64):
+                    kq, n = lane >> 4, lane & 15
+                    ch = 32 * tile + 2 * n + e
+                    for ts in range(2):
+                        for m in range(2):
+                            k = 8 * kt + 2 * kq + m
+                            if k < C and ch < C:
+                                U[:, k, ts * C + ch] = img[tile, kt, :, e, lane, ts, m]
+                            else:
+                                assert np.all(img[tile, kt, :, e, lane, ts, m] == 0.0)
+    return U
+
+
+@pytest.mark.parametrize("C", [32, 40])
+def test_winograd_f43_wide_image_holds_the_same_combinations(C):
+    rng = np.random.default_rng(C)
+    w = rng.normal(size=(3, C, 2 * C))
+    U_ref = _unpack_gate(engine.pack_winograd4_weights(w).astype(np.float64), C, 6, 8, True)
+    assert np.array_equal(_unpack_gate_4w(engine.pack_winograd4w_weights(w).astype(np.float64), C), U_ref)
+
+
 def _unpack_resskip(packed, C, cout):
     nct, nk, _ = packed.shape
     img = packed.reshape(nct, nk, 2, 4, 64, 4)                      # tile, slice, cc, jn, lane, st
