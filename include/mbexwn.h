@@ -20,7 +20,7 @@
  *   MBX_WINOGRAD=0|2|4   form of the dilated convolution: direct / Winograd F(2,3) only / F(4,3) with the block shape
  *                        picked by launch size (default 4; streams always run F(2,3))
  *   MBX_FOLD_SKIP=0      keep the un-folded skip path (C -> 2C res/skip layers, stage "wn_skip")
- * The optional operand-order images of the weights ("*.wino", "*.wino_split", "*.wino4", "*.packed", "*.fold",
+ * The optional operand-order images of the weights ("*.wino", "*.wino_split", "*.wino4w", "*.packed", "*.fold",
  * "wn.tail.fold", "wn.end.packed"; engine.tensor_table builds them) select the specialised kernels; a handle
  * created from the plain folded weights alone runs the generic ones.
  */

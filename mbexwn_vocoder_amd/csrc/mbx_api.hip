@@ -69,9 +69,9 @@ struct DeviceGuard {
 
 // stages of the launch sequence that mbx_profile_read can report (names in kProfNames)
 enum { PROF_GATE = 0, PROF_RES_SKIP, PROF_FRONTEND, PROF_WAVETABLE, PROF_START, PROF_TAIL, PROF_PQMF, PROF_STFT_FILTER,
-       PROF_OVERLAP_ADD, PROF_NORM_MEL, PROF_KINDS };
+       PROF_OVERLAP_ADD, PROF_NORM_MEL, PROF_GATE0, PROF_KINDS };
 static const char *const kProfNames[PROF_KINDS] = {"gate", "res_skip", "frontend", "wavetable", "start", "tail", "pqmf",
-                                                   "stft_filter", "overlap_add", "norm_mel"};
+                                                   "stft_filter", "overlap_add", "norm_mel", "gate0"};
 
 struct mbx_handle {
     mbx_config cfg;
@@ -89,6 +89,7 @@ struct mbx_handle {
     int f0_time_factor = 1, vtf_time_factor = 1;
     long long subnet_buf_per_frame = 0;   // floats per frame of one ping-pong buffer
     bool fold_skip = false;      // skip path folded into the end convolution (needs the *.fold tensors)
+    bool fold_start = false;     // start convolution folded into layer 0 (needs fold_skip and the *.start_fold / *.fold_start tensors)
     bool winograd4_always = false;   // MBX_WINOGRAD=44: F(4,3) at every size (tests)
     int winograd = 0;            // gate layer form: 0 direct, 2 Winograd F(2,3), 4 Winograd F(4,3) (needs the packed weights)
     // bench-only kernel timing (mbx_profile_*): one event pool per stage of the launch sequence
@@ -163,7 +164,7 @@ Workspace carve(const mbx_handle *hd, char *base, int B, int T) {
     w.pulse = take(B * npulse);
     w.cond = take(BT * 2 * c.wn_channels * c.cond_conv_upsampling);
     w.h = take(B * nsteps * c.wn_channels);
-    w.a = take(B * nsteps * c.wn_channels);
+    w.a = take(B * nsteps * (c.wn_channels + 16));   // layer 0 appends the excitation channels to its rows (wn_gate0.hip)
     w.skip = take(B * nsteps * c.wn_channels);
     w.wn_out = take(B * nsteps * c.wn_out_channels);
     w.sub = take(B * nsteps * c.subbands);
@@ -588,6 +589,13 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
                    expect("wn.res_skip_" + std::to_string(l) + ".fold_b", C + c.wn_out_channels);
         have = have && expect("wn.tail.fold", (long long)((C + 7) / 8) * 256) && expect("wn.tail.fold_b", c.wn_out_channels);
         hd->fold_skip = have;
+        // start convolution folded into layer 0 (wn_gate0.hip); MBX_FOLD_START=0 keeps the h0 tensor and the full layer
+        const char *sv = getenv("MBX_FOLD_START");
+        bool have0 = have && (!sv || atoi(sv) != 0) && c.wn_kernel_size == 3 && c.pulse_channels + 2 <= 8 &&
+                     expect("wn.conv1D_0.start_fold", (long long)((C + 31) / 32) * 1536);
+        if (have0 && c.wn_layers > 1)
+            have0 = expect("wn.res_skip_0.fold_start", nct * ((C + 16 + 15) / 16) * 2048);
+        hd->fold_start = have0;
     }
     {
         const char *wv = getenv("MBX_WINOGRAD");
@@ -699,7 +707,9 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                               nullptr, w.cum, w.chunk_last, st_in, st_out, stream);
     }
     // ---- WaveNet (reference custom_AE_layers.py:273-346)
-    {
+    const bool fold_start = hd->fold_start;
+    const int lda0 = (fold_start && L > 1) ? C + 16 : C;      // row stride of layer 0's output
+    if (!fold_start) {
         ScopedEvents ev(hd, PROF_START, stream);
         mbx::launch_wn_start(w.pulse, npulse, c.noise_sigma != 0.f ? noise : nullptr, nsteps, c.noise_sigma, n_frames,
                              c.steps_per_frame, (int)nsteps, B, c.pulse_channels, find(hd, "wn.start.w")->ptr,
@@ -721,7 +731,35 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         g.lerp_w1 = lerp.second;
         g.channels = C;
         g.zeros = hd->zeros;
-        {
+        if (l == 0 && fold_start) {
+            // start convolution folded into the layer: a K = 24 contraction of the excitation (wn_gate0.hip)
+            ScopedEvents ev(hd, PROF_GATE0, stream);
+            mbx::Gate0Args g0{};
+            g0.pulse = w.pulse;
+            g0.pulse_bstride = npulse;
+            g0.noise = c.noise_sigma != 0.f ? noise : nullptr;
+            g0.noise_bstride = nsteps;
+            g0.sigma = c.noise_sigma;
+            g0.pulse_channels = c.pulse_channels;
+            g0.n_frames = n_frames;
+            g0.rows_per_frame = c.steps_per_frame;
+            g0.max_rows = (int)nsteps;
+            g0.batch = B;
+            g0.w = find(hd, "wn.conv1D_0.start_fold")->ptr;
+            g0.bias = g.bias;
+            g0.channels = C;
+            g0.dil = d;
+            g0.cond = g.cond;
+            g0.cond_bstride = g.cond_bstride;
+            g0.cond_up = g.cond_up;
+            g0.lerp_w0 = g.lerp_w0;
+            g0.lerp_w1 = g.lerp_w1;
+            g0.out = w.a;
+            g0.out_bstride = nsteps * lda0;
+            g0.ldo = lda0;
+            g0.write_inputs = L > 1;
+            if (!mbx::launch_wn_gate0(g0, stream)) return fail(MBX_ERR_INVALID_ARGUMENT, "folded first layer does not fit its kernel");
+        } else {
             ScopedEvents ev(hd, PROF_GATE, stream);
             bool done = false;
             // F(4,3): 256-row blocks for large launches (>= four rounds of blocks), 128-row blocks whose waves split the
@@ -730,20 +768,12 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
             // and F(2,3) needs the shorter alignment; MBX_WINOGRAD=2 makes offline runs use it as well.
             const long long full_blocks = ((nsteps + 255) / 256) * B * ((C + 31) / 32);
             const bool use4 = hd->winograd == 4 && !st_in && !st_out;
-            const DevTensor *wino4 = use4 ? find(hd, "wn.conv1D_" + ls + ".wino4") : nullptr;
+            const DevTensor *wino4 = use4 ? find(hd, "wn.conv1D_" + ls + ".wino4w") : nullptr;
             if (wino4 && wino4->ndim == 3 && wino4->shape[0] == (C + 31) / 32 && wino4->shape[1] == (C + 7) / 8 &&
                 wino4->shape[2] == 3072) {
                 mbx::ConvArgs gw = g;
                 gw.w = wino4->ptr;
-                const DevTensor *wino4w = find(hd, "wn.conv1D_" + ls + ".wino4w");
-                const bool okw = wino4w && wino4w->ndim == 3 && wino4w->shape[0] == wino4->shape[0] &&
-                                 wino4w->shape[1] == wino4->shape[1] && wino4w->shape[2] == 3072;
-                if (hd->winograd4_always || full_blocks >= 4 * 512) {
-                    if (okw) {
-                        gw.w = wino4w->ptr;
-                        done = mbx::launch_wn_gate_winograd4w(gw, stream);
-                    } else done = mbx::launch_wn_gate_winograd4(gw, stream);
-                } else done = mbx::launch_wn_gate_winograd4k(gw, stream);
+                done = mbx::launch_wn_gate_winograd4w(gw, !(hd->winograd4_always || full_blocks >= 4 * 512), stream);
             }
             const DevTensor *wino = (!done && hd->winograd) ? find(hd, "wn.conv1D_" + ls + ".wino") : nullptr;
             if (wino && wino->ndim == 3 && wino->shape[0] == (C + 31) / 32 && wino->shape[1] == (C + 15) / 16 &&
@@ -762,9 +792,14 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
             // skip path folded into the end convolution: layers 0..L-2 update h and add a W_skip W_end to the n_out-wide
             // output accumulator; the last layer's contribution is added by the tail kernel below
             if (!last) {
-                const DevTensor *fw = find(hd, "wn.res_skip_" + ls + ".fold"), *fb = find(hd, "wn.res_skip_" + ls + ".fold_b");
-                mbx::ConvArgs r = conv_args(w.a, nsteps * C, C, n_frames, c.steps_per_frame, (int)nsteps, B, fw, fb, 1, C,
-                                            C + c.wn_out_channels, 1, 0, MBX_PAD_ZERO, nullptr, 0, 0);
+                // layer 0 with the start convolution folded in: rows [a0 | x'] (C + 16 channels) x [Wr ; Ws'], h starts from the bias
+                const bool ext = l == 0 && fold_start;
+                const int cin_l = ext ? C + 16 : C;
+                const DevTensor *fw = find(hd, "wn.res_skip_" + ls + (ext ? ".fold_start" : ".fold")),
+                                *fb = find(hd, "wn.res_skip_" + ls + ".fold_b");
+                mbx::ConvArgs r = conv_args(w.a, nsteps * cin_l, cin_l, n_frames, c.steps_per_frame, (int)nsteps, B, fw, fb, 1,
+                                            cin_l, C + c.wn_out_channels, 1, 0, MBX_PAD_ZERO, nullptr, 0, 0);
+                r.h_init = ext;
                 r.channels = C;
                 r.zeros = hd->zeros;
                 r.h = w.h;

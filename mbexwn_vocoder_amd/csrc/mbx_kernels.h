@@ -48,6 +48,7 @@ struct ConvArgs {
     int skip_ld;              // floats between rows of skip (0: C)
     long long hs_bstride;
     int skip_init;            // 1: skip = s (first layer)  0: skip += s
+    int h_init;               // 1: h = r (first layer with the start convolution folded in: x carries [a | x'], cin > C)
     int last_layer;           // 1: cout == C, everything goes to skip
     int acc_preloaded;        // set by the launcher: accumulators start from bias + old value, epilogue only stores
     int remap, n_tiles, m_tiles_per_item, m_tiles_total;   // XCD-aware 1-D grid (set by the launcher)
@@ -60,12 +61,32 @@ void launch_conv1d(const ConvArgs &a, int epilogue, hipStream_t stream);
 void launch_conv1d_group(const ConvArgs *convs, int n, hipStream_t stream);
 // Winograd F(2,3) form of the WaveNet gate layer (wn_winograd.hip); a.w = host-packed weights (ceil(C/32), ceil(C/16), 4096)
 bool launch_wn_gate_winograd(const ConvArgs &a, const float *w_split, hipStream_t stream);
-// Winograd F(4,3) form (wn_winograd4.hip); a.w = host-packed weights (ceil(C/32), ceil(C/8), 3072)
-bool launch_wn_gate_winograd4(const ConvArgs &a, hipStream_t stream);
-// same weights, small launches: 128-row blocks whose waves split the input channels (wn_winograd4k.hip)
-bool launch_wn_gate_winograd4k(const ConvArgs &a, hipStream_t stream);
-// F(4,3) on v_mfma_f32_16x16x4_f32, wave tile 16 groups x 64 columns (wn_winograd4w.hip); a.w = engine.pack_winograd4w_weights image
-bool launch_wn_gate_winograd4w(const ConvArgs &a, hipStream_t stream);
+// Winograd F(4,3) form on v_mfma_f32_16x16x4_f32, wave tile 16 groups x 64 columns (wn_winograd4w.hip); a.w = image of
+// engine.pack_winograd4w_weights (ceil(C/32), ceil(C/8), 3072); small: 128-row blocks whose waves split the input channels
+bool launch_wn_gate_winograd4w(const ConvArgs &a, bool small, hipStream_t stream);
+// First WaveNet layer with the start convolution folded into it (wn_gate0.hip)
+struct Gate0Args {
+    const float *pulse;       // (batch, rows * pulse_channels): the excitation, folded to pulse_channels per row
+    long long pulse_bstride;
+    const float *noise;       // (batch, rows) or null
+    long long noise_bstride;
+    float sigma;
+    int pulse_channels;
+    const int *n_frames;
+    int rows_per_frame, max_rows, batch;
+    const float *w;           // image of engine.fold_start_weights (ceil(C/32), 3, 2, 64, 4)
+    const float *bias;        // (2C) gate bias or null
+    int channels, dil;
+    const float *cond;        // (batch, rows/cond_up, 2C)
+    long long cond_bstride;
+    int cond_up;
+    const float *lerp_w0, *lerp_w1;
+    float *out;               // (batch, rows, ldo): C gate channels, then x' padded to 16 channels if write_inputs
+    long long out_bstride;
+    int ldo, write_inputs;
+    int n_tiles, m_tiles_per_item;   // set by the launcher
+};
+bool launch_wn_gate0(const Gate0Args &a, hipStream_t stream);
 // WaveNet residual/skip layer for large row counts (wn_resskip.hip); a.w = host-packed weights (ceil(cout/128), ceil(C/16), 2048)
 bool launch_wn_resskip(const ConvArgs &a, hipStream_t stream);
 // WaveNet end convolution + post-net in one pass over the skip tensor (wn_tail.hip); w_end_packed = host-packed

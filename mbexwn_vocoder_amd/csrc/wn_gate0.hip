@@ -1,0 +1,163 @@
+// First WaveNet layer with the start convolution folded into it.
+//
+// Reference (MBExWN_NVoc/vocoder/model/custom_AE_layers.py:280, 305-321): h0 = start(x) is a 1x1 convolution of the
+// 6-channel excitation x = [pulse folded to 5 channels | sigma * noise]; layer 0 is a dilated k = 3 convolution of h0 (zero
+// "SAME" padding) + conditioning + tanh*sigmoid.  Both are linear, so
+//     conv0(h0)[t] = sum_tau h0[t + (tau-1) d] W0_tau = sum_tau x'[t + (tau-1) d] (Ws' W0_tau),
+// with x' = [x | 1 | 0] (8 channels; the constant channel carries the start bias) and Ws' = [Ws ; bs ; 0]: rows outside
+// the item are zero in x' exactly where the reference pads h0 with zeros, so the boundary rows are exact too.  The
+// products Ws' W0_tau (8 x 2C per tap) are formed on the host in float64 (engine.fold_start_weights).  The layer then is
+// a K = 24 contraction instead of K = 3C: its (rows, C) input tensor h0 is never written or read, and 1/L of the
+// WaveNet's dominant matrix work disappears.  The residual path gets h0 the same way: the res/skip layer of layer 0
+// contracts [a0 | x'] with [Wr ; Ws'] (wn_resskip.hip, h_init), for which this kernel appends x' (padded to 16 channels)
+// to every row of its output.
+//
+// Block = 4 waves, 256 rows x 32 gate channels; wave w owns rows 64 w .. 64 w + 63 as four 16-row MFMA tiles
+// (v_mfma_f32_16x16x4_f32) x 64 weight columns ([16 tanh | 16 sigmoid] of the even and of the odd gate channels, lane n
+// <-> gate channels 2n, 2n+1 as in wn_winograd4w.hip).  MFMA step (tau, m) contracts channels {2 kq + m} of tap tau.
+// The weights of a column tile are 24 registers per lane (loaded once per wave), the excitation rows come straight from
+// the pulse / noise arrays, the conditioning from L2: the kernel is bound by the vector work of the gate activation and
+// by writing a0, not by the matrix cores.
+#include <cstdlib>
+#include "mbx_kernels.h"
+
+namespace mbx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int G0_ROWS = 256;
+
+__device__ __forceinline__ float g0_gate_act(float zt, float zs) {      // see ww_gate_act (wn_winograd4w.hip)
+    const float t = __builtin_amdgcn_exp2f(fminf(zt, 15.f) * 2.885390081777927f);
+    const float sg = __builtin_amdgcn_exp2f(zs * -1.4426950408889634f);
+    const float tp = t + 1.0f;
+    return (t - 1.0f) * __builtin_amdgcn_rcpf(fmaf(sg, tp, tp));
+}
+
+__global__ __launch_bounds__(256) void wn_gate0_kernel(Gate0Args p) {
+    const int id = blockIdx.x;
+    const int nt = id % p.n_tiles;
+    const int g = id / p.n_tiles;
+    const int b = g / p.m_tiles_per_item;
+    const int mt = g - b * p.m_tiles_per_item;
+    const int rows = p.n_frames ? p.n_frames[b] * p.rows_per_frame : p.max_rows;
+    const int m0 = mt * G0_ROWS;
+    if (m0 >= rows) return;
+    const int C = p.channels;
+    const int n0 = nt * 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const float *pb = p.pulse + (long long)b * p.pulse_bstride;
+    const float *nb = p.noise ? p.noise + (long long)b * p.noise_bstride : nullptr;
+    const int pc = p.pulse_channels;
+
+    // weights of this column tile: [tap][parity e][lane][tanh m0, tanh m1, sigmoid m0, sigmoid m1]
+    float4 bw[3][2];
+    {
+        const float *wt = p.w + (long long)nt * 1536 + lane * 4;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) bw[t][e] = *reinterpret_cast<const float4 *>(wt + (t * 2 + e) * 256);
+    }
+    const bool ch_ok = n0 + 2 * r16 < C;                 // C is even: both channels of the lane exist or neither
+    float bias[4];                                       // [2 e + (0 tanh | 1 sigmoid)]
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bias[c] = (p.bias && ch_ok) ? p.bias[(c & 1) * C + n0 + 2 * r16 + (c >> 1)] : 0.f;
+    // channels 2 kq, 2 kq + 1 of x'[s]: kq 0, 1: pulse channels; 2: pulse channel 4 | sigma * noise; 3: 1 | 0
+    auto xrow = [&](int s) -> float2 {
+        if (s < 0 || s >= rows) return make_float2(0.f, 0.f);
+        float v[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int ch = 2 * kq + m;
+            v[m] = ch < pc ? pb[(long long)s * pc + ch] : (ch == pc ? (nb ? p.sigma * nb[s] : 0.f) : (ch == pc + 1 ? 1.f : 0.f));
+        }
+        return make_float2(v[0], v[1]);
+    };
+    const int cond_up = p.cond_up;
+    const int n2 = rows / cond_up;
+    const float *cb = p.cond + (long long)b * p.cond_bstride + n0 + 2 * r16;
+    float *ob = p.out + (long long)b * p.out_bstride;
+
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+        const int t0 = m0 + 64 * wave + 16 * i;
+        if (t0 >= rows) break;
+        float2 xv[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) xv[t] = xrow(t0 + r16 + (t - 1) * p.dil);
+        f32x4 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[c][r] = bias[c];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[t].x, bw[t][0].x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[t].x, bw[t][0].z, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[t].x, bw[t][1].x, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[t].x, bw[t][1].z, acc[3], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[t].y, bw[t][0].y, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[t].y, bw[t][0].w, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[t].y, bw[t][1].y, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[t].y, bw[t][1].w, acc[3], 0, 0, 0);
+        }
+        // register v of a tile = row t0 + 4 kq + v, gate channels n0 + 2 r16 (+1)
+        const int rbase = t0 + 4 * kq;
+        int t2 = rbase / cond_up;
+        int u = rbase - t2 * cond_up;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int row = rbase + v;
+            const float w0 = p.lerp_w0[u], w1 = p.lerp_w1[u];
+            const float *c0 = cb + (long long)min(t2, n2 - 1) * (2 * C);
+            const float *c1 = cb + (long long)min(t2 + 1, n2 - 1) * (2 * C);
+            float2 ct0 = make_float2(0.f, 0.f), ct1 = ct0, cs0 = ct0, cs1 = ct0;
+            if (ch_ok) {
+                ct0 = *reinterpret_cast<const float2 *>(c0);
+                ct1 = *reinterpret_cast<const float2 *>(c1);
+                cs0 = *reinterpret_cast<const float2 *>(c0 + C);
+                cs1 = *reinterpret_cast<const float2 *>(c1 + C);
+            }
+            float2 res;
+            res.x = g0_gate_act(acc[0][v] + (ct0.x * w0 + ct1.x * w1), acc[1][v] + (cs0.x * w0 + cs1.x * w1));
+            res.y = g0_gate_act(acc[2][v] + (ct0.y * w0 + ct1.y * w1), acc[3][v] + (cs0.y * w0 + cs1.y * w1));
+            if (ch_ok && row < rows) *reinterpret_cast<float2 *>(ob + (long long)row * p.ldo + n0 + 2 * r16) = res;
+            if (++u == cond_up) { u = 0; ++t2; }
+        }
+        // x' (8 channels, padded to 16) behind the C gate channels of the rows of this tile: lane -> row lane / 4, 4 floats
+        if (p.write_inputs && nt == 0) {
+            const int row = t0 + (lane >> 2), q = lane & 3;
+            if (row < rows) {
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                float *ov = &o.x;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int ch = 4 * q + k;
+                    ov[k] = ch < pc ? pb[(long long)row * pc + ch] : (ch == pc ? (nb ? p.sigma * nb[row] : 0.f) : (ch == pc + 1 ? 1.f : 0.f));
+                }
+                *reinterpret_cast<float4 *>(ob + (long long)row * p.ldo + C + 4 * q) = o;
+            }
+        }
+    }
+}
+
+// a.w: image of engine.fold_start_weights (ceil(C/32), 3, 2, 64, 4); false: the layer does not fit
+bool launch_wn_gate0(const Gate0Args &a, hipStream_t stream) {
+    const bool ok = a.pulse_channels >= 1 && a.pulse_channels + 2 <= 8 && a.channels % 4 == 0 && a.ldo % 4 == 0 &&
+                    a.out_bstride % 4 == 0 && (uintptr_t)a.out % 16 == 0 && (uintptr_t)a.w % 16 == 0 && a.cond &&
+                    (uintptr_t)a.cond % 8 == 0 && a.cond_bstride % 2 == 0 && a.cond_up >= 1 && a.lerp_w0 && a.lerp_w1 &&
+                    a.dil >= 1 && (!a.write_inputs || a.ldo >= a.channels + 16);
+    if (!ok) return false;
+    if (a.max_rows <= 0 || a.batch <= 0) return true;
+    Gate0Args r = a;
+    r.n_tiles = (a.channels + 31) / 32;
+    r.m_tiles_per_item = (a.max_rows + G0_ROWS - 1) / G0_ROWS;
+    const long long blocks = (long long)r.m_tiles_per_item * a.batch * r.n_tiles;
+    hipLaunchKernelGGL(wn_gate0_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, r);
+    return true;
+}
+
+}  // namespace mbx

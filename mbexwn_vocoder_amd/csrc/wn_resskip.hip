@@ -14,7 +14,8 @@
 //   three (large shape) or two LDS stages of 16 / 12 KB; operand groups of 8 MFMAs, the operands of group n+1 are requested from
 //   LDS before the MFMAs of group n issue.
 // The accumulators start from (old value + bias), so the epilogue is a plain store (same arithmetic as the
-// acc_preloaded path of conv1d_mfma_kernel).
+// acc_preloaded path of conv1d_mfma_kernel).  h_init (layer 0 with the start convolution folded in, wn_gate0.hip): the
+// input rows are [a | x'] (cin = C + 16), the weights [Wr ; Ws'], and h starts from the bias alone.
 #include <cstdlib>
 #include "mbx_kernels.h"
 
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 4) void wn_resskip_kernel(ConvAr
             ld[j] = to_h ? C : skip_ld;
             off_last[j] = (rows - 1) * ld[j];
             const int off0 = lane_row * ld[j];
-            const bool accumulate = (to_h || !p.skip_init) && col_ok[j];
+            const bool accumulate = (to_h ? !p.h_init : !p.skip_init) && col_ok[j];
             const float bias = (p.bias && col_ok[j]) ? p.bias[colc] : 0.f;
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 4) void wn_resskip_kernel(ConvAr
 
 // a.w must point at the host-packed weights (ceil(cout/128), ceil(C/16), 2048); returns false if the layer does not fit
 bool launch_wn_resskip(const ConvArgs &a, hipStream_t stream) {
-    const bool ok = a.ks == 1 && a.cin == a.channels && a.cin % 4 == 0 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 &&
+    const bool ok = a.ks == 1 && (a.h_init ? a.cin >= a.channels && !a.last_layer : a.cin == a.channels) && a.cin % 4 == 0 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 &&
                     (uintptr_t)a.x % 16 == 0 && (uintptr_t)a.w % 16 == 0 && a.zeros && a.h && a.skip && a.cout > 0 &&
                     (long long)a.max_rows * a.channels < (1LL << 31) &&
                     (a.skip_ld ? a.cout <= a.channels + a.skip_ld : a.cout == (a.last_layer ? a.channels : 2 * a.channels));

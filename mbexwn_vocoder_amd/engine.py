@@ -263,27 +263,6 @@ _WINOGRAD43_G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 
                           [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=np.float64)
 
 
-def pack_winograd4_weights(w):
-    """Winograd F(4,3) combinations U = G W of the three taps (3, C, 2C) of a dilated WaveNet convolution, packed for
-    wn_gate_winograd4_kernel (csrc/wn_winograd4.hip); formed in float64, stored float32.
-
-    Layout (ceil(C/32) column tiles, ceil(C/8) channel slices, 3072): the 12 KB image of one (tile, slice) is copied
-    verbatim into LDS, ordered [product j][wave column wn][lane = 32*lk + n][k step st] with input channel
-    8*slice + 4*lk + st and output column (n // 16)*C + 32*tile + 16*wn + n % 16; out-of-range entries are zero.
-    """
-    w = np.asarray(w, dtype=np.float64)
-    C = w.shape[1]
-    assert w.shape == (3, C, 2 * C)
-    u = np.einsum("ij,jcn->icn", _WINOGRAD43_G, w)
-    nt, nk = (C + 31) // 32, (C + 7) // 8
-    wp = np.zeros((6, nk * 8, 2, nt * 32))
-    wp[:, :C, 0, :C] = u[:, :, :C]
-    wp[:, :C, 1, :C] = u[:, :, C:]
-    wp = wp.reshape(6, nk * 8, 2, nt, 2, 16).transpose(0, 1, 4, 3, 2, 5).reshape(6, nk * 8, 2, nt * 32)
-    wp = wp.reshape(6, nk, 2, 4, 2, nt, 32)                       # j, slice, lk, st, wn, tile, n
-    return np.ascontiguousarray(wp.transpose(5, 1, 0, 4, 2, 6, 3).reshape(nt, nk, 3072), dtype=np.float32)
-
-
 def pack_winograd4w_weights(w):
     """Winograd F(4,3) combinations U = G W of the three taps (3, C, 2C) of a dilated WaveNet convolution, packed for
     wn_gate_winograd4w_kernel (csrc/wn_winograd4w.hip, v_mfma_f32_16x16x4_f32); formed in float64, stored float32.
@@ -366,6 +345,8 @@ def fold_skip_weights(folded, n_layers, channels):
             out["wn.tail.fold"] = pack_end_weights(proj[None])
         else:
             out[f"wn.res_skip_{ll}.fold"] = pack_resskip_weights(np.concatenate((w[0][:, :C], proj), axis=1)[None])
+            if ll == 0:
+                out["__proj_0"] = proj                 # for fold_start_weights; not a device tensor
             biases.append(np.concatenate((b[:C], np.zeros(n_out))))
     if biases:
         biases[0][C:] = const                 # layer 0 initialises the accumulator
@@ -374,6 +355,47 @@ def fold_skip_weights(folded, n_layers, channels):
         out["wn.tail.fold_b"] = np.zeros(n_out)
     else:
         out["wn.tail.fold_b"] = const
+    return out
+
+
+def fold_start_weights(folded, dims, fold_skip):
+    """Fold the WaveNet's start convolution (1x1, reference custom_AE_layers.py:177-182,280) into layer 0.
+
+    With x' = [x | 1 | 0] (8 channels; x = pulse channels (+ noise), the constant channel carries the start bias) and
+    Ws' = [Ws ; bs ; 0], h0 = x' Ws' and conv0(h0) = sum_tau x'[t + (tau-1) d] (Ws' W0_tau): the dilated convolution of
+    layer 0 becomes a K = 24 contraction of the excitation itself (csrc/wn_gate0.hip), and its res/skip layer obtains
+    h0 by contracting [a0 | x'] with [Wr ; Ws'] (csrc/wn_resskip.hip, h_init).  Products are formed in float64.
+    Returns {name: array}: the (ceil(C/32), 3, 2, 64, 4) image of the tap products -- [tap][channel parity e][lane =
+    16*kq + n][tanh step 0, tanh step 1, sigmoid step 0, sigmoid step 1], input channel 2*kq + step, output column
+    (0 | C) + 32*tile + 2*n + e -- and the K-extended res/skip image; {} if the layout does not allow it.
+    """
+    C, L = dims.wn_channels, dims.wn_layers
+    ws = np.asarray(folded["wn.start.w"], dtype=np.float64)
+    w0 = np.asarray(folded["wn.conv1D_0.w"], dtype=np.float64)
+    cin = dims.wn_in_channels
+    if ws.shape != (1, cin, C) or w0.shape != (3, C, 2 * C) or cin + 1 > 8 or dims.pulse_channels + 2 > 8:
+        return {}
+    wsp = np.zeros((8, C))
+    wsp[:cin] = ws[0]
+    wsp[dims.pulse_channels + 1] = np.asarray(folded["wn.start.b"], dtype=np.float64)   # the constant channel
+    prod = np.einsum("kc,tcn->tkn", wsp, w0)                       # (3, 8, 2C)
+    nt = (C + 31) // 32
+    wp = np.zeros((3, 8, 2, nt * 32))
+    wp[:, :, 0, :C] = prod[:, :, :C]
+    wp[:, :, 1, :C] = prod[:, :, C:]
+    wp = wp.reshape(3, 4, 2, 2, nt, 16, 2)                         # tap, kq, step, tanh|sigmoid, tile, n, e
+    out = {"wn.conv1D_0.start_fold": np.ascontiguousarray(wp.transpose(4, 0, 6, 1, 5, 3, 2).reshape(nt, 3, 512))}
+    if L > 1:
+        if not fold_skip or "wn.res_skip_0.fold" not in fold_skip:
+            return {}
+        n_out = dims.wn_out_channels
+        wr = np.asarray(folded["wn.res_skip_0.w"], dtype=np.float64)[0]
+        proj = np.asarray(fold_skip["__proj_0"], dtype=np.float64)    # Ws_0 We (C, n_out)
+        ext = np.zeros((C + 16, C + n_out))
+        ext[:C, :C] = wr[:, :C]
+        ext[:C, C:] = proj
+        ext[C:C + 8, :C] = wsp
+        out["wn.res_skip_0.fold_start"] = pack_resskip_weights(ext[None])
     return out
 
 
@@ -388,14 +410,17 @@ def tensor_table(config, raw_weights, wavetables):
     out["table.pqmf_syn"] = syn
     if out["wn.end.w"].shape[0] == 1 and out["wn.end.w"].shape[2] <= 32:
         out["wn.end.packed"] = pack_end_weights(out["wn.end.w"])
-        out.update(fold_skip_weights(out, dims.wn_layers, dims.wn_channels))
+        fs = fold_skip_weights(out, dims.wn_layers, dims.wn_channels)
+        if dims.wn_kernel_size == 3:
+            out.update(fold_start_weights(out, dims, fs))
+        fs.pop("__proj_0", None)
+        out.update(fs)
     for ll in range(dims.wn_layers):
         out[f"wn.res_skip_{ll}.packed"] = pack_resskip_weights(out[f"wn.res_skip_{ll}.w"])
     if dims.wn_kernel_size == 3:
         for ll in range(dims.wn_layers):
             out[f"wn.conv1D_{ll}.wino"] = pack_winograd_weights(out[f"wn.conv1D_{ll}.w"])
             out[f"wn.conv1D_{ll}.wino_split"] = pack_winograd_weights(out[f"wn.conv1D_{ll}.w"], split=True)
-            out[f"wn.conv1D_{ll}.wino4"] = pack_winograd4_weights(out[f"wn.conv1D_{ll}.w"])
             out[f"wn.conv1D_{ll}.wino4w"] = pack_winograd4w_weights(out[f"wn.conv1D_{ll}.w"])
     out["table.hann"] = tb.hann_periodic_f32(dims.stft_win)
     out["table.inv_win"] = tb.inverse_stft_window_f32(dims.stft_win, dims.hop_size)
