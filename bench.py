@@ -196,7 +196,7 @@ def run_batch(args, name, rank, world, fence, torch, profile):
         for _ in range(max(3, min(args.steps, 10))):
             eng.forward(mel, noise=noise, out=out)
         torch.cuda.synchronize()
-        stages = {kk: eng.profile_read(kk) for kk in ("gate", "res_skip", "frontend", "wavetable", "start", "tail",
+        stages = {kk: eng.profile_read(kk) for kk in ("gate", "gate0", "res_skip", "frontend", "wavetable", "start", "tail",
                                                        "pqmf", "stft_filter", "overlap_add")}
         eng.profile_enable(False)
         ctx = {"stages": stages, "cfg": cfg, "raw": raw, "wt": wt, "dims": dims, "eng": eng, "mel_h": mel_h,
@@ -227,7 +227,9 @@ def roofline(ctx, workload):
     n_out, M, hop, ppf = dims.wn_out_channels, dims.subbands, dims.hop_size, dims.pulse_per_frame
     spf, nceps, win = dims.steps_per_frame, dims.n_ceps, dims.stft_win
     stage_bytes = {            # algorithmic bytes of one launch (inputs read once + outputs written once)
-        "start": B * T * (ppf * 4 + spf * 4 + spf * C * 4),                       # pulse + noise -> h
+        # layer 0 with the start convolution folded in (wn_gate0.hip): pulse + noise + conditioning -> a0 (+ 16 channels)
+        "gate0": B * T * (ppf * 4 + spf * 4 + 2 * 2 * C * 4 + spf * (C + 16) * 4),
+        "start": B * T * (ppf * 4 + spf * 4 + spf * C * 4),                       # pulse + noise -> h (un-folded graph only)
         "tail": B * T * spf * (C * 4 + 2 * n_out * 4 + M * 4),                    # a + output accumulator r/w -> sub-bands
         "pqmf": B * T * (spf * M * 4 + hop * 4),                                   # sub-bands -> excitation
         "stft_filter": B * T * (hop * 4 + nceps * 4 + ppf * 4 + win * 4),          # excitation + cepstrum + f0 -> frames
@@ -237,6 +239,8 @@ def roofline(ctx, workload):
     stage_list = []
     for name, nbytes in stage_bytes.items():
         ms, cnt = stages[name]
+        if not cnt:
+            continue                                  # stage not on this graph (start: folded into layer 0; gate0: un-folded)
         avg_s = ms / max(cnt, 1) * 1e-3
         gbs = nbytes / avg_s / 1e9 if avg_s > 0 else None
         stage_list.append({"stage": name, "bound": "hbm", "avg_launch_ms": avg_s * 1e3, "bytes": nbytes,
@@ -252,7 +256,10 @@ def roofline(ctx, workload):
             "note": "achieved / frac = FLOPs the matrix cores execute (Winograd F(4,3): 1/2, F(2,3): 2/3 of the direct "
                     "convolution's 2*rows*3C*2C) / launch time: <= 1, comparable with MfmaUtil in profiles/; "
                     "*_algorithmic = the direct convolution's FLOPs / launch time (can exceed 1)",
-            "avg_launch_ms": gate_s * 1e3, "launches_timed": gate_n, "launches_per_step": L,
+            "avg_launch_ms": gate_s * 1e3, "launches_timed": gate_n,
+            "launches_per_step": L - 1 if eng.folds_start else L,
+            "first_layer": ("start convolution folded into layer 0: a K=24 contraction of the excitation (wn_gate0_kernel, "
+                            "listed under stages), not one of these launches") if eng.folds_start else "same kernel",
             "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
             "traffic_source": traffic_src,
             "res_skip": {"avg_launch_ms": rs_ms / max(rs_n, 1), "flop_per_launch": rs_flop,

@@ -762,10 +762,10 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         } else {
             ScopedEvents ev(hd, PROF_GATE, stream);
             bool done = false;
-            // F(4,3): 256-row blocks for large launches (>= four rounds of blocks), 128-row blocks whose waves split the
-            // input channels below that (finer granularity of the last round).  Streams run F(2,3): a window is
-            // bit-identical to an offline result only if both use one form with one group alignment (streaming.py),
-            // and F(2,3) needs the shorter alignment; MBX_WINOGRAD=2 makes offline runs use it as well.
+            // F(4,3): 256-row blocks once they fill the 512 resident slots (2 per CU), below that 128-row blocks whose waves
+            // split the input channels (finer granularity; measured equal at 630 blocks, i.e. one 10 s utterance).
+            // Streams run F(2,3): a window is bit-identical to an offline result only if both use one form with one group
+            // alignment (streaming.py), and F(2,3) needs the shorter alignment; MBX_WINOGRAD=2 makes offline runs use it too.
             const long long full_blocks = ((nsteps + 255) / 256) * B * ((C + 31) / 32);
             const bool use4 = hd->winograd == 4 && !st_in && !st_out;
             const DevTensor *wino4 = use4 ? find(hd, "wn.conv1D_" + ls + ".wino4w") : nullptr;
@@ -773,7 +773,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                 wino4->shape[2] == 3072) {
                 mbx::ConvArgs gw = g;
                 gw.w = wino4->ptr;
-                done = mbx::launch_wn_gate_winograd4w(gw, !(hd->winograd4_always || full_blocks >= 4 * 512), stream);
+                done = mbx::launch_wn_gate_winograd4w(gw, !(hd->winograd4_always || full_blocks >= 512), stream);
             }
             const DevTensor *wino = (!done && hd->winograd) ? find(hd, "wn.conv1D_" + ls + ".wino") : nullptr;
             if (wino && wino->ndim == 3 && wino->shape[0] == (C + 31) / 32 && wino->shape[1] == (C + 15) / 16 &&

@@ -574,8 +574,8 @@ class MBExWNEngine:
 
     def gate_form(self, batch, max_frames):
         """Which implementation of the dilated convolution a forward of this size runs (mirror of the policy in
-        csrc/mbx_api.hip: MBX_WINOGRAD, read by mbx_create, default 4 = F(4,3), with 256-row blocks from four rounds of
-        blocks on and 128-row channel-split blocks below; streams always run F(2,3)):
+        csrc/mbx_api.hip: MBX_WINOGRAD, read by mbx_create, default 4 = F(4,3), with 256-row blocks once they fill the
+        512 resident slots and 128-row channel-split blocks below; streams always run F(2,3)):
         "direct", "winograd_f23", "winograd_f43" or "winograd_f43_small"."""
         mode = int(os.environ.get("MBX_WINOGRAD", "4"))
         if mode == 0 or self.dims.wn_kernel_size != 3:
@@ -584,9 +584,17 @@ class MBExWNEngine:
             return "winograd_f23"
         rows = max_frames * self.dims.steps_per_frame
         full_blocks = ((rows + 255) // 256) * batch * ((self.dims.wn_channels + 31) // 32)
-        if mode == 44 or full_blocks >= 4 * 512:
+        if mode == 44 or full_blocks >= 512:
             return "winograd_f43"
         return "winograd_f43_small"
+
+    @property
+    def folds_start(self):
+        """True when layer 0 runs with the start convolution folded in (csrc/wn_gate0.hip): mirror of mbx_create's
+        policy (MBX_FOLD_SKIP / MBX_FOLD_START not 0 and the folded tensors exist)."""
+        return (int(os.environ.get("MBX_FOLD_SKIP", "1")) != 0 and int(os.environ.get("MBX_FOLD_START", "1")) != 0 and
+                "wn.conv1D_0.start_fold" in self._tensors and
+                (self.dims.wn_layers == 1 or "wn.res_skip_0.fold_start" in self._tensors))
 
     def stage(self, name):
         """Intermediate tensor of the last forward (copy), shaped (B, count); see mbx_stage."""

@@ -10,13 +10,13 @@ cd /tmp && export TMPDIR=/tmp
 for WL in config2_sp_b1_10s config3_si_b16_10s; do
   STEPS=20; [ $WL = config3_si_b16_10s ] && STEPS=5
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_trace_$WL -- \
-      python3 $R/bench.py --workload $WL --steps $STEPS --warmup 3 --no-cpu-baseline > $R/gpurun_out/${TAG}_trace_$WL.log 2>&1
+      python3 $R/bench.py --workload $WL --steps $STEPS --warmup 3 --no-cpu-baseline --no-secondary > $R/gpurun_out/${TAG}_trace_$WL.log 2>&1
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_pmc_fetch_$WL -- \
-      python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/${TAG}_pmc_fetch_$WL.log 2>&1
+      python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $R/gpurun_out/${TAG}_pmc_fetch_$WL.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_pmc_write_$WL -- \
-      python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/${TAG}_pmc_write_$WL.log 2>&1
+      python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $R/gpurun_out/${TAG}_pmc_write_$WL.log 2>&1
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE \
       --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_pmc_sq_$WL -- \
-      python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/${TAG}_pmc_sq_$WL.log 2>&1
+      python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $R/gpurun_out/${TAG}_pmc_sq_$WL.log 2>&1
   tail -1 $R/gpurun_out/${TAG}_trace_$WL.log | cut -c1-200
 done

@@ -251,6 +251,31 @@ def test_gate_layer_forms_match_oracle(torch, monkeypatch, form, key, spec, batc
         assert np.all(rag[1, ll * 300:] == 0.0)
 
 
+@pytest.mark.parametrize("key,spec", [("canon", CANON), ("voice", VOICE)])
+def test_start_convolution_folded_into_layer_0_matches_the_unfolded_graph(torch, monkeypatch, key, spec):
+    """Layer 0 with the start convolution folded in (csrc/wn_gate0.hip, the default) against the un-folded graph
+    (MBX_FOLD_START=0: start kernel writes h0, layer 0 runs the full dilated convolution): same audio to float32
+    rounding, both inside the tolerance against the oracle; ragged batch, item shorter than one block."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    cfg, raw, wt = build_case(*spec)
+    om = get_engine(key, *spec)[1]
+    mel, noise = synthetic_inputs(7, 3, 45)
+    lengths = [45, 13, 1]
+    nf = torch.as_tensor(lengths, dtype=torch.int32).cuda()
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MBX_FOLD_START", flag)
+        eng = MBExWNEngine(cfg, raw, wt)
+        assert eng.folds_start == (flag == "1")
+        outs[flag] = eng.forward(dev(torch, mel), n_frames=nf, noise=dev(torch, noise)).cpu().numpy()
+    for ii, ll in enumerate(lengths):
+        ref = om.forward(mel[ii:ii + 1, :ll], noise[ii:ii + 1, :ll * 20])[0]
+        for flag in ("1", "0"):
+            assert _maxdiff(outs[flag][ii, :ll * 300], ref) <= _tol(ref, E2E_TOL)
+            assert np.all(outs[flag][ii, ll * 300:] == 0.0)
+        assert _maxdiff(outs["1"][ii], outs["0"][ii]) <= _tol(ref, 2e-5)
+
+
 @pytest.mark.parametrize("overrides", [
     {"mbexwn_config:pp_mod_subnet:n_channels": 36, "mbexwn_config:pp_mod_subnet:n_layers": 3},      # C not a multiple of 8
     {"mbexwn_config:pp_mod_subnet:n_channels": 24, "mbexwn_config:pp_mod_subnet:n_layers": 7,

@@ -177,3 +177,47 @@ def test_folded_skip_path_is_the_same_linear_map(layers):
         P[k] = tail[k // 8, (k % 8) // 4, :n_out, k % 4]
     y = y + acts[-1] @ P + extra["wn.tail.fold_b"]
     assert np.max(np.abs(y - ref)) < 1e-5 * np.max(np.abs(ref))
+
+
+def test_start_convolution_folds_into_layer_0_including_the_item_edges():
+    """engine.fold_start_weights: the K = 24 contraction of x' = [x | 1 | 0] with the tap products Ws' W0_tau equals the
+    dilated convolution of h0 = start(x) with zero "SAME" padding -- also in the first and last rows, where a tap falls
+    outside the item (the constant channel is zero there, exactly where the reference pads h0) -- and [a0 | x'] times
+    the K-extended res/skip image equals h0 + a0 Wr (+ the folded skip columns)."""
+    from types import SimpleNamespace
+    rng = np.random.default_rng(11)
+    C, pc, n_out, T = 40, 5, 30, 37
+    dims = SimpleNamespace(wn_channels=C, wn_layers=2, wn_in_channels=pc + 1, pulse_channels=pc, wn_out_channels=n_out)
+    folded = {"wn.start.w": rng.normal(size=(1, pc + 1, C)), "wn.start.b": rng.normal(size=C),
+              "wn.conv1D_0.w": rng.normal(size=(3, C, 2 * C)),
+              "wn.res_skip_0.w": rng.normal(size=(1, C, 2 * C)), "wn.res_skip_0.b": rng.normal(size=2 * C)}
+    proj = rng.normal(size=(C, n_out))
+    out = engine.fold_start_weights(folded, dims, {"wn.res_skip_0.fold": None, "__proj_0": proj})
+    img = out["wn.conv1D_0.start_fold"].astype(np.float64)
+    nt = img.shape[0]
+    img = img.reshape(nt, 3, 2, 64, 2, 2)                          # tile, tap, e, lane, tanh|sigmoid, step
+    P = np.zeros((3, 8, 2 * C))
+    for tile in range(nt):
+        for e in range(2):
+            for lane in range(64):
+                kq, n = lane >> 4, lane & 15
+                ch = 32 * tile + 2 * n + e
+                for ts in range(2):
+                    for m in range(2):
+                        if ch < C:
+                            P[:, 2 * kq + m, ts * C + ch] = img[tile, :, e, lane, ts, m]
+                        else:
+                            assert np.all(img[tile, :, e, lane, ts, m] == 0.0)
+    x = rng.normal(size=(T, pc + 1))
+    xp = np.concatenate((x, np.ones((T, 1)), np.zeros((T, 1))), axis=1)          # x' (T, 8)
+    h0 = x @ folded["wn.start.w"][0] + folded["wn.start.b"]
+    for d in (1, 4):
+        ref = _direct_dilated(h0, folded["wn.conv1D_0.w"], d)
+        xpp = np.concatenate((np.zeros((d, 8)), xp, np.zeros((d, 8))))
+        got = sum(xpp[tau * d:tau * d + T] @ P[tau] for tau in range(3))
+        assert np.max(np.abs(got - ref)) < 2e-6 * np.max(np.abs(ref))
+    W = _unpack_resskip(out["wn.res_skip_0.fold_start"], C + 16, C + n_out)
+    a0 = rng.normal(size=(T, C))
+    rows = np.concatenate((a0, xp, np.zeros((T, 8))), axis=1)
+    ref = np.concatenate((h0 + a0 @ folded["wn.res_skip_0.w"][0][:, :C], a0 @ proj), axis=1)
+    assert np.max(np.abs(rows @ W - ref)) < 2e-6 * np.max(np.abs(ref))
