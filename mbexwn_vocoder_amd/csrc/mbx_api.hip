@@ -808,7 +808,20 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                 r.hs_bstride = nsteps * C;
                 r.skip_init = (l == 0);
                 ScopedEvents ev(hd, PROF_RES_SKIP, stream);
-                if (!mbx::launch_wn_resskip(r, stream)) return fail(MBX_ERR_INVALID_ARGUMENT, "folded res/skip layer does not fit its kernel");
+                // large launches (>= two rounds of the 512 resident 128-row blocks): one block owns all columns of its rows.
+                // Like the gate kernels' block shape this follows the launch size only under the default policy: a pinned
+                // form (MBX_WINOGRAD=0|2|44, streams) pins the kernel, so results do not depend on the batch they ran in.
+                bool done = false;
+                const DevTensor *fww = find(hd, "wn.res_skip_" + ls + (ext ? ".fold_start_wide" : ".fold_wide"));
+                const long long wide_blocks = ((nsteps + 127) / 128) * B;
+                const int npair = (C + c.wn_out_channels + 31) / 32;
+                if (fww && fww->ndim == 3 && fww->shape[0] == (cin_l + 7) / 8 && fww->shape[1] == npair && fww->shape[2] == 256 &&
+                    (hd->winograd4_always || (hd->winograd == 4 && !st_in && !st_out && wide_blocks >= 2 * 512))) {
+                    mbx::ConvArgs rw = r;
+                    rw.w = fww->ptr;
+                    done = mbx::launch_wn_resskip_wide(rw, stream);
+                }
+                if (!done && !mbx::launch_wn_resskip(r, stream)) return fail(MBX_ERR_INVALID_ARGUMENT, "folded res/skip layer does not fit its kernel");
             }
             continue;
         }

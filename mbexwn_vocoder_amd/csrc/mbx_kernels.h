@@ -89,6 +89,9 @@ struct Gate0Args {
 bool launch_wn_gate0(const Gate0Args &a, hipStream_t stream);
 // WaveNet residual/skip layer for large row counts (wn_resskip.hip); a.w = host-packed weights (ceil(cout/128), ceil(C/16), 2048)
 bool launch_wn_resskip(const ConvArgs &a, hipStream_t stream);
+// the same layer for large launches, one block owning all columns of its rows (wn_resskip_wide.hip); a.w = image of
+// engine.pack_resskip_wide_weights (ceil(cin/8), ceil(cout/32), 256)
+bool launch_wn_resskip_wide(const ConvArgs &a, hipStream_t stream);
 // WaveNet end convolution + post-net in one pass over the skip tensor (wn_tail.hip); w_end_packed = host-packed
 // weights (ceil(C/8), 2, 32, 4); false: shapes do not fit
 bool launch_wn_tail(const float *skip, long long skip_bstride, const int *n_frames, int rows_per_frame, int max_rows,

@@ -301,6 +301,24 @@ def pack_resskip_weights(w):
     return np.ascontiguousarray(wp.transpose(4, 0, 1, 5, 2, 6, 3).reshape(nct, nk, 2048))
 
 
+def pack_resskip_wide_weights(w):
+    """Weights (1, K, cout) of a WaveNet res/skip 1x1 convolution packed for wn_resskip_wide_kernel
+    (csrc/wn_resskip_wide.hip, v_mfma_f32_16x16x4_f32).
+
+    Layout (ceil(K/8) channel slices, NP = ceil(cout/32) column tile pairs, 256): [pair p][lane = 16*kq + n][even tile
+    step 0, even tile step 1, odd tile step 0, odd tile step 1] with input channel 8*slice + 2*kq + step and output
+    column 32*p + 2*n + (0 even | 1 odd); out-of-range entries are zero.
+    """
+    w = np.asarray(w, dtype=np.float32)
+    assert w.ndim == 3 and w.shape[0] == 1
+    K, cout = w.shape[1], w.shape[2]
+    nk, npair = (K + 7) // 8, (cout + 31) // 32
+    wp = np.zeros((nk * 8, npair * 32), dtype=np.float32)
+    wp[:K, :cout] = w[0]
+    wp = wp.reshape(nk, 4, 2, npair, 16, 2)                        # slice, kq, step, pair, n, parity
+    return np.ascontiguousarray(wp.transpose(0, 3, 1, 4, 5, 2).reshape(nk, npair, 256))
+
+
 def pack_end_weights(w):
     """Weights (1, C, n_out <= 32) of the WaveNet end convolution packed for wn_tail_kernel (csrc/wn_tail.hip):
     (ceil(C/8), 2, 32, 4) = [channel group c][lane half lk][column n][k step st] with input channel 8c + 4lk + st,
@@ -345,6 +363,7 @@ def fold_skip_weights(folded, n_layers, channels):
             out["wn.tail.fold"] = pack_end_weights(proj[None])
         else:
             out[f"wn.res_skip_{ll}.fold"] = pack_resskip_weights(np.concatenate((w[0][:, :C], proj), axis=1)[None])
+            out[f"wn.res_skip_{ll}.fold_wide"] = pack_resskip_wide_weights(np.concatenate((w[0][:, :C], proj), axis=1)[None])
             if ll == 0:
                 out["__proj_0"] = proj                 # for fold_start_weights; not a device tensor
             biases.append(np.concatenate((b[:C], np.zeros(n_out))))
@@ -396,6 +415,7 @@ def fold_start_weights(folded, dims, fold_skip):
         ext[:C, C:] = proj
         ext[C:C + 8, :C] = wsp
         out["wn.res_skip_0.fold_start"] = pack_resskip_weights(ext[None])
+        out["wn.res_skip_0.fold_start_wide"] = pack_resskip_wide_weights(ext[None])
     return out
 
 

@@ -221,3 +221,27 @@ def test_start_convolution_folds_into_layer_0_including_the_item_edges():
     rows = np.concatenate((a0, xp, np.zeros((T, 8))), axis=1)
     ref = np.concatenate((h0 + a0 @ folded["wn.res_skip_0.w"][0][:, :C], a0 @ proj), axis=1)
     assert np.max(np.abs(rows @ W - ref)) < 2e-6 * np.max(np.abs(ref))
+
+
+def test_resskip_wide_image_is_a_permutation_of_the_weights():
+    """engine.pack_resskip_wide_weights unpacked with the lane/step map of wn_resskip_wide_kernel."""
+    rng = np.random.default_rng(5)
+    K, cout = 44, 70
+    w = rng.normal(size=(1, K, cout)).astype(np.float32)
+    img = engine.pack_resskip_wide_weights(w)
+    nk, npair = (K + 7) // 8, (cout + 31) // 32
+    assert img.shape == (nk, npair, 256)
+    img = img.reshape(nk, npair, 64, 2, 2)                          # slice, pair, lane, parity, step
+    W = np.zeros((K, cout), np.float32)
+    for kt in range(nk):
+        for pr in range(npair):
+            for lane in range(64):
+                kq, n = lane >> 4, lane & 15
+                for par in range(2):
+                    for m in range(2):
+                        k, col = 8 * kt + 2 * kq + m, 32 * pr + 2 * n + par
+                        if k < K and col < cout:
+                            W[k, col] = img[kt, pr, lane, par, m]
+                        else:
+                            assert img[kt, pr, lane, par, m] == 0.0
+    assert np.array_equal(W, w[0])
