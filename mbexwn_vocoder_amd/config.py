@@ -248,8 +248,10 @@ class ModelDims:
         if self.wn_kernel_size % 2 != 1 or self.wn_channels % 2 != 0:
             # reference custom_AE_layers.py:134-135
             raise AssertionError("WaveNet kernel_size must be odd and n_channels even")
-        if self.wn_groups != 1:
-            raise NotImplementedError("n_ch_groups > 1 is not supported by the HIP path")
+        if self.wn_groups < 1 or self.wn_channels % self.wn_groups or (self.wn_channels // self.wn_groups) % 2:
+            # reference custom_AE_layers.py:165-166; the groups run as block-diagonal dense layers (weights.merge_channel_groups)
+            raise RuntimeError(f"WaveNetAE::error::n_channels parameter {self.wn_channels} has to be a multiple of chanel "
+                               f"groups parameter {self.wn_groups}")
         if self.wn_activation != "gtu":
             raise NotImplementedError("only the gtu (tanh*sigmoid) gate is supported")
         # keys of WaveNetAE.__init__ (reference custom_AE_layers.py:120-131) that change the arithmetic and are not built:

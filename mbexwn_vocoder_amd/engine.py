@@ -17,7 +17,7 @@ from . import tables as tb
 from .build import LIB_PATH
 from .config import ModelDims
 from .subnet import build_subnet
-from .weights import fold_weights
+from .weights import fold_weights, merge_channel_groups
 
 MBX_ABI_VERSION = 2
 MBX_MAX_SUBNET_OPS = 32
@@ -424,7 +424,7 @@ def tensor_table(config, raw_weights, wavetables):
     dims = ModelDims(config)
     mb = config["mbexwn_config"]
     mbc = mb["multi_band_config"]
-    out = dict(fold_weights(raw_weights))
+    out = dict(merge_channel_groups(fold_weights(raw_weights), dims))
     _, syn = tb.pqmf_filters(int(mbc["subbands"]), int(mbc["taps"]), float(mbc["cutoff_ratio"]), float(mbc["beta"]),
                              mbc.get("max_band", None))
     out["table.pqmf_syn"] = syn

@@ -126,11 +126,17 @@ class MELInverter(object):
     def generate_mel_from_snd(self, snd, srate):
         """Audio -> ``.mell`` dictionary (reference mel_inverter.py:156-182), host side (analysis.py).
         The reference resamples when ``srate`` differs from the model rate through a function it never imports
-        (mel_inverter.py:173); here a different rate is an error."""
+        (mel_inverter.py:173, a NameError there); here the sound is resampled with a polyphase FIR
+        (scipy.signal.resample_poly, Kaiser window) along the last axis."""
         from .analysis import compute_log_mel
         if srate != self.srate:
-            raise NotImplementedError(f"generate_mel_from_snd: resampling from {srate} Hz to {self.srate} Hz is not "
-                                      "part of this build")
+            from math import gcd
+            from scipy.signal import resample_poly
+            srate, target = int(round(srate)), int(round(self.srate))
+            if srate <= 0:
+                raise ValueError(f"generate_mel_from_snd: invalid sample rate {srate}")
+            gg = gcd(srate, target)
+            snd = resample_poly(np.asarray(snd, dtype=np.float64), target // gg, srate // gg, axis=-1)
         data_dict = {'nfft': self.fft_size,
                      'hoplen': self.hop_size,
                      'winlen': self.win_len,

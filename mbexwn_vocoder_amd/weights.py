@@ -37,9 +37,15 @@ def layer_table(config):
     C, L = dims.wn_channels, dims.wn_layers
     convs.append(("wn.start", 1, dims.wn_in_channels, C))
     convs.append(("wn.cond", dims.cond_kernel_size, dims.mel_channels, 2 * C * dims.cond_conv_upsampling))
+    # n_ch_groups independent channel groups, each with its own layers "conv1D_<l>", "conv1D_<l>g1", ...
+    # (reference custom_AE_layers.py:235-260)
+    G = dims.wn_groups
+    Cg = C // G
     for ll in range(L):
-        convs.append((f"wn.conv1D_{ll}", dims.wn_kernel_size, C, 2 * C))
-        convs.append((f"wn.res_skip_{ll}", 1, C, 2 * C if ll < L - 1 else C))
+        for gg in range(G):
+            sfx = f"g{gg}" if gg else ""
+            convs.append((f"wn.conv1D_{ll}{sfx}", dims.wn_kernel_size, Cg, 2 * Cg))
+            convs.append((f"wn.res_skip_{ll}{sfx}", 1, Cg, 2 * Cg if ll < L - 1 else Cg))
     convs.append(("wn.end", 1, C, dims.wn_out_channels))
     convs.append(("post", 1, dims.wn_out_channels, dims.subbands))
     return convs, prelus
@@ -88,6 +94,57 @@ def fold_weights(raw):
             out[name + ".b"] = np.asarray(raw[name + ".bias"], dtype=np.float32)
         elif key.endswith(".alpha"):
             out[key] = np.asarray(val, dtype=np.float32)
+    return out
+
+
+def merge_channel_groups(folded, dims):
+    """n_ch_groups > 1 (reference custom_AE_layers.py:303-340): the WaveNet is G independent stacks of C/G channels
+    between a shared start and end convolution.  The HIP kernels run ONE stack of C channels, so the per-group layers
+    become block-diagonal dense layers (a group's channels only meet that group's weights; the zero blocks cost matrix
+    work but no accuracy), with the channel order the dense layout implies:
+
+      conv1D_l    (ks, C, 2C): group g rows [g Cg, (g+1) Cg) -> tanh columns [g Cg, ..) and sigmoid columns C + [g Cg, ..)
+      res_skip_l  (1, C, 2C):  res columns [g Cg, ..), skip columns C + [g Cg, ..)   (last layer: (1, C, C), skip only)
+      cond        the reference splits its 2C channels into G chunks [tanh_g | sigmoid_g] (:289): its output columns are
+                  permuted to [tanh_0 .. tanh_G-1 | sigmoid_0 .. sigmoid_G-1] inside every sub-pixel phase
+    Returns a new dict; per-group entries ("...g1.w") are replaced by the dense ones under the group-0 names."""
+    G = dims.wn_groups
+    if G == 1:
+        return folded
+    C, L, ks = dims.wn_channels, dims.wn_layers, dims.wn_kernel_size
+    Cg = C // G
+    import re
+    out = {kk: vv for kk, vv in folded.items() if not re.fullmatch(r"wn\.(conv1D|res_skip)_\d+g\d+\.[wb]", kk)}
+    for ll in range(L):
+        last = ll == L - 1
+        wc = np.zeros((ks, C, 2 * C), dtype=np.float32)
+        bc = np.zeros((2 * C,), dtype=np.float32)
+        wr = np.zeros((1, C, C if last else 2 * C), dtype=np.float32)
+        br = np.zeros((C if last else 2 * C,), dtype=np.float32)
+        for gg in range(G):
+            sfx = f"g{gg}" if gg else ""
+            rows = slice(gg * Cg, (gg + 1) * Cg)
+            w, b = folded[f"wn.conv1D_{ll}{sfx}.w"], folded[f"wn.conv1D_{ll}{sfx}.b"]
+            wc[:, rows, gg * Cg:(gg + 1) * Cg] = w[:, :, :Cg]
+            wc[:, rows, C + gg * Cg:C + (gg + 1) * Cg] = w[:, :, Cg:]
+            bc[gg * Cg:(gg + 1) * Cg] = b[:Cg]
+            bc[C + gg * Cg:C + (gg + 1) * Cg] = b[Cg:]
+            w, b = folded[f"wn.res_skip_{ll}{sfx}.w"], folded[f"wn.res_skip_{ll}{sfx}.b"]
+            if last:
+                wr[:, rows, gg * Cg:(gg + 1) * Cg] = w
+                br[gg * Cg:(gg + 1) * Cg] = b
+            else:
+                wr[:, rows, gg * Cg:(gg + 1) * Cg] = w[:, :, :Cg]
+                wr[:, rows, C + gg * Cg:C + (gg + 1) * Cg] = w[:, :, Cg:]
+                br[gg * Cg:(gg + 1) * Cg] = b[:Cg]
+                br[C + gg * Cg:C + (gg + 1) * Cg] = b[Cg:]
+        out[f"wn.conv1D_{ll}.w"], out[f"wn.conv1D_{ll}.b"] = wc, bc
+        out[f"wn.res_skip_{ll}.w"], out[f"wn.res_skip_{ll}.b"] = wr, br
+    # conditioning: new column (u, [tanh | sigmoid], g, i) <- old column (u, g, [tanh | sigmoid], i)
+    up = dims.cond_conv_upsampling
+    perm = np.arange(up * 2 * C).reshape(up, G, 2, Cg).transpose(0, 2, 1, 3).reshape(-1)
+    out["wn.cond.w"] = np.ascontiguousarray(folded["wn.cond.w"][:, :, perm])
+    out["wn.cond.b"] = np.ascontiguousarray(folded["wn.cond.b"][perm])
     return out
 
 

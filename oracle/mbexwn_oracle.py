@@ -330,32 +330,43 @@ class OracleModel:
         return lin_interp(c, lin_up, self.f32)
 
     def wavenet(self, x, mel, return_layers=False):
-        """custom_AE_layers.py:273-346 (WaveNetAE.call), n_ch_groups == 1, activation gtu."""
+        """custom_AE_layers.py:273-346 (WaveNetAE.call), activation gtu; n_ch_groups independent channel groups between
+        the shared start and end convolutions (:303-340; layers of group g > 0 are named "<layer>g<g>", :249,260)."""
         C = self.wn["n_channels"]
         L = self.wn.get("n_layers", 12)
+        G = int(self.wn.get("n_ch_groups", 1))
+        Cg = C // G
         w, b = self.weight("wn.start")
-        h = conv1d_valid(x, w, b)                                                 # :280
-        cond = self.conditioning(mel)                                             # :287-289
-        skip = None
+        started = np.split(conv1d_valid(x, w, b), G, axis=-1)                     # :280, :303-304
+        started = [np.array(ss) for ss in started]
+        cond = np.split(self.conditioning(mel), G, axis=-1)                       # :287-289
+        output = [None] * G
         acts = []
         for ll in range(L):
-            w, b = self.weight(f"wn.conv1D_{ll}")
-            z = conv1d_same_zero(h, w, b, dilation=self.dilation(ll)) + cond      # :307-309
-            a = np.tanh(z[..., :C]) * (1 / (1 + np.exp(-z[..., C:])))             # :312-321
-            w, b = self.weight(f"wn.res_skip_{ll}")
-            r = conv1d_valid(a, w, b)                                             # :324
-            if ll < L - 1:
-                h = h + r[..., :C]                                                # :326-328
-                s = r[..., C:]
-            else:
-                s = r                                                             # :330
-            skip = s if skip is None else skip + s                                # :332-335
-            if return_layers:
-                acts.append(a)
+            for gg in range(G):
+                sfx = f"g{gg}" if gg else ""
+                w, b = self.weight(f"wn.conv1D_{ll}{sfx}")
+                z = conv1d_same_zero(started[gg], w, b, dilation=self.dilation(ll)) + cond[gg]   # :307-309
+                a = np.tanh(z[..., :Cg]) * (1 / (1 + np.exp(-z[..., Cg:])))       # :312-321
+                w, b = self.weight(f"wn.res_skip_{ll}{sfx}")
+                r = conv1d_valid(a, w, b)                                         # :324
+                if ll < L - 1:
+                    started[gg] = started[gg] + r[..., :Cg]                       # :326-328
+                    s = r[..., Cg:]
+                else:
+                    s = r                                                         # :330
+                output[gg] = s if output[gg] is None else output[gg] + s          # :332-335
+                if return_layers:
+                    acts.append(a)
+        skip = np.concatenate(output, axis=-1) if G > 1 else output[0]            # :337-340
         w, b = self.weight("wn.end")
-        out = conv1d_valid(skip, w, b)                                            # :337-340
+        out = conv1d_valid(skip, w, b)
         if return_layers:
-            return out, h, skip, acts, cond
+            h = np.concatenate(started, axis=-1) if G > 1 else started[0]
+            if G > 1:       # per layer: the groups' gate outputs side by side, as the dense layout of the HIP path holds them
+                acts = [np.concatenate(acts[ll * G:(ll + 1) * G], axis=-1) for ll in range(L)]
+                cond = [np.concatenate([cc[..., :Cg] for cc in cond] + [cc[..., Cg:] for cc in cond], axis=-1)]
+            return out, h, skip, acts, cond[0]
         return out
 
     # ------------------------------------------------------------------ PQMF (A10)

@@ -37,9 +37,12 @@ CASES = {
     # at 5x the pulse rate and generate_f0 cuts it, :787)
     "grammar": ("SPEECH", {"mbexwn_config:pp_subnet": [[5, 32, 2], [3, 64, "L2"], ["L", 5]],
                            "mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3}, 2, 9),
+    # two independent channel groups between the shared start and end convolutions (reference custom_AE_layers.py:303-340)
+    "groups": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                          "mbexwn_config:pp_mod_subnet:n_ch_groups": 2}, 2, 9),
 }
 # the long cases keep the small stage outputs only (the full conditioning / envelope tensors would be megabytes)
-LEAN = {"canon60", "voice", "grammar"}
+LEAN = {"canon60", "voice", "grammar", "groups"}
 
 
 def assign_conv(layer, raw, name):
@@ -61,8 +64,13 @@ def load_into_reference(model, raw):
                 used.add(ll.name + ".alpha")
     wn = model.pp_waveNetBlocks[0].wavenet
     pairs = [(wn.start, "wn.start"), (wn.end, "wn.end"), (wn.cond_layer, "wn.cond"), (model.wn_post_net[0], "post")]
-    pairs += [(ll, f"wn.conv1D_{ii}") for ii, ll in enumerate(wn.conv_layers)]
-    pairs += [(ll, f"wn.res_skip_{ii}") for ii, ll in enumerate(wn.res_skip_layers)]
+    # layer list index = layer * n_ch_groups + group; group g > 0 is named "<layer>g<g>" (reference custom_AE_layers.py:249,260)
+    ng = wn.n_ch_groups
+
+    def wn_name(base, ii):
+        return f"wn.{base}_{ii // ng}" + (f"g{ii % ng}" if ii % ng else "")
+    pairs += [(ll, wn_name("conv1D", ii)) for ii, ll in enumerate(wn.conv_layers)]
+    pairs += [(ll, wn_name("res_skip", ii)) for ii, ll in enumerate(wn.res_skip_layers)]
     for layer, name in pairs:
         assign_conv(layer, raw, name)
         used.update({name + ".v", name + ".g", name + ".bias"})

@@ -15,8 +15,10 @@ GOLDEN_CASES = {
     "voice": ("VOICE", {}, 2, 41),
     "grammar": ("SPEECH", {"mbexwn_config:pp_subnet": [[5, 32, 2], [3, 64, "L2"], ["L", 5]],
                            "mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3}, 2, 9),
+    "groups": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                          "mbexwn_config:pp_mod_subnet:n_ch_groups": 2}, 2, 9),
 }
-LEAN_GOLDEN_CASES = {"canon60", "voice", "grammar"}     # cond subsampled [:, ::37], no envelope / wavetables (see the generator)
+LEAN_GOLDEN_CASES = {"canon60", "voice", "grammar", "groups"}     # cond subsampled [:, ::37], no envelope / wavetables (see the generator)
 
 
 @functools.lru_cache(maxsize=None)

@@ -154,5 +154,11 @@ def test_generate_mel_from_snd():
     assert dd["mell"].shape == (80, 21) and dd["hoplen"] == 300 and dd["nfft"] == 2048 and dd["sr"] == 24000
     # the dictionary feeds straight back into scale_mel (round trip of the CLI's -v check)
     assert inv.scale_mel(dd).shape == (1, 21, 80)
-    with pytest.raises(NotImplementedError):
-        inv.generate_mel_from_snd(np.zeros(100), 16000)
+    # another sample rate: resampled to the model rate first (the reference calls a function it never imports there);
+    # a 1 kHz sine analysed at 16 kHz and at 24 kHz gives the same mel frames away from the edges
+    tt = np.arange(24000) / 24000.0
+    ref = inv.generate_mel_from_snd(np.sin(2 * np.pi * 1000.0 * tt).astype(np.float32), 24000)["mell"]
+    tt16 = np.arange(16000) / 16000.0
+    got = inv.generate_mel_from_snd(np.sin(2 * np.pi * 1000.0 * tt16).astype(np.float32), 16000)["mell"]
+    assert got.shape == ref.shape
+    assert np.max(np.abs(np.exp(got[:, 5:-5]) - np.exp(ref[:, 5:-5]))) < 2e-3 * np.max(np.exp(ref))

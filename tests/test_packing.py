@@ -245,3 +245,35 @@ def test_resskip_wide_image_is_a_permutation_of_the_weights():
                         else:
                             assert img[kt, pr, lane, par, m] == 0.0
     assert np.array_equal(W, w[0])
+
+
+def test_channel_groups_become_block_diagonal_dense_layers():
+    """weights.merge_channel_groups: the oracle's grouped WaveNet (reference custom_AE_layers.py:303-340, per-group layers)
+    against the same oracle run as ONE group on the merged dense weights -- the layout the HIP kernels consume."""
+    import copy
+    from mbexwn_vocoder_amd.config import ModelDims, canonical_config
+    from mbexwn_vocoder_amd.tables import WaveTables
+    from mbexwn_vocoder_amd.weights import fold_weights, merge_channel_groups, synthetic_weights
+    from oracle.mbexwn_oracle import OracleModel, synthetic_mel
+    cfg = canonical_config("SPEECH", **{"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                                        "mbexwn_config:pp_mod_subnet:n_ch_groups": 2})
+    dims = ModelDims(cfg)
+    raw = synthetic_weights(cfg, seed=5, bias_std=0.05, alpha_jitter=0.05)
+    assert "wn.conv1D_1g1.v" in raw and raw["wn.conv1D_1g1.v"].shape == (3, 16, 32)
+    wt = WaveTables(sample_rate=dims.pulse_rate, **cfg["mbexwn_config"]["wavetable_config"])
+    rng = np.random.default_rng(1)
+    mel = synthetic_mel(rng, 1, 12)
+    noise = rng.normal(size=(1, 12 * 20)).astype(np.float32)
+    ref = OracleModel(cfg, raw, wt).forward(mel, noise)
+
+    merged = merge_channel_groups(fold_weights(raw), dims)
+    assert merged["wn.conv1D_1.w"].shape == (3, 32, 64) and "wn.conv1D_1g1.w" not in merged
+    assert np.all(merged["wn.conv1D_1.w"][:, :16, 16:32] == 0) and np.all(merged["wn.conv1D_1.w"][:, 16:, :16] == 0)
+
+    class Dense(OracleModel):                      # folded tensors taken as they are
+        def weight(self, name):
+            return (np.asarray(merged[name + ".w"], dtype=self.dtype), np.asarray(merged[name + ".b"], dtype=self.dtype))
+    cfg1 = copy.deepcopy(cfg)
+    cfg1["mbexwn_config"]["pp_mod_subnet"]["n_ch_groups"] = 1
+    got = Dense(cfg1, raw, wt).forward(mel, noise)
+    assert np.max(np.abs(got - ref)) < 5e-6 * max(1.0, np.max(np.abs(ref)))      # float32 storage of the folded weights

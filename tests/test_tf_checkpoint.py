@@ -133,7 +133,11 @@ def test_unbuilt_wavenet_options_raise():
     """Keys of WaveNetAE.__init__ that change the arithmetic and are not built must not be ignored silently."""
     from mbexwn_vocoder_amd.config import ModelDims
     for key, value in (("use_equalized_lr", True), ("pre_cond_layer_channels", [64]), ("disable_conditioning", True),
-                       ("padding", "VALID"), ("n_ch_groups", 2)):
+                       ("padding", "VALID")):
         cfg = canonical_config("SPEECH", **{f"mbexwn_config:pp_mod_subnet:{key}": value})
         with pytest.raises(NotImplementedError):
             ModelDims(cfg)
+    # channel groups are built (block-diagonal dense layers); the reference's divisibility check stays
+    assert ModelDims(canonical_config("SPEECH", **{"mbexwn_config:pp_mod_subnet:n_ch_groups": 2})).wn_groups == 2
+    with pytest.raises(RuntimeError, match="multiple of chanel groups"):
+        ModelDims(canonical_config("SPEECH", **{"mbexwn_config:pp_mod_subnet:n_ch_groups": 3}))
