@@ -324,7 +324,7 @@ def run_streaming(args, name, rank, world, fence, torch):
         syn.open(sid)
         mm, nn = synthetic_batch(np.random.default_rng(1000 * rank + sid), 1, total, dims.steps_per_frame)
         syn.push(sid, mm[0], nn[0])
-    dev_ms, host_ms, frames = [], [], []
+    dev_ms, host_ms, frames, act_frames = [], [], [], []
     for tick in range(n_ticks):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -335,6 +335,7 @@ def run_streaming(args, name, rank, world, fence, torch):
             host_ms.append((time.perf_counter() - t1) * 1e3)
             dev_ms.append(syn.last_tick_device_ms)
             frames.append(syn.last_tick_frames)
+            act_frames.append(syn.last_tick_active_frames)
     fence()
     elapsed = fence.max_over_ranks(float(np.sum(dev_ms)) * 1e-3)       # device time of the timed ticks
     samples = world * n_streams * chunk * dims.hop_size * args.steps
@@ -347,7 +348,9 @@ def run_streaming(args, name, rank, world, fence, torch):
             "tick_ms_device_p50": float(np.percentile(dev_ms, 50)), "tick_ms_device_p99": float(np.percentile(dev_ms, 99)),
             "tick_ms_host_inclusive_p50": float(np.percentile(host_ms, 50)),
             "tick_ms_host_inclusive_p99": float(np.percentile(host_ms, 99)),
-            "frames_computed_per_emitted_frame": float(np.mean(frames)) / (n_streams * chunk)}
+            # window frames (mel-rate stages, phase) and frames of the active region (WaveNet ... overlap-add) per emitted frame
+            "frames_computed_per_emitted_frame": float(np.mean(frames)) / (n_streams * chunk),
+            "wavenet_frames_per_emitted_frame": float(np.mean(act_frames)) / (n_streams * chunk)}
 
 
 def spawn_ranks(args):

@@ -173,6 +173,14 @@ typedef struct {
     const float *f0;
     const mbx_stream_state *state_in;
     mbx_stream_state *state_out;
+    /* Streaming windows: the mel-rate stages and the phase run on the whole window, every stage from the WaveNet on
+     * (WaveNet, PQMF, STFT filter, overlap-add: the expensive ones) only on the frames [active_begin, active_begin +
+     * active_frames[b]) of item b, as if that region were the item (its edges get the item-edge padding, so the caller
+     * keeps a margin inside it).  `audio` is written for that region only, at the same positions as for a whole window.
+     *   active_begin   first frame of the region (0 with active_frames == NULL: whole window)
+     *   active_frames  device (batch) int32 frames of each item inside the region, or NULL */
+    int32_t active_begin;
+    const int32_t *active_frames;
 } mbx_forward_options;
 
 mbx_status mbx_forward_ex(mbx_handle *handle, const float *mel, const int32_t *n_frames, int32_t batch,

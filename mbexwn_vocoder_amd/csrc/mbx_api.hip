@@ -629,7 +629,8 @@ size_t mbx_workspace_size(const mbx_handle *handle, int32_t batch, int32_t max_f
 static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *n_frames, int32_t batch,
                                int32_t max_frames, const float *noise, float *audio, void *workspace,
                                size_t workspace_bytes, const mbx::StreamState *st_in, mbx::StreamState *st_out,
-                               void *hip_stream, const float *f0_in = nullptr, float transposition = 1.f) {
+                               void *hip_stream, const float *f0_in = nullptr, float transposition = 1.f,
+                               int active_begin = 0, const int32_t *active_frames = nullptr) {
     if (!hd || !mel || !audio || !workspace) return fail(MBX_ERR_INVALID_ARGUMENT, "null argument");
     if (batch <= 0 || max_frames <= 0) return fail(MBX_ERR_INVALID_ARGUMENT, "batch and max_frames must be positive");
     DeviceGuard guard(hd->device);
@@ -638,6 +639,8 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     if (c.noise_sigma != 0.f && !noise) return fail(MBX_ERR_INVALID_ARGUMENT, "noise is required when noise_sigma != 0");
     if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return fail(MBX_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
     const int B = batch, T = max_frames;
+    if (active_begin < 0 || active_begin >= T || (active_begin > 0 && !active_frames))
+        return fail(MBX_ERR_INVALID_ARGUMENT, "active_begin must lie inside the window and needs active_frames");
     Workspace w = carve(hd, static_cast<char *>(workspace), B, T);
     if (w.total > workspace_bytes) return fail(MBX_ERR_WORKSPACE, "workspace too small, see mbx_workspace_size");
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
@@ -706,6 +709,28 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         mbx::launch_wavetable(wavetable_consts(hd), w.f0, npulse, n_frames, c.pulse_per_frame, (int)npulse, B, w.pulse,
                               nullptr, w.cum, w.chunk_last, st_in, st_out, stream);
     }
+    // ---- active region (streaming windows, mbx_forward_options): from here on every stage sees the frames
+    // [active_begin, active_begin + active_frames[b]) of the window as the item.  All buffers are (batch, frames * k)
+    // with the batch stride of the whole window, so the region is a pointer offset plus the per-item frame counts.
+    const Workspace w_base = w;                      // the stage table below points at the whole window
+    if (active_frames) {
+        const long long a0 = active_begin;
+        n_frames = active_frames;
+        w.pulse += a0 * c.pulse_per_frame;
+        w.f0 += a0 * c.pulse_per_frame;
+        if (noise) noise += a0 * c.steps_per_frame;
+        w.cond += a0 * cond_cout;
+        w.h += a0 * c.steps_per_frame * C;
+        w.skip += a0 * c.steps_per_frame * C;
+        w.wn_out += a0 * c.steps_per_frame * c.wn_out_channels;
+        w.sub += a0 * c.steps_per_frame * M;
+        w.exc += a0 * c.hop_size;
+        w.ceps += a0 * c.n_ceps;
+        w.ceps_index += a0;
+        w.frames += a0 * c.stft_win;
+        audio += a0 * c.hop_size;
+    }
+    const long long a_off = active_frames ? (long long)active_begin * c.steps_per_frame : 0;   // rows; `a` has a per-layer row stride
     // ---- WaveNet (reference custom_AE_layers.py:273-346)
     const bool fold_start = hd->fold_start;
     const int lda0 = (fold_start && L > 1) ? C + 16 : C;      // row stride of layer 0's output
@@ -722,7 +747,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         const int d = c.wn_dilations[l];
         mbx::ConvArgs g = conv_args(w.h, nsteps * C, C, n_frames, c.steps_per_frame, (int)nsteps, B,
                                     find(hd, "wn.conv1D_" + ls + ".w"), find(hd, "wn.conv1D_" + ls + ".b"),
-                                    c.wn_kernel_size, C, 2 * C, d, d * (c.wn_kernel_size - 1) / 2, MBX_PAD_ZERO, w.a,
+                                    c.wn_kernel_size, C, 2 * C, d, d * (c.wn_kernel_size - 1) / 2, MBX_PAD_ZERO, w.a + a_off * C,
                                     nsteps * C, C);
         g.cond = w.cond;
         g.cond_bstride = (long long)T * cond_cout;
@@ -754,7 +779,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
             g0.cond_up = g.cond_up;
             g0.lerp_w0 = g.lerp_w0;
             g0.lerp_w1 = g.lerp_w1;
-            g0.out = w.a;
+            g0.out = w.a + a_off * lda0;
             g0.out_bstride = nsteps * lda0;
             g0.ldo = lda0;
             g0.write_inputs = L > 1;
@@ -797,7 +822,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                 const int cin_l = ext ? C + 16 : C;
                 const DevTensor *fw = find(hd, "wn.res_skip_" + ls + (ext ? ".fold_start" : ".fold")),
                                 *fb = find(hd, "wn.res_skip_" + ls + ".fold_b");
-                mbx::ConvArgs r = conv_args(w.a, nsteps * cin_l, cin_l, n_frames, c.steps_per_frame, (int)nsteps, B, fw, fb, 1,
+                mbx::ConvArgs r = conv_args(w.a + a_off * cin_l, nsteps * cin_l, cin_l, n_frames, c.steps_per_frame, (int)nsteps, B, fw, fb, 1,
                                             cin_l, C + c.wn_out_channels, 1, 0, MBX_PAD_ZERO, nullptr, 0, 0);
                 r.h_init = ext;
                 r.channels = C;
@@ -825,7 +850,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
             }
             continue;
         }
-        mbx::ConvArgs r = conv_args(w.a, nsteps * C, C, n_frames, c.steps_per_frame, (int)nsteps, B,
+        mbx::ConvArgs r = conv_args(w.a + a_off * C, nsteps * C, C, n_frames, c.steps_per_frame, (int)nsteps, B,
                                     find(hd, "wn.res_skip_" + ls + ".w"), find(hd, "wn.res_skip_" + ls + ".b"), 1, C,
                                     last ? C : 2 * C, 1, 0, MBX_PAD_ZERO, nullptr, 0, 0);
         r.channels = C;
@@ -856,7 +881,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                         *bpn = find(hd, "post.b");
         if (fold) {
             const DevTensor *tw = find(hd, "wn.tail.fold"), *tb = find(hd, "wn.tail.fold_b");
-            if (!mbx::launch_wn_tail(w.a, nsteps * C, n_frames, c.steps_per_frame, (int)nsteps, B, C, tw->ptr, tb->ptr,
+            if (!mbx::launch_wn_tail(w.a + a_off * C, nsteps * C, n_frames, c.steps_per_frame, (int)nsteps, B, C, tw->ptr, tb->ptr,
                                      c.wn_out_channels, wpn->ptr, bpn ? bpn->ptr : nullptr, M, L > 1 ? w.wn_out : nullptr,
                                      w.wn_out, nsteps * c.wn_out_channels, w.sub, nsteps * M, stream))
                 return fail(MBX_ERR_INVALID_ARGUMENT, "folded WaveNet tail does not fit its kernel");
@@ -894,7 +919,8 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     }
     {
         ScopedEvents ev(hd, PROF_OVERLAP_ADD, stream);
-        mbx::launch_overlap_add(sc, w.frames, n_frames, T, B, audio, (long long)T * c.hop_size, stream);
+        mbx::launch_overlap_add(sc, w.frames, n_frames, T, T - (active_frames ? active_begin : 0), B, audio,
+                                (long long)T * c.hop_size, stream);
     }
     if (nm_gain_src) {
         ScopedEvents ev(hd, PROF_NORM_MEL, stream);
@@ -905,20 +931,20 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     if (e != hipSuccess) return fail(MBX_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
 
     auto &sg = hd->stages;
-    if (nm_gain_src) sg["mel_norm"] = {w.mel_norm, (long long)T * c.mel_channels, (long long)T * c.mel_channels};
+    if (nm_gain_src) sg["mel_norm"] = {w_base.mel_norm, (long long)T * c.mel_channels, (long long)T * c.mel_channels};
     else sg.erase("mel_norm");
-    sg["f0"] = {w.f0, npulse, npulse};
-    sg["pulse"] = {w.pulse, npulse, npulse};
-    sg["cond"] = {w.cond, (long long)T * cond_cout, (long long)T * cond_cout};
-    sg["wn_hidden"] = {w.h, nsteps * C, nsteps * C};
-    if (!hd->fold_skip) sg["wn_skip"] = {w.skip, nsteps * C, nsteps * C};
+    sg["f0"] = {w_base.f0, npulse, npulse};
+    sg["pulse"] = {w_base.pulse, npulse, npulse};
+    sg["cond"] = {w_base.cond, (long long)T * cond_cout, (long long)T * cond_cout};
+    sg["wn_hidden"] = {w_base.h, nsteps * C, nsteps * C};
+    if (!hd->fold_skip) sg["wn_skip"] = {w_base.skip, nsteps * C, nsteps * C};
     else sg.erase("wn_skip");
-    sg["wn_out"] = {w.wn_out, nsteps * c.wn_out_channels, nsteps * c.wn_out_channels};
-    sg["subbands"] = {w.sub, nsteps * M, nsteps * M};
-    sg["excitation"] = {w.exc, (long long)T * c.hop_size, (long long)T * c.hop_size};
-    sg["cepstrum"] = {w.ceps, (long long)T * c.n_ceps, (long long)T * c.n_ceps};
-    sg["ceps_index"] = {w.ceps_index, (long long)T, (long long)T};
-    sg["frames"] = {w.frames, (long long)T * c.stft_win, (long long)T * c.stft_win};
+    sg["wn_out"] = {w_base.wn_out, nsteps * c.wn_out_channels, nsteps * c.wn_out_channels};
+    sg["subbands"] = {w_base.sub, nsteps * M, nsteps * M};
+    sg["excitation"] = {w_base.exc, (long long)T * c.hop_size, (long long)T * c.hop_size};
+    sg["cepstrum"] = {w_base.ceps, (long long)T * c.n_ceps, (long long)T * c.n_ceps};
+    sg["ceps_index"] = {w_base.ceps_index, (long long)T, (long long)T};
+    sg["frames"] = {w_base.frames, (long long)T * c.stft_win, (long long)T * c.stft_win};
     return MBX_OK;
 }
 
@@ -948,7 +974,7 @@ mbx_status mbx_forward_ex(mbx_handle *hd, const float *mel, const int32_t *n_fra
     return forward_impl(hd, mel, n_frames, batch, max_frames, noise, audio, workspace, workspace_bytes,
                         reinterpret_cast<const mbx::StreamState *>(options->state_in),
                         reinterpret_cast<mbx::StreamState *>(options->state_out), hip_stream, options->f0,
-                        options->transposition);
+                        options->transposition, options->active_begin, options->active_frames);
 }
 
 mbx_status mbx_profile_enable(mbx_handle *handle, int32_t enabled) {
@@ -1070,7 +1096,7 @@ mbx_status mbx_stft_filter(mbx_handle *hd, const float *excitation, const float 
     mbx::launch_stft_filter(sc, excitation, (long long)frames * c.hop_size, cepstrum, (long long)frames * c.n_ceps,
                             c.n_ceps_windows ? ceps_index : nullptr, nullptr, 0, nullptr, nullptr, frames, batch, scratch,
                             stream);
-    mbx::launch_overlap_add(sc, scratch, nullptr, frames, batch, audio, (long long)frames * c.hop_size, stream);
+    mbx::launch_overlap_add(sc, scratch, nullptr, frames, frames, batch, audio, (long long)frames * c.hop_size, stream);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MBX_OK : fail(MBX_ERR_HIP, hipGetErrorString(e));
 }

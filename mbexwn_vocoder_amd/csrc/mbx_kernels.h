@@ -167,8 +167,8 @@ void launch_stft_filter(const StftConsts &c, const float *exc, long long exc_bst
                         long long ceps_bstride, const int *index, const float *f0, long long f0_bstride,
                         int *index_out, const int *n_frames, int max_frames, int batch, float *frames,
                         hipStream_t stream);
-// overlap-add of the windowed frames + slice -> audio (B, max_frames*hop), tail zeroed
-void launch_overlap_add(const StftConsts &c, const float *frames, const int *n_frames, int max_frames, int batch,
+// overlap-add of the windowed frames + slice -> audio (B, out_frames*hop), tail zeroed; max_frames = item stride of `frames`
+void launch_overlap_add(const StftConsts &c, const float *frames, const int *n_frames, int max_frames, int out_frames, int batch,
                         float *audio, long long audio_bstride, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------

@@ -246,10 +246,10 @@ void launch_stft_filter(const StftConsts &c, const float *exc, long long exc_bst
 
 // overlap-add in frame order + slice [win/2, win/2 + T*hop)
 __global__ void overlap_add_kernel(StftConsts c, const float *frames, const int *n_frames, int max_frames,
-                                   float *audio, long long audio_bstride) {
+                                   int out_frames, float *audio, long long audio_bstride) {
     const int b = blockIdx.y;
     const int T = n_frames ? n_frames[b] : max_frames;
-    const int n_valid = T * c.hop, n_all = max_frames * c.hop;
+    const int n_valid = T * c.hop, n_all = out_frames * c.hop;
     const float *fb = frames + (long long)b * max_frames * c.win;
     float *ab = audio + (long long)b * audio_bstride;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_all; i += gridDim.x * blockDim.x) {
@@ -264,12 +264,12 @@ __global__ void overlap_add_kernel(StftConsts c, const float *frames, const int 
     }
 }
 
-void launch_overlap_add(const StftConsts &c, const float *frames, const int *n_frames, int max_frames, int batch,
-                        float *audio, long long audio_bstride, hipStream_t stream) {
-    if (max_frames <= 0 || batch <= 0) return;
-    const int n_all = max_frames * c.hop;
+void launch_overlap_add(const StftConsts &c, const float *frames, const int *n_frames, int max_frames, int out_frames,
+                        int batch, float *audio, long long audio_bstride, hipStream_t stream) {
+    if (max_frames <= 0 || out_frames <= 0 || batch <= 0) return;
+    const int n_all = out_frames * c.hop;
     hipLaunchKernelGGL(overlap_add_kernel, dim3(min((n_all + 255) / 256, 2048), batch), dim3(256), 0, stream, c,
-                       frames, n_frames, max_frames, audio, audio_bstride);
+                       frames, n_frames, max_frames, out_frames, audio, audio_bstride);
 }
 
 }  // namespace mbx

@@ -65,7 +65,8 @@ class mbx_config(ctypes.Structure):
 
 class mbx_forward_options(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_int32), ("transposition", ctypes.c_float), ("f0", ctypes.c_void_p),
-                ("state_in", ctypes.c_void_p), ("state_out", ctypes.c_void_p)]
+                ("state_in", ctypes.c_void_p), ("state_out", ctypes.c_void_p), ("active_begin", ctypes.c_int32),
+                ("active_frames", ctypes.c_void_p)]
 
 
 class mbx_tensor(ctypes.Structure):
@@ -535,12 +536,15 @@ class MBExWNEngine:
             self._workspace = self._torch.empty(need, dtype=self._torch.uint8, device=self.device)
         return self._workspace, need
 
-    def forward(self, mel, n_frames=None, noise=None, out=None, stream_state=None):
+    def forward(self, mel, n_frames=None, noise=None, out=None, stream_state=None, active=None):
         """mel (B,T,80) float32 cuda tensor; n_frames int32 cuda tensor (B,) or None;
         noise (B, T*steps_per_frame) float32 cuda tensor (N(0,1) draw) -> audio (B, T*hop) cuda tensor.
 
         stream_state: optional int32 cuda tensor (B, 6) holding one ``mbx_stream_state`` per item (see
-        streaming.pack_state); the call then returns (audio, state_out) with the carried phase state."""
+        streaming.pack_state); the call then returns (audio, state_out) with the carried phase state.
+        active: optional (begin_frame, int32 cuda tensor (B,) of frames) with stream_state: the stages from the WaveNet
+        on run on that region of the window only (``mbx_forward_options.active_begin / active_frames``); the audio
+        outside the region is undefined."""
         torch = self._torch
         if mel.dim() != 3 or mel.shape[2] != self.dims.mel_channels:
             raise ValueError(f"mel must be (batch, frames, {self.dims.mel_channels})")
@@ -569,6 +573,22 @@ class MBExWNEngine:
                 raise ValueError("stream_state must be an int32 tensor of shape (batch, 6) on the engine's device")
             stream_state = stream_state.contiguous()
             state_out = torch.empty_like(stream_state)
+            if active is not None:
+                a0, act = int(active[0]), active[1]
+                if act.dtype != torch.int32 or tuple(act.shape) != (B,) or act.device != self.device or not 0 <= a0 < T:
+                    raise ValueError("active = (begin frame inside the window, int32 tensor of shape (batch,) on the device)")
+                act = act.contiguous()
+                opt = mbx_forward_options()
+                opt.struct_size = ctypes.sizeof(mbx_forward_options)
+                opt.transposition = 1.0
+                opt.state_in, opt.state_out = stream_state.data_ptr(), state_out.data_ptr()
+                opt.active_begin, opt.active_frames = a0, act.data_ptr()
+                _check(self._lib.mbx_forward_ex(self._handle, mel.data_ptr(),
+                                                n_frames.data_ptr() if n_frames is not None else None, B, T,
+                                                noise.data_ptr() if noise is not None else None, out.data_ptr(),
+                                                ws.data_ptr(), need, ctypes.byref(opt), self._stream()))
+                self._last_shape = (B, T)
+                return out, state_out
             _check(self._lib.mbx_forward_stream(self._handle, mel.data_ptr(),
                                                 n_frames.data_ptr() if n_frames is not None else None, B, T,
                                                 noise.data_ptr() if noise is not None else None, out.data_ptr(),

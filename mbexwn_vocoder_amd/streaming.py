@@ -28,7 +28,7 @@ def pack_state(cum=0.0, offset_sum=0.0, pos_in_chunk=0, start_sample=0, save_sam
 
 
 def stream_margins(dims, config):
-    """(left, right, pulse_lead) in mel frames, from the layer geometry of the model."""
+    """(left, right, pulse_lead, act_left, act_right) in mel frames, from the layer geometry of the model."""
     mb = config["mbexwn_config"]
 
     def subnet_reach(specs):
@@ -55,7 +55,10 @@ def stream_margins(dims, config):
     smooth = 3                                             # F0 smoother of the lifter selection: +-3 frames of valid F0
     left = max(left, pulse_lead + smooth + 1)
     right = max(right, f0_r + smooth + 2)
-    return left, right, pulse_lead
+    # margins of the stages from the WaveNet on (the active region of a window, mbx_forward_options.active_begin)
+    act_left = wn_frames + pqmf_frames + stft_l
+    act_right = wn_frames + pqmf_frames + stft_r
+    return left, right, pulse_lead, act_left, act_right
 
 
 class _Stream:
@@ -76,7 +79,7 @@ class StreamingSynthesizer:
         self.engine = engine
         self.dims = engine.dims
         self.chunk = int(chunk_frames)
-        self.left, self.right, self.lead = stream_margins(engine.dims, engine.config)
+        self.left, self.right, self.lead, self.act_left, self.act_right = stream_margins(engine.dims, engine.config)
         # The Winograd form of the dilated convolution pairs outputs t and t+d inside blocks of 2d steps counted from
         # the first row of the item; a window that starts on a multiple of 2*d_max steps pairs exactly like the offline
         # run, which keeps the streamed audio bit-identical (any other start is equal up to float32 rounding only).
@@ -86,7 +89,8 @@ class StreamingSynthesizer:
         self.streams = {}
         self.time_device = False          # bench: bracket the engine call of a tick with events on its stream
         self.last_tick_device_ms = None
-        self.last_tick_frames = 0         # frames the engine computed in the last tick (all streams)
+        self.last_tick_frames = 0         # window frames of the last tick (all streams): mel-rate stages
+        self.last_tick_active_frames = 0  # frames of the active regions: stages from the WaveNet on
 
     @property
     def lookahead_ms(self):
@@ -131,6 +135,22 @@ class StreamingSynthesizer:
             windows.append((ws, we))
         tmax = max(we - ws for ws, we in windows)
         B = len(todo)
+        # active region: the mel-rate stages and the phase need the whole window (their receptive fields are long: F0-net,
+        # smoother of the lifter selection), the stages from the WaveNet on only the frames around what is emitted.
+        # It starts on an aligned frame (same Winograd pairing as offline), at least `lead` frames inside a window that
+        # does not start the utterance (pulses are reproducible from there), and is the same offset for every item.
+        a0 = None
+        for (sid, st, nn), (ws, we) in zip(todo, windows):
+            ab = max(0, ((st.emitted - self.act_left) // self.align) * self.align) - ws
+            if ws > 0 and ab < self.lead:
+                ab = 0
+            a0 = ab if a0 is None else min(a0, ab)
+        if any(ws > 0 for ws, _ in windows) and 0 < a0 < self.lead:
+            a0 = 0
+        act = np.zeros((B,), dtype=np.int32)
+        for bb, ((sid, st, nn), (ws, we)) in enumerate(zip(todo, windows)):
+            a1 = we if we - (st.emitted + nn) <= self.act_right else st.emitted + nn + self.act_right
+            act[bb] = a1 - ws - a0
         mel = np.zeros((B, tmax, self.dims.mel_channels), dtype=np.float32)
         noise = np.zeros((B, tmax * spf), dtype=np.float32)
         nfr = np.zeros((B,), dtype=np.int32)
@@ -157,7 +177,9 @@ class StreamingSynthesizer:
         if self.time_device:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        audio, state_out = self.engine.forward(mel_d, n_frames=nfr_d, noise=noise_d, stream_state=states_d)
+        self.last_tick_active_frames = int(act.sum())
+        audio, state_out = self.engine.forward(mel_d, n_frames=nfr_d, noise=noise_d, stream_state=states_d,
+                                               active=(a0, torch.as_tensor(act, device=dev)))
         if self.time_device:
             ev1.record()
             ev1.synchronize()
