@@ -234,6 +234,18 @@ mbx_status mbx_stft_filter(mbx_handle *handle, const float *excitation, const fl
                            const int32_t *ceps_index, int32_t batch, int32_t frames, float *audio, float *scratch,
                            void *hip_stream);
 
+/* Audio -> log-mel analysis, the step in front of the mel inversion (reference MELInverter.generate_mel_from_snd,
+ * mel_inverter.py:156-182 -> compute_mel_spectrogram_internal, vocoder/model/preprocess.py:417-572, with
+ * calc_stft(center=True, magnitude), sig_proc/spec/stft.py:14-96).  Needs no handle: every table is an argument.
+ *   audio      device (batch, max_samples) float32; n_samples device int32 (batch) or NULL
+ *   window     device (win) analysis window; twiddle device (fft_size/2, 2) = exp(-2 pi i m / fft_size)
+ *   basis      device (n_mels, fft_size/2+1) mel filters, bin_lo / bin_hi device int32 (n_mels): non-zero range of a row
+ *   out        device (batch, max_frames, n_mels): log(max(|STFT| . basis^T, eps)); item b has n_samples[b]/hop + 1 frames */
+mbx_status mbx_mel_analysis(const float *audio, const int32_t *n_samples, int32_t batch, int32_t max_samples,
+                            int32_t win, int32_t hop, int32_t fft_size, int32_t n_mels, const float *window,
+                            const float *twiddle, const float *basis, const int32_t *bin_lo, const int32_t *bin_hi,
+                            float eps, float *out, int32_t max_frames, void *hip_stream);
+
 /* NormMelComponents.normalize_inputs_by_rms(None, mell, synth_length) (reference wavegen_1d.py:638-769), only for
  * models with nm_iters > 0: mel (batch, frames, mel_channels) -> mel_out (same shape) and, if gain != NULL,
  * gain (batch, frames*hop) = upsampled_rms (what mbx_forward multiplies onto the audio).  n_frames: device int32

@@ -92,3 +92,42 @@ def compute_log_mel(sound, preprocess_config, dtype=np.float32):
     mel = np.dot(spec, basis.T)
     mell = np.log(np.fmax(mel, np.finfo(mel.dtype).eps))
     return mell, preprocess_config["sample_rate"] / preprocess_config["hop_size"]
+
+
+def compute_log_mel_device(sound, preprocess_config, n_samples=None):
+    """:func:`compute_log_mel` on the GPU (csrc/mel_analysis.hip through ``mbx_mel_analysis``): sound is a float32 cuda
+    tensor (batch, time), ``n_samples`` an optional int32 cuda tensor (batch,) of item lengths.  Returns a cuda tensor
+    (batch, time // hop + 1, mel_channels) -- rows of item b beyond ``n_samples[b] // hop + 1`` are not written -- and the
+    mel frame rate.  The window and the mel basis are the tables of this module; the transform runs in float32 (the
+    host path transforms in float64 and rounds: the two agree to float32 rounding of the magnitudes)."""
+    import ctypes
+    import torch
+    from .engine import _check, load_library
+    if sound.dim() != 2 or sound.dtype != torch.float32 or not sound.is_cuda:
+        raise ValueError("sound must be a float32 cuda tensor of shape (batch, time)")
+    cfg = preprocess_config
+    win_len = int(cfg.get("win_size", cfg["fft_size"]))
+    hop, fft_size, n_mels = int(cfg["hop_size"]), int(cfg["fft_size"]), int(cfg["mel_channels"])
+    dev = sound.device
+    basis = mel_basis_slaney(cfg["sample_rate"], fft_size, n_mels, cfg["fmin"], cfg["fmax"], dtype=np.float32)
+    nz = basis != 0
+    lo = np.where(nz.any(axis=1), nz.argmax(axis=1), 1).astype(np.int32)
+    hi = np.where(nz.any(axis=1), basis.shape[1] - 1 - nz[:, ::-1].argmax(axis=1), 0).astype(np.int32)
+    ang = -2.0 * np.pi * np.arange(fft_size // 2) / fft_size
+    tables = [torch.as_tensor(np.ascontiguousarray(tt), device=dev) for tt in
+              (hann_symmetric(win_len).astype(np.float32), np.stack((np.cos(ang), np.sin(ang)), axis=1).astype(np.float32),
+               basis, lo, hi)]
+    sound = sound.contiguous()
+    B, N = int(sound.shape[0]), int(sound.shape[1])
+    frames = N // hop + 1
+    out = torch.zeros((B, frames, n_mels), dtype=torch.float32, device=dev)
+    if n_samples is not None:
+        if n_samples.dtype != torch.int32 or tuple(n_samples.shape) != (B,) or n_samples.device != dev:
+            raise ValueError("n_samples must be an int32 tensor of shape (batch,) on the device of sound")
+        n_samples = n_samples.contiguous()
+    _check(load_library().mbx_mel_analysis(sound.data_ptr(), n_samples.data_ptr() if n_samples is not None else None, B, N,
+                                           win_len, hop, fft_size, n_mels, tables[0].data_ptr(), tables[1].data_ptr(),
+                                           tables[2].data_ptr(), tables[3].data_ptr(), tables[4].data_ptr(),
+                                           ctypes.c_float(float(np.finfo(np.float32).eps)), out.data_ptr(), frames,
+                                           torch.cuda.current_stream(dev).cuda_stream))
+    return out, cfg["sample_rate"] / hop

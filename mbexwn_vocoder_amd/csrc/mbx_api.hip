@@ -977,6 +977,36 @@ mbx_status mbx_forward_ex(mbx_handle *hd, const float *mel, const int32_t *n_fra
                         options->transposition, options->active_begin, options->active_frames);
 }
 
+mbx_status mbx_mel_analysis(const float *audio, const int32_t *n_samples, int32_t batch, int32_t max_samples,
+                            int32_t win, int32_t hop, int32_t fft_size, int32_t n_mels, const float *window,
+                            const float *twiddle, const float *basis, const int32_t *bin_lo, const int32_t *bin_hi,
+                            float eps, float *out, int32_t max_frames, void *hip_stream) {
+    mbx::MelAnalysisArgs a{};
+    a.audio = audio;
+    a.audio_bstride = max_samples;
+    a.n_samples = n_samples;
+    a.max_samples = max_samples;
+    a.batch = batch;
+    a.win = win;
+    a.hop = hop;
+    a.fft_size = fft_size;
+    a.n_mels = n_mels;
+    a.window = window;
+    a.twiddle = twiddle;
+    a.basis = basis;
+    a.bin_lo = bin_lo;
+    a.bin_hi = bin_hi;
+    a.eps = eps;
+    a.out = out;
+    a.max_frames = max_frames;
+    if (!mbx::launch_mel_analysis(a, static_cast<hipStream_t>(hip_stream)))
+        return fail(MBX_ERR_INVALID_ARGUMENT, "mel analysis: sizes do not fit the kernel (fft_size a power of two <= 2048, "
+                                              "win <= fft_size, max_samples > win/2, max_frames >= max_samples/hop + 1)");
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MBX_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return MBX_OK;
+}
+
 mbx_status mbx_profile_enable(mbx_handle *handle, int32_t enabled) {
     if (!handle) return fail(MBX_ERR_INVALID_ARGUMENT, "null argument");
     handle->profiling = enabled != 0;

@@ -171,6 +171,23 @@ void launch_stft_filter(const StftConsts &c, const float *exc, long long exc_bst
 void launch_overlap_add(const StftConsts &c, const float *frames, const int *n_frames, int max_frames, int out_frames, int batch,
                         float *audio, long long audio_bstride, hipStream_t stream);
 
+// audio -> log-mel analysis (mel_analysis.hip); tables from the host module analysis.py
+struct MelAnalysisArgs {
+    const float *audio;       // (batch, max_samples)
+    long long audio_bstride;
+    const int *n_samples;     // (batch) or null
+    int max_samples, batch;
+    int win, hop, fft_size, n_mels;
+    const float *window;      // (win)
+    const float *twiddle;     // (fft_size/2, 2): exp(-2 pi i m / fft_size)
+    const float *basis;       // (n_mels, fft_size/2 + 1) dense rows
+    const int *bin_lo, *bin_hi;   // (n_mels) first / last non-zero bin of a row
+    float eps;
+    float *out;               // (batch, max_frames, n_mels), frames of item b: n_samples[b] / hop + 1
+    int max_frames;
+};
+bool launch_mel_analysis(const MelAnalysisArgs &a, hipStream_t stream);
+
 // ---------------------------------------------------------------------------------------------
 // optional RMS normalisation of the mel input / de-normalisation of the audio (norm_mel.hip)
 // ---------------------------------------------------------------------------------------------

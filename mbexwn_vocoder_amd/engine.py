@@ -127,13 +127,15 @@ def load_library():
     lib.mbx_stft_filter.argtypes = [vp, fp, fp, vp, i32, i32, fp, fp, vp]
     lib.mbx_norm_mel.restype = i32
     lib.mbx_norm_mel.argtypes = [vp, fp, vp, i32, i32, fp, fp, fp, vp]
+    lib.mbx_mel_analysis.restype = i32
+    lib.mbx_mel_analysis.argtypes = [fp, vp, i32, i32, i32, i32, i32, i32, fp, fp, fp, vp, vp, ctypes.c_float, fp, i32, vp]
     _lib = lib
     return lib
 
 
 EXPORTED_SYMBOLS = ["mbx_last_error", "mbx_create", "mbx_destroy", "mbx_workspace_size", "mbx_forward",
                     "mbx_forward_stream", "mbx_forward_ex", "mbx_stage",
-                    "mbx_profile_enable", "mbx_profile_read", "mbx_pqmf_synthesis", "mbx_conv1d", "mbx_lin_interp", "mbx_wavetable", "mbx_stft_filter", "mbx_norm_mel"]
+                    "mbx_profile_enable", "mbx_profile_read", "mbx_pqmf_synthesis", "mbx_conv1d", "mbx_lin_interp", "mbx_wavetable", "mbx_stft_filter", "mbx_norm_mel", "mbx_mel_analysis"]
 
 
 def _check(status):

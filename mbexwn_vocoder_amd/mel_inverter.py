@@ -123,8 +123,9 @@ class MELInverter(object):
                                      noise=noise).numpy()
         return syn_audio.ravel()
 
-    def generate_mel_from_snd(self, snd, srate):
-        """Audio -> ``.mell`` dictionary (reference mel_inverter.py:156-182), host side (analysis.py).
+    def generate_mel_from_snd(self, snd, srate, on_device=False):
+        """Audio -> ``.mell`` dictionary (reference mel_inverter.py:156-182); host side (analysis.py) or, with
+        ``on_device=True``, the HIP kernel of csrc/mel_analysis.hip (same tables, float32 transform).
         The reference resamples when ``srate`` differs from the model rate through a function it never imports
         (mel_inverter.py:173, a NameError there); here the sound is resampled with a polyphase FIR
         (scipy.signal.resample_poly, Kaiser window) along the last axis."""
@@ -152,7 +153,14 @@ class MELInverter(object):
         snd = np.asarray(snd)
         if snd.ndim == 1:
             snd = snd[np.newaxis]
-        mel_ref, _ = compute_log_mel(snd, self.preprocess_config, dtype=np.float32)
+        if on_device:
+            import torch
+            from .analysis import compute_log_mel_device
+            mel_dev, _ = compute_log_mel_device(torch.as_tensor(np.ascontiguousarray(snd, dtype=np.float32)).cuda(),
+                                                self.preprocess_config)
+            mel_ref = mel_dev.cpu().numpy()
+        else:
+            mel_ref, _ = compute_log_mel(snd, self.preprocess_config, dtype=np.float32)
         data_dict['mell'] = mel_ref[0].T
         return data_dict
 

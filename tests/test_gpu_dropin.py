@@ -139,3 +139,31 @@ def test_rms_normalised_model_end_to_end(tmp_path):
     ref = OracleModel(cfg, load_weights(os.path.join(mdir, "weights.npz")), wt).forward(mel_n.astype(np.float32), noise)[0] * gain[0]
     assert audio.shape == ref.shape
     assert np.max(np.abs(audio - ref)) <= 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_mel_analysis_on_the_device_matches_the_host_analysis():
+    """csrc/mel_analysis.hip (mbx_mel_analysis, the step in front of the hot path) against analysis.compute_log_mel, whose
+    STFT is pinned to the reference's own numpy code (tests/test_mel_inverter.py, reference_constants.npz): ragged batch,
+    a frame count that is not a multiple of anything, edges reflected."""
+    import torch
+    from mbexwn_vocoder_amd.analysis import compute_log_mel, compute_log_mel_device
+    from mbexwn_vocoder_amd.config import canonical_config
+    pre = canonical_config("SPEECH")["preprocess_config"]
+    rng = np.random.default_rng(17)
+    lengths = [7231, 3000, 1201]
+    snd = np.zeros((3, max(lengths)), dtype=np.float32)
+    for ii, ll in enumerate(lengths):
+        tt = np.arange(ll) / pre["sample_rate"]
+        snd[ii, :ll] = (0.3 * np.sin(2 * np.pi * (110.0 * (ii + 1)) * tt) + 0.05 * rng.normal(size=ll)).astype(np.float32)
+    got, rate = compute_log_mel_device(torch.as_tensor(snd).cuda(), pre,
+                                       n_samples=torch.as_tensor(lengths, dtype=torch.int32).cuda())
+    got = got.cpu().numpy()
+    assert rate == pre["sample_rate"] / pre["hop_size"]
+    for ii, ll in enumerate(lengths):
+        ref, _ = compute_log_mel(snd[ii:ii + 1, :ll], pre, dtype=np.float32)
+        nfr = ll // pre["hop_size"] + 1
+        assert ref.shape == (1, nfr, pre["mel_channels"])
+        # float32 transform against the float64 transform of the host path, compared on the amplitudes
+        err = np.abs(np.exp(got[ii, :nfr]) - np.exp(ref[0]))
+        assert np.max(err) <= 2e-5 * np.max(np.exp(ref[0])), f"item {ii}: {np.max(err)}"
+        assert np.max(np.abs(got[ii, :nfr] - ref[0])) <= 2e-3          # log domain, including the quiet channels
