@@ -17,12 +17,17 @@
  *   - all tensors are float32, channels-last, row-major
  *
  * Environment switches read by mbx_create (the defaults are the measured best):
- *   MBX_WINOGRAD=0|2|4   form of the dilated convolution: direct / Winograd F(2,3) only / F(4,3) with the block shape
- *                        picked by launch size (default 4; streams always run F(2,3))
+ *   MBX_WINOGRAD=0|2|4|44  form of the dilated convolution: direct / Winograd F(2,3) only / F(4,3) with the block shape
+ *                        (and the res/skip kernel) picked by launch size (default 4; streams always run F(2,3)) /
+ *                        F(4,3) with the large-launch kernel shapes at every size (tests).  A pinned form pins the
+ *                        kernels: results then do not depend on the batch an item ran in.
  *   MBX_FOLD_SKIP=0      keep the un-folded skip path (C -> 2C res/skip layers, stage "wn_skip")
+ *   MBX_FOLD_START=0     keep the start convolution and the full first layer (default: start convolution folded into
+ *                        layer 0, a K = 24 contraction of the excitation; needs the folded skip path)
  * The optional operand-order images of the weights ("*.wino", "*.wino_split", "*.wino4w", "*.packed", "*.fold",
- * "wn.tail.fold", "wn.end.packed"; engine.tensor_table builds them) select the specialised kernels; a handle
- * created from the plain folded weights alone runs the generic ones.
+ * "*.fold_wide", "*.start_fold", "*.fold_start", "*.fold_start_wide", "wn.tail.fold", "wn.end.packed";
+ * engine.tensor_table builds them) select the specialised kernels; a handle created from the plain folded weights
+ * alone runs the generic ones.
  */
 #ifndef MBEXWN_H
 #define MBEXWN_H
@@ -34,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MBX_ABI_VERSION 2
+#define MBX_ABI_VERSION 3
 #define MBX_MAX_SUBNET_OPS 32
 #define MBX_MAX_WN_LAYERS 64
 #define MBX_NAME_LEN 64

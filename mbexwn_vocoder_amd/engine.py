@@ -19,7 +19,7 @@ from .config import ModelDims
 from .subnet import build_subnet
 from .weights import fold_weights, merge_channel_groups
 
-MBX_ABI_VERSION = 2
+MBX_ABI_VERSION = 3
 MBX_MAX_SUBNET_OPS = 32
 MBX_MAX_WN_LAYERS = 64
 MBX_NAME_LEN = 64
