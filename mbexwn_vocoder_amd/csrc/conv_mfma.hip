@@ -572,48 +572,69 @@ __global__ __launch_bounds__(256) void conv1d_mfma_dma_kernel(ConvArgs p) {
 // the MFMA registers: the tile is too small to amortise an LDS stage.  Lane (row r, half h) loads A[r][8g+4h..+3]
 // as one float4 and feeds it to four MFMA steps; the B lane (col c, half h) loads W[8g+4h+s][c] for the same steps.
 // Needs cin % 8 == 0 and 16-byte aligned rows (checked by the launcher).
-__device__ __forceinline__ void conv1d_small_tile(const ConvArgs &p, int bx, int by, int b, float (*red)[16][64]) {
+// RT x CT output tiles of 32 x 32 per block (1 x 1: batch 1; 2 x 2: large launches -- the A rows are then shared by two
+// column tiles and the weight columns by two row tiles: 10 instead of 20 loads per 16 MFMAs).  Every output element is
+// summed in the same order whatever the tiling: four K quarters, each one sequential MFMA chain, combined as
+// ((q0 + q1) + q2) + q3 + bias -- so a padded batch stays bit-identical to one-at-a-time runs (the F0 contour feeds the
+// phase accumulator: rounding there is audible in the last bits everywhere downstream).
+template <int RT, int CT>
+__device__ __forceinline__ void conv1d_small_tile(const ConvArgs &p, int bx, int by, int b, float *red) {
     const int rows = p.n_frames ? p.n_frames[b] * p.rows_per_frame : p.max_rows;
-    const int m0 = bx * 32;
+    const int m0 = bx * 32 * RT;
     if (m0 >= rows) return;
-    const int n0 = by * 32;
+    const int n0 = by * 32 * CT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 31, lk = lane >> 5;
     const float *xb = p.x + (long long)b * p.x_bstride;
     const int groups_per_tap = p.cin >> 3;                 // groups of 8 input channels
     const int n_groups = p.ks * groups_per_tap;
     const int g_begin = (n_groups * wave) / 4, g_end = (n_groups * (wave + 1)) / 4;
-    const int col = n0 + lrow;
-    const bool col_ok = col < p.cout;
-    const float *wcol = p.w + min(col, p.cout - 1);
-
-    f32x16 acc;
+    bool col_ok[CT];
+    const float *wcol[CT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int ct = 0; ct < CT; ++ct) {
+        const int col = n0 + 32 * ct + lrow;
+        col_ok[ct] = col < p.cout;
+        wcol[ct] = p.w + min(col, p.cout - 1);
+    }
 
-    auto load_group = [&](int g, float4 &av, float (&bv)[4]) {
+    f32x16 acc[RT][CT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
+
+    auto load_group = [&](int g, float4 (&av)[RT], float (&bv)[CT][4]) {
         const int tap = g / groups_per_tap;
         const int ci = (g - tap * groups_per_tap) * 8 + 4 * lk;
-        const int src = map_row(m0 + lrow - p.pad_l + tap * p.dil, rows, p.pad_mode);
-        const float4 t = *reinterpret_cast<const float4 *>(xb + (long long)max(src, 0) * p.ldx + ci);
-        const bool ok = src >= 0;
-        av.x = ok ? t.x : 0.f;
-        av.y = ok ? t.y : 0.f;
-        av.z = ok ? t.z : 0.f;
-        av.w = ok ? t.w : 0.f;
-        const float *wk = wcol + (long long)(tap * p.cin + ci) * p.cout;
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            const float t2 = wk[(long long)st * p.cout];
-            bv[st] = col_ok ? t2 : 0.f;
+        for (int rt = 0; rt < RT; ++rt) {
+            const int src = map_row(m0 + 32 * rt + lrow - p.pad_l + tap * p.dil, rows, p.pad_mode);
+            const float4 t = *reinterpret_cast<const float4 *>(xb + (long long)max(src, 0) * p.ldx + ci);
+            const bool ok = src >= 0;
+            av[rt].x = ok ? t.x : 0.f;
+            av[rt].y = ok ? t.y : 0.f;
+            av[rt].z = ok ? t.z : 0.f;
+            av[rt].w = ok ? t.w : 0.f;
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const float *wk = wcol[ct] + (long long)(tap * p.cin + ci) * p.cout;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const float t2 = wk[(long long)st * p.cout];
+                bv[ct][st] = col_ok[ct] ? t2 : 0.f;
+            }
         }
     };
 
     // the loads of a batch of DEPTH groups are all in flight while the previous batch feeds the matrix pipe
-    // (one group = 4 MFMAs = 0.1 us, an L2 round trip is several times that)
-    constexpr int DEPTH = 6;
-    float4 a_cur[DEPTH], a_nxt[DEPTH];
-    float b_cur[DEPTH][4], b_nxt[DEPTH][4];
+    // (one group = 4 MFMAs per tile = 0.1 us, an L2 round trip is several times that)
+    constexpr int DEPTH = RT * CT == 1 ? 6 : 3;
+    float4 a_cur[DEPTH][RT], a_nxt[DEPTH][RT];
+    float b_cur[DEPTH][CT][4], b_nxt[DEPTH][CT][4];
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
         if (g_begin + d < g_end) load_group(g_begin + d, a_cur[d], b_cur[d]);
@@ -624,45 +645,73 @@ __device__ __forceinline__ void conv1d_small_tile(const ConvArgs &p, int bx, int
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             if (g + d < g_end) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[d].x, b_cur[d][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[d].y, b_cur[d][1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[d].z, b_cur[d][2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[d].w, b_cur[d][3], acc, 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        f32x16 c = acc[rt][ct];
+                        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[d][rt].x, b_cur[d][ct][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[d][rt].y, b_cur[d][ct][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[d][rt].z, b_cur[d][ct][2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[d][rt].w, b_cur[d][ct][3], c, 0, 0, 0);
+                        acc[rt][ct] = c;
+                    }
             }
         }
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
-            a_cur[d] = a_nxt[d];
 #pragma unroll
-            for (int st = 0; st < 4; ++st) b_cur[d][st] = b_nxt[d][st];
+            for (int rt = 0; rt < RT; ++rt) a_cur[d][rt] = a_nxt[d][rt];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int st = 0; st < 4; ++st) b_cur[d][ct][st] = b_nxt[d][ct][st];
         }
     }
-    // reduce the four K quarters: waves 1..3 park their partial tile in LDS, wave 0 adds them in wave order
-    if (wave > 0) {
+    // reduce the four K quarters: every wave parks its partial tiles in LDS, tile (rt, ct) is then finished by wave
+    // rt * CT + ct (1 x 1: by wave 0), which adds the quarters in wave order
+    auto slot = [&](int w, int tile, int r) { return red + (((w * RT * CT + tile) * 16 + r) * 64 + lane); };
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
-    }
-    __syncthreads();
-    if (wave == 0 && col_ok) {
-        const float bias = p.bias ? p.bias[col] : 0.f;
-        const float slope = p.alpha ? p.alpha[col] : p.leaky;
-        const bool act = p.alpha != nullptr || p.use_leaky;
-        float *ob = p.out + (long long)b * p.out_bstride;
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            if (row < rows) {
-                float v = ((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane] + bias;
-                if (act) v = v > 0.f ? v : slope * v;
-                ob[(long long)row * p.ldo + col] = v;
+        for (int ct = 0; ct < CT; ++ct) {
+            const int tile = rt * CT + ct;
+            if (wave != tile) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) *slot(wave, tile, r) = acc[rt][ct][r];
             }
         }
-    }
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int tile = rt * CT + ct;
+            if (wave != tile || !col_ok[ct]) continue;
+            const int col = n0 + 32 * ct + lrow;
+            const float bias = p.bias ? p.bias[col] : 0.f;
+            const float slope = p.alpha ? p.alpha[col] : p.leaky;
+            const bool act = p.alpha != nullptr || p.use_leaky;
+            float *ob = p.out + (long long)b * p.out_bstride;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (row < rows) {
+                    // quarters in wave order 0, 1, 2, 3; the one of this wave is in registers
+                    float q[4];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) q[w] = w == tile ? acc[rt][ct][r] : *slot(w, tile, r);
+                    float v = ((q[0] + q[1]) + q[2]) + q[3] + bias;
+                    if (act) v = v > 0.f ? v : slope * v;
+                    ob[(long long)row * p.ldo + col] = v;
+                }
+            }
+        }
 }
 
 __global__ __launch_bounds__(256) void conv1d_small_kernel(ConvArgs p) {
-    __shared__ float red[3][16][64];
-    conv1d_small_tile(p, blockIdx.x, blockIdx.y, blockIdx.z, red);
+    __shared__ float red[4 * 16 * 64];
+    conv1d_small_tile<1, 1>(p, blockIdx.x, blockIdx.y, blockIdx.z, red);
 }
 
 // Up to three independent small convolutions in one launch (the n-th layers of the F0-net, the VTF-net and the
@@ -674,14 +723,15 @@ struct SmallConvGroup {
     int gx[3], gy[3];
 };
 
+template <int RT, int CT>
 __global__ __launch_bounds__(256) void conv1d_small_group_kernel(SmallConvGroup g) {
-    __shared__ float red[3][16][64];
+    __shared__ float red[4 * RT * CT * 16 * 64];
     const int id = blockIdx.x;
     const int k = (id >= g.start[1]) + (id >= g.start[2]);
     const int local = id - g.start[k];
     const int bx = local % g.gx[k];
     const int t = local / g.gx[k];
-    conv1d_small_tile(g.c[k], bx, t % g.gy[k], t / g.gy[k], red);
+    conv1d_small_tile<RT, CT>(g.c[k], bx, t % g.gy[k], t / g.gy[k], red);
 }
 
 template <int WM, int WN, int TM, int TN, int EPI, int BK = 16>
@@ -741,14 +791,19 @@ void launch_conv1d_group(const ConvArgs *convs, int n, hipStream_t stream) {
                 small[i] = small[j];
                 small[j] = t;
             }
+    // large launches: 64 x 64 output tiles per block (same sums, fewer loads per MFMA)
+    long long work = 0;
+    for (int k = 0; k < n_small; ++k) work += (long long)convs[small[k]].max_rows * convs[small[k]].batch;
+    const bool big = work >= 3 * 4096;
+    const int tile = big ? 64 : 32;
     SmallConvGroup g;
     int total = 0;
     for (int k = 0; k < 3; ++k) {
         g.start[k] = total;
         if (k < n_small) {
             g.c[k] = convs[small[k]];
-            g.gx[k] = (g.c[k].max_rows + 31) / 32;
-            g.gy[k] = (g.c[k].cout + 31) / 32;
+            g.gx[k] = (g.c[k].max_rows + tile - 1) / tile;
+            g.gy[k] = (g.c[k].cout + tile - 1) / tile;
             total += g.gx[k] * g.gy[k] * g.c[k].batch;
         } else {
             g.c[k] = convs[small[0]];
@@ -757,7 +812,8 @@ void launch_conv1d_group(const ConvArgs *convs, int n, hipStream_t stream) {
     }
     g.start[3] = total;
     for (int k = n_small; k < 3; ++k) g.start[k] = 0x7fffffff;
-    hipLaunchKernelGGL(conv1d_small_group_kernel, dim3((unsigned)total), dim3(256), 0, stream, g);
+    if (big) hipLaunchKernelGGL((conv1d_small_group_kernel<2, 2>), dim3((unsigned)total), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((conv1d_small_group_kernel<1, 1>), dim3((unsigned)total), dim3(256), 0, stream, g);
     for (int i = 0; i < n; ++i) {
         bool in_group = false;
         for (int k = 0; k < n_small; ++k) in_group |= small[k] == i;
