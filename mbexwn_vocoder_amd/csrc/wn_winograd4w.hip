@@ -22,7 +22,9 @@
 //
 // Two block shapes (template):
 //   <256, 1>  large launches: 256 consecutive output rows (64 groups; wave w owns groups 16 w .. 16 w + 15) x 32 gate
-//             channels; K slices of 8 channels, three LDS stages.
+//             channels; K slices of 8 channels, two LDS stages (52.5 KB with the conditioning tile: 3 blocks per CU --
+//             a third wave per SIMD fills matrix-pipe slots the other two leave: 1.40 -> 1.35 ms at batch 16 x 10 s;
+//             a third stage at 2 blocks per CU measured the same as two).
 //   <128, 2>  small launches (batch 1: a launch is only a few rounds of resident blocks, so what decides its time is how
 //             finely the work divides over the 1024 SIMDs): 128 rows x 32 gate channels, waves = 2 row halves x 2 channel
 //             halves: wave (rw, kh) contracts the channels 16 s + 8 kh .. + 7 of every double slice s, i.e. half of K, so
@@ -39,8 +41,8 @@
 //      contracts channels {2 kq + m}.
 //   B: 6 products x 8 channels x 64 columns, packed on the host in MFMA operand order [product j][channel parity e]
 //      [lane][tanh step 0, tanh step 1, sigmoid step 0, sigmoid step 1]: one ds_read_b128 = the weight operands of four MFMAs
-// LDS: stages (66 KB / 72 KB) + the conditioning rows of the block and the per-row interpolation tables (11 KB / 5.5 KB)
-// -> 2 blocks per CU.  The stage loop is unrolled by the number of stages so that every LDS address is a loop-invariant
+// LDS: stages (44 KB / 72 KB) + the conditioning rows of the block and the per-row interpolation table (8.5 KB / 5 KB)
+// -> 3 / 2 blocks per CU.  The stage loop is unrolled by the number of stages so that every LDS address is a loop-invariant
 // register plus an immediate.
 // (Measured and rejected, batch 16 x 10 s: a fifth wave that issues all LDS-DMA requests, 1.50 ms against 1.39 ms per
 // launch -- the requests then queue on one SIMD whose MFMA waves become the stragglers of every barrier; spreading a
@@ -66,17 +68,20 @@ struct WwShape {
     static constexpr int A_CHUNKS = A_FLOATS / 256;             // 1 KB LDS-DMA instructions per slice (A): 10 | 6
     static constexpr int SUB = A_FLOATS + WW_B_FLOATS;          // one 8-channel slice: A, B behind it
     static constexpr int STAGE = KSPLIT * SUB;                  // 5632 | 9216 floats
-    static constexpr int NSTAGE = KSPLIT == 1 ? 3 : 2;
+    static constexpr int NSTAGE = 2;
     static constexpr int ROW_WAVES = ROWS / 64;                 // 4 | 2
     static constexpr int B_INST = 3 * KSPLIT;                   // weight requests per wave and stage
     static constexpr int DMA_PER_STAGE = 3 + B_INST;            // 6 | 9
-    static constexpr int COND_ROWS = ROWS / 8;                  // 32 | 16 conditioning rows of 64 floats
-    static constexpr int COND_INST = COND_ROWS * 64 / 256 / 4;  // conditioning requests per wave: 2 | 1
-    // behind the stages: conditioning tile, (w0, w1) of block row lr, float offset of its conditioning row
+    static constexpr int COND_ROWS = ROWS == 256 ? 28 : 16;     // conditioning rows of 64 floats (cond_up >= 10)
+    static constexpr int COND_CHUNKS = COND_ROWS / 4;           // 1 KB LDS-DMA requests: 7 | 4, dealt round-robin
+    // behind the stages: conditioning tile; per block row lr: (float offset of its conditioning row) << 8 | phase u of
+    // the interpolation; the interpolation weights w0[64], w1[64]
     static constexpr int COND = NSTAGE * STAGE;
-    static constexpr int TABW = COND + COND_ROWS * 64;
-    static constexpr int TABO = TABW + 2 * ROWS;
-    static constexpr int LDS_FLOATS = TABO + ROWS;
+    static constexpr int TAB = COND + COND_ROWS * 64;
+    static constexpr int LERP = TAB + ROWS;
+    static constexpr int LDS_FLOATS = LERP + 128;
+    // <256,1>: 45056 + 7168 + 1024 + 512 = 53760 bytes -> 3 blocks per CU; <128,2>: 79 KB -> 2
+    static constexpr int BLOCKS_PER_CU = LDS_FLOATS * 4 * 3 <= 160 * 1024 ? 3 : 2;
     static_assert(ROW_WAVES * KSPLIT == 4, "four waves per block");
 };
 
@@ -111,7 +116,7 @@ template <int N>
 using ww_int = std::integral_constant<int, N>;
 
 template <int ROWS, int KSPLIT>
-__global__ __launch_bounds__(256, 2) void wn_gate_winograd4w_kernel(ConvArgs p, int log2d) {
+__global__ __launch_bounds__(256, (WwShape<ROWS, KSPLIT>::BLOCKS_PER_CU)) void wn_gate_winograd4w_kernel(ConvArgs p, int log2d) {
     using SH = WwShape<ROWS, KSPLIT>;
     constexpr int NSTAGE = SH::NSTAGE, STAGE = SH::STAGE, SUB = SH::SUB, A_FLOATS = SH::A_FLOATS, PHASE = SH::PHASE;
     typedef __attribute__((address_space(3))) float lds_float;
@@ -211,7 +216,8 @@ __global__ __launch_bounds__(256, 2) void wn_gate_winograd4w_kernel(ConvArgs p, 
         const int n2 = rows / cond_up;
         const float *cbase = p.cond + (long long)b * p.cond_bstride;
 #pragma unroll
-        for (int i = 0; i < SH::COND_INST; ++i) {
+        for (int i = 0; i < (SH::COND_CHUNKS + 3) / 4; ++i) {
+            if (wave + 4 * i >= SH::COND_CHUNKS) break;
             const int pos = (wave + 4 * i) * 64 + lane;
             const int crow = pos >> 4, cq = pos & 15;
             const int chn = n0 + 4 * (cq & 7);
@@ -243,8 +249,11 @@ __global__ __launch_bounds__(256, 2) void wn_gate_winograd4w_kernel(ConvArgs p, 
             const int row = m0 + tid;
             const int t2 = row / cond_up;
             const int u = row - t2 * cond_up;
-            reinterpret_cast<float2 *>(lds + SH::TABW)[tid] = make_float2(p.lerp_w0[u], p.lerp_w1[u]);
-            reinterpret_cast<int *>(lds + SH::TABO)[tid] = (t2 - t2base) * 64;
+            reinterpret_cast<int *>(lds + SH::TAB)[tid] = (((t2 - t2base) * 64) << 8) | u;
+        }
+        if (tid < 64) {
+            lds[SH::LERP + tid] = tid < cond_up ? p.lerp_w0[tid] : 0.f;
+            lds[SH::LERP + 64 + tid] = tid < cond_up ? p.lerp_w1[tid] : 0.f;
         }
     }
 
@@ -430,8 +439,9 @@ __global__ __launch_bounds__(256, 2) void wn_gate_winograd4w_kernel(ConvArgs p, 
         for (int o = 0; o < 4; ++o) {
             const int lr = lr0 + (o << log2d);
             const int row = m0 + lr;
-            const float2 w = reinterpret_cast<const float2 *>(lds + SH::TABW)[lr];
-            const float *c0 = clane + reinterpret_cast<const int *>(lds + SH::TABO)[lr];
+            const int e = reinterpret_cast<const int *>(lds + SH::TAB)[lr];
+            const float2 w = make_float2(lds[SH::LERP + (e & 255)], lds[SH::LERP + 64 + (e & 255)]);
+            const float *c0 = clane + (e >> 8);
             const float2 ct0 = *reinterpret_cast<const float2 *>(c0), ct1 = *reinterpret_cast<const float2 *>(c0 + 64);
             const float2 cs0 = *reinterpret_cast<const float2 *>(c0 + 32), cs1 = *reinterpret_cast<const float2 *>(c0 + 96);
             float2 res;
@@ -453,7 +463,7 @@ bool launch_wn_gate_winograd4w(const ConvArgs &a, bool small, hipStream_t stream
                     a.cin % 4 == 0 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 && a.channels % 4 == 0 &&
                     a.cout == 2 * a.channels && (uintptr_t)a.x % 16 == 0 && (uintptr_t)a.w % 16 == 0 && a.zeros &&
                     a.cond && (uintptr_t)a.cond % 16 == 0 && a.cond_bstride % 4 == 0 && a.cond_up >= 1 &&
-                    (rows_blk + a.cond_up - 2) / a.cond_up + 2 <= rows_blk / 8 && a.lerp_w0 && a.lerp_w1 && a.max_rows < (1 << 24);
+                    a.cond_up <= 64 && (rows_blk + a.cond_up - 2) / a.cond_up + 2 <= (small ? 16 : 28) && a.lerp_w0 && a.lerp_w1 && a.max_rows < (1 << 24);
     if (!ok) return false;
     ConvArgs r = a;
     r.fast_dma = (long long)a.max_rows * a.ldx * 4 < (1LL << 32);
