@@ -335,7 +335,7 @@ def run_streaming(args, name, rank, world, fence, torch):
             host_ms.append((time.perf_counter() - t1) * 1e3)
             dev_ms.append(syn.last_tick_device_ms)
             frames.append(syn.last_tick_frames)
-            act_frames.append(syn.last_tick_active_frames)
+            act_frames.append(syn.last_tick_wavenet_frames)
     fence()
     elapsed = fence.max_over_ranks(float(np.sum(dev_ms)) * 1e-3)       # device time of the timed ticks
     samples = world * n_streams * chunk * dims.hop_size * args.steps

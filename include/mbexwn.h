@@ -186,6 +186,21 @@ typedef struct {
      *   active_frames  device (batch) int32 frames of each item inside the region, or NULL */
     int32_t active_begin;
     const int32_t *active_frames;
+    /* Streaming windows, second level: the WaveNet (first layer .. output stage) runs only on the frames [wn_begin,
+     * wn_begin + wn_frames[b]) of the window (inside the active region, which then only bounds PQMF, STFT filter and
+     * overlap-add); NULL: the WaveNet runs on the active region.  The sub-band rows the later stages need from in front
+     * of that region were computed by the previous tick and are carried:
+     *   sub_store   device (slots, sub_store_rows, subbands) persistent buffer of the caller, or NULL
+     *   sub_carry   device (batch, 5) int32: slot of the item, first sub-band row (window-relative) and number of rows
+     *               to take from its slot before the PQMF, first row and number of rows to save to its slot afterwards */
+    int32_t wn_begin;
+    const int32_t *wn_frames;
+    /* host-side upper bounds of active_frames[] and wn_frames[] (0: up to the end of the window): the launch grids are
+     * sized from them */
+    int32_t active_max_frames, wn_max_frames;
+    float *sub_store;
+    int32_t sub_store_rows;
+    const int32_t *sub_carry;
 } mbx_forward_options;
 
 mbx_status mbx_forward_ex(mbx_handle *handle, const float *mel, const int32_t *n_frames, int32_t batch,

@@ -149,4 +149,29 @@ void launch_wn_start(const float *pulse, long long pulse_bstride, const float *n
                        h, h_bstride);
 }
 
+// Sub-band rows carried between the ticks of a stream (mbx_forward_options.sub_carry): per item b the descriptor
+// desc[b] = (slot, inject row, inject rows, extract row, extract rows); `store` (slot, carry_rows, row_floats) is the
+// caller's persistent buffer, `sub` (batch, ...) the sub-band tensor of the window.  dir 0: store -> sub rows
+// [inject row, + inject rows); dir 1: sub rows [extract row, + extract rows) -> store.
+__global__ void sub_carry_kernel(float *sub, long long sub_bstride, float *store, long long slot_stride, const int *desc,
+                                 int row_floats, int dir) {
+    const int b = blockIdx.y;
+    const int *d = desc + 5 * b;
+    const int row0 = dir ? d[3] : d[1], n = (dir ? d[4] : d[2]) * row_floats;
+    float *sp = sub + (long long)b * sub_bstride + (long long)row0 * row_floats;
+    float *st = store + (long long)d[0] * slot_stride;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (dir) st[i] = sp[i];
+        else sp[i] = st[i];
+    }
+}
+
+void launch_sub_carry(float *sub, long long sub_bstride, float *store, long long slot_stride, const int *desc, int batch,
+                      int max_rows, int row_floats, int dir, hipStream_t stream) {
+    if (batch <= 0 || max_rows <= 0) return;
+    const int n = max_rows * row_floats;
+    hipLaunchKernelGGL(sub_carry_kernel, dim3((n + 255) / 256, batch), dim3(256), 0, stream, sub, sub_bstride, store,
+                       slot_stride, desc, row_floats, dir);
+}
+
 }  // namespace mbx

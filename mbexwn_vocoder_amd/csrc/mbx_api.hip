@@ -630,7 +630,9 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                                int32_t max_frames, const float *noise, float *audio, void *workspace,
                                size_t workspace_bytes, const mbx::StreamState *st_in, mbx::StreamState *st_out,
                                void *hip_stream, const float *f0_in = nullptr, float transposition = 1.f,
-                               int active_begin = 0, const int32_t *active_frames = nullptr) {
+                               int active_begin = 0, const int32_t *active_frames = nullptr, int wn_begin = 0,
+                               const int32_t *wn_frames = nullptr, float *sub_store = nullptr, int sub_store_rows = 0,
+                               const int32_t *sub_carry = nullptr, int active_max_frames = 0, int wn_max_frames = 0) {
     if (!hd || !mel || !audio || !workspace) return fail(MBX_ERR_INVALID_ARGUMENT, "null argument");
     if (batch <= 0 || max_frames <= 0) return fail(MBX_ERR_INVALID_ARGUMENT, "batch and max_frames must be positive");
     DeviceGuard guard(hd->device);
@@ -641,6 +643,10 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     const int B = batch, T = max_frames;
     if (active_begin < 0 || active_begin >= T || (active_begin > 0 && !active_frames))
         return fail(MBX_ERR_INVALID_ARGUMENT, "active_begin must lie inside the window and needs active_frames");
+    if (wn_frames && (!active_frames || wn_begin < active_begin || wn_begin >= T))
+        return fail(MBX_ERR_INVALID_ARGUMENT, "wn_frames needs active_frames and wn_begin inside the active region");
+    if ((sub_store != nullptr) != (sub_carry != nullptr) || (sub_store && sub_store_rows <= 0))
+        return fail(MBX_ERR_INVALID_ARGUMENT, "sub_store, sub_store_rows and sub_carry go together");
     Workspace w = carve(hd, static_cast<char *>(workspace), B, T);
     if (w.total > workspace_bytes) return fail(MBX_ERR_WORKSPACE, "workspace too small, see mbx_workspace_size");
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
@@ -713,31 +719,36 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     // [active_begin, active_begin + active_frames[b]) of the window as the item.  All buffers are (batch, frames * k)
     // with the batch stride of the whole window, so the region is a pointer offset plus the per-item frame counts.
     const Workspace w_base = w;                      // the stage table below points at the whole window
+    const int32_t *n_frames_act = active_frames ? active_frames : n_frames;   // PQMF, STFT filter, overlap-add
+    const long long act0 = active_frames ? active_begin : 0;
     if (active_frames) {
-        const long long a0 = active_begin;
-        n_frames = active_frames;
+        // the WaveNet may have a region of its own inside the active one (wn_begin / wn_frames)
+        const long long a0 = wn_frames ? wn_begin : active_begin;
+        n_frames = wn_frames ? wn_frames : active_frames;
         w.pulse += a0 * c.pulse_per_frame;
-        w.f0 += a0 * c.pulse_per_frame;
         if (noise) noise += a0 * c.steps_per_frame;
         w.cond += a0 * cond_cout;
         w.h += a0 * c.steps_per_frame * C;
         w.skip += a0 * c.steps_per_frame * C;
         w.wn_out += a0 * c.steps_per_frame * c.wn_out_channels;
         w.sub += a0 * c.steps_per_frame * M;
-        w.exc += a0 * c.hop_size;
-        w.ceps += a0 * c.n_ceps;
-        w.ceps_index += a0;
-        w.frames += a0 * c.stft_win;
-        audio += a0 * c.hop_size;
     }
-    const long long a_off = active_frames ? (long long)active_begin * c.steps_per_frame : 0;   // rows; `a` has a per-layer row stride
+    // upper bounds of the rows an item can have in its region: the launchers size their grids (and pick block shapes)
+    // from them; batch strides stay those of the whole window
+    int wn_frames_max = T - (int)(active_frames ? (wn_frames ? wn_begin : active_begin) : 0);
+    const int wn_bound = wn_frames ? wn_max_frames : active_max_frames;
+    if (active_frames && wn_bound > 0) wn_frames_max = std::min(wn_frames_max, wn_bound);
+    const int wn_rows = wn_frames_max * c.steps_per_frame;
+    int act_frames_max = T - (int)act0;
+    if (active_frames && active_max_frames > 0) act_frames_max = std::min(act_frames_max, active_max_frames);
+    const long long a_off = active_frames ? (long long)(wn_frames ? wn_begin : active_begin) * c.steps_per_frame : 0;   // rows; `a` has a per-layer row stride
     // ---- WaveNet (reference custom_AE_layers.py:273-346)
     const bool fold_start = hd->fold_start;
     const int lda0 = (fold_start && L > 1) ? C + 16 : C;      // row stride of layer 0's output
     if (!fold_start) {
         ScopedEvents ev(hd, PROF_START, stream);
         mbx::launch_wn_start(w.pulse, npulse, c.noise_sigma != 0.f ? noise : nullptr, nsteps, c.noise_sigma, n_frames,
-                             c.steps_per_frame, (int)nsteps, B, c.pulse_channels, find(hd, "wn.start.w")->ptr,
+                             c.steps_per_frame, wn_rows, B, c.pulse_channels, find(hd, "wn.start.w")->ptr,
                              find(hd, "wn.start.b")->ptr, C, w.h, nsteps * C, stream);
     }
     auto lerp = hd->lerp[c.cond_lin_upsampling];
@@ -745,7 +756,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     for (int l = 0; l < L; ++l) {
         const std::string ls = std::to_string(l);
         const int d = c.wn_dilations[l];
-        mbx::ConvArgs g = conv_args(w.h, nsteps * C, C, n_frames, c.steps_per_frame, (int)nsteps, B,
+        mbx::ConvArgs g = conv_args(w.h, nsteps * C, C, n_frames, c.steps_per_frame, wn_rows, B,
                                     find(hd, "wn.conv1D_" + ls + ".w"), find(hd, "wn.conv1D_" + ls + ".b"),
                                     c.wn_kernel_size, C, 2 * C, d, d * (c.wn_kernel_size - 1) / 2, MBX_PAD_ZERO, w.a + a_off * C,
                                     nsteps * C, C);
@@ -768,7 +779,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
             g0.pulse_channels = c.pulse_channels;
             g0.n_frames = n_frames;
             g0.rows_per_frame = c.steps_per_frame;
-            g0.max_rows = (int)nsteps;
+            g0.max_rows = wn_rows;
             g0.batch = B;
             g0.w = find(hd, "wn.conv1D_0.start_fold")->ptr;
             g0.bias = g.bias;
@@ -822,7 +833,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                 const int cin_l = ext ? C + 16 : C;
                 const DevTensor *fw = find(hd, "wn.res_skip_" + ls + (ext ? ".fold_start" : ".fold")),
                                 *fb = find(hd, "wn.res_skip_" + ls + ".fold_b");
-                mbx::ConvArgs r = conv_args(w.a + a_off * cin_l, nsteps * cin_l, cin_l, n_frames, c.steps_per_frame, (int)nsteps, B, fw, fb, 1,
+                mbx::ConvArgs r = conv_args(w.a + a_off * cin_l, nsteps * cin_l, cin_l, n_frames, c.steps_per_frame, wn_rows, B, fw, fb, 1,
                                             cin_l, C + c.wn_out_channels, 1, 0, MBX_PAD_ZERO, nullptr, 0, 0);
                 r.h_init = ext;
                 r.channels = C;
@@ -830,6 +841,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                 r.h = w.h;
                 r.skip = w.wn_out;
                 r.skip_ld = c.wn_out_channels;
+                r.skip_bstride = nsteps * c.wn_out_channels;
                 r.hs_bstride = nsteps * C;
                 r.skip_init = (l == 0);
                 ScopedEvents ev(hd, PROF_RES_SKIP, stream);
@@ -850,7 +862,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
             }
             continue;
         }
-        mbx::ConvArgs r = conv_args(w.a + a_off * C, nsteps * C, C, n_frames, c.steps_per_frame, (int)nsteps, B,
+        mbx::ConvArgs r = conv_args(w.a + a_off * C, nsteps * C, C, n_frames, c.steps_per_frame, wn_rows, B,
                                     find(hd, "wn.res_skip_" + ls + ".w"), find(hd, "wn.res_skip_" + ls + ".b"), 1, C,
                                     last ? C : 2 * C, 1, 0, MBX_PAD_ZERO, nullptr, 0, 0);
         r.channels = C;
@@ -881,46 +893,61 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                         *bpn = find(hd, "post.b");
         if (fold) {
             const DevTensor *tw = find(hd, "wn.tail.fold"), *tb = find(hd, "wn.tail.fold_b");
-            if (!mbx::launch_wn_tail(w.a + a_off * C, nsteps * C, n_frames, c.steps_per_frame, (int)nsteps, B, C, tw->ptr, tb->ptr,
+            if (!mbx::launch_wn_tail(w.a + a_off * C, nsteps * C, n_frames, c.steps_per_frame, wn_rows, B, C, tw->ptr, tb->ptr,
                                      c.wn_out_channels, wpn->ptr, bpn ? bpn->ptr : nullptr, M, L > 1 ? w.wn_out : nullptr,
                                      w.wn_out, nsteps * c.wn_out_channels, w.sub, nsteps * M, stream))
                 return fail(MBX_ERR_INVALID_ARGUMENT, "folded WaveNet tail does not fit its kernel");
         }
         const DevTensor *wep = find(hd, "wn.end.packed");
         const bool fused = fold || (wep && wep->count == (long long)((C + 7) / 8) * 256 &&
-            mbx::launch_wn_tail(w.skip, nsteps * C, n_frames, c.steps_per_frame, (int)nsteps, B, C, wep->ptr,
+            mbx::launch_wn_tail(w.skip, nsteps * C, n_frames, c.steps_per_frame, wn_rows, B, C, wep->ptr,
                                 be ? be->ptr : nullptr, c.wn_out_channels, wpn->ptr, bpn ? bpn->ptr : nullptr, M, nullptr,
                                 w.wn_out, nsteps * c.wn_out_channels, w.sub, nsteps * M, stream));
         if (!fused) {
-            mbx::ConvArgs a = conv_args(w.skip, nsteps * C, C, n_frames, c.steps_per_frame, (int)nsteps, B, we, be, 1, C,
+            mbx::ConvArgs a = conv_args(w.skip, nsteps * C, C, n_frames, c.steps_per_frame, wn_rows, B, we, be, 1, C,
                                         c.wn_out_channels, 1, 0, MBX_PAD_ZERO, w.wn_out, nsteps * c.wn_out_channels,
                                         c.wn_out_channels);
             mbx::launch_conv1d(a, mbx::EPI_LINEAR, stream);
             // post-net 1x1 (reference custom_pulsed_generator.py:490-493,913-914)
             mbx::ConvArgs pn = conv_args(w.wn_out, nsteps * c.wn_out_channels, c.wn_out_channels, n_frames,
-                                         c.steps_per_frame, (int)nsteps, B, wpn, bpn, 1, c.wn_out_channels, M, 1, 0,
+                                         c.steps_per_frame, wn_rows, B, wpn, bpn, 1, c.wn_out_channels, M, 1, 0,
                                          MBX_PAD_ZERO, w.sub, nsteps * M, M);
             mbx::launch_conv1d(pn, mbx::EPI_LINEAR, stream);
         }
     }
+    // ---- sub-band rows carried between the ticks of a stream: rows in front of the WaveNet region come from the
+    // caller's store (computed by the previous tick), the rows the next tick will need go there
+    if (sub_carry) {
+        mbx::launch_sub_carry(w_base.sub, nsteps * M, sub_store, (long long)sub_store_rows * M, sub_carry, B, sub_store_rows,
+                              M, 0, stream);
+        mbx::launch_sub_carry(w_base.sub, nsteps * M, sub_store, (long long)sub_store_rows * M, sub_carry, B, sub_store_rows,
+                              M, 1, stream);
+    }
+    // the stages below see the active region (which contains the WaveNet's) as the item
+    float *sub_act = w_base.sub + act0 * c.steps_per_frame * M;
+    float *exc_act = w_base.exc + act0 * c.hop_size;
+    float *ceps_act = w_base.ceps + act0 * c.n_ceps;
+    float *f0_act = w_base.f0 + act0 * c.pulse_per_frame;
+    int *cidx_act = w_base.ceps_index + act0;
+    float *frames_act = w_base.frames + act0 * c.stft_win;
+    float *audio_act = audio + act0 * c.hop_size;
     // ---- PQMF synthesis (reference :920-921)
     {
         ScopedEvents ev(hd, PROF_PQMF, stream);
-        mbx::launch_pqmf(w.sub, nsteps * M, n_frames, c.steps_per_frame, (int)nsteps, B, M, hd->poly, hd->poly_ndm,
-                         hd->poly_dm_min, w.exc, (long long)T * c.hop_size, stream);
+        mbx::launch_pqmf(sub_act, nsteps * M, n_frames_act, c.steps_per_frame, act_frames_max * c.steps_per_frame, B, M, hd->poly, hd->poly_ndm,
+                         hd->poly_dm_min, exc_act, (long long)T * c.hop_size, stream);
     }
     // ---- STFT-domain filtering with the spectral envelope (reference :681-724, 801-855)
     // (the lifter row of a frame is selected from the F0 contour inside the kernel, reference :507-525)
     {
         ScopedEvents ev(hd, PROF_STFT_FILTER, stream);
-        mbx::launch_stft_filter(sc, w.exc, (long long)T * c.hop_size, w.ceps, (long long)T * c.n_ceps, nullptr,
-                                c.n_ceps_windows ? w.f0 : nullptr, npulse, c.n_ceps_windows ? w.ceps_index : nullptr,
-                                n_frames, T, B, w.frames, stream);
+        mbx::launch_stft_filter(sc, exc_act, (long long)T * c.hop_size, ceps_act, (long long)T * c.n_ceps, nullptr,
+                                c.n_ceps_windows ? f0_act : nullptr, npulse, c.n_ceps_windows ? cidx_act : nullptr,
+                                n_frames_act, T, B, frames_act, stream);
     }
     {
         ScopedEvents ev(hd, PROF_OVERLAP_ADD, stream);
-        mbx::launch_overlap_add(sc, w.frames, n_frames, T, T - (active_frames ? active_begin : 0), B, audio,
-                                (long long)T * c.hop_size, stream);
+        mbx::launch_overlap_add(sc, frames_act, n_frames_act, T, T - (int)act0, B, audio_act, (long long)T * c.hop_size, stream);
     }
     if (nm_gain_src) {
         ScopedEvents ev(hd, PROF_NORM_MEL, stream);
@@ -974,7 +1001,9 @@ mbx_status mbx_forward_ex(mbx_handle *hd, const float *mel, const int32_t *n_fra
     return forward_impl(hd, mel, n_frames, batch, max_frames, noise, audio, workspace, workspace_bytes,
                         reinterpret_cast<const mbx::StreamState *>(options->state_in),
                         reinterpret_cast<mbx::StreamState *>(options->state_out), hip_stream, options->f0,
-                        options->transposition, options->active_begin, options->active_frames);
+                        options->transposition, options->active_begin, options->active_frames, options->wn_begin,
+                        options->wn_frames, options->sub_store, options->sub_store_rows, options->sub_carry,
+                        options->active_max_frames, options->wn_max_frames);
 }
 
 mbx_status mbx_mel_analysis(const float *audio, const int32_t *n_samples, int32_t batch, int32_t max_samples,

@@ -46,6 +46,7 @@ struct ConvArgs {
     float *h;                 // (batch, rows, C) updated in place
     float *skip;              // (batch, rows, skip_ld)
     int skip_ld;              // floats between rows of skip (0: C)
+    long long skip_bstride;   // floats between batch items of skip (0: max_rows * skip_ld, or hs_bstride when skip_ld == 0)
     long long hs_bstride;
     int skip_init;            // 1: skip = s (first layer)  0: skip += s
     int h_init;               // 1: h = r (first layer with the start convolution folded in: x carries [a | x'], cin > C)
@@ -107,6 +108,9 @@ void launch_lin_interp(const float *x, long long x_bstride, const int *n_frames,
                        int batch, int channels, int up, const float *w0, const float *w1, int act, float scale,
                        float offset, float *y, long long y_bstride, hipStream_t stream);
 // y = act(x)*scale + offset on (B, rows, C)
+// sub-band rows carried between the ticks of a stream (elementwise.hip); desc (batch, 5) int32 on the device
+void launch_sub_carry(float *sub, long long sub_bstride, float *store, long long slot_stride, const int *desc, int batch,
+                      int max_rows, int row_floats, int dir, hipStream_t stream);
 void launch_activation(const float *x, long long x_bstride, const int *n_frames, int rows_per_frame, int max_rows,
                        int batch, int channels, int act, float scale, float offset, float *y, long long y_bstride,
                        hipStream_t stream);

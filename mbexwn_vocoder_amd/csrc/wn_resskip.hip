@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 4) void wn_resskip_kernel(ConvAr
     int ld[2];
     bool col_ok[2];
     const int skip_ld = p.skip_ld ? p.skip_ld : C;
-    const long long skip_bstride = p.skip_ld ? (long long)p.max_rows * p.skip_ld : p.hs_bstride;
+    const long long skip_bstride = p.skip_bstride ? p.skip_bstride : (p.skip_ld ? (long long)p.max_rows * p.skip_ld : p.hs_bstride);
     const int lane_row = m0 + 32 * MT * wm + 4 * lk;      // row of register r of row tile i: lane_row + 32 i + (r & 3) + 8 (r >> 2)
     int off_last[2];                                      // element offset of the last valid row (clamp target)
     {

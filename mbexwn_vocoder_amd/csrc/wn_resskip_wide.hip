@@ -104,7 +104,7 @@ __global__ __launch_bounds__(512, NP <= 11 ? 4 : 2) void wn_resskip_wide_kernel(
     // register v of column tile ct: row m0 + 16 wave + 4 kq + v, column 32 (ct >> 1) + 2 r16 + (ct & 1)
     f32x4 acc[2 * NP];
     const int skip_ld = p.skip_ld ? p.skip_ld : C;
-    const long long skip_bstride = p.skip_ld ? (long long)p.max_rows * p.skip_ld : p.hs_bstride;
+    const long long skip_bstride = p.skip_bstride ? p.skip_bstride : (p.skip_ld ? (long long)p.max_rows * p.skip_ld : p.hs_bstride);
     float *hb = p.h + (long long)b * p.hs_bstride;
     float *sb = p.skip + (long long)b * skip_bstride;
     const int row0 = m0 + 16 * wave + 4 * kq;

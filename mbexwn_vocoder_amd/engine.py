@@ -66,7 +66,8 @@ class mbx_config(ctypes.Structure):
 class mbx_forward_options(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_int32), ("transposition", ctypes.c_float), ("f0", ctypes.c_void_p),
                 ("state_in", ctypes.c_void_p), ("state_out", ctypes.c_void_p), ("active_begin", ctypes.c_int32),
-                ("active_frames", ctypes.c_void_p)]
+                ("active_frames", ctypes.c_void_p), ("wn_begin", ctypes.c_int32), ("wn_frames", ctypes.c_void_p),
+                ("active_max_frames", ctypes.c_int32), ("wn_max_frames", ctypes.c_int32), ("sub_store", ctypes.c_void_p), ("sub_store_rows", ctypes.c_int32), ("sub_carry", ctypes.c_void_p)]
 
 
 class mbx_tensor(ctypes.Structure):
@@ -538,15 +539,17 @@ class MBExWNEngine:
             self._workspace = self._torch.empty(need, dtype=self._torch.uint8, device=self.device)
         return self._workspace, need
 
-    def forward(self, mel, n_frames=None, noise=None, out=None, stream_state=None, active=None):
+    def forward(self, mel, n_frames=None, noise=None, out=None, stream_state=None, active=None, wavenet=None, carry=None):
         """mel (B,T,80) float32 cuda tensor; n_frames int32 cuda tensor (B,) or None;
         noise (B, T*steps_per_frame) float32 cuda tensor (N(0,1) draw) -> audio (B, T*hop) cuda tensor.
 
         stream_state: optional int32 cuda tensor (B, 6) holding one ``mbx_stream_state`` per item (see
         streaming.pack_state); the call then returns (audio, state_out) with the carried phase state.
-        active: optional (begin_frame, int32 cuda tensor (B,) of frames) with stream_state: the stages from the WaveNet
+        active: optional (begin_frame, int32 cuda tensor (B,) of frames[, max of them]) with stream_state: the stages from the WaveNet
         on run on that region of the window only (``mbx_forward_options.active_begin / active_frames``); the audio
-        outside the region is undefined."""
+        outside the region is undefined.  wavenet: optional (begin_frame, int32 tensor (B,)) inner region of the WaveNet;
+        carry: optional (store float32 tensor (slots, rows, subbands), int32 tensor (B, 5)) sub-band rows carried between
+        ticks (``wn_begin / wn_frames / sub_store / sub_carry``)."""
         torch = self._torch
         if mel.dim() != 3 or mel.shape[2] != self.dims.mel_channels:
             raise ValueError(f"mel must be (batch, frames, {self.dims.mel_channels})")
@@ -585,6 +588,28 @@ class MBExWNEngine:
                 opt.transposition = 1.0
                 opt.state_in, opt.state_out = stream_state.data_ptr(), state_out.data_ptr()
                 opt.active_begin, opt.active_frames = a0, act.data_ptr()
+                if len(active) > 2:
+                    opt.active_max_frames = int(active[2])
+                keep = [act]
+                if wavenet is not None:
+                    w0, wfr = int(wavenet[0]), wavenet[1]
+                    if wfr.dtype != torch.int32 or tuple(wfr.shape) != (B,) or wfr.device != self.device or not a0 <= w0 < T:
+                        raise ValueError("wavenet = (begin frame inside the active region, int32 tensor (batch,) on the device)")
+                    wfr = wfr.contiguous()
+                    keep.append(wfr)
+                    opt.wn_begin, opt.wn_frames = w0, wfr.data_ptr()
+                    if len(wavenet) > 2:
+                        opt.wn_max_frames = int(wavenet[2])
+                if carry is not None:
+                    store, desc = carry
+                    if (store.dtype != torch.float32 or store.dim() != 3 or store.shape[2] != self.dims.subbands or
+                            store.device != self.device or not store.is_contiguous()):
+                        raise ValueError("carry store must be a contiguous float32 tensor (slots, rows, subbands) on the device")
+                    if desc.dtype != torch.int32 or tuple(desc.shape) != (B, 5) or desc.device != self.device:
+                        raise ValueError("carry descriptors must be an int32 tensor of shape (batch, 5) on the device")
+                    desc = desc.contiguous()
+                    keep.append(desc)
+                    opt.sub_store, opt.sub_store_rows, opt.sub_carry = store.data_ptr(), int(store.shape[1]), desc.data_ptr()
                 _check(self._lib.mbx_forward_ex(self._handle, mel.data_ptr(),
                                                 n_frames.data_ptr() if n_frames is not None else None, B, T,
                                                 noise.data_ptr() if noise is not None else None, out.data_ptr(),

@@ -28,7 +28,7 @@ def pack_state(cum=0.0, offset_sum=0.0, pos_in_chunk=0, start_sample=0, save_sam
 
 
 def stream_margins(dims, config):
-    """(left, right, pulse_lead, act_left, act_right) in mel frames, from the layer geometry of the model."""
+    """(left, right, pulse_lead, act_left, act_right, wn_reach) in mel frames, from the layer geometry of the model."""
     mb = config["mbexwn_config"]
 
     def subnet_reach(specs):
@@ -58,7 +58,7 @@ def stream_margins(dims, config):
     # margins of the stages from the WaveNet on (the active region of a window, mbx_forward_options.active_begin)
     act_left = wn_frames + pqmf_frames + stft_l
     act_right = wn_frames + pqmf_frames + stft_r
-    return left, right, pulse_lead, act_left, act_right
+    return left, right, pulse_lead, act_left, act_right, wn_frames
 
 
 class _Stream:
@@ -67,6 +67,9 @@ class _Stream:
         self.noise = np.zeros((0,), dtype=np.float32)
         self.emitted = 0          # frames of audio already produced
         self.closed = False
+        self.slot = -1            # row of the synthesizer's sub-band store
+        self.carry_pos = None     # the store holds the sub-bands of frames [carry_pos - sr_left, + carry_frames)
+        self.carry_frames = 0
         # phase state valid just in front of absolute pulse sample `state_frame * pulse_per_frame`
         self.state = (0.0, 0.0, 0)
         self.state_frame = 0
@@ -79,7 +82,16 @@ class StreamingSynthesizer:
         self.engine = engine
         self.dims = engine.dims
         self.chunk = int(chunk_frames)
-        self.left, self.right, self.lead, self.act_left, self.act_right = stream_margins(engine.dims, engine.config)
+        (self.left, self.right, self.lead, self.act_left, self.act_right,
+         self.wn_reach) = stream_margins(engine.dims, engine.config)
+        # sub-band rows carried from tick to tick: the stages behind the WaveNet reach sr_left frames in front of the
+        # emitted ones and sr_right behind them; these frames were computed exactly by the previous tick, so the WaveNet
+        # of a tick only runs on the frames behind them (plus its own reach)
+        self.sr_left = self.act_left - self.wn_reach
+        self.sr_right = self.act_right - self.wn_reach
+        self.carry = True
+        self._store = None            # (slots, (sr_left + sr_right) * steps_per_frame, subbands) on the device
+        self._free_slots = []
         # The Winograd form of the dilated convolution pairs outputs t and t+d inside blocks of 2d steps counted from
         # the first row of the item; a window that starts on a multiple of 2*d_max steps pairs exactly like the offline
         # run, which keeps the streamed audio bit-identical (any other start is equal up to float32 rounding only).
@@ -90,14 +102,32 @@ class StreamingSynthesizer:
         self.time_device = False          # bench: bracket the engine call of a tick with events on its stream
         self.last_tick_device_ms = None
         self.last_tick_frames = 0         # window frames of the last tick (all streams): mel-rate stages
-        self.last_tick_active_frames = 0  # frames of the active regions: stages from the WaveNet on
+        self.last_tick_active_frames = 0  # frames of the active regions: PQMF, STFT filter, overlap-add
+        self.last_tick_wavenet_frames = 0 # frames the WaveNet ran on
 
     @property
     def lookahead_ms(self):
         return 1000.0 * self.right * self.dims.hop_size / self.dims.sample_rate
 
     def open(self, stream_id):
-        self.streams[stream_id] = _Stream(self.dims.mel_channels)
+        st = _Stream(self.dims.mel_channels)
+        import torch
+        rows = (self.sr_left + self.sr_right) * self.dims.steps_per_frame
+        if not self._free_slots:
+            old = self._store
+            n_old = 0 if old is None else int(old.shape[0])
+            n_new = max(16, 2 * n_old)
+            self._store = torch.zeros((n_new, rows, self.dims.subbands), dtype=torch.float32, device=self.engine.device)
+            if old is not None:
+                self._store[:n_old] = old
+            self._free_slots = list(range(n_new - 1, n_old - 1, -1))
+        st.slot = self._free_slots.pop()
+        self.streams[stream_id] = st
+
+    def close(self, stream_id):
+        """Forget a finished stream (its slot of the sub-band store is reused)."""
+        st = self.streams.pop(stream_id)
+        self._free_slots.append(st.slot)
 
     def push(self, stream_id, mel_frames, noise=None, last=False):
         """Append mel frames (n, mel_channels) and the matching N(0,1) draw (n*steps_per_frame,) to a stream."""
@@ -148,9 +178,46 @@ class StreamingSynthesizer:
         if any(ws > 0 for ws, _ in windows) and 0 < a0 < self.lead:
             a0 = 0
         act = np.zeros((B,), dtype=np.int32)
+        ends = []
         for bb, ((sid, st, nn), (ws, we)) in enumerate(zip(todo, windows)):
             a1 = we if we - (st.emitted + nn) <= self.act_right else st.emitted + nn + self.act_right
+            ends.append(a1)
             act[bb] = a1 - ws - a0
+        # carried sub-bands: usable when every item of the tick has a valid store and the same geometry
+        sl, sr, wr = self.sr_left, self.sr_right, self.wn_reach
+        wn = None
+        desc = np.zeros((B, 5), dtype=np.int32)
+        use_carry = self.carry
+        sa = wa = None
+        for (sid, st, nn), (ws, we) in zip(todo, windows):
+            if not use_carry:
+                break
+            ok = st.carry_pos == st.emitted and st.emitted - sl >= ws
+            sab = st.emitted - sl - ws
+            wab = ((st.emitted + min(sr, st.carry_frames - sl) - wr) // self.align) * self.align - ws
+            ok = ok and wab >= sab and (ws == 0 or wab >= self.lead) and st.carry_frames > sl
+            ok = ok and (sa is None or (sab == sa and wab == wa))
+            sa, wa = sab, wab
+            use_carry = ok
+        if use_carry and todo:
+            a0 = sa
+            wn = np.zeros((B,), dtype=np.int32)
+            for bb, ((sid, st, nn), (ws, we)) in enumerate(zip(todo, windows)):
+                act[bb] = ends[bb] - ws - sa
+                wn[bb] = ends[bb] - ws - wa
+                desc[bb, 1:3] = sa * spf, st.carry_frames * spf
+        # rows the next tick will need: frames [e' - sr_left, e' + sr_right) around the next emit position e', if this tick
+        # computes them exactly (its region reaches wn_reach frames beyond them, or to the end of the utterance)
+        next_carry = []
+        for bb, ((sid, st, nn), (ws, we)) in enumerate(zip(todo, windows)):
+            e1 = st.emitted + nn
+            lo, hi = e1 - sl, min(e1 + sr, ends[bb] if ends[bb] == we and st.closed else ends[bb] - wr)
+            region_lo = ws + a0 if use_carry else ws + a0 + (wr if ws + a0 > 0 else 0)
+            good = self.carry and lo >= region_lo and hi > lo + sl and lo >= ws
+            desc[bb, 0] = st.slot
+            if good:
+                desc[bb, 3:5] = (lo - ws) * spf, (hi - lo) * spf
+            next_carry.append((e1, hi - lo) if good else (None, 0))
         mel = np.zeros((B, tmax, self.dims.mel_channels), dtype=np.float32)
         noise = np.zeros((B, tmax * spf), dtype=np.float32)
         nfr = np.zeros((B,), dtype=np.int32)
@@ -178,8 +245,12 @@ class StreamingSynthesizer:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         self.last_tick_active_frames = int(act.sum())
-        audio, state_out = self.engine.forward(mel_d, n_frames=nfr_d, noise=noise_d, stream_state=states_d,
-                                               active=(a0, torch.as_tensor(act, device=dev)))
+        self.last_tick_wavenet_frames = int(wn.sum()) if wn is not None else int(act.sum())
+        audio, state_out = self.engine.forward(
+            mel_d, n_frames=nfr_d, noise=noise_d, stream_state=states_d,
+            active=(a0, torch.as_tensor(act, device=dev), int(act.max())),
+            wavenet=(wa, torch.as_tensor(wn, device=dev), int(wn.max())) if wn is not None else None,
+            carry=(self._store, torch.as_tensor(desc, device=dev)) if self.carry else None)
         if self.time_device:
             ev1.record()
             ev1.synchronize()
@@ -191,6 +262,7 @@ class StreamingSynthesizer:
             a0 = (st.emitted - ws) * hop
             result[sid] = audio[bb, a0:a0 + nn * hop].copy()
             st.emitted += nn
+            st.carry_pos, st.carry_frames = next_carry[bb]
             if next_state_frame[bb] < we:
                 ff = state_out[bb, :2].copy().view(np.float32)
                 st.state = (float(ff[0]), float(ff[1]), int(state_out[bb, 2]))
