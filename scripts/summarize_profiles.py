@@ -21,7 +21,7 @@ summary = {}
 def short(name):
     if "wn_gate_winograd" in name or ("conv1d_mfma_dma_kernel" in name and ", 1>" in name):
         return "gate"
-    if "wn_resskip_kernel" in name or ("conv1d_mfma_kernel" in name and ", 2, true" in name):
+    if "wn_resskip_kernel" in name or "wn_resskip_wide_kernel" in name or ("conv1d_mfma_kernel" in name and ", 2, true" in name):
         return "res_skip"
     return None
 
