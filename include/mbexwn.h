@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MBX_ABI_VERSION 3
+#define MBX_ABI_VERSION 4
 #define MBX_MAX_SUBNET_OPS 32
 #define MBX_MAX_WN_LAYERS 64
 #define MBX_NAME_LEN 64
@@ -201,7 +201,33 @@ typedef struct {
     float *sub_store;
     int32_t sub_store_rows;
     const int32_t *sub_carry;
+    /* Streaming windows, third level: the per-layer state of the WaveNet carried between the ticks of a stream, so that a
+     * tick runs every layer only on the rows that are new.  Layer l is exact up to its own reach in front of the rows
+     * layer l-1 is exact for (a staircase that ends mbx_layer_state_info().reach_rows in front of the end of the WaveNet
+     * region); a slot of the store keeps, per layer, the rows of the layer's input and of the output accumulator the next
+     * tick reads from in front of its own rows.
+     *   layer_store         device (slots, layer_store_floats) persistent buffer of the caller
+     *   layer_store_floats  floats per slot (mbx_layer_state_info)
+     *   layer_carry         device (batch, 3) int32: slot of the item; window row (WaveNet rate) the stored state ends at =
+     *                       the end of the WaveNet region of the call that stored it, in this window's coordinates (-1: none);
+     *                       window row the state stored by this call ends at = the end of this call's region (-1: none)
+     *   layer_rows          0: the WaveNet runs on its whole region (state is stored where layer_carry asks for it, none
+     *                       is read); > 0: every item reads its stored state and every layer runs on layer_rows rows:
+     *                       all items then share one geometry -- region end E = (wn_begin + wn_max_frames) *
+     *                       steps_per_frame, stored end = E - layer_rows >= min_rows behind -- and none of them ends
+     *                       its utterance inside the window.  The sub-band rows [E - layer_rows - reach_rows,
+     *                       E - reach_rows) are produced; wn_begin must be the frame of the first of them. */
+    float *layer_store;
+    int32_t layer_store_floats;
+    const int32_t *layer_carry;
+    int32_t layer_rows;
 } mbx_forward_options;
+
+/* Geometry of the per-layer state (mbx_forward_options.layer_store): floats per slot (0: the handle cannot carry layer
+ * state -- it needs the folded graph and the Winograd F(2,3) images), rows between the end of a WaveNet region and the
+ * last sub-band row that is exact, smallest layer_rows a steady tick may use. */
+mbx_status mbx_layer_state_info(const mbx_handle *handle, int32_t *floats_per_slot, int32_t *reach_rows,
+                                int32_t *min_rows);
 
 mbx_status mbx_forward_ex(mbx_handle *handle, const float *mel, const int32_t *n_frames, int32_t batch,
                           int32_t max_frames, const float *noise, float *audio, void *workspace,

@@ -174,4 +174,48 @@ void launch_sub_carry(float *sub, long long sub_bstride, float *store, long long
                        slot_stride, desc, row_floats, dir);
 }
 
+// Per-layer WaveNet state carried between the ticks of a stream (mbx_forward_options.layer_carry): launched in front
+// of the gate launch of layer l >= 1.  Per item b the descriptor desc[b] = (slot, end row of the stored state, end row
+// of the state to store), rows at the WaveNet rate inside the window, -1: none.  With `end` the first row behind the
+// region an item's WaveNet could read, layer l is exact up to row e_l = end + a.base_off (a staircase: every layer ends
+// its own reach in front of the layer before it); the slot keeps, for this layer, the rows [e_l - h_before, + h_rows) of
+// its input h_l and the rows [e_l, + acc_rows) of the output accumulator, which hold the contributions of the layers
+// in front of l at this point of the sequence.  One thread moves one float both ways (slot -> window for the stored
+// state, window -> slot for the new one); the two row ranges of an item must not overlap (checked by the caller:
+// the new state ends at least h_rows + acc_rows rows behind the stored one).
+__global__ void layer_carry_kernel(LayerCarryArgs a) {
+    const int b = blockIdx.y;
+    const int *d = a.desc + 3 * b;
+    const int in_end = a.inject ? d[1] : -1, out_end = d[2];
+    if (in_end < 0 && out_end < 0) return;
+    float *st = a.store + (long long)d[0] * a.slot_stride + a.layer_off;
+    float *hb = a.h + (long long)b * a.h_bstride;
+    float *ab = a.acc + (long long)b * a.acc_bstride;
+    const int n_h = a.h_rows * a.C, n = n_h + a.acc_rows * a.n_out;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float *buf;
+        long long off_in, off_out;
+        if (i < n_h) {
+            buf = hb;
+            off_in = (long long)(in_end + a.base_off - a.h_before) * a.C + i;
+            off_out = (long long)(out_end + a.base_off - a.h_before) * a.C + i;
+        } else {
+            buf = ab;
+            off_in = (long long)(in_end + a.base_off) * a.n_out + (i - n_h);
+            off_out = (long long)(out_end + a.base_off) * a.n_out + (i - n_h);
+        }
+        const bool do_in = in_end >= 0 && off_in >= 0, do_out = out_end >= 0 && off_out >= 0;
+        const float v_in = do_in ? st[i] : 0.f;
+        const float v_out = do_out ? buf[off_out] : 0.f;
+        if (do_in) buf[off_in] = v_in;
+        if (do_out) st[i] = v_out;
+    }
+}
+
+void launch_layer_carry(const LayerCarryArgs &a, int batch, hipStream_t stream) {
+    const int n = a.h_rows * a.C + a.acc_rows * a.n_out;
+    if (batch <= 0 || n <= 0) return;
+    hipLaunchKernelGGL(layer_carry_kernel, dim3(std::min((n + 255) / 256, 64), batch), dim3(256), 0, stream, a);
+}
+
 }  // namespace mbx

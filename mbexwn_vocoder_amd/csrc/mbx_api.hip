@@ -626,13 +626,71 @@ size_t mbx_workspace_size(const mbx_handle *handle, int32_t batch, int32_t max_f
     return carve(handle, nullptr, batch, max_frames).total;
 }
 
+// Geometry of the per-layer state a stream carries between ticks (mbx_forward_options.layer_store): layer l reaches
+// r[l] rows to either side; it is exact up to row e_l = E - reach_rows + c[l] when the region ends at row E, with
+// e_l = e_{l-1} - step[l] (step = the reach rounded up to even rows: the rows of the n_out-wide accumulator stay 8-byte
+// aligned).  A slot keeps per layer l >= 1 the rows [e_l - r[l], e_l + step[l]) of h_l and [e_l, e_l + step[l]) of the
+// accumulator.
+struct LayerGeom {
+    int floats, reach_rows, min_rows;
+    int r[MBX_MAX_WN_LAYERS], step[MBX_MAX_WN_LAYERS], c[MBX_MAX_WN_LAYERS];
+    long long off[MBX_MAX_WN_LAYERS];
+};
+
+static LayerGeom layer_geom(const mbx_handle *hd) {
+    LayerGeom g{};
+    const mbx_config &c = hd->cfg;
+    const int L = c.wn_layers, C = c.wn_channels;
+    // needs the folded graph (no separate start / skip tensors to carry) and the F(2,3) gate kernel (per-layer regions
+    // start between conditioning rows: ConvArgs::cond_phase)
+    if (!hd->fold_skip || !hd->fold_start || !hd->winograd || c.wn_kernel_size != 3 || L < 2) return g;
+    for (int l = 1; l < L; ++l) {
+        const DevTensor *wino = find(hd, "wn.conv1D_" + std::to_string(l) + ".wino");
+        const int d = c.wn_dilations[l];
+        if (!wino || d > 16 || (d & (d - 1)) != 0) return g;
+    }
+    for (int l = 0; l < L; ++l) {
+        g.r[l] = c.wn_dilations[l] * (c.wn_kernel_size - 1) / 2;
+        g.step[l] = (g.r[l] + 1) & ~1;
+    }
+    g.c[L - 1] = 0;
+    for (int l = L - 2; l >= 0; --l) g.c[l] = g.c[l + 1] + g.step[l + 1];
+    const int spf = c.steps_per_frame;
+    g.reach_rows = (g.c[0] + g.r[0] + spf - 1) / spf * spf;
+    long long off = 0;
+    for (int l = 1; l < L; ++l) {
+        g.off[l] = off;
+        off += (long long)(g.r[l] + g.step[l]) * C + (long long)g.step[l] * c.wn_out_channels;
+        g.min_rows = std::max(g.min_rows, g.r[l] + g.step[l]);
+    }
+    g.floats = (int)off;
+    return g;
+}
+
+mbx_status mbx_layer_state_info(const mbx_handle *hd, int32_t *floats_per_slot, int32_t *reach_rows, int32_t *min_rows) {
+    if (!hd) return fail(MBX_ERR_INVALID_ARGUMENT, "null handle");
+    const LayerGeom g = layer_geom(hd);
+    if (floats_per_slot) *floats_per_slot = g.floats;
+    if (reach_rows) *reach_rows = g.reach_rows;
+    if (min_rows) *min_rows = g.min_rows;
+    return MBX_OK;
+}
+
+struct LayerOpts {
+    float *store;
+    int floats;
+    const int32_t *carry;
+    int rows;
+};
+
 static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *n_frames, int32_t batch,
                                int32_t max_frames, const float *noise, float *audio, void *workspace,
                                size_t workspace_bytes, const mbx::StreamState *st_in, mbx::StreamState *st_out,
                                void *hip_stream, const float *f0_in = nullptr, float transposition = 1.f,
                                int active_begin = 0, const int32_t *active_frames = nullptr, int wn_begin = 0,
                                const int32_t *wn_frames = nullptr, float *sub_store = nullptr, int sub_store_rows = 0,
-                               const int32_t *sub_carry = nullptr, int active_max_frames = 0, int wn_max_frames = 0) {
+                               const int32_t *sub_carry = nullptr, int active_max_frames = 0, int wn_max_frames = 0,
+                               const LayerOpts *lay = nullptr) {
     if (!hd || !mel || !audio || !workspace) return fail(MBX_ERR_INVALID_ARGUMENT, "null argument");
     if (batch <= 0 || max_frames <= 0) return fail(MBX_ERR_INVALID_ARGUMENT, "batch and max_frames must be positive");
     DeviceGuard guard(hd->device);
@@ -717,52 +775,89 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     }
     // ---- active region (streaming windows, mbx_forward_options): from here on every stage sees the frames
     // [active_begin, active_begin + active_frames[b]) of the window as the item.  All buffers are (batch, frames * k)
-    // with the batch stride of the whole window, so the region is a pointer offset plus the per-item frame counts.
-    const Workspace w_base = w;                      // the stage table below points at the whole window
+    // with the batch stride of the whole window, so a region is a row offset into every buffer plus per-item row counts.
+    const Workspace &w_base = w;                     // the stage table below points at the whole window
     const int32_t *n_frames_act = active_frames ? active_frames : n_frames;   // PQMF, STFT filter, overlap-add
     const long long act0 = active_frames ? active_begin : 0;
-    if (active_frames) {
-        // the WaveNet may have a region of its own inside the active one (wn_begin / wn_frames)
-        const long long a0 = wn_frames ? wn_begin : active_begin;
-        n_frames = wn_frames ? wn_frames : active_frames;
-        w.pulse += a0 * c.pulse_per_frame;
-        if (noise) noise += a0 * c.steps_per_frame;
-        w.cond += a0 * cond_cout;
-        w.h += a0 * c.steps_per_frame * C;
-        w.skip += a0 * c.steps_per_frame * C;
-        w.wn_out += a0 * c.steps_per_frame * c.wn_out_channels;
-        w.sub += a0 * c.steps_per_frame * M;
-    }
+    // the WaveNet may have a region of its own inside the active one (wn_begin / wn_frames)
+    const long long wn0 = active_frames ? (wn_frames ? wn_begin : active_begin) : 0;
+    const int32_t *n_frames_wn = active_frames ? (wn_frames ? wn_frames : active_frames) : n_frames;
     // upper bounds of the rows an item can have in its region: the launchers size their grids (and pick block shapes)
     // from them; batch strides stay those of the whole window
-    int wn_frames_max = T - (int)(active_frames ? (wn_frames ? wn_begin : active_begin) : 0);
+    int wn_frames_max = T - (int)wn0;
     const int wn_bound = wn_frames ? wn_max_frames : active_max_frames;
     if (active_frames && wn_bound > 0) wn_frames_max = std::min(wn_frames_max, wn_bound);
     const int wn_rows = wn_frames_max * c.steps_per_frame;
     int act_frames_max = T - (int)act0;
     if (active_frames && active_max_frames > 0) act_frames_max = std::min(act_frames_max, active_max_frames);
-    const long long a_off = active_frames ? (long long)(wn_frames ? wn_begin : active_begin) * c.steps_per_frame : 0;   // rows; `a` has a per-layer row stride
     // ---- WaveNet (reference custom_AE_layers.py:273-346)
     const bool fold_start = hd->fold_start;
+    const bool fold = hd->fold_skip;
+    const int n_out = c.wn_out_channels, spf = c.steps_per_frame, cond_up = c.cond_lin_upsampling;
     const int lda0 = (fold_start && L > 1) ? C + 16 : C;      // row stride of layer 0's output
+    // A span = the rows of the window one launch treats as the item: first row, per-item row counts (nf[b] * rpf, or
+    // max_rows for every item when nf is null), conditioning-rate phase of the first row.  Whole-region runs use one span
+    // for every launch; a steady streaming tick (layer state carried, mbx_forward_options.layer_rows) one per layer.
+    struct Span { long long row0; const int32_t *nf; int rpf, max_rows, cphase; };
+    const Span region{wn0 * spf, n_frames_wn, spf, wn_rows, 0};
+    std::vector<Span> gate_sp(L, region), res_sp(L, region);
+    Span tail_sp = region;
+    const bool carry_layers = lay && lay->carry;
+    const bool layered = carry_layers && lay->rows > 0;
+    LayerGeom geo{};
+    if (carry_layers) {
+        geo = layer_geom(hd);
+        if (!geo.floats) return fail(MBX_ERR_UNSUPPORTED, "this handle cannot carry layer state (mbx_layer_state_info)");
+        if (!lay->store || lay->floats != geo.floats)
+            return fail(MBX_ERR_INVALID_ARGUMENT, "layer_store / layer_store_floats do not match mbx_layer_state_info");
+    }
+    if (layered) {
+        // every item: state stored up to row E - N, region end E; layer l runs on [s_l, s_l + N), s_l = E - N - reach + c_l
+        const int N = lay->rows;
+        if (!wn_frames || wn_max_frames <= 0 || N < geo.min_rows)
+            return fail(MBX_ERR_INVALID_ARGUMENT, "layer_rows needs wn_frames, wn_max_frames and at least min_rows rows");
+        const long long E = (long long)(wn_begin + wn_max_frames) * spf;
+        if (E > nsteps || E - N - geo.reach_rows != (long long)wn_begin * spf)
+            return fail(MBX_ERR_INVALID_ARGUMENT, "layer_rows: wn_begin must be the frame of the first new sub-band row");
+        for (int l = 0; l < L; ++l) {
+            const long long s = E - N - geo.reach_rows + geo.c[l], e = s + N;
+            const int align = l == 0 ? cond_up : 2 * c.wn_dilations[l];      // Winograd F(2,3) pairs rows t, t+d in blocks of 2d
+            const long long A = ((s - geo.r[l]) / align) * align;
+            if (s - geo.r[l] < 0) return fail(MBX_ERR_INVALID_ARGUMENT, "layer_rows: the window does not reach far enough back");
+            const int phase = (int)(A % cond_up);
+            // rows of the launch: up to the layer's reach behind the last new row, and far enough that the conditioning
+            // row behind the last new row is not the item's last one (which is where the interpolation clamps)
+            const long long n1 = e + geo.r[l] - A;
+            const long long n2 = (long long)cond_up * ((e - 1 - A + phase) / cond_up + 2) - phase;
+            const long long need = std::max(n1, n2);
+            if (A + need > nsteps) return fail(MBX_ERR_INVALID_ARGUMENT, "layer_rows: the region ends too close to the window end");
+            gate_sp[l] = Span{A, nullptr, 1, (int)need, phase};
+            res_sp[l] = Span{s, nullptr, 1, N, 0};
+        }
+        tail_sp = res_sp[L - 1];
+    }
+    const int ppr = c.pulse_per_frame / spf;                   // excitation samples per WaveNet row
+    if (c.pulse_per_frame % spf != 0) return fail(MBX_ERR_INVALID_ARGUMENT, "pulse_per_frame must be a multiple of steps_per_frame");
     if (!fold_start) {
         ScopedEvents ev(hd, PROF_START, stream);
-        mbx::launch_wn_start(w.pulse, npulse, c.noise_sigma != 0.f ? noise : nullptr, nsteps, c.noise_sigma, n_frames,
-                             c.steps_per_frame, wn_rows, B, c.pulse_channels, find(hd, "wn.start.w")->ptr,
-                             find(hd, "wn.start.b")->ptr, C, w.h, nsteps * C, stream);
+        const Span &sp = region;
+        mbx::launch_wn_start(w.pulse + sp.row0 * ppr, npulse, c.noise_sigma != 0.f ? noise + sp.row0 : nullptr, nsteps, c.noise_sigma,
+                             sp.nf, sp.rpf, sp.max_rows, B, c.pulse_channels, find(hd, "wn.start.w")->ptr,
+                             find(hd, "wn.start.b")->ptr, C, w.h + sp.row0 * C, nsteps * C, stream);
     }
-    auto lerp = hd->lerp[c.cond_lin_upsampling];
-    const bool fold = hd->fold_skip;
+    auto lerp = hd->lerp[cond_up];
     for (int l = 0; l < L; ++l) {
         const std::string ls = std::to_string(l);
         const int d = c.wn_dilations[l];
-        mbx::ConvArgs g = conv_args(w.h, nsteps * C, C, n_frames, c.steps_per_frame, wn_rows, B,
+        const Span &gs = gate_sp[l];
+        mbx::ConvArgs g = conv_args(w.h + gs.row0 * C, nsteps * C, C, gs.nf, gs.rpf, gs.max_rows, B,
                                     find(hd, "wn.conv1D_" + ls + ".w"), find(hd, "wn.conv1D_" + ls + ".b"),
-                                    c.wn_kernel_size, C, 2 * C, d, d * (c.wn_kernel_size - 1) / 2, MBX_PAD_ZERO, w.a + a_off * C,
+                                    c.wn_kernel_size, C, 2 * C, d, d * (c.wn_kernel_size - 1) / 2, MBX_PAD_ZERO, w.a + gs.row0 * C,
                                     nsteps * C, C);
-        g.cond = w.cond;
+        g.cond = w.cond + (gs.row0 / cond_up) * (2 * C);
         g.cond_bstride = (long long)T * cond_cout;
-        g.cond_up = c.cond_lin_upsampling;
+        g.cond_up = cond_up;
+        g.cond_phase = gs.cphase;
         g.lerp_w0 = lerp.first;
         g.lerp_w1 = lerp.second;
         g.channels = C;
@@ -771,15 +866,15 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
             // start convolution folded into the layer: a K = 24 contraction of the excitation (wn_gate0.hip)
             ScopedEvents ev(hd, PROF_GATE0, stream);
             mbx::Gate0Args g0{};
-            g0.pulse = w.pulse;
+            g0.pulse = w.pulse + gs.row0 * ppr;
             g0.pulse_bstride = npulse;
-            g0.noise = c.noise_sigma != 0.f ? noise : nullptr;
+            g0.noise = c.noise_sigma != 0.f ? noise + gs.row0 : nullptr;
             g0.noise_bstride = nsteps;
             g0.sigma = c.noise_sigma;
             g0.pulse_channels = c.pulse_channels;
-            g0.n_frames = n_frames;
-            g0.rows_per_frame = c.steps_per_frame;
-            g0.max_rows = wn_rows;
+            g0.n_frames = gs.nf;
+            g0.rows_per_frame = gs.rpf;
+            g0.max_rows = gs.max_rows;
             g0.batch = B;
             g0.w = find(hd, "wn.conv1D_0.start_fold")->ptr;
             g0.bias = g.bias;
@@ -790,13 +885,35 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
             g0.cond_up = g.cond_up;
             g0.lerp_w0 = g.lerp_w0;
             g0.lerp_w1 = g.lerp_w1;
-            g0.out = w.a + a_off * lda0;
+            g0.out = w.a + gs.row0 * lda0;
             g0.out_bstride = nsteps * lda0;
             g0.ldo = lda0;
             g0.write_inputs = L > 1;
-            if (!mbx::launch_wn_gate0(g0, stream)) return fail(MBX_ERR_INVALID_ARGUMENT, "folded first layer does not fit its kernel");
+            if (gs.cphase != 0 || !mbx::launch_wn_gate0(g0, stream))
+                return fail(MBX_ERR_INVALID_ARGUMENT, "folded first layer does not fit its kernel");
         } else {
             ScopedEvents ev(hd, PROF_GATE, stream);
+            // per-layer state of a stream: the rows this layer reads from in front of its own come from the item's slot,
+            // the rows the next tick will read go there (layer_carry_kernel)
+            if (carry_layers && l >= 1) {
+                mbx::LayerCarryArgs lc{};
+                lc.h = w.h;
+                lc.h_bstride = nsteps * C;
+                lc.C = C;
+                lc.acc = w.wn_out;
+                lc.acc_bstride = nsteps * n_out;
+                lc.n_out = n_out;
+                lc.store = lay->store;
+                lc.slot_stride = geo.floats;
+                lc.layer_off = geo.off[l];
+                lc.desc = lay->carry;
+                lc.inject = layered;
+                lc.base_off = geo.c[l] - geo.reach_rows;
+                lc.h_before = geo.r[l];
+                lc.h_rows = geo.r[l] + geo.step[l];
+                lc.acc_rows = geo.step[l];
+                mbx::launch_layer_carry(lc, B, stream);
+            }
             bool done = false;
             // F(4,3): 256-row blocks once they fill the 512 resident slots (2 per CU), below that 128-row blocks whose waves
             // split the input channels (finer granularity; measured equal at 630 blocks, i.e. one 10 s utterance).
@@ -806,7 +923,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
             const bool use4 = hd->winograd == 4 && !st_in && !st_out;
             const DevTensor *wino4 = use4 ? find(hd, "wn.conv1D_" + ls + ".wino4w") : nullptr;
             if (wino4 && wino4->ndim == 3 && wino4->shape[0] == (C + 31) / 32 && wino4->shape[1] == (C + 7) / 8 &&
-                wino4->shape[2] == 3072) {
+                wino4->shape[2] == 3072 && gs.cphase == 0) {
                 mbx::ConvArgs gw = g;
                 gw.w = wino4->ptr;
                 done = mbx::launch_wn_gate_winograd4w(gw, !(hd->winograd4_always || full_blocks >= 512), stream);
@@ -821,9 +938,11 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                                  wino2->shape[1] == wino->shape[1] && wino2->shape[2] == 4096;
                 done = mbx::launch_wn_gate_winograd(gw, ok2 ? wino2->ptr : nullptr, stream);
             }
+            if (!done && gs.cphase != 0) return fail(MBX_ERR_UNSUPPORTED, "per-layer regions need the Winograd F(2,3) gate kernel");
             if (!done) mbx::launch_conv1d(g, mbx::EPI_GATE, stream);
         }
         const bool last = (l == L - 1);
+        const Span &rs = res_sp[l];
         if (fold) {
             // skip path folded into the end convolution: layers 0..L-2 update h and add a W_skip W_end to the n_out-wide
             // output accumulator; the last layer's contribution is added by the tail kernel below
@@ -833,15 +952,15 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                 const int cin_l = ext ? C + 16 : C;
                 const DevTensor *fw = find(hd, "wn.res_skip_" + ls + (ext ? ".fold_start" : ".fold")),
                                 *fb = find(hd, "wn.res_skip_" + ls + ".fold_b");
-                mbx::ConvArgs r = conv_args(w.a + a_off * cin_l, nsteps * cin_l, cin_l, n_frames, c.steps_per_frame, wn_rows, B, fw, fb, 1,
-                                            cin_l, C + c.wn_out_channels, 1, 0, MBX_PAD_ZERO, nullptr, 0, 0);
+                mbx::ConvArgs r = conv_args(w.a + rs.row0 * cin_l, nsteps * cin_l, cin_l, rs.nf, rs.rpf, rs.max_rows, B, fw, fb, 1,
+                                            cin_l, C + n_out, 1, 0, MBX_PAD_ZERO, nullptr, 0, 0);
                 r.h_init = ext;
                 r.channels = C;
                 r.zeros = hd->zeros;
-                r.h = w.h;
-                r.skip = w.wn_out;
-                r.skip_ld = c.wn_out_channels;
-                r.skip_bstride = nsteps * c.wn_out_channels;
+                r.h = w.h + rs.row0 * C;
+                r.skip = w.wn_out + rs.row0 * n_out;
+                r.skip_ld = n_out;
+                r.skip_bstride = nsteps * n_out;
                 r.hs_bstride = nsteps * C;
                 r.skip_init = (l == 0);
                 ScopedEvents ev(hd, PROF_RES_SKIP, stream);
@@ -851,7 +970,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                 bool done = false;
                 const DevTensor *fww = find(hd, "wn.res_skip_" + ls + (ext ? ".fold_start_wide" : ".fold_wide"));
                 const long long wide_blocks = ((nsteps + 127) / 128) * B;
-                const int npair = (C + c.wn_out_channels + 31) / 32;
+                const int npair = (C + n_out + 31) / 32;
                 if (fww && fww->ndim == 3 && fww->shape[0] == (cin_l + 7) / 8 && fww->shape[1] == npair && fww->shape[2] == 256 &&
                     (hd->winograd4_always || (hd->winograd == 4 && !st_in && !st_out && wide_blocks >= 2 * 512))) {
                     mbx::ConvArgs rw = r;
@@ -862,13 +981,13 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
             }
             continue;
         }
-        mbx::ConvArgs r = conv_args(w.a + a_off * C, nsteps * C, C, n_frames, c.steps_per_frame, wn_rows, B,
+        mbx::ConvArgs r = conv_args(w.a + rs.row0 * C, nsteps * C, C, rs.nf, rs.rpf, rs.max_rows, B,
                                     find(hd, "wn.res_skip_" + ls + ".w"), find(hd, "wn.res_skip_" + ls + ".b"), 1, C,
                                     last ? C : 2 * C, 1, 0, MBX_PAD_ZERO, nullptr, 0, 0);
         r.channels = C;
         r.zeros = hd->zeros;
-        r.h = w.h;
-        r.skip = w.skip;
+        r.h = w.h + rs.row0 * C;
+        r.skip = w.skip + rs.row0 * C;
         r.hs_bstride = nsteps * C;
         r.skip_init = (l == 0);
         r.last_layer = last;
@@ -891,27 +1010,27 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         ScopedEvents ev(hd, PROF_TAIL, stream);
         const DevTensor *we = find(hd, "wn.end.w"), *be = find(hd, "wn.end.b"), *wpn = find(hd, "post.w"),
                         *bpn = find(hd, "post.b");
+        const Span &ts = tail_sp;
+        float *acc_t = w.wn_out + ts.row0 * n_out, *sub_t = w.sub + ts.row0 * M, *skip_t = w.skip + ts.row0 * C;
         if (fold) {
             const DevTensor *tw = find(hd, "wn.tail.fold"), *tb = find(hd, "wn.tail.fold_b");
-            if (!mbx::launch_wn_tail(w.a + a_off * C, nsteps * C, n_frames, c.steps_per_frame, wn_rows, B, C, tw->ptr, tb->ptr,
-                                     c.wn_out_channels, wpn->ptr, bpn ? bpn->ptr : nullptr, M, L > 1 ? w.wn_out : nullptr,
-                                     w.wn_out, nsteps * c.wn_out_channels, w.sub, nsteps * M, stream))
+            if (!mbx::launch_wn_tail(w.a + ts.row0 * C, nsteps * C, ts.nf, ts.rpf, ts.max_rows, B, C, tw->ptr, tb->ptr,
+                                     n_out, wpn->ptr, bpn ? bpn->ptr : nullptr, M, L > 1 ? acc_t : nullptr,
+                                     acc_t, nsteps * n_out, sub_t, nsteps * M, stream))
                 return fail(MBX_ERR_INVALID_ARGUMENT, "folded WaveNet tail does not fit its kernel");
         }
         const DevTensor *wep = find(hd, "wn.end.packed");
         const bool fused = fold || (wep && wep->count == (long long)((C + 7) / 8) * 256 &&
-            mbx::launch_wn_tail(w.skip, nsteps * C, n_frames, c.steps_per_frame, wn_rows, B, C, wep->ptr,
-                                be ? be->ptr : nullptr, c.wn_out_channels, wpn->ptr, bpn ? bpn->ptr : nullptr, M, nullptr,
-                                w.wn_out, nsteps * c.wn_out_channels, w.sub, nsteps * M, stream));
+            mbx::launch_wn_tail(skip_t, nsteps * C, ts.nf, ts.rpf, ts.max_rows, B, C, wep->ptr,
+                                be ? be->ptr : nullptr, n_out, wpn->ptr, bpn ? bpn->ptr : nullptr, M, nullptr,
+                                acc_t, nsteps * n_out, sub_t, nsteps * M, stream));
         if (!fused) {
-            mbx::ConvArgs a = conv_args(w.skip, nsteps * C, C, n_frames, c.steps_per_frame, wn_rows, B, we, be, 1, C,
-                                        c.wn_out_channels, 1, 0, MBX_PAD_ZERO, w.wn_out, nsteps * c.wn_out_channels,
-                                        c.wn_out_channels);
+            mbx::ConvArgs a = conv_args(skip_t, nsteps * C, C, ts.nf, ts.rpf, ts.max_rows, B, we, be, 1, C,
+                                        n_out, 1, 0, MBX_PAD_ZERO, acc_t, nsteps * n_out, n_out);
             mbx::launch_conv1d(a, mbx::EPI_LINEAR, stream);
             // post-net 1x1 (reference custom_pulsed_generator.py:490-493,913-914)
-            mbx::ConvArgs pn = conv_args(w.wn_out, nsteps * c.wn_out_channels, c.wn_out_channels, n_frames,
-                                         c.steps_per_frame, wn_rows, B, wpn, bpn, 1, c.wn_out_channels, M, 1, 0,
-                                         MBX_PAD_ZERO, w.sub, nsteps * M, M);
+            mbx::ConvArgs pn = conv_args(acc_t, nsteps * n_out, n_out, ts.nf, ts.rpf, ts.max_rows, B, wpn, bpn, 1, n_out, M, 1, 0,
+                                         MBX_PAD_ZERO, sub_t, nsteps * M, M);
             mbx::launch_conv1d(pn, mbx::EPI_LINEAR, stream);
         }
     }
@@ -998,12 +1117,15 @@ mbx_status mbx_forward_ex(mbx_handle *hd, const float *mel, const int32_t *n_fra
     if (!options || options->struct_size != (int32_t)sizeof(mbx_forward_options))
         return fail(MBX_ERR_INVALID_ARGUMENT, "mbx_forward_options ABI mismatch (struct_size)");
     if (!(options->transposition > 0.f)) return fail(MBX_ERR_INVALID_ARGUMENT, "transposition must be positive");
+    if (!options->layer_carry && options->layer_rows != 0)
+        return fail(MBX_ERR_INVALID_ARGUMENT, "layer_rows needs layer_carry");
+    const LayerOpts lay{options->layer_store, options->layer_store_floats, options->layer_carry, options->layer_rows};
     return forward_impl(hd, mel, n_frames, batch, max_frames, noise, audio, workspace, workspace_bytes,
                         reinterpret_cast<const mbx::StreamState *>(options->state_in),
                         reinterpret_cast<mbx::StreamState *>(options->state_out), hip_stream, options->f0,
                         options->transposition, options->active_begin, options->active_frames, options->wn_begin,
                         options->wn_frames, options->sub_store, options->sub_store_rows, options->sub_carry,
-                        options->active_max_frames, options->wn_max_frames);
+                        options->active_max_frames, options->wn_max_frames, options->layer_carry ? &lay : nullptr);
 }
 
 mbx_status mbx_mel_analysis(const float *audio, const int32_t *n_samples, int32_t batch, int32_t max_samples,

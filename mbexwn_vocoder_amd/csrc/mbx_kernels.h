@@ -40,6 +40,7 @@ struct ConvArgs {
     const float *cond;
     long long cond_bstride;
     int cond_up;
+    int cond_phase;           // item row r sits at conditioning-rate position r + cond_phase (0 <= cond_phase < cond_up; F(2,3) gate kernel only)
     const float *lerp_w0, *lerp_w1;   // (cond_up) float32 interpolation weights
     int channels;             // C (gate: cout == 2C, out has C columns; res/skip: split point)
     // EPI_RESSKIP extras
@@ -111,6 +112,23 @@ void launch_lin_interp(const float *x, long long x_bstride, const int *n_frames,
 // sub-band rows carried between the ticks of a stream (elementwise.hip); desc (batch, 5) int32 on the device
 void launch_sub_carry(float *sub, long long sub_bstride, float *store, long long slot_stride, const int *desc, int batch,
                       int max_rows, int row_floats, int dir, hipStream_t stream);
+// per-layer WaveNet state carried between the ticks of a stream (elementwise.hip); desc (batch, 3) int32 on the device
+struct LayerCarryArgs {
+    float *h;                 // (batch, rows, C) hidden state of the window
+    long long h_bstride;
+    int C;
+    float *acc;               // (batch, rows, n_out) output accumulator of the window (folded skip path)
+    long long acc_bstride;
+    int n_out;
+    float *store;             // (slots, slot_stride) caller's persistent buffer
+    long long slot_stride, layer_off;   // floats: between slots, of this layer inside a slot
+    const int *desc;          // (batch, 3): slot, end row of the stored state, end row of the state to store (-1: none)
+    int inject;               // 0: desc[b][1] is ignored (nothing is taken from the store)
+    int base_off;             // e_l - end: last exact row (+1) of this layer relative to the end row
+    int h_before, h_rows;     // stored rows of h: [e_l - h_before, + h_rows)
+    int acc_rows;             // stored rows of acc: [e_l, + acc_rows)
+};
+void launch_layer_carry(const LayerCarryArgs &a, int batch, hipStream_t stream);
 void launch_activation(const float *x, long long x_bstride, const int *n_frames, int rows_per_frame, int max_rows,
                        int batch, int channels, int act, float scale, float offset, float *y, long long y_bstride,
                        hipStream_t stream);

@@ -150,9 +150,12 @@ __global__ __launch_bounds__(256, NS == 1 ? 2 : 3) void wn_gate_winograd_kernel(
 
     // conditioning rows of this block (<= 32 rows x (32 tanh | 32 sigmoid) columns) go to a free A stage during the last
     // slice, so that the epilogue reads them from LDS: row index = cond row - t2base, rows clamped to the last one
+    // (p.cond_phase: conditioning-rate position of item row 0 inside its conditioning row, for items that start
+    // between two conditioning rows: the per-layer regions of a streaming tick)
     const int cond_up = p.cond_up;
-    const int n2 = rows / cond_up;
-    const int t2base = m0 / cond_up;
+    const int cphase = p.cond_phase;
+    const int n2 = (rows + cphase) / cond_up;
+    const int t2base = (m0 + cphase) / cond_up;
     const float *cbase = p.cond + (long long)b * p.cond_bstride;
     auto issue_cond = [&](int buf) {
         const unsigned cdst = lds_base + 4u * (unsigned)(buf * A_FLOATS);
@@ -266,8 +269,9 @@ __global__ __launch_bounds__(256, NS == 1 ? 2 : 3) void wn_gate_winograd_kernel(
     float *obase = p.out + (long long)b * p.out_bstride;
     // conditioning (tanh | sigmoid column of tile channel tc) interpolated at output row `row`
     auto finish = [&](int row, int tc, float yt, float ys, float bt, float bsg) {
-        int t2 = (int)((float)row * inv_up);                       // row / cond_up (rows < 2^24)
-        int u = row - t2 * cond_up;
+        const int crow = row + cphase;
+        int t2 = (int)((float)crow * inv_up);                      // crow / cond_up (rows < 2^24)
+        int u = crow - t2 * cond_up;
         if (u < 0) { --t2; u += cond_up; }
         if (u >= cond_up) { ++t2; u -= cond_up; }
         const float w0 = lerp_lds[u], w1 = lerp_lds[64 + u];
@@ -327,7 +331,8 @@ bool launch_wn_gate_winograd(const ConvArgs &a, const float *w_split, hipStream_
                     a.cin % 4 == 0 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 && a.channels % 4 == 0 &&
                     a.cout == 2 * a.channels && (uintptr_t)a.x % 16 == 0 && (uintptr_t)a.w % 16 == 0 && a.zeros &&
                     a.cond && (uintptr_t)a.cond % 16 == 0 && a.cond_bstride % 4 == 0 && a.cond_up <= 64 &&
-                    256 / a.cond_up + 2 <= 32 && a.max_rows < (1 << 24);
+                    (256 + a.cond_up - 1) / a.cond_up + 2 <= 32 && a.max_rows < (1 << 24) && a.cond_phase >= 0 &&
+                    a.cond_phase < a.cond_up;
     if (!ok) return false;
     ConvArgs r = a;
     r.fast_dma = (long long)a.max_rows * a.ldx * 4 < (1LL << 32);

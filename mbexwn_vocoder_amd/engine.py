@@ -19,7 +19,7 @@ from .config import ModelDims
 from .subnet import build_subnet
 from .weights import fold_weights, merge_channel_groups
 
-MBX_ABI_VERSION = 3
+MBX_ABI_VERSION = 4
 MBX_MAX_SUBNET_OPS = 32
 MBX_MAX_WN_LAYERS = 64
 MBX_NAME_LEN = 64
@@ -67,7 +67,9 @@ class mbx_forward_options(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_int32), ("transposition", ctypes.c_float), ("f0", ctypes.c_void_p),
                 ("state_in", ctypes.c_void_p), ("state_out", ctypes.c_void_p), ("active_begin", ctypes.c_int32),
                 ("active_frames", ctypes.c_void_p), ("wn_begin", ctypes.c_int32), ("wn_frames", ctypes.c_void_p),
-                ("active_max_frames", ctypes.c_int32), ("wn_max_frames", ctypes.c_int32), ("sub_store", ctypes.c_void_p), ("sub_store_rows", ctypes.c_int32), ("sub_carry", ctypes.c_void_p)]
+                ("active_max_frames", ctypes.c_int32), ("wn_max_frames", ctypes.c_int32), ("sub_store", ctypes.c_void_p), ("sub_store_rows", ctypes.c_int32), ("sub_carry", ctypes.c_void_p),
+                ("layer_store", ctypes.c_void_p), ("layer_store_floats", ctypes.c_int32), ("layer_carry", ctypes.c_void_p),
+                ("layer_rows", ctypes.c_int32)]
 
 
 class mbx_tensor(ctypes.Structure):
@@ -110,6 +112,8 @@ def load_library():
     lib.mbx_forward_ex.restype = i32
     lib.mbx_forward_ex.argtypes = [vp, fp, vp, i32, i32, fp, fp, vp, ctypes.c_size_t,
                                    ctypes.POINTER(mbx_forward_options), vp]
+    lib.mbx_layer_state_info.restype = i32
+    lib.mbx_layer_state_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
     lib.mbx_stage.restype = i32
     lib.mbx_stage.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p), i64p, i64p]
     lib.mbx_profile_enable.restype = i32
@@ -135,7 +139,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = ["mbx_last_error", "mbx_create", "mbx_destroy", "mbx_workspace_size", "mbx_forward",
-                    "mbx_forward_stream", "mbx_forward_ex", "mbx_stage",
+                    "mbx_forward_stream", "mbx_forward_ex", "mbx_layer_state_info", "mbx_stage",
                     "mbx_profile_enable", "mbx_profile_read", "mbx_pqmf_synthesis", "mbx_conv1d", "mbx_lin_interp", "mbx_wavetable", "mbx_stft_filter", "mbx_norm_mel", "mbx_mel_analysis"]
 
 
@@ -539,7 +543,15 @@ class MBExWNEngine:
             self._workspace = self._torch.empty(need, dtype=self._torch.uint8, device=self.device)
         return self._workspace, need
 
-    def forward(self, mel, n_frames=None, noise=None, out=None, stream_state=None, active=None, wavenet=None, carry=None):
+    def layer_state_info(self):
+        """(floats per slot of the per-layer state store, rows between the end of a WaveNet region and its last exact
+        sub-band row, smallest number of new rows of a steady tick); floats == 0: this handle cannot carry layer state."""
+        ff, rr, mm = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        _check(self._lib.mbx_layer_state_info(self._handle, ctypes.byref(ff), ctypes.byref(rr), ctypes.byref(mm)))
+        return ff.value, rr.value, mm.value
+
+    def forward(self, mel, n_frames=None, noise=None, out=None, stream_state=None, active=None, wavenet=None, carry=None,
+                layers=None):
         """mel (B,T,80) float32 cuda tensor; n_frames int32 cuda tensor (B,) or None;
         noise (B, T*steps_per_frame) float32 cuda tensor (N(0,1) draw) -> audio (B, T*hop) cuda tensor.
 
@@ -549,7 +561,9 @@ class MBExWNEngine:
         on run on that region of the window only (``mbx_forward_options.active_begin / active_frames``); the audio
         outside the region is undefined.  wavenet: optional (begin_frame, int32 tensor (B,)) inner region of the WaveNet;
         carry: optional (store float32 tensor (slots, rows, subbands), int32 tensor (B, 5)) sub-band rows carried between
-        ticks (``wn_begin / wn_frames / sub_store / sub_carry``)."""
+        ticks (``wn_begin / wn_frames / sub_store / sub_carry``); layers: optional (store float32 tensor (slots, floats),
+        int32 tensor (B, 3), new rows) per-layer WaveNet state carried between ticks (``layer_store / layer_carry /
+        layer_rows``)."""
         torch = self._torch
         if mel.dim() != 3 or mel.shape[2] != self.dims.mel_channels:
             raise ValueError(f"mel must be (batch, frames, {self.dims.mel_channels})")
@@ -610,6 +624,17 @@ class MBExWNEngine:
                     desc = desc.contiguous()
                     keep.append(desc)
                     opt.sub_store, opt.sub_store_rows, opt.sub_carry = store.data_ptr(), int(store.shape[1]), desc.data_ptr()
+                if layers is not None:
+                    lstore, ldesc, lrows = layers
+                    if (lstore.dtype != torch.float32 or lstore.dim() != 2 or lstore.device != self.device or
+                            not lstore.is_contiguous()):
+                        raise ValueError("layer store must be a contiguous float32 tensor (slots, floats) on the device")
+                    if ldesc.dtype != torch.int32 or tuple(ldesc.shape) != (B, 3) or ldesc.device != self.device:
+                        raise ValueError("layer descriptors must be an int32 tensor of shape (batch, 3) on the device")
+                    ldesc = ldesc.contiguous()
+                    keep.append(ldesc)
+                    opt.layer_store, opt.layer_store_floats = lstore.data_ptr(), int(lstore.shape[1])
+                    opt.layer_carry, opt.layer_rows = ldesc.data_ptr(), int(lrows)
                 _check(self._lib.mbx_forward_ex(self._handle, mel.data_ptr(),
                                                 n_frames.data_ptr() if n_frames is not None else None, B, T,
                                                 noise.data_ptr() if noise is not None else None, out.data_ptr(),

@@ -70,6 +70,7 @@ class _Stream:
         self.slot = -1            # row of the synthesizer's sub-band store
         self.carry_pos = None     # the store holds the sub-bands of frames [carry_pos - sr_left, + carry_frames)
         self.carry_frames = 0
+        self.layer_end = None     # the layer store holds the WaveNet state of a region that ended at this frame
         # phase state valid just in front of absolute pulse sample `state_frame * pulse_per_frame`
         self.state = (0.0, 0.0, 0)
         self.state_frame = 0
@@ -91,6 +92,13 @@ class StreamingSynthesizer:
         self.sr_right = self.act_right - self.wn_reach
         self.carry = True
         self._store = None            # (slots, (sr_left + sr_right) * steps_per_frame, subbands) on the device
+        # per-layer WaveNet state carried from tick to tick (mbx_forward_options.layer_store): layer l is exact up to its
+        # own reach in front of layer l-1, so a steady tick runs every layer on the new rows only instead of on the
+        # region [emitted, emitted + chunk + act_right) with the WaveNet's reach recomputed on both sides
+        ff, reach, min_rows = engine.layer_state_info()
+        self.layer_carry = ff > 0 and reach == self.wn_reach * engine.dims.steps_per_frame
+        self._layer_floats, self._layer_min_rows = ff, min_rows
+        self._layer_store = None      # (slots, floats per slot) on the device
         self._free_slots = []
         # The Winograd form of the dilated convolution pairs outputs t and t+d inside blocks of 2d steps counted from
         # the first row of the item; a window that starts on a multiple of 2*d_max steps pairs exactly like the offline
@@ -104,6 +112,7 @@ class StreamingSynthesizer:
         self.last_tick_frames = 0         # window frames of the last tick (all streams): mel-rate stages
         self.last_tick_active_frames = 0  # frames of the active regions: PQMF, STFT filter, overlap-add
         self.last_tick_wavenet_frames = 0 # frames the WaveNet ran on
+        self.last_tick_layer_rows = 0     # > 0: steady tick (every WaveNet layer ran on that many new rows per stream only)
 
     @property
     def lookahead_ms(self):
@@ -120,6 +129,11 @@ class StreamingSynthesizer:
             self._store = torch.zeros((n_new, rows, self.dims.subbands), dtype=torch.float32, device=self.engine.device)
             if old is not None:
                 self._store[:n_old] = old
+            if self.layer_carry:
+                old_l = self._layer_store
+                self._layer_store = torch.zeros((n_new, self._layer_floats), dtype=torch.float32, device=self.engine.device)
+                if old_l is not None:
+                    self._layer_store[:n_old] = old_l
             self._free_slots = list(range(n_new - 1, n_old - 1, -1))
         st.slot = self._free_slots.pop()
         self.streams[stream_id] = st
@@ -218,6 +232,39 @@ class StreamingSynthesizer:
             if good:
                 desc[bb, 3:5] = (lo - ws) * spf, (hi - lo) * spf
             next_carry.append((e1, hi - lo) if good else (None, 0))
+        # per-layer WaveNet state.  Steady tick: every item has the state of a region that ended layer_rows rows in front
+        # of this tick's region end, the sub-bands up to the WaveNet's reach in front of that, the same geometry inside
+        # its window, and does not end its utterance here.  Any other tick runs the whole region and stores the state.
+        ldesc = np.full((B, 3), -1, dtype=np.int32)
+        layer_rows = 0
+        next_layer_end = [None] * B
+        if self.layer_carry:
+            steady = bool(use_carry)
+            geom = None
+            for bb, ((sid, st, nn), (ws, we)) in enumerate(zip(todo, windows)):
+                final = st.closed and ends[bb] >= we
+                ldesc[bb, 0] = st.slot
+                if st.layer_end is None or final or st.layer_end >= ends[bb]:
+                    steady = False
+                elif steady:
+                    gg = ((ends[bb] - st.layer_end) * spf, ends[bb] - ws)
+                    steady = (gg[0] >= self._layer_min_rows and (geom is None or gg == geom) and st.layer_end - wr >= ws + sa and
+                              st.emitted - sl + st.carry_frames == st.layer_end - wr)
+                    geom = gg
+            region0 = (wa if use_carry else a0)
+            for bb, ((sid, st, nn), (ws, we)) in enumerate(zip(todo, windows)):
+                final = st.closed and ends[bb] >= we
+                # state of this tick's region: exact if the region starts the utterance or reaches 2 * reach + 1 frames back
+                long_enough = ws + region0 == 0 or ends[bb] - ws - region0 >= 3 * wr + 1
+                if not final and (steady or long_enough):
+                    ldesc[bb, 2] = (ends[bb] - ws) * spf
+                    next_layer_end[bb] = ends[bb]
+            if steady:
+                layer_rows = geom[0]
+                wa = geom[1] - layer_rows // spf - wr                 # frame of the first new sub-band row
+                for bb, ((sid, st, nn), (ws, we)) in enumerate(zip(todo, windows)):
+                    ldesc[bb, 1] = (st.layer_end - ws) * spf
+                    wn[bb] = ends[bb] - ws - wa
         mel = np.zeros((B, tmax, self.dims.mel_channels), dtype=np.float32)
         noise = np.zeros((B, tmax * spf), dtype=np.float32)
         nfr = np.zeros((B,), dtype=np.int32)
@@ -246,11 +293,15 @@ class StreamingSynthesizer:
             ev0.record()
         self.last_tick_active_frames = int(act.sum())
         self.last_tick_wavenet_frames = int(wn.sum()) if wn is not None else int(act.sum())
+        self.last_tick_layer_rows = layer_rows
+        if layer_rows:
+            self.last_tick_wavenet_frames = B * layer_rows // spf
         audio, state_out = self.engine.forward(
             mel_d, n_frames=nfr_d, noise=noise_d, stream_state=states_d,
             active=(a0, torch.as_tensor(act, device=dev), int(act.max())),
             wavenet=(wa, torch.as_tensor(wn, device=dev), int(wn.max())) if wn is not None else None,
-            carry=(self._store, torch.as_tensor(desc, device=dev)) if self.carry else None)
+            carry=(self._store, torch.as_tensor(desc, device=dev)) if self.carry else None,
+            layers=(self._layer_store, torch.as_tensor(ldesc, device=dev), layer_rows) if self.layer_carry else None)
         if self.time_device:
             ev1.record()
             ev1.synchronize()
@@ -263,6 +314,7 @@ class StreamingSynthesizer:
             result[sid] = audio[bb, a0:a0 + nn * hop].copy()
             st.emitted += nn
             st.carry_pos, st.carry_frames = next_carry[bb]
+            st.layer_end = next_layer_end[bb]
             if next_state_frame[bb] < we:
                 ff = state_out[bb, :2].copy().view(np.float32)
                 st.state = (float(ff[0]), float(ff[1]), int(state_out[bb, 2]))

@@ -34,16 +34,19 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_c(tmp_path):
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mbexwn.h"\n'
-                   'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(mbx_config), sizeof(mbx_subnet_op),'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mbx_config), sizeof(mbx_subnet_op),'
                    ' sizeof(mbx_tensor), offsetof(mbx_config, n_f0_ops), offsetof(mbx_config, vtf_ops),'
-                   ' offsetof(mbx_config, wt_nominal_f0)); return 0;}\n')
+                   ' offsetof(mbx_config, wt_nominal_f0), sizeof(mbx_forward_options), offsetof(mbx_forward_options, wn_frames),'
+                   ' offsetof(mbx_forward_options, sub_carry), offsetof(mbx_forward_options, layer_rows)); return 0;}\n')
     exe = tmp_path / "sizes"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     got = [int(vv) for vv in out]
     cc = engine.mbx_config
     assert got == [ctypes.sizeof(cc), ctypes.sizeof(engine.mbx_subnet_op), ctypes.sizeof(engine.mbx_tensor),
-                   cc.n_f0_ops.offset, cc.vtf_ops.offset, cc.wt_nominal_f0.offset]
+                   cc.n_f0_ops.offset, cc.vtf_ops.offset, cc.wt_nominal_f0.offset,
+                   ctypes.sizeof(engine.mbx_forward_options), engine.mbx_forward_options.wn_frames.offset,
+                   engine.mbx_forward_options.sub_carry.offset, engine.mbx_forward_options.layer_rows.offset]
 
 
 def test_make_config_and_tensor_table():

@@ -127,7 +127,7 @@ def test_canonical_streaming_64_streams_bit_equal(torch, monkeypatch):
         syn.open(sid)
     got = {sid: [] for sid in range(n_streams)}
     pos = [0] * n_streams
-    ticks = 0
+    ticks = steady = 0
     while not all(syn.finished(sid) for sid in range(n_streams)):
         for sid, ll in enumerate(lengths):                 # packets of 8 frames arrive, the last one closes the stream
             if pos[sid] < ll:
@@ -138,8 +138,12 @@ def test_canonical_streaming_64_streams_bit_equal(torch, monkeypatch):
         for sid, audio in syn.tick().items():
             got[sid].append(audio)
         ticks += 1
+        steady += syn.last_tick_layer_rows == chunk * 20
         assert ticks < 200
     assert ticks >= 5
+    # both kinds of tick ran: steady ones (per-layer WaveNet state carried, every layer on the 160 new rows only) and
+    # whole-region ones (first tick, ticks in which a stream ends)
+    assert 2 <= steady < ticks
     for sid in range(0, n_streams, 1):
         ll = lengths[sid]
         offline = eng.forward(dev(torch, utts[sid][0][None]), noise=dev(torch, utts[sid][1][None])).cpu().numpy()[0]

@@ -85,6 +85,7 @@ def test_streaming_equals_offline(engine, offline_f23_engine, chunk):
         syn.open(sid)
     got = {sid: [] for sid in offline}
     rng = np.random.default_rng(0)
+    kinds = set()
     for _ in range(400):
         for sid, (mel, noise, pos) in pending.items():          # frames arrive in irregular packets
             if pos < mel.shape[0]:
@@ -92,10 +93,14 @@ def test_streaming_equals_offline(engine, offline_f23_engine, chunk):
                 end = min(pos + nn, mel.shape[0])
                 syn.push(sid, mel[pos:end], noise[pos * 20:end * 20], last=end == mel.shape[0])
                 pending[sid] = (mel, noise, end)
-        for sid, audio in syn.tick().items():
+        out = syn.tick()
+        if out:
+            kinds.add(syn.last_tick_layer_rows > 0)
+        for sid, audio in out.items():
             got[sid].append(audio)
         if all(syn.finished(sid) for sid in offline):
             break
+    assert kinds == {False, True}          # ticks with the per-layer WaveNet state carried, and whole-region ticks
     for sid in offline:
         stream_audio = np.concatenate(got[sid])
         assert stream_audio.shape == offline[sid].shape
