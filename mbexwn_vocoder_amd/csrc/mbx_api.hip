@@ -1117,8 +1117,8 @@ mbx_status mbx_forward_ex(mbx_handle *hd, const float *mel, const int32_t *n_fra
     if (!options || options->struct_size != (int32_t)sizeof(mbx_forward_options))
         return fail(MBX_ERR_INVALID_ARGUMENT, "mbx_forward_options ABI mismatch (struct_size)");
     if (!(options->transposition > 0.f)) return fail(MBX_ERR_INVALID_ARGUMENT, "transposition must be positive");
-    if (!options->layer_carry && options->layer_rows != 0)
-        return fail(MBX_ERR_INVALID_ARGUMENT, "layer_rows needs layer_carry");
+    if ((!options->layer_carry && options->layer_rows != 0) || options->layer_rows < 0)
+        return fail(MBX_ERR_INVALID_ARGUMENT, "layer_rows must be >= 0 and needs layer_carry");
     const LayerOpts lay{options->layer_store, options->layer_store_floats, options->layer_carry, options->layer_rows};
     return forward_impl(hd, mel, n_frames, batch, max_frames, noise, audio, workspace, workspace_bytes,
                         reinterpret_cast<const mbx::StreamState *>(options->state_in),

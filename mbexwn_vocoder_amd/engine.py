@@ -592,6 +592,8 @@ class MBExWNEngine:
                 raise ValueError("stream_state must be an int32 tensor of shape (batch, 6) on the engine's device")
             stream_state = stream_state.contiguous()
             state_out = torch.empty_like(stream_state)
+            if active is None and (wavenet is not None or carry is not None or layers is not None):
+                raise ValueError("wavenet / carry / layers describe regions inside the active one: pass active as well")
             if active is not None:
                 a0, act = int(active[0]), active[1]
                 if act.dtype != torch.int32 or tuple(act.shape) != (B,) or act.device != self.device or not 0 <= a0 < T:

@@ -48,6 +48,35 @@ def test_phase_state_carry_is_bit_exact(engine):
     assert np.all(pulse_win[:lo] == 0.0)
 
 
+def test_layer_state_geometry_and_argument_checks(engine):
+    """mbx_layer_state_info: per layer l >= 1 a slot keeps 2 d_l rows of the hidden state and d_l rows of the 30-wide
+    output accumulator; the staircase ends 40 rows (2 frames) in front of the region end.  Malformed layer options are
+    refused with the argument error of the C ABI."""
+    import torch
+    from mbexwn_vocoder_amd.streaming import pack_state
+    floats, reach, min_rows = engine.layer_state_info()
+    assert (reach, min_rows) == (40, 32)
+    assert floats == sum(2 * d * 32 + d * 30 for d in (2, 4, 8, 16))
+    mel, noise = synthetic_inputs(3, 1, 40)
+    mel_d, noise_d = torch.as_tensor(mel).cuda(), torch.as_tensor(noise).cuda()
+    st = torch.as_tensor(pack_state(0.0, 0.0, 0, 0, -1)[None]).cuda()
+    act = torch.full((1,), 24, dtype=torch.int32, device="cuda")
+    store = torch.zeros((2, floats), dtype=torch.float32, device="cuda")
+    desc = torch.tensor([[0, -1, 30 * 20]], dtype=torch.int32, device="cuda")
+    # a whole-region run that stores the state: fine
+    engine.forward(mel_d, noise=noise_d, stream_state=st, active=(8, act, 24), layers=(store, desc, 0))
+    assert float(store[0].abs().sum()) > 0 and float(store[1].abs().sum()) == 0
+    with pytest.raises(ValueError):          # wrong slot size
+        engine.forward(mel_d, noise=noise_d, stream_state=st, active=(8, act, 24), layers=(store[:, :-1].contiguous(), desc, 0))
+    with pytest.raises(ValueError):          # a steady tick needs the WaveNet region and >= min_rows new rows
+        engine.forward(mel_d, noise=noise_d, stream_state=st, active=(8, act, 24), layers=(store, desc, 160))
+    wn = torch.full((1,), 10, dtype=torch.int32, device="cuda")
+    with pytest.raises(ValueError):
+        engine.forward(mel_d, noise=noise_d, stream_state=st, active=(8, act, 24), wavenet=(20, wn, 10), layers=(store, desc, 20))
+    with pytest.raises(ValueError):          # regions without the active one
+        engine.forward(mel_d, noise=noise_d, stream_state=st, layers=(store, desc, 0))
+
+
 @pytest.fixture(scope="module")
 def offline_f23_engine():
     """Offline engine pinned to the convolution form the streams use (Winograd F(2,3); MBX_WINOGRAD is read by
