@@ -269,6 +269,7 @@ class StreamingSynthesizer:
         noise = np.zeros((B, tmax * spf), dtype=np.float32)
         nfr = np.zeros((B,), dtype=np.int32)
         states = np.zeros((B, 6), dtype=np.int32)
+        st_f = np.zeros((B, 2), dtype=np.float32)
         next_state_frame = []
         for bb, ((sid, st, nn), (ws, we)) in enumerate(zip(todo, windows)):
             mel[bb, :we - ws] = st.mel[ws:we]
@@ -279,14 +280,19 @@ class StreamingSynthesizer:
             # reproducible from there on.  The next state is captured where the NEXT window's reproducible region
             # starts: `lag` = left - lead frames in front of the next emit position.
             nxt = max(st.state_frame, st.emitted + nn - (self.left - self.lead))
-            cum, off, pos = st.state
-            states[bb] = pack_state(cum, off, pos, (st.state_frame - ws) * ppf,
-                                    (nxt - ws) * ppf if nxt < we else -1)
+            st_f[bb, 0], st_f[bb, 1] = st.state[0], st.state[1]
+            states[bb, 2:5] = st.state[2], (st.state_frame - ws) * ppf, (nxt - ws) * ppf if nxt < we else -1
             next_state_frame.append(nxt)
+        states[:, :2] = st_f.view(np.int32)                   # one mbx_stream_state per item (pack_state)
         dev = self.engine.device
-        mel_d, nfr_d = torch.as_tensor(mel, device=dev), torch.as_tensor(nfr, device=dev)
+        mel_d = torch.as_tensor(mel, device=dev)
         noise_d = torch.as_tensor(noise, device=dev) if self.dims.noise_sigma else None
-        states_d = torch.as_tensor(states, device=dev)
+        # every int32 argument of the call in one upload
+        parts = [states.ravel(), desc.ravel(), ldesc.ravel(), nfr, act, wn if wn is not None else act]
+        ints_d = torch.as_tensor(np.concatenate(parts), device=dev)
+        cuts = np.cumsum([0] + [pp.size for pp in parts])
+        states_d, desc_d, ldesc_d, nfr_d, act_d, wn_d = (ints_d[cuts[ii]:cuts[ii + 1]] for ii in range(6))
+        states_d, desc_d, ldesc_d = states_d.view(B, 6), desc_d.view(B, 5), ldesc_d.view(B, 3)
         self.last_tick_frames = int(nfr.sum())
         if self.time_device:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -298,19 +304,22 @@ class StreamingSynthesizer:
             self.last_tick_wavenet_frames = B * layer_rows // spf
         audio, state_out = self.engine.forward(
             mel_d, n_frames=nfr_d, noise=noise_d, stream_state=states_d,
-            active=(a0, torch.as_tensor(act, device=dev), int(act.max())),
-            wavenet=(wa, torch.as_tensor(wn, device=dev), int(wn.max())) if wn is not None else None,
-            carry=(self._store, torch.as_tensor(desc, device=dev)) if self.carry else None,
-            layers=(self._layer_store, torch.as_tensor(ldesc, device=dev), layer_rows) if self.layer_carry else None)
+            active=(a0, act_d, int(act.max())),
+            wavenet=(wa, wn_d, int(wn.max())) if wn is not None else None,
+            carry=(self._store, desc_d) if self.carry else None,
+            layers=(self._layer_store, ldesc_d, layer_rows) if self.layer_carry else None)
         if self.time_device:
             ev1.record()
             ev1.synchronize()
             self.last_tick_device_ms = ev0.elapsed_time(ev1)
-        audio = audio.cpu().numpy()
+        # only the emitted samples come back: the columns [lo, hi) of the window that hold some item's chunk
+        lo = min((st.emitted - ws) * hop for (sid, st, nn), (ws, we) in zip(todo, windows))
+        hi = max((st.emitted - ws + nn) * hop for (sid, st, nn), (ws, we) in zip(todo, windows))
+        audio = audio[:, lo:hi].cpu().numpy()
         state_out = state_out.cpu().numpy()
         result = {}
         for bb, ((sid, st, nn), (ws, we)) in enumerate(zip(todo, windows)):
-            a0 = (st.emitted - ws) * hop
+            a0 = (st.emitted - ws) * hop - lo
             result[sid] = audio[bb, a0:a0 + nn * hop].copy()
             st.emitted += nn
             st.carry_pos, st.carry_frames = next_carry[bb]
