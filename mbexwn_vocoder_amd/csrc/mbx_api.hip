@@ -83,6 +83,7 @@ struct mbx_handle {
     float *twiddle = nullptr;
     float *zeros = nullptr;   // 256 bytes of zeros (padding source of the LDS-DMA GEMMs)
     float *poly = nullptr;
+    float *poly_t = nullptr;          // the same table as the MFMA B operand: (4 * ceil(K / 4), 16), K = poly_ndm * subbands, zero padded
     int poly_ndm = 0, poly_dm_min = 0;
     std::map<std::string, StageRef> stages;
     // derived
@@ -472,13 +473,19 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
             if (j >= 0 && j <= c.pqmf_taps)
                 for (int k = 0; k < M; ++k) poly[((size_t)p * hd->poly_ndm + i) * M + k] = syn->data[(size_t)j * M + k];
         }
+    const int poly_k = hd->poly_ndm * M, poly_kpad = (poly_k + 3) / 4 * 4;
+    std::vector<float> poly_t(M <= 16 ? (size_t)poly_kpad * 16 : 0, 0.f);
+    if (M <= 16)
+        for (int p = 0; p < M; ++p)
+            for (int i = 0; i < poly_k; ++i) poly_t[(size_t)i * 16 + p] = poly[(size_t)p * poly_k + i];
     std::vector<float> tw((size_t)c.fft_size);
     for (int k = 0; k < c.fft_size / 2; ++k) {
         const double ang = -2.0 * M_PI * (double)k / (double)c.fft_size;
         tw[2 * k] = (float)std::cos(ang);
         tw[2 * k + 1] = (float)std::sin(ang);
     }
-    total += align_up(poly.size() * sizeof(float), 256) + align_up(tw.size() * sizeof(float), 256) + 256;
+    total += align_up(poly.size() * sizeof(float), 256) + align_up(poly_t.size() * sizeof(float), 256) +
+             align_up(tw.size() * sizeof(float), 256) + 256;
     for (int u : ups) total += 2 * align_up((size_t)u * sizeof(float), 256);
 
     e = hipMalloc(reinterpret_cast<void **>(&hd->arena), total);
@@ -504,6 +511,7 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
         hd->tensors[tensors[i].name] = t;
     }
     hd->poly = upload(poly.data(), poly.size());
+    if (!poly_t.empty()) hd->poly_t = upload(poly_t.data(), poly_t.size());
     hd->twiddle = upload(tw.data(), tw.size());
     {
         std::vector<float> zz(64, 0.f);
@@ -1053,7 +1061,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     // ---- PQMF synthesis (reference :920-921)
     {
         ScopedEvents ev(hd, PROF_PQMF, stream);
-        mbx::launch_pqmf(sub_act, nsteps * M, n_frames_act, c.steps_per_frame, act_frames_max * c.steps_per_frame, B, M, hd->poly, hd->poly_ndm,
+        mbx::launch_pqmf(sub_act, nsteps * M, n_frames_act, c.steps_per_frame, act_frames_max * c.steps_per_frame, B, M, hd->poly, hd->poly_t, hd->poly_ndm,
                          hd->poly_dm_min, exc_act, (long long)T * c.hop_size, stream);
     }
     // ---- STFT-domain filtering with the spectral envelope (reference :681-724, 801-855)
@@ -1200,7 +1208,7 @@ mbx_status mbx_pqmf_synthesis(mbx_handle *hd, const float *x, int32_t batch, int
     if (!hd || !x || !y || batch <= 0 || n_steps <= 0) return fail(MBX_ERR_INVALID_ARGUMENT, "bad argument");
     DeviceGuard guard(hd->device);
     const int M = hd->cfg.subbands;
-    mbx::launch_pqmf(x, (long long)n_steps * M, nullptr, 1, n_steps, batch, M, hd->poly, hd->poly_ndm,
+    mbx::launch_pqmf(x, (long long)n_steps * M, nullptr, 1, n_steps, batch, M, hd->poly, hd->poly_t, hd->poly_ndm,
                      hd->poly_dm_min, y, (long long)n_steps * M, static_cast<hipStream_t>(hip_stream));
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MBX_OK : fail(MBX_ERR_HIP, hipGetErrorString(e));

@@ -167,10 +167,11 @@ void launch_wavetable(const WaveTableConsts &c, const float *f0, long long bstri
 // ---------------------------------------------------------------------------------------------
 // PQMF synthesis (pqmf.hip)
 // ---------------------------------------------------------------------------------------------
-// x (B, steps, M) -> y (B, steps*M); g = polyphase table (M, n_dm, M) with dm_min
+// x (B, steps, M) -> y (B, steps*M); poly = polyphase table (M, n_dm, M) with dm_min; poly_t = the same table as the MFMA
+// B operand (4 * ceil(n_dm * M / 4), 16), zero padded, or null (M > 16)
 void launch_pqmf(const float *x, long long x_bstride, const int *n_frames, int steps_per_frame, int max_steps,
-                 int batch, int subbands, const float *poly, int n_dm, int dm_min, float *y, long long y_bstride,
-                 hipStream_t stream);
+                 int batch, int subbands, const float *poly, const float *poly_t, int n_dm, int dm_min, float *y,
+                 long long y_bstride, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // STFT-domain envelope filter (stft_filter.hip)
