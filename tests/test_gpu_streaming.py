@@ -95,7 +95,7 @@ def offline_f23_engine():
             os.environ["MBX_WINOGRAD"] = old
 
 
-@pytest.mark.parametrize("chunk", [8, 5])
+@pytest.mark.parametrize("chunk", [8, 5, 2])
 def test_streaming_equals_offline(engine, offline_f23_engine, chunk):
     import torch
     from mbexwn_vocoder_amd.streaming import StreamingSynthesizer
