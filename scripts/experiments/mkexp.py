@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Timing ablations of the product kernels WITHOUT touching the product sources (profiles/README.md quotes their results).
+
+A variant = textual patches applied to a scratch copy of one kernel source (EXP_FILE, default wn_winograd4w.hip), compiled
+and linked against the product's other objects into scripts/experiments/libs/lib_<name>.so (git-ignored; travels to the
+GPU box).  Most patches make the outputs wrong on purpose (no epilogue, no barrier, ...): they answer "what does this part
+cost", nothing else, and are never part of the product library.
+
+    python -m mbexwn_vocoder_amd.build                       # objects of the product build
+    EXP_FILE=wn_gate0.hip python scripts/experiments/mkexp.py g0_base:base g0_nostore:g0_nostore
+    gpurun -- 'bash scripts/experiments/runvariants.sh g0_base g0_nostore'
+
+A spec is name:patch+patch+...; patches whose text no longer matches the source fail loudly.
+"""
+import glob, os, subprocess, sys
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+TMP = '/tmp/mbx_exp'
+os.makedirs(TMP, exist_ok=True)
+os.makedirs(f'{R}/scripts/experiments/libs', exist_ok=True)
+FILE = os.environ.get('EXP_FILE', 'wn_winograd4w.hip')
+src = open(f'{R}/mbexwn_vocoder_amd/csrc/{FILE}').read()
+PATCHES = {
+    # wn_gate0.hip
+    'g0_nostore': [
+        ('            if (ch_ok && row < rows) *reinterpret_cast<float2 *>(ob + (long long)row * p.ldo + n0 + 2 * r16) = res;',
+         '            if (ch_ok && row < rows && res.x == 123.456f) *reinterpret_cast<float2 *>(ob + (long long)row * p.ldo + n0 + 2 * r16) = res;'),
+    ],
+    # wn_gate0.hip, wn_winograd4w.hip
+    'g0_noact': [
+        ('    const float t = __builtin_amdgcn_exp2f(fminf(zt, 15.f) * 2.885390081777927f);\n    const float sg = __builtin_amdgcn_exp2f(zs * -1.4426950408889634f);\n    const float tp = t + 1.0f;\n    return (t - 1.0f) * __builtin_amdgcn_rcpf(fmaf(sg, tp, tp));',
+         '    return zt + zs;'),
+    ],
+    # conv_mfma.hip
+    'g0_nolerp': [
+        ('            const float w0 = p.lerp_w0[u], w1 = p.lerp_w1[u];',
+         '            const float w0 = 0.3f, w1 = 0.7f;'),
+    ],
+    # wn_resskip_wide.hip
+    'rw_stagA': [
+        ('    const int m0 = mt * RW_ROWS;\n    if (m0 >= rows) return;\n',
+         '    const int m0 = mt * RW_ROWS;\n    if (m0 >= rows) return;\n    if (blockIdx.x >= 256 && blockIdx.x < 512) {\n        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();\n        while (__builtin_amdgcn_s_memrealtime() - t0 < 3000ull) __builtin_amdgcn_s_sleep(32);\n    }\n'),
+    ],
+    # wn_resskip_wide.hip
+    'rw_stagB': [
+        ('    const int m0 = mt * RW_ROWS;\n    if (m0 >= rows) return;\n',
+         '    const int m0 = mt * RW_ROWS;\n    if (m0 >= rows) return;\n    if (blockIdx.x < 512 && ((blockIdx.x >> 3) & 1)) {\n        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();\n        while (__builtin_amdgcn_s_memrealtime() - t0 < 3000ull) __builtin_amdgcn_s_sleep(32);\n    }\n'),
+    ],
+    # wn_resskip_wide.hip
+    'rw_stagC': [
+        ('    const int m0 = mt * RW_ROWS;\n    if (m0 >= rows) return;\n',
+         '    const int m0 = mt * RW_ROWS;\n    if (m0 >= rows) return;\n    if (blockIdx.x < 512 && (blockIdx.x & 1)) {\n        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();\n        while (__builtin_amdgcn_s_memrealtime() - t0 < 3000ull) __builtin_amdgcn_s_sleep(32);\n    }\n'),
+    ],
+    # wn_resskip_wide.hip
+    'rw_nodma': [
+        ('        if (kt + 3 < nk) issue(kt + 3, S);\n        RW_FENCE();',
+         '        RW_FENCE();'),
+    ],
+    # wn_resskip_wide.hip
+    'rw_nobar': [
+        ('        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");       // slice kt+2 may still be in flight\n        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n        __syncthreads();\n',
+         ''),
+    ],
+    # wn_resskip_wide.hip
+    'rw_nopre': [
+        ('            const float2 old = *reinterpret_cast<const float2 *>(src + (long long)row * ld);',
+         '            const float2 old = make_float2(0.f, 0.f);'),
+    ],
+    # wn_resskip_wide.hip
+    'rw_nostore': [
+        ('            if (row < rows) *reinterpret_cast<float2 *>(dst + (long long)row * ld) = make_float2(acc[2 * pr][v], acc[2 * pr + 1][v]);',
+         '            if (row < rows && acc[2 * pr][v] == 123.456f) *reinterpret_cast<float2 *>(dst + (long long)row * ld) = make_float2(acc[2 * pr][v], acc[2 * pr + 1][v]);'),
+    ],
+    # conv_mfma.hip
+    'sgd2': [
+        ('    constexpr int DEPTH = RT * CT == 1 ? 6 : 3;',
+         '    constexpr int DEPTH = RT * CT == 1 ? 6 : 2;'),
+    ],
+    # conv_mfma.hip
+    'sgd4': [
+        ('    constexpr int DEPTH = RT * CT == 1 ? 6 : 3;',
+         '    constexpr int DEPTH = RT * CT == 1 ? 6 : 4;'),
+    ],
+    # conv_mfma.hip
+    'mel4': [
+        ('    constexpr int MEL_RT = 2;',
+         '    constexpr int MEL_RT = 4;'),
+    ],
+    # conv_mfma.hip
+    'mel1': [
+        ('    constexpr int MEL_RT = 2;',
+         '    constexpr int MEL_RT = 1;'),
+    ],
+    # conv_mfma.hip
+    'melb4': [
+        ('__global__ __launch_bounds__(256, RT <= 2 ? 3 : 2) void conv1d_mel_group_kernel',
+         '__global__ __launch_bounds__(256, 4) void conv1d_mel_group_kernel'),
+    ],
+    # stft_filter.hip
+    'sf_fast': [
+        ('            const float re = (c.max_log_range > 0.f) ? c.max_log_range * tanhf(s.x) : s.x;\n            const float mag = expf(re);\n            float sn, cs;\n            sincosf(s.y, &sn, &cs);',
+         '            const float e2 = __expf(2.f * s.x);\n            const float re = (c.max_log_range > 0.f) ? c.max_log_range * (1.f - 2.f / (e2 + 1.f)) : s.x;\n            const float mag = __expf(re);\n            float sn, cs;\n            __sincosf(s.y, &sn, &cs);'),
+    ],
+    # stft_filter.hip
+    'sf_nomath': [
+        ('            const float re = (c.max_log_range > 0.f) ? c.max_log_range * tanhf(s.x) : s.x;\n            const float mag = expf(re);\n            float sn, cs;\n            sincosf(s.y, &sn, &cs);',
+         '            const float re = s.x;\n            const float mag = re;\n            float sn = s.y, cs = s.x;'),
+    ],
+    # wn_resskip_wide.hip
+    'rw12_4': [
+        ('__global__ __launch_bounds__(512, NP <= 11 ? 4 : 2) void wn_resskip_wide_kernel',
+         '__global__ __launch_bounds__(512, 4) void wn_resskip_wide_kernel'),
+    ],
+    # wn_tail.hip
+    'tail_coal': [
+        ('    const float *xr = skip + (long long)b * skip_bstride + (long long)min(m0 + lrow, rows - 1) * C + 4 * lk;',
+         '    const float *xr = skip + (long long)b * skip_bstride + (long long)min(m0 + 8 * wave + (lane >> 3), rows - 1) * C + 4 * (lane & 7);'),
+        ('        const float4 a = in_row ? *reinterpret_cast<const float4 *>(xr + 8 * c) : make_float4(0.f, 0.f, 0.f, 0.f);',
+         '        const float4 a = in_row ? *reinterpret_cast<const float4 *>(xr + 32 * (c >> 2)) : make_float4(0.f, 0.f, 0.f, 0.f);'),
+    ],
+    # wn_tail.hip
+    'tail_noload': [
+        ('        const float4 a = in_row ? *reinterpret_cast<const float4 *>(xr + 8 * c) : make_float4(0.f, 0.f, 0.f, 0.f);',
+         '        const float4 a = make_float4(1.f, 2.f, (float)c, 0.f);'),
+    ],
+    'base': [],
+    # wn_winograd4w.hip
+    'nodma': [
+        ('        if (st + NSTAGE < nst) issue(st + NSTAGE, S);\n',
+         ''),
+    ],
+    # wn_winograd4w.hip
+    'nobar': [
+        ('        if (NSTAGE == 3 && st + 2 < nst) {\n            if (SH::DMA_PER_STAGE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");\n            else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");\n        } else {\n            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n        }\n        __syncthreads();\n',
+         ''),
+    ],
+    # wn_winograd4w.hip
+    'nowait': [
+        ('        } else {\n            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n        }\n        __syncthreads();',
+         '        } else {\n        }\n        __syncthreads();'),
+    ],
+    # wn_winograd4w.hip
+    'noepi': [
+        ('    // ---- epilogue: combine the six products, add the conditioning',
+         '    {\n        float ssum = 0.f;\n#pragma unroll\n        for (int j = 0; j < 6; ++j)\n#pragma unroll\n            for (int c = 0; c < 4; ++c)\n#pragma unroll\n                for (int r = 0; r < 4; ++r) ssum += acc[j][c][r];\n        if (ssum == 123.456f) p.out[tid] = ssum;\n        return;\n    }\n    // ---- epilogue: combine the six products, add the conditioning'),
+    ],
+    # wn_winograd4w.hip
+    'noexch': [
+        ('    if (KSPLIT == 2) {\n        __syncthreads();                             // all LDS operand reads are done',
+         '    if (false) {\n        __syncthreads();'),
+    ],
+    # wn_winograd4w.hip
+    'nocomb': [
+        ('        constexpr int J = decltype(jc)::value;\n        if (J == 0) u[0] = ww_fma(4.f, x[0]',
+         '        constexpr int J = decltype(jc)::value;\n        u[J & 1] = x[J];\n        return;\n        if (J == 0) u[0] = ww_fma(4.f, x[0]'),
+    ],
+}
+def build(name, keys, flags=()):
+    s = src
+    for k in keys:
+        for old, new in PATCHES[k]:
+            assert old in s, (k, old[:40])
+            s = s.replace(old, new, 1)
+    f = f'{TMP}/exp_{name}.hip'
+    open(f, 'w').write(s)
+    objs = [o for o in glob.glob(f'{R}/mbexwn_vocoder_amd/build/*.o') if not o.endswith(FILE + '.o')]
+    o = f'{TMP}/exp_{name}.o'
+    subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', *flags, '-I', f'{R}/mbexwn_vocoder_amd/csrc', '-c', f, '-o', o], check=True, stderr=subprocess.DEVNULL)
+    subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-fPIC', '-shared', '-o', f'{R}/scripts/experiments/libs/lib_{name}.so', *objs, o], check=True)
+    print('built', name)
+if __name__ == '__main__':
+    for spec in sys.argv[1:]:
+        name, _, keys = spec.partition(':')
+        build(name, [k for k in keys.split('+') if k])
