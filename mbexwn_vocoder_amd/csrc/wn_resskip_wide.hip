@@ -5,11 +5,13 @@
 // the skip path folded into the end convolution (engine.fold_skip_weights: cout = C + n_out).  That kernel tiles the
 // columns in blocks of 128: C + n_out = 350 columns cost 384 (9.7 % of the matrix work is padding), the rows of `a` are
 // fetched by three blocks, and a wave requests 4 LDS-DMA kilobytes per 16 MFMAs.  Here:
-//   block = 8 waves, 128 rows x all columns, NP <= 12 pairs of 16-column MFMA tiles (v_mfma_f32_16x16x4_f32): 352
-//   columns for C + n_out = 350; wave w owns rows 16 w .. 16 w + 15 x 2 NP column tiles (88 / 96 accumulator registers;
-//   2 blocks per CU = 4 waves per SIMD);
-//   K slices of 8 channels, three LDS stages of (4 + NP) KB: the rows of `a` are fetched once, a wave requests 2
-//   LDS-DMA kilobytes per 44 / 48 MFMAs and meets one barrier per slice;
+//   block = 8 waves, 128 rows x NP pairs of 16-column MFMA tiles (v_mfma_f32_16x16x4_f32).  C + n_out = 350 (C = 320):
+//   NP = 11, all 352 columns; wave w owns rows 16 w .. 16 w + 15 x 22 column tiles (88 accumulator registers; 2 blocks
+//   per CU = 4 waves per SIMD).  C + n_out = 370 (C = 340) needs 12 pairs = 96 accumulator registers, which leaves one
+//   block per CU (162 VGPRs, 0.53 of the MFMA peak measured): two blocks per row tile own 6 pairs each instead (NP = 6,
+//   p.n_tiles = 2 column splits; the rows of `a` are then read twice, the second time from L2; config 4: 144.8 -> 139.9 ms);
+//   K slices of 8 channels, three LDS stages of (4 + NP) KB: a wave requests 2 LDS-DMA kilobytes per 4 NP MFMAs and
+//   meets one barrier per slice;
 //   lane n of column tile pair p holds columns 32 p + 2 n and 32 p + 2 n + 1 (pairing done by the host-side packing),
 //   so h and the output accumulator are read (accumulator start = old value + bias) and written as float2.
 //   A: rows [m0, m0+128) x 8 channels, 32 bytes per row, 16-byte chunk c at 2*row + (c ^ ((row>>3)&1)); lane (r = lane & 15,
@@ -44,14 +46,17 @@ template <int N>
 using rw_int = std::integral_constant<int, N>;
 
 template <int NP>
-__global__ __launch_bounds__(512, NP <= 11 ? 4 : 2) void wn_resskip_wide_kernel(ConvArgs p) {
+__global__ __launch_bounds__(512, 4) void wn_resskip_wide_kernel(ConvArgs p) {
     constexpr int B_FLOATS = NP * 256;             // packed weights of one slice
     constexpr int STAGE = RW_A_FLOATS + B_FLOATS;
     typedef __attribute__((address_space(3))) float lds_float;
     __shared__ __attribute__((aligned(16))) float lds[3 * STAGE];
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float *)lds);
 
-    const int g = blockIdx.x;
+    // p.n_tiles column splits: block -> (row tile g, pairs [pair0, pair0 + NP) of the n_tiles * NP pairs of the image)
+    const int split = p.n_tiles;
+    const int g = blockIdx.x / split;
+    const int pair0 = (blockIdx.x - g * split) * NP;
     const int b = g / p.m_tiles_per_item;
     const int mt = g - b * p.m_tiles_per_item;
     const int rows = p.n_frames ? p.n_frames[b] * p.rows_per_frame : p.max_rows;
@@ -78,12 +83,12 @@ __global__ __launch_bounds__(512, NP <= 11 ? 4 : 2) void wn_resskip_wide_kernel(
     }
     const bool fast = p.fast_dma && m0 + RW_ROWS <= rows && p.cin % RW_BK == 0;
     const unsigned b_voff = 16u * (unsigned)lane;
-    const int bk0 = wave, bk1 = min(wave + 4, NP - 1);
+    const int bk0 = min(wave, NP - 1), bk1 = min(wave + 4, NP - 1);
     auto issue = [&](int kt, int stage) {
         const int ci0 = kt * RW_BK;
         const unsigned adst = lds_base + 4u * (unsigned)(stage * STAGE);
         const unsigned bdst = adst + 4u * (unsigned)RW_A_FLOATS;
-        const float *bbase = p.w + (long long)kt * B_FLOATS;
+        const float *bbase = p.w + ((long long)kt * split * NP + pair0) * 256;
         if (wave < 4) {
             if (fast) {
                 rw_lds_dma16_s(xb + ci0, a_voff, adst + 1024u * (unsigned)wave);
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(512, NP <= 11 ? 4 : 2) void wn_resskip_wide_kernel(
 #pragma unroll
     for (int pr = 0; pr < NP; ++pr) {
         // unconditional loads from clamped addresses (no branch, all requests in flight), selected afterwards
-        const int col = 32 * pr + 2 * r16;                         // even: both columns of the lane on the same side of C
+        const int col = 32 * (pair0 + pr) + 2 * r16;               // even: both columns of the lane on the same side of C
         const bool col_ok = col < p.cout;
         const int colc = min(col, p.cout - 2);
         const bool to_h = colc < C;
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(512, NP <= 11 ? 4 : 2) void wn_resskip_wide_kernel(
     // ---- epilogue: the accumulators are the new values
 #pragma unroll
     for (int pr = 0; pr < NP; ++pr) {
-        const int col = 32 * pr + 2 * r16;
+        const int col = 32 * (pair0 + pr) + 2 * r16;
         if (col >= p.cout) continue;
         const bool to_h = col < C;
         float *dst = to_h ? hb + col : sb + (col - C);
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(512, NP <= 11 ? 4 : 2) void wn_resskip_wide_kernel(
     }
 }
 
-// a.w must point at the image of engine.pack_resskip_wide_weights (ceil(cin/8), NP, 256) with NP = ceil(cout/32) in
+// a.w must point at the image of engine.pack_resskip_wide_weights (ceil(cin/8), np, 256) with np = ceil(cout/32) in
 // {11, 12}; returns false if the layer does not fit (the caller then uses launch_wn_resskip)
 bool launch_wn_resskip_wide(const ConvArgs &a, hipStream_t stream) {
     const int np = (a.cout + 31) / 32;
@@ -241,8 +246,12 @@ bool launch_wn_resskip_wide(const ConvArgs &a, hipStream_t stream) {
     r.fast_dma = (long long)a.max_rows * a.ldx * 4 < (1LL << 32);
     r.m_tiles_per_item = (a.max_rows + RW_ROWS - 1) / RW_ROWS;
     const long long blocks = (long long)r.m_tiles_per_item * a.batch;
+    // 11 pairs (C = 320): one block owns all columns of its rows.  12 pairs (C = 340) would need 96 accumulator registers
+    // per wave, which leaves one 8-wave block per CU (162 VGPRs; measured 0.53 of the peak): two blocks per row tile own
+    // six pairs each instead and read the rows of `a` twice (the second read is an L2 hit)
+    r.n_tiles = np == 11 ? 1 : 2;
     if (np == 11) hipLaunchKernelGGL((wn_resskip_wide_kernel<11>), dim3((unsigned)blocks), dim3(512), 0, stream, r);
-    else hipLaunchKernelGGL((wn_resskip_wide_kernel<12>), dim3((unsigned)blocks), dim3(512), 0, stream, r);
+    else hipLaunchKernelGGL((wn_resskip_wide_kernel<6>), dim3((unsigned)(2 * blocks)), dim3(512), 0, stream, r);
     return true;
 }
 
