@@ -9,7 +9,7 @@
 //   NP = 11, all 352 columns; wave w owns rows 16 w .. 16 w + 15 x 22 column tiles (88 accumulator registers; 2 blocks
 //   per CU = 4 waves per SIMD).  C + n_out = 370 (C = 340) needs 12 pairs = 96 accumulator registers, which leaves one
 //   block per CU (162 VGPRs, 0.53 of the MFMA peak measured): two blocks per row tile own 6 pairs each instead (NP = 6,
-//   p.n_tiles = 2 column splits; the rows of `a` are then read twice, the second time from L2; config 4: 144.8 -> 139.9 ms);
+//   SPLIT = 2; the rows of `a` are then read twice, the second time from L2; config 4: 144.8 -> 139.9 ms);
 //   K slices of 8 channels, three LDS stages of (4 + NP) KB: a wave requests 2 LDS-DMA kilobytes per 4 NP MFMAs and
 //   meets one barrier per slice;
 //   lane n of column tile pair p holds columns 32 p + 2 n and 32 p + 2 n + 1 (pairing done by the host-side packing),
@@ -45,7 +45,7 @@ __device__ __forceinline__ void rw_lds_dma16_s(const float *sbase, unsigned voff
 template <int N>
 using rw_int = std::integral_constant<int, N>;
 
-template <int NP>
+template <int NP, int SPLIT>
 __global__ __launch_bounds__(512, 4) void wn_resskip_wide_kernel(ConvArgs p) {
     constexpr int B_FLOATS = NP * 256;             // packed weights of one slice
     constexpr int STAGE = RW_A_FLOATS + B_FLOATS;
@@ -53,10 +53,10 @@ __global__ __launch_bounds__(512, 4) void wn_resskip_wide_kernel(ConvArgs p) {
     __shared__ __attribute__((aligned(16))) float lds[3 * STAGE];
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float *)lds);
 
-    // p.n_tiles column splits: block -> (row tile g, pairs [pair0, pair0 + NP) of the n_tiles * NP pairs of the image)
-    const int split = p.n_tiles;
-    const int g = blockIdx.x / split;
-    const int pair0 = (blockIdx.x - g * split) * NP;
+    // SPLIT column splits: block -> (row tile g, pairs [pair0, pair0 + NP) of the SPLIT * NP pairs of the image)
+    // (compile-time: with a run-time split the 11-pair kernel measured 3 % slower)
+    const int g = SPLIT == 1 ? blockIdx.x : blockIdx.x / SPLIT;
+    const int pair0 = SPLIT == 1 ? 0 : (blockIdx.x - g * SPLIT) * NP;
     const int b = g / p.m_tiles_per_item;
     const int mt = g - b * p.m_tiles_per_item;
     const int rows = p.n_frames ? p.n_frames[b] * p.rows_per_frame : p.max_rows;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(512, 4) void wn_resskip_wide_kernel(ConvArgs p) {
         const int ci0 = kt * RW_BK;
         const unsigned adst = lds_base + 4u * (unsigned)(stage * STAGE);
         const unsigned bdst = adst + 4u * (unsigned)RW_A_FLOATS;
-        const float *bbase = p.w + ((long long)kt * split * NP + pair0) * 256;
+        const float *bbase = p.w + (long long)kt * (SPLIT * B_FLOATS) + pair0 * 256;
         if (wave < 4) {
             if (fast) {
                 rw_lds_dma16_s(xb + ci0, a_voff, adst + 1024u * (unsigned)wave);
@@ -249,9 +249,8 @@ bool launch_wn_resskip_wide(const ConvArgs &a, hipStream_t stream) {
     // 11 pairs (C = 320): one block owns all columns of its rows.  12 pairs (C = 340) would need 96 accumulator registers
     // per wave, which leaves one 8-wave block per CU (162 VGPRs; measured 0.53 of the peak): two blocks per row tile own
     // six pairs each instead and read the rows of `a` twice (the second read is an L2 hit)
-    r.n_tiles = np == 11 ? 1 : 2;
-    if (np == 11) hipLaunchKernelGGL((wn_resskip_wide_kernel<11>), dim3((unsigned)blocks), dim3(512), 0, stream, r);
-    else hipLaunchKernelGGL((wn_resskip_wide_kernel<6>), dim3((unsigned)(2 * blocks)), dim3(512), 0, stream, r);
+    if (np == 11) hipLaunchKernelGGL((wn_resskip_wide_kernel<11, 1>), dim3((unsigned)blocks), dim3(512), 0, stream, r);
+    else hipLaunchKernelGGL((wn_resskip_wide_kernel<6, 2>), dim3((unsigned)(2 * blocks)), dim3(512), 0, stream, r);
     return true;
 }
 
