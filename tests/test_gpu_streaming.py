@@ -134,3 +134,30 @@ def test_streaming_equals_offline(engine, offline_f23_engine, chunk):
         stream_audio = np.concatenate(got[sid])
         assert stream_audio.shape == offline[sid].shape
         assert np.array_equal(stream_audio, offline[sid]), f"stream {sid} differs from the offline synthesis"
+
+
+def test_streaming_without_layer_state(monkeypatch):
+    """A handle that cannot carry the per-layer state (direct form of the dilated convolution: MBX_WINOGRAD=0) still
+    streams -- every tick runs the WaveNet on its whole region -- and is bit-equal to its own offline synthesis."""
+    import torch
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    from mbexwn_vocoder_amd.streaming import StreamingSynthesizer
+    monkeypatch.setenv("MBX_WINOGRAD", "0")
+    cfg, raw, wt = build_case("SPEECH", SMALL)
+    eng = MBExWNEngine(cfg, raw, wt)
+    assert eng.layer_state_info()[0] == 0
+    syn = StreamingSynthesizer(eng, chunk_frames=8)
+    assert not syn.layer_carry
+    mel, noise = synthetic_inputs(77, 1, 61)
+    offline = eng.forward(torch.as_tensor(mel).cuda(), noise=torch.as_tensor(noise).cuda()).cpu().numpy()[0]
+    syn.open(0)
+    syn.push(0, mel[0], noise[0], last=True)
+    got = []
+    for _ in range(50):
+        out = syn.tick()
+        assert syn.last_tick_layer_rows == 0
+        if 0 in out:
+            got.append(out[0])
+        if syn.finished(0):
+            break
+    assert np.array_equal(np.concatenate(got), offline)
