@@ -691,14 +691,35 @@ struct LayerOpts {
     int rows;
 };
 
+// everything mbx_forward_stream / mbx_forward_ex add to mbx_forward (see mbx_forward_options in mbexwn.h)
+struct ForwardExtras {
+    const mbx::StreamState *st_in = nullptr;
+    mbx::StreamState *st_out = nullptr;
+    const float *f0_in = nullptr;
+    float transposition = 1.f;
+    int active_begin = 0;
+    const int32_t *active_frames = nullptr;
+    int wn_begin = 0;
+    const int32_t *wn_frames = nullptr;
+    float *sub_store = nullptr;
+    int sub_store_rows = 0;
+    const int32_t *sub_carry = nullptr;
+    int active_max_frames = 0, wn_max_frames = 0;
+    const LayerOpts *lay = nullptr;
+};
+
 static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *n_frames, int32_t batch,
                                int32_t max_frames, const float *noise, float *audio, void *workspace,
-                               size_t workspace_bytes, const mbx::StreamState *st_in, mbx::StreamState *st_out,
-                               void *hip_stream, const float *f0_in = nullptr, float transposition = 1.f,
-                               int active_begin = 0, const int32_t *active_frames = nullptr, int wn_begin = 0,
-                               const int32_t *wn_frames = nullptr, float *sub_store = nullptr, int sub_store_rows = 0,
-                               const int32_t *sub_carry = nullptr, int active_max_frames = 0, int wn_max_frames = 0,
-                               const LayerOpts *lay = nullptr) {
+                               size_t workspace_bytes, void *hip_stream, const ForwardExtras &ex = ForwardExtras()) {
+    const mbx::StreamState *st_in = ex.st_in;
+    mbx::StreamState *st_out = ex.st_out;
+    const float *f0_in = ex.f0_in;
+    const float transposition = ex.transposition;
+    const int active_begin = ex.active_begin, wn_begin = ex.wn_begin, sub_store_rows = ex.sub_store_rows;
+    const int32_t *active_frames = ex.active_frames, *wn_frames = ex.wn_frames, *sub_carry = ex.sub_carry;
+    float *sub_store = ex.sub_store;
+    const int active_max_frames = ex.active_max_frames, wn_max_frames = ex.wn_max_frames;
+    const LayerOpts *lay = ex.lay;
     if (!hd || !mel || !audio || !workspace) return fail(MBX_ERR_INVALID_ARGUMENT, "null argument");
     if (batch <= 0 || max_frames <= 0) return fail(MBX_ERR_INVALID_ARGUMENT, "batch and max_frames must be positive");
     DeviceGuard guard(hd->device);
@@ -1104,8 +1125,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
 
 mbx_status mbx_forward(mbx_handle *hd, const float *mel, const int32_t *n_frames, int32_t batch, int32_t max_frames,
                        const float *noise, float *audio, void *workspace, size_t workspace_bytes, void *hip_stream) {
-    return forward_impl(hd, mel, n_frames, batch, max_frames, noise, audio, workspace, workspace_bytes, nullptr, nullptr,
-                        hip_stream);
+    return forward_impl(hd, mel, n_frames, batch, max_frames, noise, audio, workspace, workspace_bytes, hip_stream);
 }
 
 mbx_status mbx_forward_stream(mbx_handle *hd, const float *mel, const int32_t *n_frames, int32_t batch,
@@ -1114,9 +1134,10 @@ mbx_status mbx_forward_stream(mbx_handle *hd, const float *mel, const int32_t *n
                               void *hip_stream) {
     static_assert(sizeof(mbx_stream_state) == sizeof(mbx::StreamState), "stream state layout");
     if (!state_in) return fail(MBX_ERR_INVALID_ARGUMENT, "state_in is required (use mbx_forward for whole utterances)");
-    return forward_impl(hd, mel, n_frames, batch, max_frames, noise, audio, workspace, workspace_bytes,
-                        reinterpret_cast<const mbx::StreamState *>(state_in),
-                        reinterpret_cast<mbx::StreamState *>(state_out), hip_stream);
+    ForwardExtras ex;
+    ex.st_in = reinterpret_cast<const mbx::StreamState *>(state_in);
+    ex.st_out = reinterpret_cast<mbx::StreamState *>(state_out);
+    return forward_impl(hd, mel, n_frames, batch, max_frames, noise, audio, workspace, workspace_bytes, hip_stream, ex);
 }
 
 mbx_status mbx_forward_ex(mbx_handle *hd, const float *mel, const int32_t *n_frames, int32_t batch, int32_t max_frames,
@@ -1128,12 +1149,22 @@ mbx_status mbx_forward_ex(mbx_handle *hd, const float *mel, const int32_t *n_fra
     if ((!options->layer_carry && options->layer_rows != 0) || options->layer_rows < 0)
         return fail(MBX_ERR_INVALID_ARGUMENT, "layer_rows must be >= 0 and needs layer_carry");
     const LayerOpts lay{options->layer_store, options->layer_store_floats, options->layer_carry, options->layer_rows};
-    return forward_impl(hd, mel, n_frames, batch, max_frames, noise, audio, workspace, workspace_bytes,
-                        reinterpret_cast<const mbx::StreamState *>(options->state_in),
-                        reinterpret_cast<mbx::StreamState *>(options->state_out), hip_stream, options->f0,
-                        options->transposition, options->active_begin, options->active_frames, options->wn_begin,
-                        options->wn_frames, options->sub_store, options->sub_store_rows, options->sub_carry,
-                        options->active_max_frames, options->wn_max_frames, options->layer_carry ? &lay : nullptr);
+    ForwardExtras ex;
+    ex.st_in = reinterpret_cast<const mbx::StreamState *>(options->state_in);
+    ex.st_out = reinterpret_cast<mbx::StreamState *>(options->state_out);
+    ex.f0_in = options->f0;
+    ex.transposition = options->transposition;
+    ex.active_begin = options->active_begin;
+    ex.active_frames = options->active_frames;
+    ex.wn_begin = options->wn_begin;
+    ex.wn_frames = options->wn_frames;
+    ex.sub_store = options->sub_store;
+    ex.sub_store_rows = options->sub_store_rows;
+    ex.sub_carry = options->sub_carry;
+    ex.active_max_frames = options->active_max_frames;
+    ex.wn_max_frames = options->wn_max_frames;
+    ex.lay = options->layer_carry ? &lay : nullptr;
+    return forward_impl(hd, mel, n_frames, batch, max_frames, noise, audio, workspace, workspace_bytes, hip_stream, ex);
 }
 
 mbx_status mbx_mel_analysis(const float *audio, const int32_t *n_samples, int32_t batch, int32_t max_samples,
