@@ -664,7 +664,9 @@ static LayerGeom layer_geom(const mbx_handle *hd) {
     g.c[L - 1] = 0;
     for (int l = L - 2; l >= 0; --l) g.c[l] = g.c[l + 1] + g.step[l + 1];
     const int spf = c.steps_per_frame;
-    g.reach_rows = (g.c[0] + g.r[0] + spf - 1) / spf * spf;
+    // (+ cond_lin_upsampling - 1: a whole-region run interpolates the conditioning of its last rows towards the clamped
+    // last conditioning row; that error spreads backwards through the layers behind, streaming.py::stream_margins)
+    g.reach_rows = (g.c[0] + g.r[0] + c.cond_lin_upsampling - 1 + spf - 1) / spf * spf;
     long long off = 0;
     for (int l = 1; l < L; ++l) {
         g.off[l] = off;

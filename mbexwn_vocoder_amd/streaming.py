@@ -14,7 +14,8 @@ serves BASELINE config 5 (many concurrent streams, short ticks) on top of the of
   semantics (symmetric / zero padding, un-normalised head and tail of the inverse STFT) apply where they should.
 
 Receptive field in mel frames (canonical model): F0-net 3 convs k=3 (+-3) and the interpolator (+1); the phase needs
-valid F0, so pulses are valid from window frame 4; WaveNet (dilations 1..16, k=3: +-31 steps = +-2 frames) -> 6;
+valid F0, so pulses are valid from window frame 4; WaveNet (dilations 1..16, k=3: +-31 steps, + 9 steps of conditioning
+interpolation towards a row that a region's end clamps = 2 frames) -> 6;
 PQMF (+-4 steps) -> 7; STFT frame + overlap-add (-3 / +4 frames) -> LEFT = 10, RIGHT = 11 (look-ahead 137.5 ms).
 ``StreamingSynthesizer`` derives the margins from the model configuration.
 """
@@ -45,6 +46,10 @@ def stream_margins(dims, config):
     f0_r += 1                                             # interpolation towards the next frame
     spf = dims.steps_per_frame
     wn_steps = sum(dims.wn_dilation(ll) * (dims.wn_kernel_size - 1) // 2 for ll in range(dims.wn_layers))
+    # the conditioning is interpolated towards the next conditioning row, which at the end of a region is the clamped
+    # last one: the last cond_lin_upsampling - 1 rows of every layer's gate are off, and that spreads backwards by the
+    # reach of the layers behind
+    wn_steps += dims.cond_lin_upsampling - 1
     wn_frames = -(-wn_steps // spf)
     pqmf_frames = -(-(int(mb["multi_band_config"]["taps"]) // 2) // dims.hop_size)
     cond_r = (dims.cond_kernel_size - 1) // 2 + 1

@@ -161,3 +161,40 @@ def test_streaming_without_layer_state(monkeypatch):
         if syn.finished(0):
             break
     assert np.array_equal(np.concatenate(got), offline)
+
+
+def test_streaming_dilation_cycle_model(monkeypatch):
+    """Per-layer state with a dilation cycle (7 layers: 1 2 4 1 2 4 1): the staircase of exact rows has repeated steps,
+    two inner layers of dilation 1 whose reach is rounded up to 2 rows; 15 rows of reach + 9 rows of conditioning clamp = 2 frames.  Steady ticks must occur and the stream must be
+    bit-equal to the offline F(2,3) synthesis."""
+    import torch
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    from mbexwn_vocoder_amd.streaming import StreamingSynthesizer
+    over = {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 7,
+            "mbexwn_config:pp_mod_subnet:max_log2_dilation_rate": 3}
+    monkeypatch.setenv("MBX_WINOGRAD", "2")
+    cfg, raw, wt = build_case("SPEECH", over)
+    eng = MBExWNEngine(cfg, raw, wt)
+    floats, reach, min_rows = eng.layer_state_info()
+    dil = [2, 4, 1, 2, 4, 1]                                   # layers 1..6
+    assert floats == sum((d + d + d % 2) * 32 + (d + d % 2) * 30 for d in dil) and reach == 40 and min_rows == 8
+    syn = StreamingSynthesizer(eng, chunk_frames=8)
+    assert syn.layer_carry
+    lengths = [70, 52]
+    offline, got = {}, {0: [], 1: []}
+    for sid, ll in enumerate(lengths):
+        mel, noise = synthetic_inputs(300 + sid, 1, ll)
+        offline[sid] = eng.forward(torch.as_tensor(mel).cuda(), noise=torch.as_tensor(noise).cuda()).cpu().numpy()[0]
+        syn.open(sid)
+        syn.push(sid, mel[0], noise[0], last=True)
+    steady = 0
+    for _ in range(60):
+        out = syn.tick()
+        steady += syn.last_tick_layer_rows > 0
+        for sid, audio in out.items():
+            got[sid].append(audio)
+        if all(syn.finished(sid) for sid in offline):
+            break
+    assert steady >= 3
+    for sid in offline:
+        assert np.array_equal(np.concatenate(got[sid]), offline[sid])
