@@ -599,7 +599,8 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
         hd->fold_skip = have;
         // start convolution folded into layer 0 (wn_gate0.hip); MBX_FOLD_START=0 keeps the h0 tensor and the full layer
         const char *sv = getenv("MBX_FOLD_START");
-        bool have0 = have && (!sv || atoi(sv) != 0) && c.wn_kernel_size == 3 && c.pulse_channels + 2 <= 8 &&
+        bool have0 = have && (!sv || atoi(sv) != 0) && c.wn_kernel_size == 3 &&
+                     mbx::wn_gate0_fits(C, c.pulse_channels, c.wn_dilations[0], c.cond_lin_upsampling) &&
                      expect("wn.conv1D_0.start_fold", (long long)((C + 31) / 32) * 1536);
         if (have0 && c.wn_layers > 1)
             have0 = expect("wn.res_skip_0.fold_start", nct * ((C + 16 + 15) / 16) * 2048);

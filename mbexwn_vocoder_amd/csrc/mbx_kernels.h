@@ -89,6 +89,7 @@ struct Gate0Args {
     int n_tiles, m_tiles_per_item;   // set by the launcher
 };
 bool launch_wn_gate0(const Gate0Args &a, hipStream_t stream);
+bool wn_gate0_fits(int channels, int pulse_channels, int dil, int cond_up);
 // WaveNet residual/skip layer for large row counts (wn_resskip.hip); a.w = host-packed weights (ceil(cout/128), ceil(C/16), 2048)
 bool launch_wn_resskip(const ConvArgs &a, hipStream_t stream);
 // the same layer for large launches, one block owning all columns of its rows (wn_resskip_wide.hip); a.w = image of

@@ -168,6 +168,12 @@ __global__ __launch_bounds__(256) void wn_gate0_kernel(Gate0Args p) {
     }
 }
 
+// geometry the kernel is built for (mbx_create keeps the un-folded first layer otherwise)
+bool wn_gate0_fits(int channels, int pulse_channels, int dil, int cond_up) {
+    return pulse_channels >= 1 && pulse_channels + 2 <= 8 && channels % 4 == 0 && cond_up >= 1 && dil >= 1 &&
+           dil <= G0_MAX_DIL && (G0_ROWS + cond_up - 2) / cond_up + 2 <= G0_COND_ROWS;
+}
+
 // a.w: image of engine.fold_start_weights (ceil(C/32), 3, 2, 64, 4); false: the layer does not fit
 bool launch_wn_gate0(const Gate0Args &a, hipStream_t stream) {
     const bool ok = a.pulse_channels >= 1 && a.pulse_channels + 2 <= 8 && a.channels % 4 == 0 && a.ldo % 4 == 0 &&

@@ -685,8 +685,11 @@ class MBExWNEngine:
     @property
     def folds_start(self):
         """True when layer 0 runs with the start convolution folded in (csrc/wn_gate0.hip): mirror of mbx_create's
-        policy (MBX_FOLD_SKIP / MBX_FOLD_START not 0 and the folded tensors exist)."""
-        return (int(os.environ.get("MBX_FOLD_SKIP", "1")) != 0 and int(os.environ.get("MBX_FOLD_START", "1")) != 0 and
+        policy (MBX_FOLD_SKIP / MBX_FOLD_START not 0, the folded tensors exist and the layer fits the kernel)."""
+        cu = self.dims.cond_lin_upsampling
+        fits = ((256 + cu - 2) // cu + 2 <= 32 and self.dims.wn_dilation(0) <= 16 and self.dims.pulse_channels + 2 <= 8 and
+                self.dims.wn_kernel_size == 3)                     # wn_gate0_fits (csrc/wn_gate0.hip)
+        return (int(os.environ.get("MBX_FOLD_SKIP", "1")) != 0 and int(os.environ.get("MBX_FOLD_START", "1")) != 0 and fits and
                 "wn.conv1D_0.start_fold" in self._tensors and
                 (self.dims.wn_layers == 1 or "wn.res_skip_0.fold_start" in self._tensors))
 

@@ -281,10 +281,16 @@ def test_start_convolution_folded_into_layer_0_matches_the_unfolded_graph(torch,
     {"mbexwn_config:pp_mod_subnet:n_channels": 24, "mbexwn_config:pp_mod_subnet:n_layers": 7,
      "mbexwn_config:pp_mod_subnet:max_log2_dilation_rate": 3},                                         # dilation cycle 1..8,1..4
     {"mbexwn_config:pp_mod_subnet:n_channels": 64, "mbexwn_config:pp_mod_subnet:n_layers": 1},       # one layer: tail only
-], ids=["C36_L3", "C24_L7_cycle", "C64_L1"])
+    {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 4,
+     "mbexwn_config:pp_mod_subnet:cond_lin_upsampling": 5},                                            # 4 x 5 conditioning: un-folded first layer, generic gate
+    {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 4,
+     "mbexwn_config:pp_mod_subnet:cond_lin_upsampling": 20, "mbexwn_config:pp_mod_subnet:cond_kernel_size": 5},
+], ids=["C36_L3", "C24_L7_cycle", "C64_L1", "cond_4x5", "cond_1x20_k5"])
 def test_other_wavenet_geometries(torch, overrides):
     """Every size is configuration driven: partial channel tiles and slices, repeating dilation cycles, a single layer
-    (the folded skip path then consists of the tail kernel alone)."""
+    (the folded skip path then consists of the tail kernel alone), other splits of the conditioning up-sampling (x5
+    does not fit the folded first layer's kernel nor the Winograd kernels' conditioning stage: the handle keeps the
+    un-folded first layer and the generic gate kernel)."""
     from mbexwn_vocoder_amd.engine import MBExWNEngine
     cfg, raw, wt = build_case("SPEECH", overrides)
     eng, om = MBExWNEngine(cfg, raw, wt), orc.OracleModel(cfg, raw, wt)
