@@ -81,7 +81,8 @@ __global__ __launch_bounds__(512, 4) void wn_resskip_wide_kernel(ConvArgs p) {
         a_ok = m0 + row < rows;
         a_voff = 4u * (unsigned)(min(m0 + row, rows - 1) * p.ldx + 4 * (int)a_hi);
     }
-    const bool fast = p.fast_dma && m0 + RW_ROWS <= rows && p.cin % RW_BK == 0;
+    const bool fast_rows = p.fast_dma && m0 + RW_ROWS <= rows;     // (cin = 340: only the last, half slice takes the masked path)
+    const int whole_slices = p.cin / RW_BK;
     const unsigned b_voff = 16u * (unsigned)lane;
     const int bk0 = min(wave, NP - 1), bk1 = min(wave + 4, NP - 1);
     auto issue = [&](int kt, int stage) {
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(512, 4) void wn_resskip_wide_kernel(ConvArgs p) {
         const unsigned bdst = adst + 4u * (unsigned)RW_A_FLOATS;
         const float *bbase = p.w + (long long)kt * (SPLIT * B_FLOATS) + pair0 * 256;
         if (wave < 4) {
-            if (fast) {
+            if (fast_rows && kt < whole_slices) {
                 rw_lds_dma16_s(xb + ci0, a_voff, adst + 1024u * (unsigned)wave);
             } else {
                 const bool ok = a_ok && (ci0 + 4 * (int)a_hi < p.cin);

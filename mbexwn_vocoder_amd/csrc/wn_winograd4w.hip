@@ -170,14 +170,16 @@ __global__ __launch_bounds__(256, (WwShape<ROWS, KSPLIT>::BLOCKS_PER_CU)) void w
         a_voff[i] = 4u * (unsigned)(min(max(src, 0), rows - 1) * p.ldx + 8 * a_sub[i] + 4 * hi);
     }
     // interior blocks (every staged row exists, whole stage fills): uniform base + per-lane byte offset, no selects
-    const bool fast = p.fast_dma && m0 >= WW_HALO && m0 + ROWS + WW_HALO <= rows && p.cin % (WW_BK * KSPLIT) == 0;
+    // (C = 340: every stage fill but the last one is whole, so only that one takes the masked path)
+    const bool fast_rows = p.fast_dma && m0 >= WW_HALO && m0 + ROWS + WW_HALO <= rows;
+    const int whole_fills = p.cin / (WW_BK * KSPLIT);
     const float *wtile = p.w + (long long)nt * nk8 * WW_B_FLOATS;
     const unsigned b_voff = 16u * (unsigned)lane;
     // LDS-DMA of stage fill st (channels 8 KSPLIT st ..) into a stage: 3 A + 3 KSPLIT B instructions per wave
     auto issue = [&](int st, int stage) {
         const int ci0 = st * WW_BK * KSPLIT;
         const unsigned sdst = lds_base + 4u * (unsigned)(stage * STAGE);
-        if (fast) {
+        if (fast_rows && st < whole_fills) {
             const float *abase = xb + ci0;
 #pragma unroll
             for (int i = 0; i < 3; ++i)
