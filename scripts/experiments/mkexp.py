@@ -122,6 +122,10 @@ PATCHES = {
         ('        const float4 a = in_row ? *reinterpret_cast<const float4 *>(xr + 8 * c) : make_float4(0.f, 0.f, 0.f, 0.f);',
          '        const float4 a = make_float4(1.f, 2.f, (float)c, 0.f);'),
     ],
+    # wn_winograd.hip: 256-row blocks (NS = 1) already from 512 blocks on (streaming ticks: 640 blocks)
+    'f23_big512': [
+        ('    const bool split = w_split && (uintptr_t)w_split % 16 == 0 && full_blocks < 4 * 512;', '    const bool split = w_split && (uintptr_t)w_split % 16 == 0 && full_blocks < 512;'),
+    ],
     'base': [],
     # wn_winograd4w.hip
     'nodma': [
