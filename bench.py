@@ -10,8 +10,10 @@ resident in HBM.  Default workload at every N: BASELINE.json configs[2] -- MW-SI
 batches (weak scaling, no data-path collective; RCCL only carries the barrier and the max-over-ranks of the timing).
 Started without a launcher and with --gpus N > 1 the script starts the N ranks itself (one process per GPU, RCCL).
 Rank 0 prints ONE JSON line: the default workload's throughput, max|delta| against the float64 oracle, the roofline
-of the dominant kernel and of the bandwidth-type stages, the CPU baseline (2 threads and all cores), and as secondary
-fields the step times of configs[1] (1 x 10 s) and configs[3] (256 utterances sharded over the ranks, strong scaling).
+of the dominant kernel and of the bandwidth-type stages, the CPU baseline (best leg of a thread sweep), and as secondary
+fields the other four BASELINE configurations: configs[0]'s 3 s utterance and configs[1] (1 x 10 s) on the GPU,
+configs[3] (256 utterances sharded over the ranks, strong scaling, with its own max|delta|) and configs[4] (64 streams).
+max|delta| is computed from the output buffer the timed steps wrote (prefix property), not from a separate forward.
 """
 import argparse
 import json
@@ -41,7 +43,9 @@ DEFAULT_WORKLOAD = "config3_si_b16_10s"
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 HBM_PEAK_GBS = 8000.0             # same guide: HBM3E 8 TB/s (spec; 6.3 TB/s measured for a float4 copy)
 DELTA_FRAMES = 80                 # prefix of the benchmark input the oracle is run on for max|delta|
+DELTA_MARGIN = 12                 # frames at the end of a prefix that reach into what follows (receptive field of the path)
 DELTA_TOL = 1e-4                  # tolerance of max|delta|, relative to max(1, max|oracle audio|) (tests/test_gpu_parity.py)
+PORT_IN_USE_EXIT = 98             # exit status of a rank that found the rendezvous port taken (EADDRINUSE)
 REJECTED_ENV = ("MBX_WG_ABLATE",)  # switches of timing experiments that produce wrong audio: never measured
 
 
@@ -94,10 +98,13 @@ def pmc_traffic(workload):
 
 
 def cpu_baseline(cfg, raw, wt, seconds=3.0):
-    """The oracle (numpy float32 port of the reference graph) timed on the host cores on a bounded sample: one 3 s
-    utterance (the reference's own CPU-runnable case, configs[0]) at 2 threads -- the reference CLI's default
-    `-nt 2`, bin/resynth_mel.py:120 -- and at all cores.  Timing protocol of the reference CLI
-    (bin/resynth_mel.py:86-88): wall clock around the synthesis call only, one warm-up call first."""
+    """The oracle (numpy float32 port of the reference graph; its matrix products go to the host BLAS) timed on the
+    host cores on a bounded sample: one 3 s utterance (the reference's own CPU-runnable case, configs[0]) at 2 threads --
+    the reference CLI's default `-nt 2`, bin/resynth_mel.py:120 --, 8, 32 and all cores.  `value` is the BEST leg of the
+    sweep (more threads than the utterance has parallel work oversubscribe the BLAS calls and run slower); every leg is
+    listed.  Timing protocol of the reference CLI (bin/resynth_mel.py:86-88): wall clock around the synthesis call only,
+    one warm-up call first.  Only the numpy port was timed: torch-CPU and TensorFlow runs of the reference graph are not
+    available (no TensorFlow on the box; the product has no torch graph)."""
     from oracle.mbexwn_oracle import OracleModel
     from threadpoolctl import threadpool_limits
     frames = int(round(seconds * 80))
@@ -106,41 +113,70 @@ def cpu_baseline(cfg, raw, wt, seconds=3.0):
     mel, noise = synthetic_batch(rng, 1, frames, 20)
     legs = {}
     all_cores = os.cpu_count() or 1
-    for tag, threads in (("threads_2", 2), ("all_cores", all_cores)):
+    sweep = sorted({tt for tt in (2, 8, 32, all_cores) if tt <= all_cores} | {min(2, all_cores)})
+    for threads in sweep:
         with threadpool_limits(limits=threads):
             om.forward(mel[:, :16], noise[:, :320])         # warm-up (weight folding, BLAS thread start)
             times = []
-            budget = time.time() + 12.0                     # bounded: ~12 s of CPU work per leg
-            while len(times) < 9 and (len(times) < 2 or time.time() < budget):
+            budget = time.time() + 6.0                      # bounded: ~6 s of CPU work per leg, <= 4 legs
+            while len(times) < 7 and (len(times) < 2 or time.time() < budget):
                 t0 = time.time()
                 om.forward(mel, noise)
                 times.append(time.time() - t0)
-        best = float(np.median(times))
-        legs[tag] = {"value": frames * 300 / best, "x_realtime": frames * 300 / best / 24000.0, "cores": threads,
-                     "runs": len(times)}
-    top = legs["all_cores"]
+        med = float(np.median(times))
+        legs[f"threads_{threads}"] = {"value": frames * 300 / med, "x_realtime": frames * 300 / med / 24000.0,
+                                      "cores": threads, "runs": len(times)}
+    top = max(legs.values(), key=lambda leg: leg["value"])
     return {"value": top["value"], "unit": "audio samples/s", "cores": top["cores"], "kind": "port",
-            "sample": f"1 utterance x {seconds:g} s (80x{frames} mel), numpy float32 oracle, median of {top['runs']} runs "
-                      f"after 1 warm-up, time.time() around the synthesis call only (reference bin/resynth_mel.py:86-88)",
-            "x_realtime": top["x_realtime"], "threads_2": legs["threads_2"], "all_cores": legs["all_cores"],
+            "sample": f"1 utterance x {seconds:g} s (80x{frames} mel), numpy float32 oracle, best of a thread sweep "
+                      f"{sweep} (median of {top['runs']} runs after 1 warm-up per leg), time.time() around the synthesis "
+                      f"call only (reference bin/resynth_mel.py:86-88)",
+            "x_realtime": top["x_realtime"], "legs": legs, "host_cores": all_cores,
             "reference_claim": "README.md:222-223: about 2x real time on one laptop core (TF-CPU)"}
 
 
-def max_abs_delta(eng, cfg, raw, wt, mel_h, noise_h, torch):
-    """Second half of BASELINE.json's metric: max|delta| of the HIP audio against the float64 oracle, on the first
-    DELTA_FRAMES frames of item 0 of the benchmark input (outside the timed region)."""
+def _delta_vs_oracle(got, cfg, raw, wt, mel, noise, keep_frames):
+    """max|got - oracle| over the first keep_frames frames; the oracle (float64) runs on the given mel / noise."""
     from oracle.mbexwn_oracle import OracleModel
+    ref = OracleModel(cfg, raw, wt).forward(mel, noise)[:, :keep_frames * 300]
+    got = np.asarray(got, dtype=np.float64)[:, :keep_frames * 300]
+    return float(np.max(np.abs(got - ref))), float(np.max(np.abs(ref)))
+
+
+def max_abs_delta_timed(samples, cfg, raw, wt, what):
+    """Second half of BASELINE.json's metric, measured ON THE OUTPUT OF THE TIMED REGION.  samples = [(label, audio the
+    timed steps wrote for one utterance (>= DELTA_FRAMES frames of it), the utterance's mel (T, 80), its noise (T*spf,))]:
+    the first DELTA_FRAMES - DELTA_MARGIN frames of that audio are compared with the float64 oracle run on the
+    utterance's DELTA_FRAMES-frame prefix.  Prefix property (finite receptive field + causal phase,
+    tests/test_gpu_parity.py::test_full_size_prefix_property): the audio of a prefix equals the prefix of the audio except
+    for the last DELTA_MARGIN frames, which reach into what follows."""
+    worst, peak, labels, keep, nf = 0.0, 0.0, [], 0, 0
+    for label, got, mel, noise in samples:
+        nf = min(DELTA_FRAMES, mel.shape[0])
+        keep = nf - DELTA_MARGIN if nf < mel.shape[0] else nf
+        spf = noise.shape[0] // mel.shape[0]
+        dd, pk = _delta_vs_oracle(got[None], cfg, raw, wt, mel[None, :nf], noise[None, :nf * spf], keep)
+        worst, peak = max(worst, dd), max(peak, pk)
+        labels.append(label)
+    scale = max(1.0, peak)
+    return {"max_abs_delta": worst, "max_abs_delta_tolerance": DELTA_TOL * scale, "max_abs_ref": peak,
+            "max_abs_delta_ok": bool(worst <= DELTA_TOL * scale),
+            "max_abs_delta_sample": f"output buffer of the timed steps ({what}): first {keep} frames ({keep / 80:g} s) of "
+                                    f"{', '.join(labels)}, float32 HIP vs float64 numpy oracle (oracle/mbexwn_oracle.py) run "
+                                    f"on the {nf}-frame prefixes (prefix property, margin {nf - keep} frames)"}
+
+
+def max_abs_delta_small(eng, cfg, raw, wt, mel_h, noise_h, torch):
+    """The same comparison on a separate small launch (1 x DELTA_FRAMES frames: the small-launch kernels -- channel-split
+    F(4,3) gate, narrow res/skip, split-K mel-rate convolutions), outside the timed region."""
     nf = min(DELTA_FRAMES, mel_h.shape[1])
     spf = noise_h.shape[1] // mel_h.shape[1]
     mel, noise = mel_h[:1, :nf], noise_h[:1, :nf * spf]
     got = eng.forward(torch.as_tensor(mel).cuda(), noise=torch.as_tensor(noise).cuda()).cpu().numpy()
-    ref = OracleModel(cfg, raw, wt).forward(mel, noise)
-    scale = max(1.0, float(np.max(np.abs(ref))))
-    delta = float(np.max(np.abs(got.astype(np.float64) - ref)))
-    return {"max_abs_delta": delta, "max_abs_delta_tolerance": DELTA_TOL * scale, "max_abs_ref": float(np.max(np.abs(ref))),
-            "max_abs_delta_ok": bool(delta <= DELTA_TOL * scale),
-            "max_abs_delta_sample": f"first {nf} frames ({nf / 80:g} s) of item 0 of the benchmark input, float32 HIP vs float64 "
-                                    "numpy oracle (oracle/mbexwn_oracle.py)"}
+    dd, pk = _delta_vs_oracle(got, cfg, raw, wt, mel, noise, nf)
+    return {"max_abs_delta_small": dd, "max_abs_delta_small_tolerance": DELTA_TOL * max(1.0, pk),
+            "max_abs_delta_small_sample": f"separate forward of the first {nf} frames of item 0 (small-launch kernels: "
+                                          f"{eng.gate_form(1, nf)})"}
 
 
 class Fence:
@@ -173,7 +209,7 @@ def time_steps(step, steps, warmup, fence):
     return fence.max_over_ranks(time.perf_counter() - t0)
 
 
-def run_batch(args, name, rank, world, fence, torch, profile):
+def run_batch(args, name, rank, world, fence, torch, profile, steps=None, warmup=None):
     """configs[0..2]: one padded batch per GPU.  Returns (result dict, context for the roofline / delta legs)."""
     voice, batch, frames = WORKLOADS[name]
     cfg, raw, wt, dims, eng = build_engine(voice)
@@ -181,26 +217,32 @@ def run_batch(args, name, rank, world, fence, torch, profile):
     mel_h, noise_h = synthetic_batch(rng, batch, frames, dims.steps_per_frame)
     mel, noise = torch.as_tensor(mel_h).cuda(), torch.as_tensor(noise_h).cuda()
     out = torch.empty((batch, frames * dims.hop_size), dtype=torch.float32, device=mel.device)
-    elapsed = time_steps(lambda: eng.forward(mel, noise=noise, out=out), args.steps, args.warmup, fence)
-    samples = world * batch * frames * dims.hop_size * args.steps
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    elapsed = time_steps(lambda: eng.forward(mel, noise=noise, out=out), steps, warmup, fence)
+    # what the timed steps left in `out` (the max|delta| leg looks at these rows, not at a separate forward)
+    delta_items = sorted({0, batch - 1})
+    keep = min(DELTA_FRAMES, frames) * dims.hop_size
+    timed_out = {ii: out[ii, :keep].cpu().numpy() for ii in delta_items} if rank == 0 else {}
+    samples = world * batch * frames * dims.hop_size * steps
     res = {"workload": f"{name}: MW-{voice[:2]}-FD canonical (C={dims.wn_channels}, L={dims.wn_layers}), batch {batch} x "
                        f"{frames / 80:g} s per GPU, 80x{frames} synthetic mel, seeded synthetic weights",
            "batch_per_gpu": batch, "frames": frames, "value": samples / elapsed, "x_realtime": samples / elapsed / 24000.0,
-           "ms_per_step": elapsed / args.steps * 1e3, "steps": args.steps, "scaling": "weak",
+           "ms_per_step": elapsed / steps * 1e3, "steps": steps, "scaling": "weak",
            "gate_form": eng.gate_form(batch, frames)}
-    ctx = None
+    ctx = {"cfg": cfg, "raw": raw, "wt": wt, "dims": dims, "eng": eng, "mel_h": mel_h, "noise_h": noise_h, "batch": batch,
+           "frames": frames, "timed_out": timed_out, "delta_items": delta_items, "stages": None}
     if profile:
         # per-stage device times from HIP events on the launch stream, in a separate pass so that the events do not sit
         # inside the throughput measurement
         eng.profile_enable(True)
-        for _ in range(max(3, min(args.steps, 10))):
+        for _ in range(max(3, min(steps, 10))):
             eng.forward(mel, noise=noise, out=out)
         torch.cuda.synchronize()
         stages = {kk: eng.profile_read(kk) for kk in ("gate", "gate0", "res_skip", "frontend", "wavetable", "start", "tail",
                                                        "pqmf", "stft_filter", "overlap_add")}
         eng.profile_enable(False)
-        ctx = {"stages": stages, "cfg": cfg, "raw": raw, "wt": wt, "dims": dims, "eng": eng, "mel_h": mel_h,
-               "noise_h": noise_h, "batch": batch, "frames": frames}
+        ctx["stages"] = stages
     return res, ctx
 
 
@@ -270,7 +312,7 @@ def roofline(ctx, workload):
             "stages": stage_list}
 
 
-def run_sharded(args, name, rank, world, dist, fence, torch, steps=None, warmup=None):
+def run_sharded(args, name, rank, world, dist, fence, torch, steps=None, warmup=None, check_delta=False):
     """configs[3]: every rank sees the same seeded list of utterance lengths, ShardedSynthesizer takes its LPT shard,
     stages the padded micro-batches in HBM once, and every step runs them and all-gathers the audio (RCCL, device
     tensors: no host copy between the forward pass and the collective)."""
@@ -283,7 +325,8 @@ def run_sharded(args, name, rank, world, dist, fence, torch, steps=None, warmup=
     lengths = [int(vv) for vv in rng.integers(160, 1201, size=n_utt)]          # 2 s .. 15 s in frames
     syn = ShardedSynthesizer(lambda mel, nfr, noise: eng.forward(mel, n_frames=nfr, noise=noise),
                              dims.hop_size, dims.steps_per_frame, rank=rank, world_size=world, max_batch=16,
-                             max_padded_frames=16 * 1200, device=torch.device("cuda", torch.cuda.current_device()))
+                             max_padded_frames=16 * 1200, device=torch.device("cuda", torch.cuda.current_device()),
+                             force_collective=dist is not None)
     from mbexwn_vocoder_amd.sharding import lpt_partition
     mine = set(lpt_partition(lengths, world)[rank])
     mels, noises = [], []
@@ -296,10 +339,22 @@ def run_sharded(args, name, rank, world, dist, fence, torch, steps=None, warmup=
             mels.append(np.zeros((ll, 80), dtype=np.float32))
             noises.append(np.zeros((ll * dims.steps_per_frame,), dtype=np.float32))
     plan = syn.stage(mels, noises)
-    elapsed = time_steps(lambda: syn.run_staged(plan, gather="all"), steps, warmup, fence)
+    last = {}
+
+    def step():
+        last["res"] = syn.run_staged(plan, gather="all")
+
+    elapsed = time_steps(step, steps, warmup, fence)
     samples = sum(lengths) * dims.hop_size * steps
     padded = sum(int(bb[1].shape[0]) * int(bb[1].shape[1]) for bb in plan["batches"])
-    return {"workload": f"{name}: MW-{voice[:2]}-FD canonical (C={dims.wn_channels}), {n_utt} utterances U[2 s,15 s] = "
+    delta = {}
+    if rank == 0 and check_delta:
+        # one utterance of this rank's shard, as the timed steps (forward + gather) left it, against the oracle on its prefix
+        pick = max(mine, key=lambda ii: (lengths[ii], -ii))                 # the longest one: first micro-batch, large launch
+        got = last["res"].item(pick)[:DELTA_FRAMES * dims.hop_size].cpu().numpy()
+        delta = max_abs_delta_timed([(f"utterance {pick} ({lengths[pick]} frames)", got, mels[pick], noises[pick])],
+                                    cfg, raw, wt, "forward + all_gather of the sharded run")
+    return {**delta, "workload": f"{name}: MW-{voice[:2]}-FD canonical (C={dims.wn_channels}), {n_utt} utterances U[2 s,15 s] = "
                         f"{sum(lengths) / 80:.0f} s of audio, LPT-sharded over {world} ranks (ShardedSynthesizer), padded "
                         f"micro-batches <= 16 items, device-resident all_gather of the audio each step",
             "value": samples / elapsed, "x_realtime": samples / elapsed / 24000.0, "ms_per_step": elapsed / steps * 1e3,
@@ -307,7 +362,7 @@ def run_sharded(args, name, rank, world, dist, fence, torch, steps=None, warmup=
             "padding_overhead": padded / max(1, sum(lengths[ii] for ii in mine))}
 
 
-def run_streaming(args, name, rank, world, fence, torch):
+def run_streaming(args, name, rank, world, fence, torch, steps=None, warmup=None):
     """configs[4]: steady-state tick of the streaming driver -- every stream advances by `chunk` frames.  `value`
     counts the emitted audio only, inputs resident in HBM; the tick is timed on the device with HIP events (events on
     the launch stream around each tick) and, separately, host-inclusive through the Python driver."""
@@ -315,10 +370,12 @@ def run_streaming(args, name, rank, world, fence, torch):
     voice, n_streams, chunk = WORKLOADS[name]
     chunk = -chunk
     cfg, raw, wt, dims, eng = build_engine(voice)
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     syn = StreamingSynthesizer(eng, chunk_frames=chunk)
     syn.time_device = True
     lead_ticks = 4                                   # ticks before the steady state (growing left context)
-    n_ticks = lead_ticks + args.warmup + args.steps
+    n_ticks = lead_ticks + warmup + steps
     total = (n_ticks + 1) * chunk + syn.right + 8
     for sid in range(n_streams):
         syn.open(sid)
@@ -331,20 +388,20 @@ def run_streaming(args, name, rank, world, fence, torch):
         res = syn.tick()
         torch.cuda.synchronize()
         assert len(res) == n_streams
-        if tick >= lead_ticks + args.warmup:
+        if tick >= lead_ticks + warmup:
             host_ms.append((time.perf_counter() - t1) * 1e3)
             dev_ms.append(syn.last_tick_device_ms)
             frames.append(syn.last_tick_frames)
             act_frames.append(syn.last_tick_wavenet_frames)
     fence()
     elapsed = fence.max_over_ranks(float(np.sum(dev_ms)) * 1e-3)       # device time of the timed ticks
-    samples = world * n_streams * chunk * dims.hop_size * args.steps
+    samples = world * n_streams * chunk * dims.hop_size * steps
     return {"workload": f"{name}: MW-SP-FD canonical, {n_streams} streams per GPU, tick = {chunk} frames "
                         f"({chunk * 12.5:g} ms) per stream, look-ahead {syn.right * 12.5:g} ms, carried phase state, "
                         f"bit-equal to offline synthesis; value = emitted audio / device time of the ticks (HIP events "
                         f"around the engine call of each tick), host-inclusive latency beside it",
-            "value": samples / elapsed, "x_realtime": samples / elapsed / 24000.0, "ms_per_step": elapsed / args.steps * 1e3,
-            "steps": args.steps, "scaling": "weak",
+            "value": samples / elapsed, "x_realtime": samples / elapsed / 24000.0, "ms_per_step": elapsed / steps * 1e3,
+            "steps": steps, "scaling": "weak",
             "tick_ms_device_p50": float(np.percentile(dev_ms, 50)), "tick_ms_device_p99": float(np.percentile(dev_ms, 99)),
             "tick_ms_host_inclusive_p50": float(np.percentile(host_ms, 50)),
             "tick_ms_host_inclusive_p99": float(np.percentile(host_ms, 99)),
@@ -353,24 +410,67 @@ def run_streaming(args, name, rank, world, fence, torch):
             "wavenet_frames_per_emitted_frame": float(np.mean(act_frames)) / (n_streams * chunk)}
 
 
+def visible_gpu_count():
+    """GPUs this process may use, WITHOUT initialising HIP in this process (the parent of the ranks must never touch the
+    GPU): the visibility variables when they are set, else torch.cuda.device_count() evaluated in a child process."""
+    counts = []
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        val = os.environ.get(var)
+        if val is not None:
+            counts.append(len([tok for tok in val.split(",") if tok.strip() != ""]))
+    if counts:
+        return min(counts)
+    res = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True,
+                         text=True, timeout=600)
+    try:
+        return int(res.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        raise SystemExit(f"bench.py: cannot count the GPUs: {res.stderr[-400:]}")
+
+
 def spawn_ranks(args):
-    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU, RCCL).  This parent never
-    touches the GPU -- torch.cuda.device_count() does not initialise it on this image -- and exits with the worst
-    child status."""
-    import torch
-    have = torch.cuda.device_count()
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (one per GPU, RCCL).
+    This parent never touches the GPU (visible_gpu_count) and never re-execs; it polls the children, and when one of
+    them fails it ends the others (a rank that died in front of a collective would otherwise leave them waiting for
+    RCCL's timeout) and exits non-zero.  The rendezvous port is --master-port / MASTER_PORT when given; else a free port
+    is probed, and a rank 0 that cannot bind it (taken in between) makes the whole attempt be repeated on another one."""
+    have = visible_gpu_count()
     if have < args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible")
-    with socket.socket() as ss:
-        ss.bind(("127.0.0.1", 0))
-        port = ss.getsockname()[1]
-    procs = []
-    for rank in range(args.gpus):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    codes = [pp.wait() for pp in procs]
-    raise SystemExit(max(abs(cc) for cc in codes))
+    fixed = args.master_port or int(os.environ.get("MASTER_PORT", "0"))
+    for attempt in range(3):
+        port = fixed
+        if not port:
+            with socket.socket() as ss:
+                ss.bind(("127.0.0.1", 0))
+                port = ss.getsockname()[1]
+        procs = []
+        for rank in range(args.gpus):
+            env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                       LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        codes = [None] * len(procs)
+        while any(cc is None for cc in codes):
+            for ii, pp in enumerate(procs):
+                if codes[ii] is None:
+                    codes[ii] = pp.poll()
+            if any(cc not in (None, 0) for cc in codes):
+                for ii, pp in enumerate(procs):                 # exactly the children started above, by PID
+                    if codes[ii] is None:
+                        pp.terminate()
+                for ii, pp in enumerate(procs):
+                    if codes[ii] is None:
+                        try:
+                            codes[ii] = pp.wait(timeout=30)
+                        except subprocess.TimeoutExpired:
+                            pp.kill()
+                            codes[ii] = pp.wait()
+                break
+            time.sleep(0.2)
+        worst = max(abs(cc) for cc in codes)
+        if worst == PORT_IN_USE_EXIT and not fixed and attempt < 2:
+            continue                                            # rank 0 lost the race for the probed port
+        raise SystemExit(worst)
 
 
 def main():
@@ -381,7 +481,8 @@ def main():
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the secondary workloads (configs[1] and configs[3]) and the max|delta| leg: profiling runs")
+                    help="skip the secondary workloads (the other four configs) and the max|delta| legs: profiling runs")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-spawned ranks (default: probe a free one)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even for one rank: exercises the N>1 code path on a 1-GPU box")
     args = ap.parse_args()
@@ -412,14 +513,19 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        try:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        except Exception as exc:                              # noqa: BLE001 -- the store's errors have no common type
+            if "address already in use" in str(exc).lower() or "EADDRINUSE" in str(exc):
+                raise SystemExit(PORT_IN_USE_EXIT)
+            raise
     fence = Fence(torch, dist)
 
     voice, batch, frames = WORKLOADS[args.workload]
     line = {"metric": "24 kHz audio samples/sec (whole job; x real-time = value / 24000) + max|delta| vs the CPU oracle"}
     ctx = None
     if frames is None:
-        main_res = run_sharded(args, args.workload, rank, world, dist, fence, torch)
+        main_res = run_sharded(args, args.workload, rank, world, dist, fence, torch, check_delta=not args.no_secondary)
     elif frames < 0:
         main_res = run_streaming(args, args.workload, rank, world, fence, torch)
     else:
@@ -427,11 +533,20 @@ def main():
 
     secondary = {}
     if args.workload == DEFAULT_WORKLOAD and not args.no_secondary:
-        # configs[1] at the same step count; configs[3] with a bounded step count (one step = 2 181 s of audio)
-        res2, _ = run_batch(args, "config2_sp_b1_10s", rank, world, fence, torch, profile=False)
+        # the other four BASELINE configurations with bounded step counts (the whole default run stays within a minute or
+        # two): configs[1] at the same step count; configs[0]'s utterance size on the GPU; configs[3] (one step = 2 181 s of
+        # audio) with its own max|delta| on a C = 340 utterance of the timed, gathered output; configs[4] streaming ticks
+        res2, ctx2 = run_batch(args, "config2_sp_b1_10s", rank, world, fence, torch, profile=False)
+        if rank == 0:
+            res2.update(max_abs_delta_timed([("item 0", ctx2["timed_out"][0], ctx2["mel_h"][0], ctx2["noise_h"][0])],
+                                            ctx2["cfg"], ctx2["raw"], ctx2["wt"], "config 2 batch"))
         secondary["config2_sp_b1_10s"] = res2
+        res1, _ = run_batch(args, "config1_sp_b1_3s", rank, world, fence, torch, profile=False)
+        secondary["config1_sp_b1_3s"] = res1
         secondary["config4_vo_256utt"] = run_sharded(args, "config4_vo_256utt", rank, world, dist, fence, torch,
-                                                     steps=min(args.steps, 3), warmup=1)
+                                                     steps=min(args.steps, 3), warmup=1, check_delta=True)
+        secondary["config5_sp_stream64"] = run_streaming(args, "config5_sp_stream64", rank, world, fence, torch,
+                                                         steps=max(20, min(args.steps, 50)), warmup=3)
 
     if rank == 0:
         line.update({
@@ -445,7 +560,10 @@ def main():
         if ctx is not None:
             line["roofline"] = roofline(ctx, args.workload)
             if not args.no_secondary:
-                line.update(max_abs_delta(ctx["eng"], ctx["cfg"], ctx["raw"], ctx["wt"], ctx["mel_h"], ctx["noise_h"], torch))
+                line.update(max_abs_delta_timed(
+                    [(f"item {ii}", ctx["timed_out"][ii], ctx["mel_h"][ii], ctx["noise_h"][ii]) for ii in ctx["delta_items"]],
+                    ctx["cfg"], ctx["raw"], ctx["wt"], f"{args.workload} batch, kernels: {main_res['gate_form']}"))
+                line.update(max_abs_delta_small(ctx["eng"], ctx["cfg"], ctx["raw"], ctx["wt"], ctx["mel_h"], ctx["noise_h"], torch))
         if secondary:
             line["secondary"] = secondary
         if not args.no_cpu_baseline:

@@ -125,9 +125,12 @@ def compute_log_mel_device(sound, preprocess_config, n_samples=None):
         if n_samples.dtype != torch.int32 or tuple(n_samples.shape) != (B,) or n_samples.device != dev:
             raise ValueError("n_samples must be an int32 tensor of shape (batch,) on the device of sound")
         n_samples = n_samples.contiguous()
-    _check(load_library().mbx_mel_analysis(sound.data_ptr(), n_samples.data_ptr() if n_samples is not None else None, B, N,
-                                           win_len, hop, fft_size, n_mels, tables[0].data_ptr(), tables[1].data_ptr(),
-                                           tables[2].data_ptr(), tables[3].data_ptr(), tables[4].data_ptr(),
-                                           ctypes.c_float(float(np.finfo(np.float32).eps)), out.data_ptr(), frames,
-                                           torch.cuda.current_stream(dev).cuda_stream))
+    # mbx_mel_analysis has no handle (hence no device of its own): it launches on the CURRENT device, which must be the one
+    # the buffers and the stream belong to
+    with torch.cuda.device(dev):
+        _check(load_library().mbx_mel_analysis(sound.data_ptr(), n_samples.data_ptr() if n_samples is not None else None, B, N,
+                                               win_len, hop, fft_size, n_mels, tables[0].data_ptr(), tables[1].data_ptr(),
+                                               tables[2].data_ptr(), tables[3].data_ptr(), tables[4].data_ptr(),
+                                               ctypes.c_float(float(np.finfo(np.float32).eps)), out.data_ptr(), frames,
+                                               torch.cuda.current_stream(dev).cuda_stream))
     return out, cfg["sample_rate"] / hop

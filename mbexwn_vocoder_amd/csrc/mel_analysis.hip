@@ -22,7 +22,8 @@ __global__ __launch_bounds__(FFT_THREADS) void mel_analysis_kernel(MelAnalysisAr
     float2 *a = smem, *bq = smem + nc, *tw = smem + 2 * nc;
     float *mag = reinterpret_cast<float *>(smem + 3 * nc);            // nc + 1 magnitudes
     const int t = blockIdx.x, b = blockIdx.y;
-    const int n = p.n_samples ? p.n_samples[b] : p.max_samples;
+    // item length from the device array, clamped to the item's row: a wrong entry must not address outside the buffer
+    const int n = p.n_samples ? min(max(p.n_samples[b], 0), p.max_samples) : p.max_samples;
     const int frames = n / p.hop + 1;
     if (t >= frames) return;
     const int tid = threadIdx.x;
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(FFT_THREADS) void mel_analysis_kernel(MelAnalysisAr
                 if (s < 0) s = -s;
                 if (s >= n) s = 2 * (n - 1) - s;
                 s = min(max(s, 0), n - 1);
-                val = p.window[j] * xb[s];
+                if (n >= 1) val = p.window[j] * xb[s];      // an empty item is one frame of silence: log(eps) rows
             }
             v[q] = val;
         }

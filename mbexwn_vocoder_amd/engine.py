@@ -91,10 +91,13 @@ def load_library():
     # live in ONE HIP runtime instance (torch bundles libamdhip64.so.7; loading ours first would give the
     # process a second, separate runtime).
     import torch  # noqa: F401
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"HIP extension {LIB_PATH} is missing: run `python -m mbexwn_vocoder_amd.build` "
+    # MBX_LIB_PATH: another build of the same library (kernel experiments, scripts/experiments/) -- never a fallback; it is
+    # an MBX_* variable, so bench.py records it in its line
+    path = os.environ.get("MBX_LIB_PATH") or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(f"HIP extension {path} is missing: run `python -m mbexwn_vocoder_amd.build` "
                            "(there is no CPU fallback for the mel-inversion path)")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     vp, i32, i64p, fp = ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p
     lib.mbx_last_error.restype = ctypes.c_char_p
     lib.mbx_last_error.argtypes = []
@@ -432,7 +435,8 @@ def tensor_table(config, raw_weights, wavetables):
     dims = ModelDims(config)
     mb = config["mbexwn_config"]
     mbc = mb["multi_band_config"]
-    out = dict(merge_channel_groups(fold_weights(raw_weights), dims))
+    wn_norm = mb.get("pp_mod_subnet", {}).get("use_weight_norm", None)
+    out = dict(merge_channel_groups(fold_weights(raw_weights, wavenet_weight_norm=wn_norm), dims))
     _, syn = tb.pqmf_filters(int(mbc["subbands"]), int(mbc["taps"]), float(mbc["cutoff_ratio"]), float(mbc["beta"]),
                              mbc.get("max_band", None))
     out["table.pqmf_syn"] = syn
@@ -587,6 +591,8 @@ class MBExWNEngine:
         if out is None:
             out = torch.empty((B, T * self.dims.hop_size), dtype=torch.float32, device=self.device)
         ws, need = self._get_workspace(B, T)
+        if stream_state is None and (active is not None or wavenet is not None or carry is not None or layers is not None):
+            raise ValueError("active / wavenet / carry / layers describe a streaming window: pass stream_state as well")
         if stream_state is not None:
             if stream_state.dtype != torch.int32 or tuple(stream_state.shape) != (B, 6) or stream_state.device != self.device:
                 raise ValueError("stream_state must be an int32 tensor of shape (batch, 6) on the engine's device")
@@ -753,6 +759,9 @@ class MBExWNEngine:
             raise NotImplementedError("infer(): training / test_grad belong to the training graph, not to the "
                                       "mel-inversion path")
         synth_length = int(synth_length) if synth_length else int(self.dims.segment_length)
+        if synth_length <= 0:
+            raise ValueError("infer(): synth_length is 0 and the model configuration has no segment_length to fall back "
+                             "to (reference wavegen_1d.py:489)")
         mel, noise = self._prepare(spect, synth_length, noise)
         # the optional RMS normalisation of the mel input and the matching output gain (reference
         # wavegen_1d.py:493-495, 506-507, row A14) run inside mbx_forward
@@ -765,7 +774,7 @@ class MBExWNEngine:
         f0 = self.stage("f0")[:, :audio.shape[1]:rate]               # the reference's own slice (:757)
         params = [["F0", _HostTensor(f0[:, :synth_length])],
                   ["PSig", _HostTensor(self.stage("excitation")[:, :audio.shape[1]][:, :synth_length])],
-                  ["PS", np.abs(self._envelope(B, T))[:, :synth_length]]]
+                  ["PS", _HostTensor(np.abs(self._envelope(B, T))[:, :synth_length])]]
         return (signals, params) if return_components else (signals[0], params)
 
     def infer_components(self, spect, synth_length=0, F0=None, transposition_factor=None, noise=None):
@@ -877,6 +886,8 @@ class _HostTensor:
         self.tensor = tensor
 
     def numpy(self):
+        if isinstance(self.tensor, np.ndarray):
+            return self.tensor
         return self.tensor.detach().cpu().numpy()
 
     @property

@@ -97,11 +97,12 @@ class MELInverter(object):
             mell = np.log(mel + self.lin_amp_off).astype(np.float32)
 
         if verbose:
-            print(f"    stats conditioning mell:: mean: {log_to_db * np.mean(mell):.3f}dB, "
-                  f"median: {log_to_db * np.median(mell):.3f}dB, max: {log_to_db * np.max(mell):.3f}dB, "
-                  f"min: {log_to_db * np.min(mell):.3f}dB mell.shape {mell.shape}", file=sys.stderr)
-            print(f"    mel params:: hoplen: {mel_config['hoplen']}, winlen: {mel_config.get('winlen')}, "
-                  f"fft size: {n_fft} srate: {mel_config['sr']}", file=sys.stderr)
+            # diagnostics only (the reference prints comparable statistics at mel_inverter.py:110-116)
+            db = log_to_db * mell
+            print(f"    scaled log-mel {mell.shape}: level in dB -- min {db.min():.3f}, median {np.median(db):.3f}, "
+                  f"mean {db.mean():.3f}, max {db.max():.3f}", file=sys.stderr)
+            print(f"    analysis of the input mel: sample rate {mel_config['sr']}, hop {mel_config['hoplen']}, "
+                  f"window {mel_config.get('winlen')}, FFT {n_fft}", file=sys.stderr)
 
         if resample_hop:
             # same expression order as the reference (mel_inverter.py:133-146): the grids decide the rounding

@@ -80,6 +80,7 @@ class ShardedSynthesizer:
 
     forward_fn(mel (B,Tmax,C) float32, n_frames (B,) int32, noise (B,Tmax*spf) float32 or None) -> audio (B, Tmax*hop)
 
+    ``force_collective`` executes the gather with a single rank too (needs an initialised process group).
     With ``device`` set (a torch device) the padded micro-batches are staged there once (:meth:`stage`), ``forward_fn``
     receives and returns tensors on that device, the shard is packed on the device and handed to the collective as it
     is -- RCCL over xGMI for CUDA tensors, no host copy between the forward pass and the gather.  Without ``device``
@@ -87,13 +88,16 @@ class ShardedSynthesizer:
     """
 
     def __init__(self, forward_fn, hop_size, steps_per_frame, rank=0, world_size=1, max_batch=16,
-                 max_padded_frames=16 * 1200, device=None):
+                 max_padded_frames=16 * 1200, device=None, force_collective=False):
         self.forward_fn = forward_fn
         self.hop = int(hop_size)
         self.spf = int(steps_per_frame)
         self.rank, self.world = int(rank), int(world_size)
         self.max_batch, self.max_padded_frames = max_batch, max_padded_frames
         self.device = device
+        # run the gather collective even with one rank (an initialised process group is then required): lets a 1-GPU
+        # box execute the RCCL path that N > 1 takes
+        self.force_collective = bool(force_collective)
 
     def stage(self, mels, noises=None):
         """Partition, pad and (with a device) upload this rank's micro-batches.  Returns the plan for run_staged."""
@@ -139,7 +143,7 @@ class ShardedSynthesizer:
             pos += nn
         assert pos == plan["totals"][self.rank]
         parts = [None] * self.world
-        if self.world == 1 or gather is None:
+        if (self.world == 1 and not self.force_collective) or gather is None:
             parts[self.rank] = flat[:pos]
         else:
             import torch.distributed as dist

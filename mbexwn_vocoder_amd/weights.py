@@ -81,15 +81,31 @@ def fold_weight_norm(v, g):
     return (np.asarray(g, dtype=np.float32) * (v * inv)).astype(np.float32)
 
 
-def fold_weights(raw):
-    """raw variables -> {'<layer>.w': (ks,cin,cout) f32, '<layer>.b': (cout,) f32, '<act>.alpha': ...}."""
+# layers the reference may build without weight normalisation: only the WaveNet's own (pp_mod_subnet.use_weight_norm,
+# reference custom_AE_layers.py:124,177-260); the F0 / VTF sub-nets and the post-net are always weight-normed
+# (reference custom_pulsed_generator.py:84-136, 491)
+_PLAIN_KERNEL_PREFIXES = ("wn.",)
+
+
+def fold_weights(raw, wavenet_weight_norm=None):
+    """raw variables -> {'<layer>.w': (ks,cin,cout) f32, '<layer>.b': (cout,) f32, '<act>.alpha': ...}.
+
+    A layer without a gain ``<layer>.g`` is taken as built with use_weight_norm=False (the kernel is the weight,
+    reference conv_layers.py:157-165) only where the reference can build it that way: the ``wn.*`` layers, and only when
+    ``wavenet_weight_norm`` is False or unknown (None: raw dicts of tests / converted checkpoints).  A missing gain on any
+    other layer -- or on a WaveNet layer of a model configured with weight normalisation -- raises KeyError instead of
+    silently using the un-normalised direction as the weight."""
     out = {}
     for key, val in raw.items():
         if key.endswith(".v"):
             name = key[:-2]
             if name + ".g" in raw:
                 out[name + ".w"] = fold_weight_norm(val, raw[name + ".g"])
-            else:       # layer built with use_weight_norm=False: the kernel is the weight (reference conv_layers.py:157-165)
+            else:
+                plain_ok = name.startswith(_PLAIN_KERNEL_PREFIXES) and wavenet_weight_norm is not True
+                if not plain_ok:
+                    raise KeyError(f"{name}.g is missing: the reference builds this layer with weight normalisation, "
+                                   f"so its checkpoint holds a gain (refusing to use {name}.v as the weight)")
                 out[name + ".w"] = np.asarray(val, dtype=np.float32)
             out[name + ".b"] = np.asarray(raw[name + ".bias"], dtype=np.float32)
         elif key.endswith(".alpha"):

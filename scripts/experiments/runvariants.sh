@@ -1,12 +1,10 @@
 #!/bin/bash
-# on the GPU box (through gpurun, from the repo root): for each variant built by mkexp.py swap it in for the product
-# library, run the bench (config 3 unless BENCH_ARGS says otherwise) and print the per-kernel times; the product
-# library is put back afterwards
+# on the GPU box (through gpurun, from the repo root): for each variant built by mkexp.py run the bench (config 3 unless
+# BENCH_ARGS says otherwise) with the engine pointed at it through MBX_LIB_PATH (engine.load_library) and print the
+# per-kernel times.  The product library is never overwritten: a killed run cannot leave a wrong-output build in the tree.
 cd $GRAFT_REPO_ROOT
-cp mbexwn_vocoder_amd/libmbexwn_hip.so /tmp/lib_orig.so
 for lib in "$@"; do
-  cp scripts/experiments/libs/lib_$lib.so mbexwn_vocoder_amd/libmbexwn_hip.so
-  timeout -k 5 120 python bench.py --no-cpu-baseline --no-secondary $BENCH_ARGS > /tmp/b.json 2>/tmp/b.err || { echo "$lib FAILED"; tail -3 /tmp/b.err; }
+  MBX_LIB_PATH=$PWD/scripts/experiments/libs/lib_$lib.so timeout -k 5 120 python bench.py --no-cpu-baseline --no-secondary $BENCH_ARGS > /tmp/b.json 2>/tmp/b.err || { echo "$lib FAILED"; tail -3 /tmp/b.err; }
   python - "$lib" <<'PY'
 import json,sys
 try:
@@ -15,4 +13,3 @@ try:
 except Exception as e: print(sys.argv[1], 'ERR', e)
 PY
 done
-cp /tmp/lib_orig.so mbexwn_vocoder_amd/libmbexwn_hip.so

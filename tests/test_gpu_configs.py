@@ -93,6 +93,51 @@ def test_voice_ragged_batch_of_16(torch, monkeypatch, voice_case, form):
     assert _maxdiff(batch[7, :keep], part[:keep]) <= 4e-5 * scale
 
 
+@pytest.fixture(scope="module")
+def canon_case():
+    cfg, raw, wt = build_case("SING", {})
+    rng = np.random.default_rng(33)
+    lengths = [int(vv) for vv in rng.integers(400, 801, size=16)]
+    lengths[2], lengths[13] = 160, 163                       # two short items for the oracle
+    lengths[5] = 800                                         # the padded length: 16 x 800 frames = the config-3 launch sizes
+    mel, noise = synthetic_inputs(303, 16, max(lengths))
+    return cfg, raw, wt, lengths, mel, noise
+
+
+def test_canon_ragged_batch_of_16(torch, monkeypatch, canon_case):
+    """the DEFAULT policy at config-3 size (C = 320, 16 x 800 frames padded) -- the kernels of the
+    driver's bench line: wn_gate_winograd4w_kernel<256,1>, wn_resskip_wide_kernel<11>, conv1d_mel_group_kernel<2> -- held
+    to the float64 oracle on the two short items, to the prefix property on the longest, and every item to its
+    one-at-a-time run (which takes the small-launch kernels: equal to float32 rounding)."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    cfg, raw, wt, lengths, mel, noise = canon_case
+    monkeypatch.delenv("MBX_WINOGRAD", raising=False)
+    eng = MBExWNEngine(cfg, raw, wt)
+    assert eng.dims.wn_channels == 320 and eng.gate_form(16, 800) == "winograd_f43" and eng.folds_start
+    nf = torch.as_tensor(lengths, dtype=torch.int32).cuda()
+    out = torch.full((16, 800 * 300), float("nan"), dtype=torch.float32).cuda()
+    batch = eng.forward(dev(torch, mel), n_frames=nf, noise=dev(torch, noise), out=out).cpu().numpy()
+    assert np.all(np.isfinite(batch))
+    scale = max(1.0, float(np.abs(batch).max()))
+    om = orc.OracleModel(cfg, raw, wt)
+    for ii in (2, 13):
+        ll = lengths[ii]
+        ref = om.forward(mel[ii:ii + 1, :ll], noise[ii:ii + 1, :ll * 20])[0]
+        assert _maxdiff(batch[ii, :ll * 300], ref) <= _tol(ref), f"item {ii} vs oracle"
+    for ii, ll in enumerate(lengths):
+        assert np.all(batch[ii, ll * 300:] == 0.0)
+        if ii % 5 == 0 or ii in (2, 13):
+            single = eng.forward(dev(torch, mel[ii:ii + 1, :ll]), noise=dev(torch, noise[ii:ii + 1, :ll * 20])).cpu().numpy()[0]
+            assert _maxdiff(batch[ii, :ll * 300], single) <= 4e-5 * scale, f"item {ii}"
+    # the longest item: its first 80 frames against the oracle on the 92-frame prefix (prefix property, margin 12)
+    ref = om.forward(mel[5:6, :92], noise[5:6, :92 * 20])[0][:80 * 300]
+    assert _maxdiff(batch[5, :80 * 300], ref) <= _tol(ref), "longest item vs oracle on its prefix"
+    cut, margin = 300, 12
+    part = eng.forward(dev(torch, mel[5:6, :cut]), noise=dev(torch, noise[5:6, :cut * 20])).cpu().numpy()[0]
+    keep = (cut - margin) * 300
+    assert _maxdiff(batch[5, :keep], part[:keep]) <= 4e-5 * scale
+
+
 def test_voice_reference_golden(torch, golden_dir):
     """C = 340, 2 x 41 frames, against the float32 run of the reference's own MBExWN.call."""
     from mbexwn_vocoder_amd.engine import MBExWNEngine

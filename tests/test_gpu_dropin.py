@@ -167,3 +167,81 @@ def test_mel_analysis_on_the_device_matches_the_host_analysis():
         err = np.abs(np.exp(got[ii, :nfr]) - np.exp(ref[0]))
         assert np.max(err) <= 2e-5 * np.max(np.exp(ref[0])), f"item {ii}: {np.max(err)}"
         assert np.max(np.abs(got[ii, :nfr] - ref[0])) <= 2e-3          # log domain, including the quiet channels
+
+
+def test_mel_analysis_clamps_item_lengths():
+    """n_samples comes from the device and must not address outside the item's row -- an empty item is one
+    frame of silence (log eps), an over-long entry is clamped to the row."""
+    import torch
+    from mbexwn_vocoder_amd.analysis import compute_log_mel_device
+    from mbexwn_vocoder_amd.config import canonical_config
+    pre = canonical_config("SPEECH")["preprocess_config"]
+    rng = np.random.default_rng(3)
+    snd = (0.1 * rng.normal(size=(3, 2400))).astype(np.float32)
+    good, _ = compute_log_mel_device(torch.as_tensor(snd).cuda(), pre)
+    got, _ = compute_log_mel_device(torch.as_tensor(snd).cuda(), pre,
+                                    n_samples=torch.as_tensor([0, 10 ** 6, 2400], dtype=torch.int32).cuda())
+    got, good = got.cpu().numpy(), good.cpu().numpy()
+    assert np.allclose(got[0, 0], np.log(np.finfo(np.float32).eps))
+    assert np.array_equal(got[1], good[1]) and np.array_equal(got[2], good[2])
+
+
+@pytest.mark.timeout(900)
+def test_rccl_single_rank_collectives(tmp_path):
+    """The N > 1 code path on the one GPU this box has, over the real `nccl` backend (= RCCL): a FRESH child process (the
+    parent of a rank must not have touched the GPU) runs bench.py with --force-dist on the sharded workload -- process group
+    on a device, barrier, max-over-ranks all_reduce, ShardedSynthesizer's device-resident all_gather with
+    force_collective -- and must print the bench line with an in-tolerance max|delta| of the gathered output."""
+    import json
+    import socket
+    with socket.socket() as ss:
+        ss.bind(("127.0.0.1", 0))
+        port = ss.getsockname()[1]
+    env = {kk: vv for kk, vv in os.environ.items() if kk not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--workload",
+                          "config4_vo_256utt", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], env=env,
+                         capture_output=True, text=True, timeout=840)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    assert line["config"]["max_abs_delta_ok"] is True, line["config"]
+
+
+def test_sharded_gather_over_rccl_equals_local_shard(model_dir):
+    """ShardedSynthesizer(force_collective=True) on device tensors with world_size 1 over `nccl`: all_gather and gather of
+    the flat shard must return exactly the local shard."""
+    code = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from helpers import synthetic_inputs
+from mbexwn_vocoder_amd.mel_inverter import MELInverter
+from mbexwn_vocoder_amd.sharding import ShardedSynthesizer
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+eng = MELInverter(sys.argv[2]).model
+lengths = [5, 33, 12, 7, 21]
+mels, noises = zip(*[(mm[0], nn[0]) for mm, nn in (synthetic_inputs(ll, 1, ll) for ll in lengths)])
+fwd = lambda mel, nfr, noise: eng.forward(mel, n_frames=nfr, noise=noise)
+dev = torch.device("cuda", 0)
+local = ShardedSynthesizer(fwd, 300, 20, max_batch=3, device=dev).run(list(mels), list(noises))
+for mode in ("all", "rank0"):
+    syn = ShardedSynthesizer(fwd, 300, 20, max_batch=3, device=dev, force_collective=True)
+    plan = syn.stage(list(mels), list(noises))
+    res = syn.run_staged(plan, gather=mode)
+    assert plan["parts"] is not None and res.parts[0].is_cuda          # the collective ran, on device tensors
+    got = res.to_list()
+    assert all(np.array_equal(aa, bb) for aa, bb in zip(got, local)), mode
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_OK")
+"""
+    import socket
+    with socket.socket() as ss:
+        ss.bind(("127.0.0.1", 0))
+        port = ss.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    res = subprocess.run([sys.executable, "-c", code, ROOT, model_dir], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "RCCL_OK" in res.stdout, res.stderr[-2000:]

@@ -277,3 +277,29 @@ def test_channel_groups_become_block_diagonal_dense_layers():
     cfg1["mbexwn_config"]["pp_mod_subnet"]["n_ch_groups"] = 1
     got = Dense(cfg1, raw, wt).forward(mel, noise)
     assert np.max(np.abs(got - ref)) < 5e-6 * max(1.0, np.max(np.abs(ref)))      # float32 storage of the folded weights
+
+
+def test_fold_weights_refuses_a_missing_gain_where_the_reference_always_normalises():
+    """only the WaveNet's own layers can be built without weight normalisation (reference
+    custom_AE_layers.py:124); a sub-net / post-net layer without its gain, or a WaveNet layer without one in a model
+    configured with use_weight_norm, must not load silently."""
+    import pytest
+    from mbexwn_vocoder_amd.weights import fold_weights
+    rng = np.random.default_rng(0)
+
+    def layer(name, with_g=True):
+        dd = {name + ".v": rng.normal(size=(1, 4, 6)).astype(np.float32), name + ".bias": np.zeros(6, np.float32)}
+        if with_g:
+            dd[name + ".g"] = np.ones(6, np.float32)
+        return dd
+
+    raw = {**layer("wn.conv1D_0", with_g=False), **layer("post")}
+    out = fold_weights(raw)                                    # unknown configuration: plain WaveNet kernels are accepted
+    assert np.array_equal(out["wn.conv1D_0.w"], raw["wn.conv1D_0.v"])
+    assert np.array_equal(fold_weights(raw, wavenet_weight_norm=False)["wn.conv1D_0.w"], raw["wn.conv1D_0.v"])
+    with pytest.raises(KeyError):
+        fold_weights(raw, wavenet_weight_norm=True)
+    with pytest.raises(KeyError):
+        fold_weights({**layer("wn.conv1D_0"), **layer("post", with_g=False)})
+    with pytest.raises(KeyError):
+        fold_weights({**layer("PS_Layer_final", with_g=False)}, wavenet_weight_norm=False)

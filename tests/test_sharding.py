@@ -101,3 +101,36 @@ def test_world_size_2_gloo(tmp_path):
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     for rank in range(2):
         assert (tmp_path / f"ok{rank}").read_text() == "1"
+
+
+def test_force_collective_runs_the_gather_with_one_rank():
+    """world_size 1 normally skips the collective; force_collective executes all_gather / gather anyway (this is how a
+    1-GPU box exercises the RCCL path, tests/test_gpu_dropin.py) -- here over gloo on CPU tensors."""
+    import torch.distributed as dist
+    with socket.socket() as ss:
+        ss.bind(("127.0.0.1", 0))
+        port = ss.getsockname()[1]
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        mels, noises = make_utterances(9, seed=5)
+        plain = ShardedSynthesizer(fake_forward, HOP, SPF, max_batch=4).run(mels, noises)
+        for mode in ("all", "rank0"):
+            syn = ShardedSynthesizer(fake_forward, HOP, SPF, max_batch=4, force_collective=True)
+            plan = syn.stage(mels, noises)
+            res = syn.run_staged(plan, gather=mode)
+            assert plan["parts"] is not None                       # the collective's receive buffers were used
+            assert all(np.array_equal(aa, bb) for aa, bb in zip(res.to_list(), plain))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_counts_gpus_without_touching_them(monkeypatch):
+    """bench.spawn_ranks' parent must not initialise HIP: the count comes from the visibility variables when they are
+    set (else from a child process)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2,3")
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0,1")
+    assert bench.visible_gpu_count() == 2
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "")
+    assert bench.visible_gpu_count() == 0
