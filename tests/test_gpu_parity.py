@@ -461,7 +461,8 @@ def test_infer_accepts_the_reference_arguments(torch):
     assert np.array_equal(sig.numpy(), base) and [pp[0] for pp in params] == ["F0", "PSig", "PS"]
     assert _maxdiff(params[0][1].numpy(), st["f0"][:, ::3]) <= 1e-3            # the reference's own slice [:, :len:3]
     assert _maxdiff(params[1][1].numpy(), st["excitation"]) <= _tol(st["excitation"], E2E_TOL)
-    assert params[2][1].shape == (1, 9, 1025) and _maxdiff(params[2][1], np.abs(st["envelope"])) <= _tol(np.abs(st["envelope"]), 2e-4)
+    assert all(hasattr(pp[1], "numpy") for pp in params)          # every entry is tensor-like, as in the reference
+    assert params[2][1].shape == (1, 9, 1025) and _maxdiff(params[2][1].numpy(), np.abs(st["envelope"])) <= _tol(np.abs(st["envelope"]), 2e-4)
     sigs = eng.infer(mel, synth_length=9 * 300, noise=noise, return_components=True)
     assert isinstance(sigs, list) and len(sigs) == 1 and np.array_equal(sigs[0].numpy(), base)
     sigs, params = eng.infer(mel, synth_length=9 * 300, noise=noise, return_components=True, return_F0=True)
@@ -469,6 +470,8 @@ def test_infer_accepts_the_reference_arguments(torch):
     for kwargs in ({"training": True}, {"test_grad": 1}):
         with pytest.raises(NotImplementedError):
             eng.infer(mel, **kwargs)
+    with pytest.raises(ValueError):                            # region arguments belong to a streaming window
+        eng.forward(dev(torch, mel), noise=dev(torch, noise), active=(0, torch.as_tensor([9], dtype=torch.int32).cuda()))
 
 
 def test_forward_is_graph_capturable(torch):
