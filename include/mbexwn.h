@@ -24,7 +24,7 @@
  *   MBX_FOLD_SKIP=0      keep the un-folded skip path (C -> 2C res/skip layers, stage "wn_skip")
  *   MBX_FOLD_START=0     keep the start convolution and the full first layer (default: start convolution folded into
  *                        layer 0, a K = 24 contraction of the excitation; needs the folded skip path)
- * The optional operand-order images of the weights ("*.wino", "*.wino_split", "*.wino4w", "*.packed", "*.fold",
+ * The optional operand-order images of the weights ("*.wino2w", "*.wino4w", "*.packed", "*.fold",
  * "*.fold_wide", "*.start_fold", "*.fold_start", "*.fold_start_wide", "wn.tail.fold", "wn.end.packed";
  * engine.tensor_table builds them) select the specialised kernels; a handle created from the plain folded weights
  * alone runs the generic ones.

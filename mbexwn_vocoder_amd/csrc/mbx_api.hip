@@ -654,7 +654,7 @@ static LayerGeom layer_geom(const mbx_handle *hd) {
     // start between conditioning rows: ConvArgs::cond_phase)
     if (!hd->fold_skip || !hd->fold_start || !hd->winograd || c.wn_kernel_size != 3 || L < 2) return g;
     for (int l = 1; l < L; ++l) {
-        const DevTensor *wino = find(hd, "wn.conv1D_" + std::to_string(l) + ".wino");
+        const DevTensor *wino = find(hd, "wn.conv1D_" + std::to_string(l) + ".wino2w");
         const int d = c.wn_dilations[l];
         if (!wino || d > 16 || (d & (d - 1)) != 0) return g;
     }
@@ -830,8 +830,9 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     // A span = the rows of the window one launch treats as the item: first row, per-item row counts (nf[b] * rpf, or
     // max_rows for every item when nf is null), conditioning-rate phase of the first row.  Whole-region runs use one span
     // for every launch; a steady streaming tick (layer state carried, mbx_forward_options.layer_rows) one per layer.
-    struct Span { long long row0; const int32_t *nf; int rpf, max_rows, cphase; };
-    const Span region{wn0 * spf, n_frames_wn, spf, wn_rows, 0};
+    // out0 / out_rows: the rows of a gate span that are consumed (the others are the layer's reach: inputs only)
+    struct Span { long long row0; const int32_t *nf; int rpf, max_rows, cphase, out0, out_rows; };
+    const Span region{wn0 * spf, n_frames_wn, spf, wn_rows, 0, 0, 0};
     std::vector<Span> gate_sp(L, region), res_sp(L, region);
     Span tail_sp = region;
     const bool carry_layers = lay && lay->carry;
@@ -863,8 +864,10 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
             const long long n2 = (long long)cond_up * ((e - 1 - A + phase) / cond_up + 2) - phase;
             const long long need = std::max(n1, n2);
             if (A + need > nsteps) return fail(MBX_ERR_INVALID_ARGUMENT, "layer_rows: the region ends too close to the window end");
-            gate_sp[l] = Span{A, nullptr, 1, (int)need, phase};
-            res_sp[l] = Span{s, nullptr, 1, N, 0};
+            // only the rows [s, e) are consumed (res_sp): the gate kernel computes the aligned blocks of output pairs that hold them
+            const long long o0 = ((s - A) / align) * align;
+            gate_sp[l] = Span{A, nullptr, 1, (int)need, phase, (int)o0, (int)(e - A - o0)};
+            res_sp[l] = Span{s, nullptr, 1, N, 0, 0, 0};
         }
         tail_sp = res_sp[L - 1];
     }
@@ -890,6 +893,8 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         g.cond_bstride = (long long)T * cond_cout;
         g.cond_up = cond_up;
         g.cond_phase = gs.cphase;
+        g.out_row0 = gs.out0;
+        g.out_rows = gs.out_rows;
         g.lerp_w0 = lerp.first;
         g.lerp_w1 = lerp.second;
         g.channels = C;
@@ -960,17 +965,16 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                 gw.w = wino4->ptr;
                 done = mbx::launch_wn_gate_winograd4w(gw, !(hd->winograd4_always || full_blocks >= 512), stream);
             }
-            const DevTensor *wino = (!done && hd->winograd) ? find(hd, "wn.conv1D_" + ls + ".wino") : nullptr;
-            if (wino && wino->ndim == 3 && wino->shape[0] == (C + 31) / 32 && wino->shape[1] == (C + 15) / 16 &&
-                wino->shape[2] == 4096) {
+            // F(2,3): wave-tiled kernel on v_mfma_f32_16x16x4_f32 (wn_winograd2w.hip): streams, per-layer regions, MBX_WINOGRAD=2
+            const DevTensor *wino = (!done && hd->winograd) ? find(hd, "wn.conv1D_" + ls + ".wino2w") : nullptr;
+            if (wino && wino->ndim == 3 && wino->shape[0] == (C + 31) / 32 && wino->shape[1] == (C + 7) / 8 &&
+                wino->shape[2] == 2048) {
                 mbx::ConvArgs gw = g;
                 gw.w = wino->ptr;
-                const DevTensor *wino2 = find(hd, "wn.conv1D_" + ls + ".wino_split");
-                const bool ok2 = wino2 && wino2->ndim == 3 && wino2->shape[0] == wino->shape[0] &&
-                                 wino2->shape[1] == wino->shape[1] && wino2->shape[2] == 4096;
-                done = mbx::launch_wn_gate_winograd(gw, ok2 ? wino2->ptr : nullptr, stream);
+                done = mbx::launch_wn_gate_winograd2w(gw, stream);
             }
-            if (!done && gs.cphase != 0) return fail(MBX_ERR_UNSUPPORTED, "per-layer regions need the Winograd F(2,3) gate kernel");
+            if (!done && (gs.cphase != 0 || gs.out_rows != 0))
+                return fail(MBX_ERR_UNSUPPORTED, "per-layer regions need the Winograd F(2,3) gate kernel");
             if (!done) mbx::launch_conv1d(g, mbx::EPI_GATE, stream);
         }
         const bool last = (l == L - 1);

@@ -54,6 +54,8 @@ struct ConvArgs {
     int last_layer;           // 1: cout == C, everything goes to skip
     int acc_preloaded;        // set by the launcher: accumulators start from bias + old value, epilogue only stores
     int remap, n_tiles, m_tiles_per_item, m_tiles_total;   // XCD-aware 1-D grid (set by the launcher)
+    int out_row0, out_rows;   // wave-tiled F(2,3) gate kernel: only the rows [out_row0, out_row0 + out_rows) of every item are
+                              // computed (out_rows == 0: all rows; out_row0 a multiple of 2 * dil)
     const float *zeros;       // >= 16 bytes of zeros in global memory (LDS-DMA source of padding lanes)
     int fast_dma;             // set by the launcher: 32-bit source offsets are safe (LDS-DMA with a uniform base)
 };
@@ -61,11 +63,12 @@ struct ConvArgs {
 void launch_conv1d(const ConvArgs &a, int epilogue, hipStream_t stream);
 // n <= 3 independent EPI_LINEAR convolutions; the small (mel-rate, small batch) ones share one launch
 void launch_conv1d_group(const ConvArgs *convs, int n, hipStream_t stream);
-// Winograd F(2,3) form of the WaveNet gate layer (wn_winograd.hip); a.w = host-packed weights (ceil(C/32), ceil(C/16), 4096)
-bool launch_wn_gate_winograd(const ConvArgs &a, const float *w_split, hipStream_t stream);
 // Winograd F(4,3) form on v_mfma_f32_16x16x4_f32, wave tile 16 groups x 64 columns (wn_winograd4w.hip); a.w = image of
 // engine.pack_winograd4w_weights (ceil(C/32), ceil(C/8), 3072); small: 128-row blocks whose waves split the input channels
 bool launch_wn_gate_winograd4w(const ConvArgs &a, bool small, hipStream_t stream);
+// Winograd F(2,3) form on v_mfma_f32_16x16x4_f32 with wave-granular tiles (wn_winograd2w.hip: streams, per-layer regions,
+// MBX_WINOGRAD=2); a.w = image of engine.pack_winograd2w_weights (ceil(C/32), ceil(C/8), 2048)
+bool launch_wn_gate_winograd2w(const ConvArgs &a, hipStream_t stream);
 // First WaveNet layer with the start convolution folded into it (wn_gate0.hip)
 struct Gate0Args {
     const float *pulse;       // (batch, rows * pulse_channels): the excitation, folded to pulse_channels per row

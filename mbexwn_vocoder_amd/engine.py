@@ -245,31 +245,6 @@ def make_config(config, wavetables):
     return cc, dims
 
 
-def pack_winograd_weights(w, split=False):
-    """Winograd F(2,3) combinations of the three taps (3, C, 2C) of a dilated WaveNet convolution, packed for
-    wn_gate_winograd_kernel (csrc/wn_winograd.hip).
-
-    Combinations W0, (W0+W1+W2)/2, (W0-W1+W2)/2, W2 are formed in float64 and stored float32.  Layout
-    (ceil(C/32) column tiles, ceil(C/16) channel slices, 4096): the 16 KB image of one (tile, slice) is what the kernel
-    copies verbatim into LDS, ordered [product j][channel half cc][tanh|sigmoid h][lane = 32*lk + n][k step st] with
-    input channel 16*slice + 8*cc + 4*lk + st and output column h*C + 32*tile + n; out-of-range entries are zero.
-    split=True is the image for the half-size block shape: column half h holds tile channels 16h..16h+15 as
-    [16 tanh | 16 sigmoid], i.e. lane column n -> output column (n // 16)*C + 32*tile + 16*h + n % 16.
-    """
-    w = np.asarray(w, dtype=np.float64)
-    C = w.shape[1]
-    assert w.shape == (3, C, 2 * C)
-    wj = np.stack((w[0], (w[0] + w[1] + w[2]) / 2, (w[0] - w[1] + w[2]) / 2, w[2]))
-    nt, nk = (C + 31) // 32, (C + 15) // 16
-    wp = np.zeros((4, nk * 16, 2, nt * 32))
-    wp[:, :C, 0, :C] = wj[:, :, :C]
-    wp[:, :C, 1, :C] = wj[:, :, C:]
-    if split:
-        wp = wp.reshape(4, nk * 16, 2, nt, 2, 16).transpose(0, 1, 4, 3, 2, 5).reshape(4, nk * 16, 2, nt * 32)
-    wp = wp.reshape(4, nk, 2, 2, 4, 2, nt, 32)                    # j, slice, cc, lk, st, h, tile, n
-    return np.ascontiguousarray(wp.transpose(6, 1, 0, 2, 5, 3, 7, 4).reshape(nt, nk, 4096), dtype=np.float32)
-
-
 _WINOGRAD43_G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
                           [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=np.float64)
 
@@ -293,6 +268,28 @@ def pack_winograd4w_weights(w):
     wp[:, :C, 1, :C] = u[:, :, C:]
     wp = wp.reshape(6, nk, 4, 2, 2, nt, 16, 2)                    # j, slice, kq, step, tanh|sigmoid, tile, n, e
     return np.ascontiguousarray(wp.transpose(5, 1, 0, 7, 2, 6, 4, 3).reshape(nt, nk, 3072), dtype=np.float32)
+
+
+def pack_winograd2w_weights(w):
+    """Winograd F(2,3) combinations W0, (W0+W1+W2)/2, (W0-W1+W2)/2, W2 of the three taps (3, C, 2C) of a dilated WaveNet
+    convolution, packed for wn_gate_winograd2w_kernel (csrc/wn_winograd2w.hip, v_mfma_f32_16x16x4_f32); formed in
+    float64, stored float32.
+
+    Layout (ceil(C/32) column tiles, ceil(C/8) channel slices, 2048): the 8 KB image of one (tile, slice) is copied
+    verbatim into LDS, ordered [product j][channel parity e][lane = 16*kq + n][tanh step 0, tanh step 1, sigmoid step 0,
+    sigmoid step 1] with input channel 8*slice + 2*kq + step and output column (0 | C) + 32*tile + 2*n + e;
+    out-of-range entries are zero.
+    """
+    w = np.asarray(w, dtype=np.float64)
+    C = w.shape[1]
+    assert w.shape == (3, C, 2 * C)
+    u = np.stack((w[0], (w[0] + w[1] + w[2]) / 2, (w[0] - w[1] + w[2]) / 2, w[2]))
+    nt, nk = (C + 31) // 32, (C + 7) // 8
+    wp = np.zeros((4, nk * 8, 2, nt * 32))
+    wp[:, :C, 0, :C] = u[:, :, :C]
+    wp[:, :C, 1, :C] = u[:, :, C:]
+    wp = wp.reshape(4, nk, 4, 2, 2, nt, 16, 2)                    # j, slice, kq, step, tanh|sigmoid, tile, n, e
+    return np.ascontiguousarray(wp.transpose(5, 1, 0, 7, 2, 6, 4, 3).reshape(nt, nk, 2048), dtype=np.float32)
 
 
 def pack_resskip_weights(w):
@@ -451,9 +448,8 @@ def tensor_table(config, raw_weights, wavetables):
         out[f"wn.res_skip_{ll}.packed"] = pack_resskip_weights(out[f"wn.res_skip_{ll}.w"])
     if dims.wn_kernel_size == 3:
         for ll in range(dims.wn_layers):
-            out[f"wn.conv1D_{ll}.wino"] = pack_winograd_weights(out[f"wn.conv1D_{ll}.w"])
-            out[f"wn.conv1D_{ll}.wino_split"] = pack_winograd_weights(out[f"wn.conv1D_{ll}.w"], split=True)
             out[f"wn.conv1D_{ll}.wino4w"] = pack_winograd4w_weights(out[f"wn.conv1D_{ll}.w"])
+            out[f"wn.conv1D_{ll}.wino2w"] = pack_winograd2w_weights(out[f"wn.conv1D_{ll}.w"])
     out["table.hann"] = tb.hann_periodic_f32(dims.stft_win)
     out["table.inv_win"] = tb.inverse_stft_window_f32(dims.stft_win, dims.hop_size)
     out["table.wavetables"] = np.ascontiguousarray(wavetables.tables, dtype=np.float32)

@@ -309,7 +309,7 @@ def test_engine_without_weight_images_runs_the_generic_kernels(torch):
     from mbexwn_vocoder_amd.engine import MBExWNEngine
     cfg, raw, wt = build_case(*CANON)
     eng = MBExWNEngine(cfg, raw, wt, weight_images=False)
-    assert not any(kk.endswith((".wino", ".wino4w", ".packed", ".fold")) for kk in eng._tensors)
+    assert not any(kk.endswith((".wino2w", ".wino4w", ".packed", ".fold")) for kk in eng._tensors)
     om = get_engine("canon", *CANON)[1]
     mel, noise = synthetic_inputs(9, 2, 25)
     got = eng.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()

@@ -14,57 +14,12 @@ def _direct_dilated(x, w, d):
     return xp[0:T] @ w[0] + xp[d:d + T] @ w[1] + xp[2 * d:2 * d + T] @ w[2]
 
 
-def _unpack_gate(packed, C, n_prod, bk, split):
-    """(tiles, slices, n_prod*bk*64) image -> U (n_prod, C, 2C) with the lane/step index map of the gate kernels."""
+def _unpack_gate_16x16x4(packed, C, n_prod):
+    """Image of engine.pack_winograd2w_weights / pack_winograd4w_weights -> U (n_prod, C, 2C) with the lane/step map of the
+    gate kernels on v_mfma_f32_16x16x4_f32: [product j][parity e][lane = 16 kq + n][tanh step 0, 1, sigmoid step 0, 1]."""
     nt, nk, _ = packed.shape
-    steps = 4
-    halves = bk // 8 if bk == 16 else 1          # channel halves cc per slice (F(2,3): 2, F(4,3): 1)
-    img = packed.reshape(nt, nk, n_prod, halves, 2, 64, steps)      # tile, slice, j, cc, h|wn, lane, st
+    img = packed.reshape(nt, nk, n_prod, 2, 64, 2, 2)               # tile, slice, j, e, lane, tanh|sigmoid, step
     U = np.zeros((n_prod, C, 2 * C))
-    for tile in range(nt):
-        for kt in range(nk):
-            for cc in range(halves):
-                for hh in range(2):
-                    for lane in range(64):
-                        lk, n = lane >> 5, lane & 31
-                        if split:
-                            ch = 32 * tile + 16 * hh + n % 16
-                            col = (n // 16) * C + ch
-                        else:
-                            ch = 32 * tile + n
-                            col = hh * C + ch
-                        for st in range(steps):
-                            k = bk * kt + 8 * cc + 4 * lk + st
-                            if k < C and ch < C:
-                                U[:, k, col] = img[tile, kt, :, cc, hh, lane, st]
-    return U
-
-
-@pytest.mark.parametrize("C", [32, 40])
-@pytest.mark.parametrize("split", [False, True])
-def test_winograd_f23_image_reproduces_the_convolution(C, split):
-    rng = np.random.default_rng(C + split)
-    w = rng.normal(size=(3, C, 2 * C))
-    U = _unpack_gate(engine.pack_winograd_weights(w, split=split).astype(np.float64), C, 4, 16, split)
-    x = rng.normal(size=(64, C))
-    for d in (1, 2, 8):
-        ref = _direct_dilated(x, w, d)
-        xp = np.concatenate((np.zeros((d, C)), x, np.zeros((2 * d, C))))
-        got = np.zeros_like(ref)
-        for t0 in range(0, 64, 2 * d):
-            for r in range(d):
-                t = t0 + r
-                x0, x1, x2, x3 = (xp[t + i * d] for i in range(4))           # h[t-d], h[t], h[t+d], h[t+2d]
-                m1, m2, m3, m4 = (x0 - x2) @ U[0], (x1 + x2) @ U[1], (x2 - x1) @ U[2], (x1 - x3) @ U[3]
-                got[t], got[t + d] = m1 + m2 + m3, m2 - m3 - m4
-        assert np.max(np.abs(got - ref)) < 2e-6 * np.max(np.abs(ref))     # float32 storage of the combinations
-
-
-def _unpack_gate_4w(packed, C):
-    """Image of engine.pack_winograd4w_weights -> U (6, C, 2C) with the lane/step map of wn_gate_winograd4w_kernel."""
-    nt, nk, _ = packed.shape
-    img = packed.reshape(nt, nk, 6, 2, 64, 2, 2)                    # tile, slice, j, e, lane, tanh|sigmoid, step
-    U = np.zeros((6, C, 2 * C))
     for tile in range(nt):
         for kt in range(nk):
             for e in range(2):
@@ -82,10 +37,48 @@ def _unpack_gate_4w(packed, C):
 
 
 @pytest.mark.parametrize("C", [32, 40])
+def test_winograd_f23_image_reproduces_the_convolution(C):
+    """wn_gate_winograd2w_kernel: pairs (t, t + d) inside blocks of 2 d rows counted from the first computed row."""
+    rng = np.random.default_rng(C)
+    w = rng.normal(size=(3, C, 2 * C))
+    packed = engine.pack_winograd2w_weights(w)
+    assert packed.shape == ((C + 31) // 32, (C + 7) // 8, 2048)
+    U = _unpack_gate_16x16x4(packed.astype(np.float64), C, 4)
+    x = rng.normal(size=(64, C))
+    for d in (1, 2, 8, 16):
+        ref = _direct_dilated(x, w, d)
+        xp = np.concatenate((np.zeros((d, C)), x, np.zeros((2 * d, C))))
+        got = np.zeros_like(ref)
+        for t0 in range(0, 64, 2 * d):
+            for r in range(d):
+                t = t0 + r
+                x0, x1, x2, x3 = (xp[t + i * d] for i in range(4))           # h[t-d], h[t], h[t+d], h[t+2d]
+                m1, m2, m3, m4 = (x0 - x2) @ U[0], (x1 + x2) @ U[1], (x2 - x1) @ U[2], (x1 - x3) @ U[3]
+                got[t], got[t + d] = m1 + m2 + m3, m2 - m3 - m4
+        assert np.max(np.abs(got - ref)) < 2e-6 * np.max(np.abs(ref))     # float32 storage of the combinations
+
+
+def test_winograd2w_staging_map_covers_every_row_once():
+    """The read-order staging of wn_winograd2w.hip: cell p = (m & 1) * 32 + (m >> 1) * d + b holds row m0 - d + d m + b;
+    pair P reads cells (i & 1) * 32 + P + (i >> 1) * d, which must be the rows t - d, t, t + d, t + 2 d of the pair, and
+    the DMA's inverse map (cell -> row) must agree."""
+    for log2d in range(5):
+        d = 1 << log2d
+        for P in range(16):
+            t = 2 * d * (P >> log2d) + (P & (d - 1))
+            for i in range(4):
+                cell = (i & 1) * 32 + P + ((i >> 1) << log2d)
+                phase, sidx = cell // 32, cell % 32
+                assert sidx < 16 + d
+                m = 2 * (sidx >> log2d) + phase
+                assert -d + (m << log2d) + (sidx & (d - 1)) == t + (i - 1) * d
+
+
+@pytest.mark.parametrize("C", [32, 40])
 def test_winograd_f43_image_reproduces_the_convolution(C):
     rng = np.random.default_rng(C)
     w = rng.normal(size=(3, C, 2 * C))
-    U = _unpack_gate_4w(engine.pack_winograd4w_weights(w).astype(np.float64), C)
+    U = _unpack_gate_16x16x4(engine.pack_winograd4w_weights(w).astype(np.float64), C, 6)
     x = rng.normal(size=(128, C))
     for d in (1, 4, 16):
         ref = _direct_dilated(x, w, d)
