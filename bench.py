@@ -398,10 +398,12 @@ def run_streaming(args, name, rank, world, fence, torch, steps=None, warmup=None
     samples = world * n_streams * chunk * dims.hop_size * steps
     return {"workload": f"{name}: MW-SP-FD canonical, {n_streams} streams per GPU, tick = {chunk} frames "
                         f"({chunk * 12.5:g} ms) per stream, look-ahead {syn.right * 12.5:g} ms, carried phase state, "
-                        f"bit-equal to offline synthesis; value = emitted audio / device time of the ticks (HIP events "
-                        f"around the engine call of each tick), host-inclusive latency beside it",
+                        f"bit-equal to offline synthesis; steady ticks are one replayed hipGraph (upload of the new frames + "
+                        f"window advance + forward + read-back of the chunk); value = emitted audio / device time of the ticks "
+                        f"(HIP events around the graph launch of each tick, copies included), host-inclusive latency beside it",
             "value": samples / elapsed, "x_realtime": samples / elapsed / 24000.0, "ms_per_step": elapsed / steps * 1e3,
             "steps": steps, "scaling": "weak",
+            "ticks_replayed_as_graph": int(syn.graph_ticks), "ticks_total": int(n_ticks),
             "tick_ms_device_p50": float(np.percentile(dev_ms, 50)), "tick_ms_device_p99": float(np.percentile(dev_ms, 99)),
             "tick_ms_host_inclusive_p50": float(np.percentile(host_ms, 50)),
             "tick_ms_host_inclusive_p99": float(np.percentile(host_ms, 99)),

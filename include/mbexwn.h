@@ -233,6 +233,15 @@ mbx_status mbx_forward_ex(mbx_handle *handle, const float *mel, const int32_t *n
                           int32_t max_frames, const float *noise, float *audio, void *workspace,
                           size_t workspace_bytes, const mbx_forward_options *options, void *hip_stream);
 
+/* Streaming windows kept on the device: before the steady tick of a set of streams, every item's window
+ * mel_window (batch, frames, mel_channels) / noise_window (batch, frames * steps_per_frame) moves step_frames frames to
+ * the left and the step_frames new frames mel_new (batch, step_frames, mel_channels) / noise_new (batch, step_frames *
+ * steps_per_frame) are appended, in place, in one launch -- so that a tick uploads only the new frames and its launch
+ * sequence (this call + mbx_forward_ex with constant arguments) can be replayed as a captured hipGraph (the practical
+ * form of the "persistent-kernel path" of BASELINE config 5; streaming.py).  noise_window / noise_new may both be NULL. */
+mbx_status mbx_window_advance(mbx_handle *handle, float *mel_window, const float *mel_new, float *noise_window,
+                              const float *noise_new, int32_t batch, int32_t frames, int32_t step_frames, void *hip_stream);
+
 /* Intermediate tensors of the most recent mbx_forward (pointers into its workspace), for stage parity
  * tests.  Names: "f0" "pulse" "cond" "wn_hidden" "wn_skip" "wn_out" "subbands" "excitation" "cepstrum"
  * "ceps_index" "frames".  `count` = floats (int32 for ceps_index) per batch item, `stride` = item stride.

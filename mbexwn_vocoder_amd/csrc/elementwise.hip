@@ -218,4 +218,34 @@ void launch_layer_carry(const LayerCarryArgs &a, int batch, hipStream_t stream) 
     hipLaunchKernelGGL(layer_carry_kernel, dim3(std::min((n + 255) / 256, 64), batch), dim3(256), 0, stream, a);
 }
 
+// Streaming windows kept on the device (mbx_window_advance): every row of `win` (batch, frames * row_floats) moves
+// `step * row_floats` floats to the left and the freed tail is filled from `fresh` (batch, step * row_floats).  One block
+// per (item, buffer); the kept part goes through LDS so that the move is safe in place.
+__global__ void window_advance_kernel(float *mel, const float *mel_new, int mel_keep, int mel_step, float *noise,
+                                      const float *noise_new, int noise_keep, int noise_step) {
+    extern __shared__ float adv_buf[];
+    const int b = blockIdx.x, second = blockIdx.y;
+    float *win = second ? noise : mel;
+    const float *fresh = second ? noise_new : mel_new;
+    const int keep = second ? noise_keep : mel_keep, step = second ? noise_step : mel_step;
+    if (!win) return;
+    float *row = win + (long long)b * (keep + step);
+    for (int i = threadIdx.x; i < keep; i += blockDim.x) adv_buf[i] = row[step + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < keep; i += blockDim.x) row[i] = adv_buf[i];
+    const float *src = fresh + (long long)b * step;
+    for (int i = threadIdx.x; i < step; i += blockDim.x) row[keep + i] = src[i];
+}
+
+bool launch_window_advance(float *mel, const float *mel_new, float *noise, const float *noise_new, int batch, int frames,
+                           int step_frames, int mel_channels, int steps_per_frame, hipStream_t stream) {
+    if (batch <= 0 || frames <= 0 || step_frames <= 0 || step_frames > frames) return false;
+    const int mel_keep = (frames - step_frames) * mel_channels, noise_keep = (frames - step_frames) * steps_per_frame;
+    const size_t smem = sizeof(float) * (size_t)std::max(mel_keep, noise ? noise_keep : 0);
+    if (smem > 64 * 1024) return false;
+    hipLaunchKernelGGL(window_advance_kernel, dim3(batch, noise ? 2 : 1), dim3(256), smem, stream, mel, mel_new, mel_keep,
+                       step_frames * mel_channels, noise, noise_new, noise_keep, step_frames * steps_per_frame);
+    return true;
+}
+
 }  // namespace mbx

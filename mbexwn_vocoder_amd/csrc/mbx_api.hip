@@ -1174,6 +1174,19 @@ mbx_status mbx_forward_ex(mbx_handle *hd, const float *mel, const int32_t *n_fra
     return forward_impl(hd, mel, n_frames, batch, max_frames, noise, audio, workspace, workspace_bytes, hip_stream, ex);
 }
 
+mbx_status mbx_window_advance(mbx_handle *hd, float *mel_window, const float *mel_new, float *noise_window,
+                              const float *noise_new, int32_t batch, int32_t frames, int32_t step_frames, void *hip_stream) {
+    if (!hd || !mel_window || !mel_new || (noise_window != nullptr) != (noise_new != nullptr))
+        return fail(MBX_ERR_INVALID_ARGUMENT, "null argument (noise_window and noise_new go together)");
+    DeviceGuard guard(hd->device);
+    if (!guard.ok) return fail(MBX_ERR_HIP, "cannot select the handle's device");
+    if (!mbx::launch_window_advance(mel_window, mel_new, noise_window, noise_new, batch, frames, step_frames,
+                                    hd->cfg.mel_channels, hd->cfg.steps_per_frame, static_cast<hipStream_t>(hip_stream)))
+        return fail(MBX_ERR_INVALID_ARGUMENT, "window advance: need 0 < step_frames <= frames and a window of at most 64 KB per item");
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MBX_OK : fail(MBX_ERR_HIP, hipGetErrorString(e));
+}
+
 mbx_status mbx_mel_analysis(const float *audio, const int32_t *n_samples, int32_t batch, int32_t max_samples,
                             int32_t win, int32_t hop, int32_t fft_size, int32_t n_mels, const float *window,
                             const float *twiddle, const float *basis, const int32_t *bin_lo, const int32_t *bin_hi,

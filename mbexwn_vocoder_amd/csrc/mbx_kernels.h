@@ -133,6 +133,9 @@ struct LayerCarryArgs {
     int acc_rows;             // stored rows of acc: [e_l, + acc_rows)
 };
 void launch_layer_carry(const LayerCarryArgs &a, int batch, hipStream_t stream);
+// device-resident streaming windows: shift every item's window left by step_frames and append the new frames
+bool launch_window_advance(float *mel, const float *mel_new, float *noise, const float *noise_new, int batch, int frames,
+                           int step_frames, int mel_channels, int steps_per_frame, hipStream_t stream);
 void launch_activation(const float *x, long long x_bstride, const int *n_frames, int rows_per_frame, int max_rows,
                        int batch, int channels, int act, float scale, float offset, float *y, long long y_bstride,
                        hipStream_t stream);

@@ -117,6 +117,8 @@ def load_library():
                                    ctypes.POINTER(mbx_forward_options), vp]
     lib.mbx_layer_state_info.restype = i32
     lib.mbx_layer_state_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    lib.mbx_window_advance.restype = i32
+    lib.mbx_window_advance.argtypes = [vp, fp, fp, fp, fp, i32, i32, i32, vp]
     lib.mbx_stage.restype = i32
     lib.mbx_stage.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p), i64p, i64p]
     lib.mbx_profile_enable.restype = i32
@@ -142,7 +144,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = ["mbx_last_error", "mbx_create", "mbx_destroy", "mbx_workspace_size", "mbx_forward",
-                    "mbx_forward_stream", "mbx_forward_ex", "mbx_layer_state_info", "mbx_stage",
+                    "mbx_forward_stream", "mbx_forward_ex", "mbx_layer_state_info", "mbx_window_advance", "mbx_stage",
                     "mbx_profile_enable", "mbx_profile_read", "mbx_pqmf_synthesis", "mbx_conv1d", "mbx_lin_interp", "mbx_wavetable", "mbx_stft_filter", "mbx_norm_mel", "mbx_mel_analysis"]
 
 
@@ -551,7 +553,7 @@ class MBExWNEngine:
         return ff.value, rr.value, mm.value
 
     def forward(self, mel, n_frames=None, noise=None, out=None, stream_state=None, active=None, wavenet=None, carry=None,
-                layers=None):
+                layers=None, state_out=None):
         """mel (B,T,80) float32 cuda tensor; n_frames int32 cuda tensor (B,) or None;
         noise (B, T*steps_per_frame) float32 cuda tensor (N(0,1) draw) -> audio (B, T*hop) cuda tensor.
 
@@ -593,7 +595,11 @@ class MBExWNEngine:
             if stream_state.dtype != torch.int32 or tuple(stream_state.shape) != (B, 6) or stream_state.device != self.device:
                 raise ValueError("stream_state must be an int32 tensor of shape (batch, 6) on the engine's device")
             stream_state = stream_state.contiguous()
-            state_out = torch.empty_like(stream_state)
+            if state_out is None:
+                state_out = torch.empty_like(stream_state)
+            elif (state_out.dtype != torch.int32 or tuple(state_out.shape) != (B, 6) or state_out.device != self.device or
+                  not state_out.is_contiguous()):
+                raise ValueError("state_out must be a contiguous int32 tensor of shape (batch, 6) on the engine's device")
             if active is None and (wavenet is not None or carry is not None or layers is not None):
                 raise ValueError("wavenet / carry / layers describe regions inside the active one: pass active as well")
             if active is not None:
@@ -658,6 +664,24 @@ class MBExWNEngine:
                                      ws.data_ptr(), need, self._stream()))
         self._last_shape = (B, T)
         return out
+
+    def window_advance(self, mel_window, mel_new, noise_window=None, noise_new=None):
+        """mbx_window_advance: shift the device-resident windows (B, T, mel_channels) / (B, T*steps_per_frame) left by the
+        frames of mel_new (B, step, mel_channels) / noise_new (B, step*steps_per_frame) and append those, in place."""
+        torch = self._torch
+        B, T, step = int(mel_window.shape[0]), int(mel_window.shape[1]), int(mel_new.shape[1])
+        for tt in (mel_window, mel_new, noise_window, noise_new):
+            if tt is not None and (tt.dtype != torch.float32 or tt.device != self.device or not tt.is_contiguous()):
+                raise ValueError("windows and new frames must be contiguous float32 tensors on the engine's device")
+        if tuple(mel_new.shape) != (B, step, self.dims.mel_channels) or mel_window.shape[2] != self.dims.mel_channels:
+            raise ValueError("mel_new must be (batch, step, mel_channels)")
+        if noise_window is not None and (tuple(noise_window.shape) != (B, T * self.dims.steps_per_frame) or
+                                         noise_new is None or tuple(noise_new.shape) != (B, step * self.dims.steps_per_frame)):
+            raise ValueError("noise_window / noise_new must be (batch, frames * steps_per_frame) / (batch, step * steps_per_frame)")
+        _check(self._lib.mbx_window_advance(self._handle, mel_window.data_ptr(), mel_new.data_ptr(),
+                                            noise_window.data_ptr() if noise_window is not None else None,
+                                            noise_new.data_ptr() if noise_window is not None else None, B, T, step,
+                                            self._stream()))
 
     def profile_enable(self, enabled=True):
         _check(self._lib.mbx_profile_enable(self._handle, 1 if enabled else 0))

@@ -67,9 +67,11 @@ def stream_margins(dims, config):
 
 
 class _Stream:
-    def __init__(self, mel_channels):
-        self.mel = np.zeros((0, mel_channels), dtype=np.float32)
-        self.noise = np.zeros((0,), dtype=np.float32)
+    def __init__(self):
+        # the frames a stream has received live in the synthesizer's shared input buffers (row `slot`): absolute frame f
+        # sits at column f - base; frames in front of the next window are dropped when the row runs full
+        self.base = 0             # absolute frame at column 0 of the stream's row
+        self.have = 0             # frames received so far (absolute)
         self.emitted = 0          # frames of audio already produced
         self.closed = False
         self.slot = -1            # row of the synthesizer's sub-band store
@@ -105,6 +107,10 @@ class StreamingSynthesizer:
         self._layer_floats, self._layer_min_rows = ff, min_rows
         self._layer_store = None      # (slots, floats per slot) on the device
         self._free_slots = []
+        # input frames of every stream, one row per slot (shared so that a tick gathers its frames with one indexed copy)
+        self._in_cap = 256            # frames per row (grows on demand)
+        self._in_mel = np.zeros((0, self._in_cap, self.dims.mel_channels), dtype=np.float32)
+        self._in_noise = np.zeros((0, self._in_cap, self.dims.steps_per_frame), dtype=np.float32)
         # The Winograd form of the dilated convolution pairs outputs t and t+d inside blocks of 2d steps counted from
         # the first row of the item; a window that starts on a multiple of 2*d_max steps pairs exactly like the offline
         # run, which keeps the streamed audio bit-identical (any other start is equal up to float32 rounding only).
@@ -112,6 +118,15 @@ class StreamingSynthesizer:
         d_max = max(engine.dims.wn_dilation(ll) for ll in range(engine.dims.wn_layers))
         self.align = (2 * d_max) // math.gcd(2 * d_max, engine.dims.steps_per_frame)
         self.streams = {}
+        # Steady ticks (every stream continues with the geometry of the tick before) are replayed as a captured hipGraph:
+        # the windows stay on the device (mbx_window_advance appends the new frames), every integer argument of the call is
+        # a constant of the capture, and one graph launch stands for the ~30 kernel launches of a tick.  This is the
+        # practical form of BASELINE config 5's "persistent-kernel path": the launch sequence persists, not a kernel.
+        self.use_graph = True
+        self._steady = None               # what the last steady tick of the launch-by-launch path left behind
+        self._graph = None                # the captured tick and its fixed buffers
+        self.graph_ticks = 0              # ticks served by a graph replay
+        self.last_tick_replayed = False
         self.time_device = False          # bench: bracket the engine call of a tick with events on its stream
         self.last_tick_device_ms = None
         self.last_tick_frames = 0         # window frames of the last tick (all streams): mel-rate stages
@@ -123,8 +138,21 @@ class StreamingSynthesizer:
     def lookahead_ms(self):
         return 1000.0 * self.right * self.dims.hop_size / self.dims.sample_rate
 
+    def _grow_inputs(self, slots, cap):
+        """Make the shared input buffers at least (slots, cap frames) large, keeping their contents."""
+        old_mel, old_noise = self._in_mel, self._in_noise
+        if slots <= old_mel.shape[0] and cap <= self._in_cap:
+            return
+        slots, cap = max(slots, old_mel.shape[0]), max(cap, self._in_cap)
+        self._in_mel = np.zeros((slots, cap, self.dims.mel_channels), dtype=np.float32)
+        self._in_noise = np.zeros((slots, cap, self.dims.steps_per_frame), dtype=np.float32)
+        self._in_mel[:old_mel.shape[0], :self._in_cap] = old_mel
+        self._in_noise[:old_noise.shape[0], :self._in_cap] = old_noise
+        self._in_cap = cap
+
     def open(self, stream_id):
-        st = _Stream(self.dims.mel_channels)
+        self._leave_steady()
+        st = _Stream()
         import torch
         rows = (self.sr_left + self.sr_right) * self.dims.steps_per_frame
         if not self._free_slots:
@@ -140,11 +168,14 @@ class StreamingSynthesizer:
                 if old_l is not None:
                     self._layer_store[:n_old] = old_l
             self._free_slots = list(range(n_new - 1, n_old - 1, -1))
+            self._graph = None            # the stores moved: a captured tick points at the old ones
+            self._grow_inputs(n_new, self._in_cap)
         st.slot = self._free_slots.pop()
         self.streams[stream_id] = st
 
     def close(self, stream_id):
         """Forget a finished stream (its slot of the sub-band store is reused)."""
+        self._leave_steady()
         st = self.streams.pop(stream_id)
         self._free_slots.append(st.slot)
 
@@ -152,15 +183,34 @@ class StreamingSynthesizer:
         """Append mel frames (n, mel_channels) and the matching N(0,1) draw (n*steps_per_frame,) to a stream."""
         st = self.streams[stream_id]
         mel_frames = np.asarray(mel_frames, dtype=np.float32).reshape(-1, self.dims.mel_channels)
-        st.mel = np.concatenate((st.mel, mel_frames), axis=0)
+        n = mel_frames.shape[0]
+        spf = self.dims.steps_per_frame
         if self.dims.noise_sigma:
             if noise is None:
                 raise ValueError("noise is required (explicit input of the path)")
-            st.noise = np.concatenate((st.noise, np.asarray(noise, dtype=np.float32).ravel()))
+            noise = np.asarray(noise, dtype=np.float32).reshape(-1, spf)
+            if noise.shape[0] != n:
+                raise ValueError("noise must hold steps_per_frame values per pushed mel frame")
+        if st.have - st.base + n > self._in_cap:
+            # drop the frames no later window can reach (windows start at aligned(emitted - left); a stale `emitted` of a
+            # stream inside a run of replayed ticks only keeps more than necessary), then grow the rows if that is not enough
+            keep_from = max(st.base, ((st.emitted - self.left) // self.align) * self.align)
+            drop, live = keep_from - st.base, st.have - keep_from
+            if drop > 0:
+                self._in_mel[st.slot, :live] = self._in_mel[st.slot, drop:drop + live]
+                self._in_noise[st.slot, :live] = self._in_noise[st.slot, drop:drop + live]
+                st.base = keep_from
+            if st.have - st.base + n > self._in_cap:
+                self._grow_inputs(self._in_mel.shape[0], max(2 * self._in_cap, st.have - st.base + n))
+        col = st.have - st.base
+        self._in_mel[st.slot, col:col + n] = mel_frames
+        if self.dims.noise_sigma:
+            self._in_noise[st.slot, col:col + n] = noise
+        st.have += n
         st.closed = st.closed or last
 
     def _ready(self, st):
-        have = st.mel.shape[0]
+        have = st.have
         if st.emitted >= have:
             return 0
         if st.closed:
@@ -170,6 +220,11 @@ class StreamingSynthesizer:
     def tick(self):
         """One batched engine call over every stream that can emit. Returns {stream_id: audio ndarray}."""
         import torch
+        self.last_tick_replayed = False
+        if self._steady is not None:
+            if self.use_graph and self._steady_continues():
+                return self._graph_tick()
+            self._leave_steady()
         todo = [(sid, st, self._ready(st)) for sid, st in self.streams.items()]
         todo = [(sid, st, nn) for sid, st, nn in todo if nn > 0]
         if not todo:
@@ -177,7 +232,7 @@ class StreamingSynthesizer:
         ppf, spf, hop = self.dims.pulse_per_frame, self.dims.steps_per_frame, self.dims.hop_size
         windows = []
         for sid, st, nn in todo:
-            have = st.mel.shape[0]
+            have = st.have
             ws = max(0, ((st.emitted - self.left) // self.align) * self.align)
             we = have if st.closed and st.emitted + nn + self.right >= have else st.emitted + nn + self.right
             we = min(we, have)
@@ -277,9 +332,9 @@ class StreamingSynthesizer:
         st_f = np.zeros((B, 2), dtype=np.float32)
         next_state_frame = []
         for bb, ((sid, st, nn), (ws, we)) in enumerate(zip(todo, windows)):
-            mel[bb, :we - ws] = st.mel[ws:we]
+            mel[bb, :we - ws] = self._in_mel[st.slot, ws - st.base:we - st.base]
             if self.dims.noise_sigma:
-                noise[bb, :(we - ws) * spf] = st.noise[ws * spf:we * spf]
+                noise[bb, :(we - ws) * spf] = self._in_noise[st.slot, ws - st.base:we - st.base].reshape(-1)
             nfr[bb] = we - ws
             # the carried state sits at frame st.state_frame (>= ws + lead, or 0 at the utterance start): pulses are
             # reproducible from there on.  The next state is captured where the NEXT window's reproducible region
@@ -322,6 +377,19 @@ class StreamingSynthesizer:
         hi = max((st.emitted - ws + nn) * hop for (sid, st, nn), (ws, we) in zip(todo, windows))
         audio = audio[:, lo:hi].cpu().numpy()
         state_out = state_out.cpu().numpy()
+        steady_ctx = None
+        if layer_rows and self.use_graph and self.chunk % self.align == 0:
+            # a steady tick: if the next one continues every stream the same way, it is this launch sequence on windows
+            # that moved by `chunk` frames -- every window-relative argument is the same (_steady_continues checks it)
+            (sid0, st0, _), (ws0, _) = todo[0], windows[0]
+            steady_ctx = {
+                "sids": [sid for sid, _, _ in todo], "streams": [st for _, st, _ in todo], "B": B, "T": tmax, "a0": a0,
+                "wa": wa, "lo": lo, "hi": hi, "layer_rows": layer_rows, "act": act.copy(), "wn": wn.copy(),
+                "nfr": nfr.copy(), "desc": desc.copy(), "ldesc": ldesc.copy(), "state_consts": states[:, 3:5].copy(),
+                "mel_d": mel_d, "noise_d": noise_d, "rel0": st0.emitted - ws0, "state_v": state_out.copy(),
+                "slots": np.asarray([st.slot for _, st, _ in todo], dtype=np.int64), "pending": 0,
+                "frames": self.last_tick_frames, "active_frames": self.last_tick_active_frames,
+                "wavenet_frames": self.last_tick_wavenet_frames}
         result = {}
         for bb, ((sid, st, nn), (ws, we)) in enumerate(zip(todo, windows)):
             a0 = (st.emitted - ws) * hop - lo
@@ -333,8 +401,140 @@ class StreamingSynthesizer:
                 ff = state_out[bb, :2].copy().view(np.float32)
                 st.state = (float(ff[0]), float(ff[1]), int(state_out[bb, 2]))
                 st.state_frame = next_state_frame[bb]
+        if steady_ctx is not None:
+            steady_ctx["emitted_v"] = np.asarray([st.emitted for _, st, _ in todo], dtype=np.int64)
+            self._steady = steady_ctx
+        return result
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # steady ticks as a replayed hipGraph
+    # ------------------------------------------------------------------------------------------------------------------
+    def _sync_streams(self):
+        """Write the progress of the replayed ticks back to the stream objects (inside a run of replayed ticks it is kept
+        in vectors: emitted frames, carried phase states)."""
+        ctx = self._steady
+        if ctx is None or not ctx["pending"]:
+            return
+        adv = ctx["pending"] * self.chunk
+        sf = ctx["state_v"][:, :2].copy().view(np.float32)
+        for bb, st in enumerate(ctx["streams"]):
+            st.emitted += adv
+            st.carry_pos = st.emitted
+            st.layer_end += adv
+            st.state_frame += adv
+            st.state = (float(sf[bb, 0]), float(sf[bb, 1]), int(ctx["state_v"][bb, 2]))
+        ctx["pending"] = 0
+
+    def _leave_steady(self):
+        self._sync_streams()
+        self._steady = None
+
+    def _steady_continues(self):
+        """True when this tick is the steady tick recorded in self._steady moved on by `chunk` frames: the same streams
+        (and no other one ready), each with a whole chunk and its look-ahead available and no utterance end inside the
+        window, the same position of the window relative to the emitted frames -- then every window-relative argument of
+        the engine call is unchanged."""
+        ctx = self._steady
+        streams, B = ctx["streams"], ctx["B"]
+        have = np.fromiter((st.have for st in streams), np.int64, B)
+        closed = np.fromiter((st.closed for st in streams), np.int64, B)
+        emitted = ctx["emitted_v"]
+        if np.any(have < emitted + (self.chunk + self.right) + closed):
+            return False
+        ws = np.maximum(0, ((emitted - self.left) // self.align) * self.align)
+        if np.any(emitted - ws != ctx["rel0"]):
+            return False
+        if len(self.streams) != B:                        # a stream outside the recorded set must not be ready
+            inside = set(ctx["sids"])
+            if any(self._ready(st) > 0 for sid, st in self.streams.items() if sid not in inside):
+                return False
+        return True
+
+    def _capture(self, ctx):
+        """Fixed buffers + the captured launch sequence of the steady tick described by ctx."""
+        import torch
+        eng, dims, dev = self.engine, self.dims, self.engine.device
+        B, T, chunk, spf, hop = ctx["B"], ctx["T"], self.chunk, dims.steps_per_frame, dims.hop_size
+        use_noise = bool(dims.noise_sigma)
+        n_mel, n_noise = B * chunk * dims.mel_channels, (B * chunk * spf if use_noise else 0)
+        # one pinned host buffer / one device buffer for everything a tick uploads: new mel frames, new noise, phase states
+        stage_host = torch.empty(n_mel + n_noise + B * 6, dtype=torch.float32).pin_memory()
+        stage_dev = torch.empty_like(stage_host, device=dev)
+        mel_new = stage_dev[:n_mel].view(B, chunk, dims.mel_channels)
+        noise_new = stage_dev[n_mel:n_mel + n_noise].view(B, chunk * spf) if use_noise else None
+        states_d = stage_dev[n_mel + n_noise:].view(torch.int32).view(B, 6)
+        ints = {kk: torch.as_tensor(ctx[kk], device=dev) for kk in ("act", "wn", "nfr", "desc", "ldesc")}
+        audio_buf = torch.empty((B, T * hop), dtype=torch.float32, device=dev)
+        state_out = torch.empty((B, 6), dtype=torch.int32, device=dev)
+        emit_buf = torch.empty((B, ctx["hi"] - ctx["lo"]), dtype=torch.float32, device=dev)
+        audio_host = torch.empty((B, ctx["hi"] - ctx["lo"]), dtype=torch.float32).pin_memory()
+        state_host = torch.empty((B, 6), dtype=torch.int32).pin_memory()
+        mel_win, noise_win = ctx["mel_d"], ctx["noise_d"] if use_noise else None
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize(dev)
+        with torch.cuda.graph(graph):
+            stage_dev.copy_(stage_host, non_blocking=True)
+            eng.window_advance(mel_win, mel_new, noise_win, noise_new)
+            eng.forward(mel_win, n_frames=ints["nfr"], noise=noise_win, stream_state=states_d,
+                        active=(ctx["a0"], ints["act"], int(ctx["act"].max())),
+                        wavenet=(ctx["wa"], ints["wn"], int(ctx["wn"].max())),
+                        carry=(self._store, ints["desc"].view(B, 5)) if self.carry else None,
+                        layers=(self._layer_store, ints["ldesc"].view(B, 3), ctx["layer_rows"]),
+                        out=audio_buf, state_out=state_out)
+            emit_buf.copy_(audio_buf[:, ctx["lo"]:ctx["hi"]])
+            audio_host.copy_(emit_buf, non_blocking=True)
+            state_host.copy_(state_out, non_blocking=True)
+        n_state = n_mel + n_noise
+        return {"ctx": ctx, "graph": graph, "stage_host": stage_host, "stage_np": stage_host.numpy(), "n_mel": n_mel,
+                "arange": np.arange(chunk, dtype=np.int64),
+                "n_noise": n_noise, "n_state": n_state, "audio_host": audio_host, "state_host": state_host,
+                "keep": (stage_dev, ints, audio_buf, state_out, emit_buf, mel_win, noise_win)}
+
+    def _graph_tick(self):
+        """A steady tick as one graph launch: gather and upload the new frames and the phase states, replay, read the
+        chunk back.  Nothing here loops over the streams."""
+        import torch
+        ctx = self._steady
+        if self._graph is None or self._graph["ctx"] is not ctx:
+            self._graph = self._capture(ctx)
+        gg = self._graph
+        dims, chunk = self.dims, self.chunk
+        hop, B = dims.hop_size, ctx["B"]
+        stage = gg["stage_np"]
+        emitted, slots = ctx["emitted_v"], ctx["slots"]
+        base = np.fromiter((st.base for st in ctx["streams"]), np.int64, B)
+        # the frames the windows gain: [emitted + right, emitted + right + chunk) of every stream
+        cols = (emitted + self.right - base)[:, None] + gg["arange"]
+        np.copyto(stage[:gg["n_mel"]].reshape(B, chunk, dims.mel_channels), self._in_mel[slots[:, None], cols])
+        if gg["n_noise"]:
+            np.copyto(stage[gg["n_mel"]:gg["n_state"]].reshape(B, chunk, dims.steps_per_frame),
+                      self._in_noise[slots[:, None], cols])
+        states = stage[gg["n_state"]:].view(np.int32).reshape(B, 6)
+        states[:, :3] = ctx["state_v"][:, :3]
+        states[:, 3:5] = ctx["state_consts"]
+        states[:, 5] = 0
+        if self.time_device:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        gg["graph"].replay()
+        if self.time_device:
+            ev1.record()
+        torch.cuda.current_stream(self.engine.device).synchronize()
+        if self.time_device:
+            self.last_tick_device_ms = ev0.elapsed_time(ev1)
+        audio = gg["audio_host"].numpy().copy()
+        ctx["state_v"] = gg["state_host"].numpy().copy()
+        a0 = ctx["rel0"] * hop - ctx["lo"]
+        result = dict(zip(ctx["sids"], audio[:, a0:a0 + chunk * hop]))
+        emitted += chunk
+        ctx["pending"] += 1
+        self.last_tick_frames, self.last_tick_active_frames = ctx["frames"], ctx["active_frames"]
+        self.last_tick_wavenet_frames, self.last_tick_layer_rows = ctx["wavenet_frames"], ctx["layer_rows"]
+        self.last_tick_replayed = True
+        self.graph_ticks += 1
         return result
 
     def finished(self, stream_id):
+        self._sync_streams()
         st = self.streams[stream_id]
-        return st.closed and st.emitted >= st.mel.shape[0]
+        return st.closed and st.emitted >= st.have

@@ -189,6 +189,7 @@ def test_canonical_streaming_64_streams_bit_equal(torch, monkeypatch):
     # both kinds of tick ran: steady ones (per-layer WaveNet state carried, every layer on the 160 new rows only) and
     # whole-region ones (first tick, ticks in which a stream ends)
     assert 2 <= steady < ticks
+    assert syn.graph_ticks >= 1                            # steady ticks behind the first one replay the captured graph
     for sid in range(0, n_streams, 1):
         ll = lengths[sid]
         offline = eng.forward(dev(torch, utts[sid][0][None]), noise=dev(torch, utts[sid][1][None])).cpu().numpy()[0]

@@ -198,3 +198,74 @@ def test_streaming_dilation_cycle_model(monkeypatch):
     assert steady >= 3
     for sid in offline:
         assert np.array_equal(np.concatenate(got[sid]), offline[sid])
+
+
+def test_steady_ticks_replay_a_graph_and_stay_bit_equal(engine, offline_f23_engine):
+    """Steady ticks are served by ONE replayed hipGraph (device-resident windows advanced by mbx_window_advance, constant
+    integer arguments): the streams stay bit-equal to the offline synthesis and to the launch-by-launch driver, graph ticks
+    take over from the second steady tick on, and a change of the stream set (one stream ends earlier, one joins later)
+    drops back to the launch-by-launch path and re-captures."""
+    import torch
+    from mbexwn_vocoder_amd.streaming import StreamingSynthesizer
+    lengths = {0: 140, 1: 140, 2: 93, 3: 140}
+    data, offline = {}, {}
+    for sid, ll in lengths.items():
+        mel, noise = synthetic_inputs(500 + sid, 1, ll)
+        data[sid] = (mel[0], noise[0])
+        offline[sid] = offline_f23_engine.forward(torch.as_tensor(mel).cuda(), noise=torch.as_tensor(noise).cuda()).cpu().numpy()[0]
+
+    def run(use_graph):
+        syn = StreamingSynthesizer(engine, chunk_frames=8)
+        syn.use_graph = use_graph
+        got = {sid: [] for sid in lengths}
+        pos = {sid: 0 for sid in lengths}
+        opened = set()
+        replayed = []
+        for tick in range(60):
+            for sid, ll in lengths.items():
+                if sid == 3 and tick < 4:
+                    continue                                   # stream 3 joins four ticks late
+                if sid not in opened:
+                    syn.open(sid)
+                    opened.add(sid)
+                if pos[sid] < ll:
+                    nn = min(8, ll - pos[sid])
+                    mel, noise = data[sid]
+                    syn.push(sid, mel[pos[sid]:pos[sid] + nn], noise[pos[sid] * 20:(pos[sid] + nn) * 20], last=pos[sid] + nn >= ll)
+                    pos[sid] += nn
+            out = syn.tick()
+            replayed.append(syn.last_tick_replayed if out else None)
+            for sid, audio in out.items():
+                got[sid].append(np.array(audio))
+            if len(opened) == len(lengths) and all(syn.finished(sid) for sid in lengths):
+                break
+        return {sid: np.concatenate(vv) for sid, vv in got.items()}, syn.graph_ticks, replayed
+
+    plain, n_plain, _ = run(False)
+    graphed, n_graph, replayed = run(True)
+    assert n_plain == 0 and n_graph >= 6
+    # replay stops when the stream set changes and resumes afterwards
+    flips = sum(1 for aa, bb in zip(replayed, replayed[1:]) if aa is True and bb is False)
+    assert flips >= 1 and replayed.count(True) == n_graph
+    for sid in lengths:
+        assert np.array_equal(graphed[sid], plain[sid]), f"stream {sid}: graph replay differs from the launch-by-launch ticks"
+        assert np.array_equal(graphed[sid], offline[sid]), f"stream {sid} differs from the offline synthesis"
+
+
+def test_window_advance(engine):
+    """mbx_window_advance: in-place shift of the device-resident windows + append of the new frames."""
+    import torch
+    rng = np.random.default_rng(0)
+    B, T, step = 3, 35, 8
+    mel = rng.normal(size=(B, T, 80)).astype(np.float32)
+    noise = rng.normal(size=(B, T * 20)).astype(np.float32)
+    mel_new = rng.normal(size=(B, step, 80)).astype(np.float32)
+    noise_new = rng.normal(size=(B, step * 20)).astype(np.float32)
+    mel_d, noise_d = torch.as_tensor(mel).cuda(), torch.as_tensor(noise).cuda()
+    engine.window_advance(mel_d, torch.as_tensor(mel_new).cuda(), noise_d, torch.as_tensor(noise_new).cuda())
+    assert np.array_equal(mel_d.cpu().numpy(), np.concatenate((mel[:, step:], mel_new), axis=1))
+    assert np.array_equal(noise_d.cpu().numpy(), np.concatenate((noise[:, step * 20:], noise_new), axis=1))
+    engine.window_advance(mel_d, torch.as_tensor(mel_new).cuda())          # mel only
+    assert np.array_equal(mel_d.cpu().numpy()[:, -step:], mel_new)
+    with pytest.raises(ValueError):
+        engine.window_advance(mel_d, torch.as_tensor(mel_new[:, :, :40]).cuda())

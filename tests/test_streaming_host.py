@@ -40,3 +40,66 @@ def test_pack_state_layout():
     assert st.dtype.name == "int32" and st.shape == (6,)
     assert list(st[2:]) == [17, 400, 1200, 0]
     assert st[:2].view("float32").tolist() == [0.25, 3.5]
+
+
+class _FakeEngine:
+    """CPU test double of the engine surface the streaming driver uses (NOT the oracle, not a product path): the audio of
+    frame t is sum(mel[t]) + noise[t * spf] on every sample of the frame, so the streamed output is known in closed form
+    and any mistake in the window assembly / the shared input rows shows up."""
+
+    def __init__(self):
+        import torch
+        cfg = canonical_config("SPEECH")
+        self.config, self.dims, self.device = cfg, ModelDims(cfg), torch.device("cpu")
+
+    def layer_state_info(self):
+        return 0, 0, 0
+
+    def forward(self, mel, n_frames=None, noise=None, stream_state=None, **_):
+        import torch
+        hop, spf = self.dims.hop_size, self.dims.steps_per_frame
+        val = mel.sum(dim=2) + noise[:, ::spf]
+        return val.repeat_interleave(hop, dim=1), torch.zeros_like(stream_state)
+
+
+def test_shared_input_rows_drop_and_grow():
+    """push() keeps the frames of all streams in shared rows: frames in front of the next window are dropped when a row
+    runs full, the rows grow when that is not enough; the windows a tick assembles are unaffected."""
+    import numpy as np
+    from mbexwn_vocoder_amd.streaming import StreamingSynthesizer
+    syn = StreamingSynthesizer(_FakeEngine(), chunk_frames=8)
+    syn.use_graph = False
+    assert syn._in_cap == 256
+    rng = np.random.default_rng(0)
+    lengths = {"a": 700, "b": 45, "c": 300}
+    data = {sid: (rng.normal(size=(ll, 80)).astype(np.float32), rng.normal(size=(ll * 20,)).astype(np.float32))
+            for sid, ll in lengths.items()}
+    got = {sid: [] for sid in lengths}
+    pos = {sid: 0 for sid in lengths}
+    syn.open("a")
+    syn.open("b")
+    syn.push("a", data["a"][0][:300], data["a"][1][:6000])        # more than a row holds: the rows grow
+    pos["a"] = 300
+    assert syn._in_cap >= 300
+    for tick in range(400):
+        if tick == 3:
+            syn.open("c")
+        for sid in list(syn.streams):
+            ll = lengths[sid]
+            if pos[sid] < ll:
+                nn = min(int(rng.integers(1, 13)), ll - pos[sid])      # slower than the ticks consume
+                mel, noise = data[sid]
+                syn.push(sid, mel[pos[sid]:pos[sid] + nn], noise[pos[sid] * 20:(pos[sid] + nn) * 20], last=pos[sid] + nn >= ll)
+                pos[sid] += nn
+        for sid, audio in syn.tick().items():
+            got[sid].append(audio)
+        if len(syn.streams) == 3 and all(syn.finished(sid) for sid in lengths):
+            break
+    assert syn._in_cap == 512                            # stream "a" never held its 700 frames at once: old frames were dropped
+    assert syn.streams["a"].base > 0
+    for sid, ll in lengths.items():
+        mel, noise = data[sid]
+        want = np.repeat(mel.sum(axis=1) + noise[::20], 300)
+        out = np.concatenate(got[sid])
+        assert out.shape == (ll * 300,)
+        np.testing.assert_allclose(out, want, rtol=0, atol=2e-5)      # float32 sums of the test double
