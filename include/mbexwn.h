@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MBX_ABI_VERSION 4
+#define MBX_ABI_VERSION 5
 #define MBX_MAX_SUBNET_OPS 32
 #define MBX_MAX_WN_LAYERS 64
 #define MBX_NAME_LEN 64
@@ -221,6 +221,23 @@ typedef struct {
     int32_t layer_store_floats;
     const int32_t *layer_carry;
     int32_t layer_rows;
+    /* Streaming windows, fourth level: the mel-rate front end (conditioning rows, cepstrum, F0 contour) carried between
+     * the ticks of a stream.  Every sub-net has a finite receptive field, so the frames a window shares with the window
+     * of the tick before keep their values; only the frames the new mel frames can reach are computed.
+     *   fe_store          device (slots, fe_ring_frames, 2 C cond_conv_upsampling + n_ceps + pulse_per_frame) persistent
+     *                     ring of the caller, or NULL; the slot of item b is sub_carry[b][0] (sub_carry is then required)
+     *   fe_ring_frames    frames of a slot's ring (>= max_frames)
+     *   fe_pos            device (batch) int32: ring frame of window frame 0 of each item (its absolute frame modulo
+     *                     fe_ring_frames, so that a frame keeps its place from tick to tick)
+     *   fe_new_frames     0: the front end runs on the whole window and every frame goes to the ring; > 0: every item spans
+     *                     the whole window (a steady tick), the sub-nets run on its last fe_new_frames + fe_margin_frames
+     *                     frames, the frames in front of the last fe_new_frames are taken from the ring, the new ones go
+     *                     there.  fe_new_frames = frames the window moved by + the frames at the window end that the
+     *                     sub-nets' look-ahead leaves inexact; fe_margin_frames = their reach into the past. */
+    float *fe_store;
+    int32_t fe_ring_frames;
+    const int32_t *fe_pos;
+    int32_t fe_new_frames, fe_margin_frames;
 } mbx_forward_options;
 
 /* Geometry of the per-layer state (mbx_forward_options.layer_store): floats per slot (0: the handle cannot carry layer

@@ -218,6 +218,37 @@ void launch_layer_carry(const LayerCarryArgs &a, int batch, hipStream_t stream) 
     hipLaunchKernelGGL(layer_carry_kernel, dim3(std::min((n + 255) / 256, 64), batch), dim3(256), 0, stream, a);
 }
 
+// Front end carried between the ticks of a stream (FrontendCarryArgs): one block row per (frame, item); float4 copies.
+__global__ void frontend_carry_kernel(FrontendCarryArgs a) {
+    const int f = blockIdx.x, b = blockIdx.y;
+    const int n = a.n_frames ? min(a.n_frames[b], a.frames) : a.frames;
+    if (f >= n) return;
+    const int per_frame = a.cond_floats + a.ceps_floats + a.f0_floats;
+    int rf = (a.pos[b] + f) % a.ring_frames;
+    if (rf < 0) rf += a.ring_frames;
+    float *ring = a.store + ((long long)a.slot_desc[5 * b] * a.ring_frames + rf) * per_frame;
+    const bool restore = f < a.first_new;
+    float *bufs[3] = {a.cond + ((long long)b * a.frames + f) * a.cond_floats, a.ceps + ((long long)b * a.frames + f) * a.ceps_floats,
+                      a.f0 + ((long long)b * a.frames + f) * a.f0_floats};
+    const int sizes[3] = {a.cond_floats, a.ceps_floats, a.f0_floats};
+    int off = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float4 *win = reinterpret_cast<float4 *>(bufs[k]);
+        float4 *rg = reinterpret_cast<float4 *>(ring + off);
+        for (int i = threadIdx.x; i < sizes[k] / 4; i += blockDim.x) {
+            if (restore) win[i] = rg[i];
+            else rg[i] = win[i];
+        }
+        off += sizes[k];
+    }
+}
+
+void launch_frontend_carry(const FrontendCarryArgs &a, int batch, hipStream_t stream) {
+    if (batch <= 0 || a.frames <= 0) return;
+    hipLaunchKernelGGL(frontend_carry_kernel, dim3(a.frames, batch), dim3(128), 0, stream, a);
+}
+
 // Streaming windows kept on the device (mbx_window_advance): every row of `win` (batch, frames * row_floats) moves
 // `step * row_floats` floats to the left and the freed tail is filled from `fresh` (batch, step * row_floats).  One block
 // per (item, buffer); the kept part goes through LDS so that the move is safe in place.

@@ -92,6 +92,7 @@ struct mbx_handle {
     bool fold_skip = false;      // skip path folded into the end convolution (needs the *.fold tensors)
     bool fold_start = false;     // start convolution folded into layer 0 (needs fold_skip and the *.start_fold / *.fold_start tensors)
     bool winograd4_always = false;   // MBX_WINOGRAD=44: F(4,3) at every size (tests)
+    long long resskip_wave_tiles = 2048;   // default policy: res/skip launches of at most this many 16-row tiles run the wave-tiled kernel
     int winograd = 0;            // gate layer form: 0 direct, 2 Winograd F(2,3), 4 Winograd F(4,3) (needs the packed weights)
     // bench-only kernel timing (mbx_profile_*): one event pool per stage of the launch sequence
     bool profiling = false;
@@ -220,8 +221,14 @@ struct SubnetRun {
     const float *cur;
     int chan, rpf = 1, pp = 0, last_writer = -1, i = 0;
     long long cur_bstride;
+    long long stride_frames = 0;   // > 0: frames between batch items of the input and of the final output (a sub-window of a
+                                   // longer window is being computed: mbx_forward_options.fe_new_frames); 0: T
     bool affine_done, finished = false;
     mbx_status status = MBX_OK;
+    void window_stride(long long frames, int cin) {
+        stride_frames = frames;
+        cur_bstride = frames * cin;
+    }
 
     SubnetRun(mbx_handle *hd_, const mbx_subnet_op *ops_, int n_ops_, const float *in, int cin, const int *n_frames_,
               int B_, int T_, float *buf0_, float *buf1_, float *final_out_, bool affine, float scale_, float offset_,
@@ -248,7 +255,7 @@ struct SubnetRun {
                 if (!w || !bias) return stop(fail(MBX_ERR_INVALID_ARGUMENT, std::string("missing tensor ") + op.name + ".w/.b"));
                 float *out = (i == last_writer) ? final_out : (pp ? buf1 : buf0);
                 pp ^= 1;
-                const long long out_bstride = (long long)T * rpf * op.cout;
+                const long long out_bstride = ((i == last_writer && stride_frames) ? stride_frames : (long long)T) * rpf * op.cout;
                 mbx::ConvArgs a = conv_args(cur, cur_bstride, chan, n_frames, rpf, T * rpf, B, w, bias, op.ks, op.cin,
                                             op.cout, 1, op.pad_l, op.pad_mode, out, out_bstride, op.cout);
                 if (i + 1 < n_ops && ops[i + 1].kind == MBX_OP_PRELU && op.up == 1) {
@@ -285,7 +292,7 @@ struct SubnetRun {
                     of = offset;
                     affine_done = true;
                 }
-                const long long out_bstride = (long long)T * rpf * op.up * chan;
+                const long long out_bstride = ((i == last_writer && stride_frames) ? stride_frames : (long long)T) * rpf * op.up * chan;
                 mbx::launch_lin_interp(cur, cur_bstride, n_frames, rpf, T * rpf, B, chan, op.up, it->second.first,
                                        it->second.second, act, sc, of, out, out_bstride, stream);
                 i += consumed;
@@ -613,6 +620,8 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
             hd->winograd = 4;
             hd->winograd4_always = true;
         }
+        const char *rv = getenv("MBX_RV_TILES");
+        if (rv) hd->resskip_wave_tiles = atoll(rv);
     }
     *out = hd;
     return MBX_OK;
@@ -709,6 +718,9 @@ struct ForwardExtras {
     const int32_t *sub_carry = nullptr;
     int active_max_frames = 0, wn_max_frames = 0;
     const LayerOpts *lay = nullptr;
+    float *fe_store = nullptr;
+    int fe_ring_frames = 0, fe_new_frames = 0, fe_margin_frames = 0;
+    const int32_t *fe_pos = nullptr;
 };
 
 static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *n_frames, int32_t batch,
@@ -724,6 +736,22 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     const int active_max_frames = ex.active_max_frames, wn_max_frames = ex.wn_max_frames;
     const LayerOpts *lay = ex.lay;
     if (!hd || !mel || !audio || !workspace) return fail(MBX_ERR_INVALID_ARGUMENT, "null argument");
+    // mel-rate front end carried between the ticks of a stream (mbx_forward_options.fe_store): fe_frames > 0 = only the
+    // last fe_frames frames of the window are computed, the frames in front of them come from the ring
+    const bool fe_on = ex.fe_store != nullptr;
+    int fe_frames = 0;
+    if (fe_on) {
+        if (!ex.fe_pos || !ex.sub_carry || ex.fe_ring_frames < max_frames || ex.fe_new_frames < 0 || ex.fe_margin_frames < 0 ||
+            ex.fe_new_frames + ex.fe_margin_frames > max_frames)
+            return fail(MBX_ERR_INVALID_ARGUMENT, "fe_store needs fe_pos, sub_carry (slots), fe_ring_frames >= max_frames and "
+                                                  "fe_new_frames + fe_margin_frames <= max_frames");
+        if (hd->cfg.nm_iters > 0 || hd->f0_time_factor > hd->cfg.pulse_per_frame || ex.f0_in)
+            return fail(MBX_ERR_UNSUPPORTED, "the front end cannot be carried for this model / call (RMS normalisation, an F0-net "
+                                             "that runs above the pulse rate, an external F0 contour)");
+        if ((2 * hd->cfg.wn_channels * hd->cfg.cond_conv_upsampling) % 4 || hd->cfg.n_ceps % 4 || hd->cfg.pulse_per_frame % 4)
+            return fail(MBX_ERR_UNSUPPORTED, "the front end ring needs per-frame sizes that are multiples of 4 floats");
+        if (ex.fe_new_frames > 0) fe_frames = ex.fe_new_frames + ex.fe_margin_frames;
+    }
     if (batch <= 0 || max_frames <= 0) return fail(MBX_ERR_INVALID_ARGUMENT, "batch and max_frames must be positive");
     DeviceGuard guard(hd->device);
     if (!guard.ok) return fail(MBX_ERR_HIP, "cannot select the handle's device");
@@ -764,15 +792,25 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     // mel-rate convolutions are latency-bound)
     {
         ScopedEvents ev(hd, PROF_FRONTEND, stream);
-        mbx::ConvArgs cond_conv = conv_args(mel, (long long)T * c.mel_channels, c.mel_channels, n_frames, 1, T, B, cw,
+        // a carried front end computes the frames [T - fe_frames, T) of every item only (all items then span the whole
+        // window: a steady tick); batch strides stay those of the window
+        const int Tf = fe_frames ? fe_frames : T;
+        const long long f_off = T - Tf;
+        const int32_t *nf_fe = fe_frames ? nullptr : n_frames;
+        const float *mel_fe = mel + f_off * c.mel_channels;
+        mbx::ConvArgs cond_conv = conv_args(mel_fe, (long long)T * c.mel_channels, c.mel_channels, nf_fe, 1, Tf, B, cw,
                                             cbias, c.cond_kernel_size, c.mel_channels, cond_cout, 1,
-                                            (c.cond_kernel_size - 1) / 2, MBX_PAD_ZERO, w.cond, (long long)T * cond_cout,
-                                            cond_cout);
-        SubnetRun vtf(hd, c.vtf_ops, c.n_vtf_ops, mel, c.mel_channels, n_frames, B, T, w.sub2, w.sub3, w.ceps, false, 1.f,
-                      0.f, stream);
+                                            (c.cond_kernel_size - 1) / 2, MBX_PAD_ZERO, w.cond + f_off * cond_cout,
+                                            (long long)T * cond_cout, cond_cout);
+        SubnetRun vtf(hd, c.vtf_ops, c.n_vtf_ops, mel_fe, c.mel_channels, nf_fe, B, Tf, w.sub2, w.sub3,
+                      w.ceps + f_off * c.n_ceps, false, 1.f, 0.f, stream);
         const bool f0_wide = hd->f0_time_factor > c.pulse_per_frame;
-        SubnetRun f0(hd, c.f0_ops, c.n_f0_ops, mel, c.mel_channels, n_frames, B, T, w.sub0, w.sub1,
-                     f0_wide ? w.f0_wide : w.f0, true, c.f0_max - c.f0_min, c.f0_min, stream);
+        SubnetRun f0(hd, c.f0_ops, c.n_f0_ops, mel_fe, c.mel_channels, nf_fe, B, Tf, w.sub0, w.sub1,
+                     f0_wide ? w.f0_wide : w.f0 + f_off * c.pulse_per_frame, true, c.f0_max - c.f0_min, c.f0_min, stream);
+        if (fe_frames) {
+            vtf.window_stride(T, c.mel_channels);
+            f0.window_stride(T, c.mel_channels);
+        }
         if (f0_in) f0.finished = true;
         bool cond_pending = true;
         for (;;) {
@@ -799,6 +837,26 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     else if (transposition != 1.f)
         mbx::launch_activation(w.f0, npulse, n_frames, c.pulse_per_frame, (int)npulse, B, 1, MBX_ACT_LINEAR,
                                transposition, 0.f, w.f0, npulse, stream);
+    if (fe_on) {
+        // frames in front of the new ones come from the ring (they were computed, exactly, by earlier ticks); the new
+        // ones (fe_new_frames == 0: the whole window) go there for the ticks to come
+        ScopedEvents ev(hd, PROF_FRONTEND, stream);
+        mbx::FrontendCarryArgs fc{};
+        fc.cond = w.cond;
+        fc.ceps = w.ceps;
+        fc.f0 = w.f0;
+        fc.cond_floats = cond_cout;
+        fc.ceps_floats = c.n_ceps;
+        fc.f0_floats = c.pulse_per_frame;
+        fc.frames = T;
+        fc.n_frames = n_frames;
+        fc.store = ex.fe_store;
+        fc.ring_frames = ex.fe_ring_frames;
+        fc.pos = ex.fe_pos;
+        fc.slot_desc = ex.sub_carry;
+        fc.first_new = fe_frames ? T - ex.fe_new_frames : 0;
+        mbx::launch_frontend_carry(fc, B, stream);
+    }
     // ---- wavetable excitation (reference :889)
     {
         ScopedEvents ev(hd, PROF_WAVETABLE, stream);
@@ -1013,6 +1071,18 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                     rw.w = fww->ptr;
                     done = mbx::launch_wn_resskip_wide(rw, stream);
                 }
+                // small launches: wave-granular tiles (wn_resskip_wave.hip).  The form pinned by the streams and by
+                // MBX_WINOGRAD=2 (F(2,3) gate) runs this kernel at every size: an output's arithmetic does not depend on
+                // its cut, so windows, per-layer regions and whole utterances agree bit for bit.
+                const DevTensor *fwv = done ? nullptr : find(hd, "wn.res_skip_" + ls + (ext ? ".fold_start_wave" : ".fold_wave"));
+                const long long wave_tiles = ((long long)rs.max_rows + 15) / 16 * B;
+                const bool pinned23 = hd->winograd == 2 || (hd->winograd != 0 && (st_in || st_out));
+                if (fwv && fwv->ndim == 3 && fwv->shape[0] == (cin_l + 15) / 16 && fwv->shape[1] == 12 && fwv->shape[2] == 512 &&
+                    (pinned23 || (hd->winograd == 4 && !hd->winograd4_always && wave_tiles <= hd->resskip_wave_tiles))) {
+                    mbx::ConvArgs rw = r;
+                    rw.w = fwv->ptr;
+                    done = mbx::launch_wn_resskip_wave(rw, stream);
+                }
                 if (!done && !mbx::launch_wn_resskip(r, stream)) return fail(MBX_ERR_INVALID_ARGUMENT, "folded res/skip layer does not fit its kernel");
             }
             continue;
@@ -1171,6 +1241,11 @@ mbx_status mbx_forward_ex(mbx_handle *hd, const float *mel, const int32_t *n_fra
     ex.active_max_frames = options->active_max_frames;
     ex.wn_max_frames = options->wn_max_frames;
     ex.lay = options->layer_carry ? &lay : nullptr;
+    ex.fe_store = options->fe_store;
+    ex.fe_ring_frames = options->fe_ring_frames;
+    ex.fe_pos = options->fe_pos;
+    ex.fe_new_frames = options->fe_new_frames;
+    ex.fe_margin_frames = options->fe_margin_frames;
     return forward_impl(hd, mel, n_frames, batch, max_frames, noise, audio, workspace, workspace_bytes, hip_stream, ex);
 }
 

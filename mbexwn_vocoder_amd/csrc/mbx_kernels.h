@@ -98,6 +98,9 @@ bool launch_wn_resskip(const ConvArgs &a, hipStream_t stream);
 // the same layer for large launches, one block owning all columns of its rows (wn_resskip_wide.hip); a.w = image of
 // engine.pack_resskip_wide_weights (ceil(cin/8), ceil(cout/32), 256)
 bool launch_wn_resskip_wide(const ConvArgs &a, hipStream_t stream);
+// the same layer for small launches (one utterance, streaming ticks), tiled at wave granularity (wn_resskip_wave.hip);
+// a.w = image of engine.pack_resskip_wave_weights (ceil(cin/16), 12, 512)
+bool launch_wn_resskip_wave(const ConvArgs &a, hipStream_t stream);
 // WaveNet end convolution + post-net in one pass over the skip tensor (wn_tail.hip); w_end_packed = host-packed
 // weights (ceil(C/8), 2, 32, 4); false: shapes do not fit
 bool launch_wn_tail(const float *skip, long long skip_bstride, const int *n_frames, int rows_per_frame, int max_rows,
@@ -133,6 +136,22 @@ struct LayerCarryArgs {
     int acc_rows;             // stored rows of acc: [e_l, + acc_rows)
 };
 void launch_layer_carry(const LayerCarryArgs &a, int batch, hipStream_t stream);
+// mel-rate front end (conditioning rows, cepstrum, F0 contour) carried between the ticks of a stream (elementwise.hip):
+// per slot a ring of ring_frames frames of [cond | ceps | f0]; window frame f of item b lives at ring frame
+// (pos[b] + f) % ring_frames.  Frames [0, first_new) of the window are read from the ring, frames [first_new, frames) --
+// [first_new, n_frames[b]) with n_frames -- are written to it.
+struct FrontendCarryArgs {
+    float *cond, *ceps, *f0;          // (batch, frames * floats) window buffers
+    int cond_floats, ceps_floats, f0_floats;
+    int frames;
+    const int *n_frames;              // (batch) or null
+    float *store;                     // (slots, ring_frames, cond_floats + ceps_floats + f0_floats)
+    int ring_frames;
+    const int *pos;                   // (batch) ring frame of window frame 0
+    const int *slot_desc;             // (batch, 5): [0] = slot of the item (the sub-band carry descriptors)
+    int first_new;
+};
+void launch_frontend_carry(const FrontendCarryArgs &a, int batch, hipStream_t stream);
 // device-resident streaming windows: shift every item's window left by step_frames and append the new frames
 bool launch_window_advance(float *mel, const float *mel_new, float *noise, const float *noise_new, int batch, int frames,
                            int step_frames, int mel_channels, int steps_per_frame, hipStream_t stream);

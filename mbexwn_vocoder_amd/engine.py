@@ -19,7 +19,7 @@ from .config import ModelDims
 from .subnet import build_subnet
 from .weights import fold_weights, merge_channel_groups
 
-MBX_ABI_VERSION = 4
+MBX_ABI_VERSION = 5
 MBX_MAX_SUBNET_OPS = 32
 MBX_MAX_WN_LAYERS = 64
 MBX_NAME_LEN = 64
@@ -69,7 +69,8 @@ class mbx_forward_options(ctypes.Structure):
                 ("active_frames", ctypes.c_void_p), ("wn_begin", ctypes.c_int32), ("wn_frames", ctypes.c_void_p),
                 ("active_max_frames", ctypes.c_int32), ("wn_max_frames", ctypes.c_int32), ("sub_store", ctypes.c_void_p), ("sub_store_rows", ctypes.c_int32), ("sub_carry", ctypes.c_void_p),
                 ("layer_store", ctypes.c_void_p), ("layer_store_floats", ctypes.c_int32), ("layer_carry", ctypes.c_void_p),
-                ("layer_rows", ctypes.c_int32)]
+                ("layer_rows", ctypes.c_int32), ("fe_store", ctypes.c_void_p), ("fe_ring_frames", ctypes.c_int32),
+                ("fe_pos", ctypes.c_void_p), ("fe_new_frames", ctypes.c_int32), ("fe_margin_frames", ctypes.c_int32)]
 
 
 class mbx_tensor(ctypes.Structure):
@@ -329,6 +330,24 @@ def pack_resskip_wide_weights(w):
     return np.ascontiguousarray(wp.transpose(0, 3, 1, 4, 5, 2).reshape(nk, npair, 256))
 
 
+def pack_resskip_wave_weights(w):
+    """Weights (1, K, cout <= 384) of a WaveNet res/skip 1x1 convolution packed for wn_resskip_wave_kernel
+    (csrc/wn_resskip_wave.hip, v_mfma_f32_16x16x4_f32, 16-channel slices).
+
+    Layout (ceil(K/16) channel slices, 12 column tile pairs, 512): [pair p][even tile | odd tile][lane = 16*kq + n][step]
+    with input channel 16*slice + 4*kq + step and output column 32*p + 2*n + (0 even | 1 odd); out-of-range entries are
+    zero (the image always has 12 pairs, so that every column split of the kernel finds its pairs).
+    """
+    w = np.asarray(w, dtype=np.float32)
+    assert w.ndim == 3 and w.shape[0] == 1 and w.shape[2] <= 384
+    K, cout = w.shape[1], w.shape[2]
+    nk = (K + 15) // 16
+    wp = np.zeros((nk * 16, 12 * 32), dtype=np.float32)
+    wp[:K, :cout] = w[0]
+    wp = wp.reshape(nk, 4, 4, 12, 16, 2)                           # slice, kq, step, pair, n, parity
+    return np.ascontiguousarray(wp.transpose(0, 3, 5, 1, 4, 2).reshape(nk, 12, 512))
+
+
 def pack_end_weights(w):
     """Weights (1, C, n_out <= 32) of the WaveNet end convolution packed for wn_tail_kernel (csrc/wn_tail.hip):
     (ceil(C/8), 2, 32, 4) = [channel group c][lane half lk][column n][k step st] with input channel 8c + 4lk + st,
@@ -374,6 +393,8 @@ def fold_skip_weights(folded, n_layers, channels):
         else:
             out[f"wn.res_skip_{ll}.fold"] = pack_resskip_weights(np.concatenate((w[0][:, :C], proj), axis=1)[None])
             out[f"wn.res_skip_{ll}.fold_wide"] = pack_resskip_wide_weights(np.concatenate((w[0][:, :C], proj), axis=1)[None])
+            if C + n_out <= 384:
+                out[f"wn.res_skip_{ll}.fold_wave"] = pack_resskip_wave_weights(np.concatenate((w[0][:, :C], proj), axis=1)[None])
             if ll == 0:
                 out["__proj_0"] = proj                 # for fold_start_weights; not a device tensor
             biases.append(np.concatenate((b[:C], np.zeros(n_out))))
@@ -426,6 +447,8 @@ def fold_start_weights(folded, dims, fold_skip):
         ext[C:C + 8, :C] = wsp
         out["wn.res_skip_0.fold_start"] = pack_resskip_weights(ext[None])
         out["wn.res_skip_0.fold_start_wide"] = pack_resskip_wide_weights(ext[None])
+        if C + n_out <= 384:
+            out["wn.res_skip_0.fold_start_wave"] = pack_resskip_wave_weights(ext[None])
     return out
 
 
@@ -553,7 +576,7 @@ class MBExWNEngine:
         return ff.value, rr.value, mm.value
 
     def forward(self, mel, n_frames=None, noise=None, out=None, stream_state=None, active=None, wavenet=None, carry=None,
-                layers=None, state_out=None):
+                layers=None, state_out=None, frontend=None):
         """mel (B,T,80) float32 cuda tensor; n_frames int32 cuda tensor (B,) or None;
         noise (B, T*steps_per_frame) float32 cuda tensor (N(0,1) draw) -> audio (B, T*hop) cuda tensor.
 
@@ -600,7 +623,7 @@ class MBExWNEngine:
             elif (state_out.dtype != torch.int32 or tuple(state_out.shape) != (B, 6) or state_out.device != self.device or
                   not state_out.is_contiguous()):
                 raise ValueError("state_out must be a contiguous int32 tensor of shape (batch, 6) on the engine's device")
-            if active is None and (wavenet is not None or carry is not None or layers is not None):
+            if active is None and (wavenet is not None or carry is not None or layers is not None or frontend is not None):
                 raise ValueError("wavenet / carry / layers describe regions inside the active one: pass active as well")
             if active is not None:
                 a0, act = int(active[0]), active[1]
@@ -645,6 +668,18 @@ class MBExWNEngine:
                     keep.append(ldesc)
                     opt.layer_store, opt.layer_store_floats = lstore.data_ptr(), int(lstore.shape[1])
                     opt.layer_carry, opt.layer_rows = ldesc.data_ptr(), int(lrows)
+                if frontend is not None:
+                    ring, fpos, fnew, fmargin = frontend
+                    if (ring.dtype != torch.float32 or ring.dim() != 3 or ring.device != self.device or not ring.is_contiguous() or
+                            ring.shape[2] != self.frontend_frame_floats):
+                        raise ValueError("front-end ring must be a contiguous float32 tensor (slots, ring frames, "
+                                         f"{self.frontend_frame_floats}) on the device")
+                    if fpos.dtype != torch.int32 or tuple(fpos.shape) != (B,) or fpos.device != self.device or carry is None:
+                        raise ValueError("front-end positions must be an int32 tensor (batch,) on the device; carry is required")
+                    fpos = fpos.contiguous()
+                    keep.append(fpos)
+                    opt.fe_store, opt.fe_ring_frames, opt.fe_pos = ring.data_ptr(), int(ring.shape[1]), fpos.data_ptr()
+                    opt.fe_new_frames, opt.fe_margin_frames = int(fnew), int(fmargin)
                 _check(self._lib.mbx_forward_ex(self._handle, mel.data_ptr(),
                                                 n_frames.data_ptr() if n_frames is not None else None, B, T,
                                                 noise.data_ptr() if noise is not None else None, out.data_ptr(),
@@ -682,6 +717,24 @@ class MBExWNEngine:
                                             noise_window.data_ptr() if noise_window is not None else None,
                                             noise_new.data_ptr() if noise_window is not None else None, B, T, step,
                                             self._stream()))
+
+    @property
+    def frontend_carry_supported(self):
+        """True when mbx_forward_ex can carry the mel-rate front end between streaming ticks (fe_store): no RMS
+        normalisation, an F0-net that ends at the pulse rate, per-frame sizes that are multiples of 4 floats."""
+        dd = self.dims
+        f0_ops, _ = subnet_ops(self.config)
+        factor = 1
+        for op in f0_ops:
+            factor *= op.get("up", 1) if op["kind"] in ("conv", "lin") else 1
+        sizes = (2 * dd.wn_channels * dd.cond_conv_upsampling, dd.n_ceps, dd.pulse_per_frame)
+        return not self.normalizes_rms and factor == dd.pulse_per_frame and all(vv % 4 == 0 for vv in sizes)
+
+    @property
+    def frontend_frame_floats(self):
+        """Floats per mel frame of the carried front end: conditioning rows, cepstrum, F0 contour."""
+        dd = self.dims
+        return 2 * dd.wn_channels * dd.cond_conv_upsampling + dd.n_ceps + dd.pulse_per_frame
 
     def profile_enable(self, enabled=True):
         _check(self._lib.mbx_profile_enable(self._handle, 1 if enabled else 0))

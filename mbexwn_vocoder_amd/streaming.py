@@ -66,6 +66,28 @@ def stream_margins(dims, config):
     return left, right, pulse_lead, act_left, act_right, wn_frames
 
 
+def frontend_reach(dims, config):
+    """(left, right) reach in mel frames of the mel-rate front end (F0-net, VTF-net, conditioning convolution): the output
+    of frame t depends on the mel frames [t - left, t + right]."""
+    mb = config["mbexwn_config"]
+
+    def reach(specs):
+        left = right = 0
+        for spec in specs:
+            if spec[0] == "L" or (isinstance(spec[0], str) and spec[0].startswith("L")):
+                continue
+            ks = int(spec[0])
+            left += (ks - 1) // 2 + ((ks - 1) % 2)
+            right += (ks - 1) // 2
+        return left, right
+
+    f0_l, f0_r = reach(mb["pp_subnet"])
+    vt_l, vt_r = reach(mb["ps_subnet"])
+    ck = (dims.cond_kernel_size - 1) // 2
+    # + 1: the interpolators (F0 contour, conditioning rows) reach the next frame
+    return max(f0_l, vt_l, ck), max(f0_r, vt_r, ck) + 1
+
+
 class _Stream:
     def __init__(self):
         # the frames a stream has received live in the synthesizer's shared input buffers (row `slot`): absolute frame f
@@ -106,6 +128,15 @@ class StreamingSynthesizer:
         self.layer_carry = ff > 0 and reach == self.wn_reach * engine.dims.steps_per_frame
         self._layer_floats, self._layer_min_rows = ff, min_rows
         self._layer_store = None      # (slots, floats per slot) on the device
+        # mel-rate front end (conditioning rows, cepstrum, F0 contour) carried from tick to tick in a ring per stream: a
+        # replayed steady tick runs the sub-nets only on the frames its new mel frames can reach
+        self.fe_left, self.fe_right = frontend_reach(engine.dims, engine.config)
+        self.fe_carry = bool(getattr(engine, "frontend_carry_supported", False)) and self.chunk >= self.fe_left
+        ring = 1
+        while ring < self.left + self.chunk + self.right + 2 * 16:
+            ring *= 2
+        self._fe_ring = ring
+        self._fe_store = None         # (slots, ring frames, floats per frame) on the device
         self._free_slots = []
         # input frames of every stream, one row per slot (shared so that a tick gathers its frames with one indexed copy)
         self._in_cap = 256            # frames per row (grows on demand)
@@ -167,6 +198,12 @@ class StreamingSynthesizer:
                 self._layer_store = torch.zeros((n_new, self._layer_floats), dtype=torch.float32, device=self.engine.device)
                 if old_l is not None:
                     self._layer_store[:n_old] = old_l
+            if self.fe_carry:
+                old_f = self._fe_store
+                self._fe_store = torch.zeros((n_new, self._fe_ring, self.engine.frontend_frame_floats), dtype=torch.float32,
+                                             device=self.engine.device)
+                if old_f is not None:
+                    self._fe_store[:n_old] = old_f
             self._free_slots = list(range(n_new - 1, n_old - 1, -1))
             self._graph = None            # the stores moved: a captured tick points at the old ones
             self._grow_inputs(n_new, self._in_cap)
@@ -348,10 +385,12 @@ class StreamingSynthesizer:
         mel_d = torch.as_tensor(mel, device=dev)
         noise_d = torch.as_tensor(noise, device=dev) if self.dims.noise_sigma else None
         # every int32 argument of the call in one upload
-        parts = [states.ravel(), desc.ravel(), ldesc.ravel(), nfr, act, wn if wn is not None else act]
+        use_fe = self.fe_carry and self.carry and tmax <= self._fe_ring
+        fpos = np.asarray([ws % self._fe_ring for ws, _ in windows], dtype=np.int32)
+        parts = [states.ravel(), desc.ravel(), ldesc.ravel(), nfr, act, wn if wn is not None else act, fpos]
         ints_d = torch.as_tensor(np.concatenate(parts), device=dev)
         cuts = np.cumsum([0] + [pp.size for pp in parts])
-        states_d, desc_d, ldesc_d, nfr_d, act_d, wn_d = (ints_d[cuts[ii]:cuts[ii + 1]] for ii in range(6))
+        states_d, desc_d, ldesc_d, nfr_d, act_d, wn_d, fpos_d = (ints_d[cuts[ii]:cuts[ii + 1]] for ii in range(7))
         states_d, desc_d, ldesc_d = states_d.view(B, 6), desc_d.view(B, 5), ldesc_d.view(B, 3)
         self.last_tick_frames = int(nfr.sum())
         if self.time_device:
@@ -367,7 +406,8 @@ class StreamingSynthesizer:
             active=(a0, act_d, int(act.max())),
             wavenet=(wa, wn_d, int(wn.max())) if wn is not None else None,
             carry=(self._store, desc_d) if self.carry else None,
-            layers=(self._layer_store, ldesc_d, layer_rows) if self.layer_carry else None)
+            layers=(self._layer_store, ldesc_d, layer_rows) if self.layer_carry else None,
+            frontend=(self._fe_store, fpos_d, 0, 0) if use_fe else None)      # whole window computed, every frame kept
         if self.time_device:
             ev1.record()
             ev1.synchronize()
@@ -387,7 +427,7 @@ class StreamingSynthesizer:
                 "wa": wa, "lo": lo, "hi": hi, "layer_rows": layer_rows, "act": act.copy(), "wn": wn.copy(),
                 "nfr": nfr.copy(), "desc": desc.copy(), "ldesc": ldesc.copy(), "state_consts": states[:, 3:5].copy(),
                 "mel_d": mel_d, "noise_d": noise_d, "rel0": st0.emitted - ws0, "state_v": state_out.copy(),
-                "slots": np.asarray([st.slot for _, st, _ in todo], dtype=np.int64), "pending": 0,
+                "slots": np.asarray([st.slot for _, st, _ in todo], dtype=np.int64), "pending": 0, "use_fe": use_fe,
                 "frames": self.last_tick_frames, "active_frames": self.last_tick_active_frames,
                 "wavenet_frames": self.last_tick_wavenet_frames}
         result = {}
@@ -458,11 +498,15 @@ class StreamingSynthesizer:
         use_noise = bool(dims.noise_sigma)
         n_mel, n_noise = B * chunk * dims.mel_channels, (B * chunk * spf if use_noise else 0)
         # one pinned host buffer / one device buffer for everything a tick uploads: new mel frames, new noise, phase states
-        stage_host = torch.empty(n_mel + n_noise + B * 6, dtype=torch.float32).pin_memory()
+        stage_host = torch.empty(n_mel + n_noise + B * 7, dtype=torch.float32).pin_memory()
         stage_dev = torch.empty_like(stage_host, device=dev)
         mel_new = stage_dev[:n_mel].view(B, chunk, dims.mel_channels)
         noise_new = stage_dev[n_mel:n_mel + n_noise].view(B, chunk * spf) if use_noise else None
-        states_d = stage_dev[n_mel + n_noise:].view(torch.int32).view(B, 6)
+        states_d = stage_dev[n_mel + n_noise:n_mel + n_noise + B * 6].view(torch.int32).view(B, 6)
+        fpos_d = stage_dev[n_mel + n_noise + B * 6:].view(torch.int32)
+        # front end: the window moved by `chunk` frames and the last fe_right frames of the window before were inexact
+        fe_new, fe_margin = chunk + self.fe_right, self.fe_left
+        use_fe = ctx["use_fe"] and fe_new + fe_margin <= T
         ints = {kk: torch.as_tensor(ctx[kk], device=dev) for kk in ("act", "wn", "nfr", "desc", "ldesc")}
         audio_buf = torch.empty((B, T * hop), dtype=torch.float32, device=dev)
         state_out = torch.empty((B, 6), dtype=torch.int32, device=dev)
@@ -480,6 +524,7 @@ class StreamingSynthesizer:
                         wavenet=(ctx["wa"], ints["wn"], int(ctx["wn"].max())),
                         carry=(self._store, ints["desc"].view(B, 5)) if self.carry else None,
                         layers=(self._layer_store, ints["ldesc"].view(B, 3), ctx["layer_rows"]),
+                        frontend=(self._fe_store, fpos_d, fe_new, fe_margin) if use_fe else None,
                         out=audio_buf, state_out=state_out)
             emit_buf.copy_(audio_buf[:, ctx["lo"]:ctx["hi"]])
             audio_host.copy_(emit_buf, non_blocking=True)
@@ -509,7 +554,9 @@ class StreamingSynthesizer:
         if gg["n_noise"]:
             np.copyto(stage[gg["n_mel"]:gg["n_state"]].reshape(B, chunk, dims.steps_per_frame),
                       self._in_noise[slots[:, None], cols])
-        states = stage[gg["n_state"]:].view(np.int32).reshape(B, 6)
+        ints = stage[gg["n_state"]:].view(np.int32)
+        states = ints[:B * 6].reshape(B, 6)
+        ints[B * 6:] = (emitted - ctx["rel0"]) % self._fe_ring              # ring frame of each window's first frame
         states[:, :3] = ctx["state_v"][:, :3]
         states[:, 3:5] = ctx["state_consts"]
         states[:, 5] = 0

@@ -296,3 +296,29 @@ def test_fold_weights_refuses_a_missing_gain_where_the_reference_always_normalis
         fold_weights({**layer("wn.conv1D_0"), **layer("post", with_g=False)})
     with pytest.raises(KeyError):
         fold_weights({**layer("PS_Layer_final", with_g=False)}, wavenet_weight_norm=False)
+
+
+def test_resskip_wave_image_is_a_permutation_of_the_weights():
+    """wn_resskip_wave_kernel: lane (n = lane & 15, kq = lane >> 4) of pair p reads [even tile steps 0..3 | odd tile steps
+    0..3]; step m contracts input channel 16 slice + 4 kq + m with output column 32 p + 2 n + parity."""
+    rng = np.random.default_rng(11)
+    K, cout = 40, 70
+    w = rng.normal(size=(1, K, cout)).astype(np.float32)
+    img = engine.pack_resskip_wave_weights(w)
+    assert img.shape == ((K + 15) // 16, 12, 512)
+    got = np.zeros((K, cout), dtype=np.float32)
+    seen = 0
+    for kt in range(img.shape[0]):
+        for pp in range(12):
+            for parity in range(2):
+                for lane in range(64):
+                    kq, n = lane >> 4, lane & 15
+                    for st in range(4):
+                        k, col = 16 * kt + 4 * kq + st, 32 * pp + 2 * n + parity
+                        val = img[kt, pp, parity * 256 + lane * 4 + st]
+                        if k < K and col < cout:
+                            got[k, col] = val
+                            seen += 1
+                        else:
+                            assert val == 0.0
+    assert seen == K * cout and np.array_equal(got, w[0])
