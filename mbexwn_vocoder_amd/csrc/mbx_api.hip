@@ -92,6 +92,7 @@ struct mbx_handle {
     bool fold_skip = false;      // skip path folded into the end convolution (needs the *.fold tensors)
     bool fold_start = false;     // start convolution folded into layer 0 (needs fold_skip and the *.start_fold / *.fold_start tensors)
     bool winograd4_always = false;   // MBX_WINOGRAD=44: F(4,3) at every size (tests)
+    int gate_small_shape = -1;       // MBX_WG_SMALL=0|1: pins the F(4,3) block shape of small launches (256-row | product-split; measurements, tests)
     long long resskip_wave_tiles = 2048;   // default policy: res/skip launches of at most this many 16-row tiles run the wave-tiled kernel
     int winograd = 0;            // gate layer form: 0 direct, 2 Winograd F(2,3), 4 Winograd F(4,3) (needs the packed weights)
     // bench-only kernel timing (mbx_profile_*): one event pool per stage of the launch sequence
@@ -620,6 +621,8 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
             hd->winograd = 4;
             hd->winograd4_always = true;
         }
+        const char *gs = getenv("MBX_WG_SMALL");
+        if (gs) hd->gate_small_shape = atoi(gs);
         const char *rv = getenv("MBX_RV_TILES");
         if (rv) hd->resskip_wave_tiles = atoll(rv);
     }
@@ -1010,18 +1013,28 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                 mbx::launch_layer_carry(lc, B, stream);
             }
             bool done = false;
-            // F(4,3): 256-row blocks once they fill the 512 resident slots (2 per CU), below that 128-row blocks whose waves
-            // split the input channels (finer granularity; measured equal at 630 blocks, i.e. one 10 s utterance).
+            // F(4,3) block shape: what a launch of a few blocks per CU costs is the largest number of wave tiles a SIMD gets.
+            // 256-row blocks put one whole tile (16 groups x 64 columns x 6 products) on every SIMD of their CU, the 128-row
+            // product-split blocks half a tile: the finer shape runs when its worst SIMD gets clearly less work (a 10 s
+            // utterance: 630 blocks = 2.46 per CU -> 3 tiles, against 1250 = 4.88 -> 5 halves).  Both give the same bits.
             // Streams run F(2,3): a window is bit-identical to an offline result only if both use one form with one group
             // alignment (streaming.py), and F(2,3) needs the shorter alignment; MBX_WINOGRAD=2 makes offline runs use it too.
             const long long full_blocks = ((nsteps + 255) / 256) * B * ((C + 31) / 32);
+            const long long half_blocks = ((nsteps + 127) / 128) * B * ((C + 31) / 32);
+            const double load_full = (double)((full_blocks + 255) / 256), load_half = 0.5 * (double)((half_blocks + 255) / 256);
+            // measured (scripts/experiments/gate_shapes.py, one item of 3 / 5 / 10 / 15 s: 51 / 65 / 102 / 155 us against 53 / 80 /
+            // 110 / 167 us; two items of 10 s: 194 against 176 us): the finer shape wins up to about one resident round of
+            // 256-row blocks and loses behind it, where both shapes divide evenly and the 128-row block's extra LDS-DMA traffic
+            // per MFMA (the weight slice serves half the rows) and shorter slices tell
+            bool split4 = !hd->winograd4_always && full_blocks <= 1024 && load_half <= load_full;
+            if (hd->gate_small_shape >= 0 && !hd->winograd4_always && full_blocks < 4 * 768) split4 = hd->gate_small_shape != 0;
             const bool use4 = hd->winograd == 4 && !st_in && !st_out;
             const DevTensor *wino4 = use4 ? find(hd, "wn.conv1D_" + ls + ".wino4w") : nullptr;
             if (wino4 && wino4->ndim == 3 && wino4->shape[0] == (C + 31) / 32 && wino4->shape[1] == (C + 7) / 8 &&
                 wino4->shape[2] == 3072 && gs.cphase == 0) {
                 mbx::ConvArgs gw = g;
                 gw.w = wino4->ptr;
-                done = mbx::launch_wn_gate_winograd4w(gw, !(hd->winograd4_always || full_blocks >= 512), stream);
+                done = mbx::launch_wn_gate_winograd4w(gw, split4, stream);
             }
             // F(2,3): wave-tiled kernel on v_mfma_f32_16x16x4_f32 (wn_winograd2w.hip): streams, per-layer regions, MBX_WINOGRAD=2
             const DevTensor *wino = (!done && hd->winograd) ? find(hd, "wn.conv1D_" + ls + ".wino2w") : nullptr;

@@ -20,17 +20,16 @@
 // float2 and stores float2 (a wave instruction writes whole 128-byte rows).  The bias is the initial value of product
 // 1's accumulators (m1 enters all four outputs with coefficient 1).
 //
-// Two block shapes (template):
-//   <256, 1>  large launches: 256 consecutive output rows (64 groups; wave w owns groups 16 w .. 16 w + 15) x 32 gate
+// Two block shapes:
+//   wn_gate_winograd4w_kernel  256 consecutive output rows (64 groups; wave w owns groups 16 w .. 16 w + 15) x 32 gate
 //             channels; K slices of 8 channels, two LDS stages (52.5 KB with the conditioning tile: 3 blocks per CU --
 //             a third wave per SIMD fills matrix-pipe slots the other two leave: 1.40 -> 1.35 ms at batch 16 x 10 s;
 //             a third stage at 2 blocks per CU measured the same as two).
-//   <128, 2>  small launches (batch 1: a launch is only a few rounds of resident blocks, so what decides its time is how
-//             finely the work divides over the 1024 SIMDs): 128 rows x 32 gate channels, waves = 2 row halves x 2 channel
-//             halves: wave (rw, kh) contracts the channels 16 s + 8 kh .. + 7 of every double slice s, i.e. half of K, so
-//             a 10 s utterance becomes 1250 blocks of 960 MFMAs per wave.  The two partial sums of a row half meet
-//             through LDS before the epilogue; each of the two waves then finishes two of the four rows a lane holds.
-//             Stages hold a double slice; two stages.
+//   wn_gate_winograd4p_kernel  128 rows x 32 gate channels, waves = 2 row halves x 2 PRODUCT halves, for launches of a
+//             few blocks per CU (one utterance); same bits; described at the kernel below.
+//   (Round 1/2 also had a 128-row shape whose waves split the input CHANNELS and summed the two halves in front of the
+//   epilogue: 118 us per launch for a 10 s utterance against 110 us for the 256-row shape and 100 us for the
+//   product-split one; removed.)
 // Group Q of the block: q = Q / d, r = Q % d, t = m0 + 4 d q + r (d a power of two <= 16).
 // Per 8-channel slice the block stages, through LDS-DMA:
 //   A: activation rows [m0-16, m0+ROWS+16) x 8 channels in read order: row = m0 - d + d*m + b (b < d) lives in 32-byte
@@ -41,9 +40,9 @@
 //      contracts channels {2 kq + m}.
 //   B: 6 products x 8 channels x 64 columns, packed on the host in MFMA operand order [product j][channel parity e]
 //      [lane][tanh step 0, tanh step 1, sigmoid step 0, sigmoid step 1]: one ds_read_b128 = the weight operands of four MFMAs
-// LDS: stages (44 KB / 72 KB) + the conditioning rows of the block and the per-row interpolation table (8.5 KB / 5 KB)
-// -> 3 / 2 blocks per CU.  The stage loop is unrolled by the number of stages so that every LDS address is a loop-invariant
-// register plus an immediate.
+// LDS: stages (44 KB) + the conditioning rows of the block and the per-row interpolation table (8.5 KB) -> 3 blocks per
+// CU.  The stage loop is unrolled by the number of stages so that every LDS address is a loop-invariant register plus an
+// immediate.
 // (Measured and rejected, batch 16 x 10 s: a fifth wave that issues all LDS-DMA requests, 1.50 ms against 1.39 ms per
 // launch -- the requests then queue on one SIMD whose MFMA waves become the stragglers of every barrier; spreading a
 // slice's requests over three phases instead of issuing them behind the barrier, and s_setprio: no change.)
@@ -59,30 +58,24 @@ constexpr int WW_HALO = 16;
 constexpr int WW_BK = 8;
 constexpr int WW_B_FLOATS = 6 * WW_BK * 64;            // 3072: packed weights of one 8-channel slice
 
-template <int ROWS, int KSPLIT>
 struct WwShape {
+    static constexpr int ROWS = 256;
     static constexpr int AROWS = ROWS + 2 * WW_HALO;            // rows that can be needed
     static constexpr int PHASE = ROWS / 4 + WW_HALO;            // cells per phase (m & 3)
     static constexpr int CELLS = 4 * PHASE;                     // 32-byte cells of 8 channels
-    static constexpr int A_FLOATS = CELLS * WW_BK;              // 2560 | 1536
-    static constexpr int A_CHUNKS = A_FLOATS / 256;             // 1 KB LDS-DMA instructions per slice (A): 10 | 6
-    static constexpr int SUB = A_FLOATS + WW_B_FLOATS;          // one 8-channel slice: A, B behind it
-    static constexpr int STAGE = KSPLIT * SUB;                  // 5632 | 9216 floats
+    static constexpr int A_FLOATS = CELLS * WW_BK;              // 2560
+    static constexpr int A_CHUNKS = A_FLOATS / 256;             // 1 KB LDS-DMA instructions per slice (A): 10
+    static constexpr int STAGE = A_FLOATS + WW_B_FLOATS;        // one 8-channel slice: A, B behind it: 5632 floats
     static constexpr int NSTAGE = 2;
-    static constexpr int ROW_WAVES = ROWS / 64;                 // 4 | 2
-    static constexpr int B_INST = 3 * KSPLIT;                   // weight requests per wave and stage
-    static constexpr int DMA_PER_STAGE = 3 + B_INST;            // 6 | 9
-    static constexpr int COND_ROWS = ROWS == 256 ? 28 : 16;     // conditioning rows of 64 floats (cond_up >= 10)
-    static constexpr int COND_CHUNKS = COND_ROWS / 4;           // 1 KB LDS-DMA requests: 7 | 4, dealt round-robin
+    static constexpr int DMA_PER_STAGE = 6;                     // 3 (A) + 3 (B) requests per wave
+    static constexpr int COND_ROWS = 28;                        // conditioning rows of 64 floats (cond_up >= 10)
+    static constexpr int COND_CHUNKS = COND_ROWS / 4;           // 1 KB LDS-DMA requests: 7, dealt round-robin
     // behind the stages: conditioning tile; per block row lr: (float offset of its conditioning row) << 8 | phase u of
     // the interpolation; the interpolation weights w0[64], w1[64]
     static constexpr int COND = NSTAGE * STAGE;
     static constexpr int TAB = COND + COND_ROWS * 64;
     static constexpr int LERP = TAB + ROWS;
-    static constexpr int LDS_FLOATS = LERP + 128;
-    // <256,1>: 45056 + 7168 + 1024 + 512 = 53760 bytes -> 3 blocks per CU; <128,2>: 79 KB -> 2
-    static constexpr int BLOCKS_PER_CU = LDS_FLOATS * 4 * 3 <= 160 * 1024 ? 3 : 2;
-    static_assert(ROW_WAVES * KSPLIT == 4, "four waves per block");
+    static constexpr int LDS_FLOATS = LERP + 128;               // 45056 + 7168 + 1024 + 512 = 53760 bytes -> 3 blocks per CU
 };
 
 __device__ __forceinline__ void ww_lds_dma16(const float *src, unsigned lds_byte_addr) {
@@ -115,10 +108,9 @@ __device__ __forceinline__ float2 ww_sub(float2 a, float2 b) { return make_float
 template <int N>
 using ww_int = std::integral_constant<int, N>;
 
-template <int ROWS, int KSPLIT>
-__global__ __launch_bounds__(256, (WwShape<ROWS, KSPLIT>::BLOCKS_PER_CU)) void wn_gate_winograd4w_kernel(ConvArgs p, int log2d) {
-    using SH = WwShape<ROWS, KSPLIT>;
-    constexpr int NSTAGE = SH::NSTAGE, STAGE = SH::STAGE, SUB = SH::SUB, A_FLOATS = SH::A_FLOATS, PHASE = SH::PHASE;
+__global__ __launch_bounds__(256, 3) void wn_gate_winograd4w_kernel(ConvArgs p, int log2d) {
+    using SH = WwShape;
+    constexpr int ROWS = SH::ROWS, NSTAGE = SH::NSTAGE, STAGE = SH::STAGE, A_FLOATS = SH::A_FLOATS, PHASE = SH::PHASE;
     typedef __attribute__((address_space(3))) float lds_float;
     __shared__ __attribute__((aligned(16))) float lds[SH::LDS_FLOATS];
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float *)lds);
@@ -139,25 +131,22 @@ __global__ __launch_bounds__(256, (WwShape<ROWS, KSPLIT>::BLOCKS_PER_CU)) void w
     const int d = 1 << log2d;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rw = wave / KSPLIT, kh = wave % KSPLIT;       // row part and channel half of this wave
+    const int rw = wave;                                    // row part of this wave
     const int r16 = lane & 15, kq = lane >> 4;
     const float *xb = p.x + (long long)b * p.x_bstride;
-    const int nk8 = (p.cin + WW_BK - 1) / WW_BK;            // 8-channel slices of the weight image
-    const int nst = (nk8 + KSPLIT - 1) / KSPLIT;            // stage fills
+    const int nk8 = (p.cin + WW_BK - 1) / WW_BK;            // 8-channel slices of the weight image = stage fills
+    const int nst = nk8;
 
     // ---- per-lane DMA sources (fixed for the whole kernel except the channel offset): byte offset of (row, chunk) from
     // the item's first element + validity bits (bit i: the row exists, bit 4 + i: the chunk is the upper half of the slice)
     unsigned a_voff[3];
     unsigned a_bits = 0;
-    int a_inst[3], a_sub[3];
+    int a_inst[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        // <256,1>: 10 chunks; 0..7 are dealt round-robin, 8 and 9 are each written by two waves (same data), which keeps
-        // the number of outstanding LDS-DMA instructions per stage the same for every wave (s_waitcnt vmcnt below)
-        // <128,2>: 2 x 6 chunks, dealt round-robin
-        const int ii = (ROWS == 256) ? (i < 2 ? wave + 4 * i : 8 + (wave & 1)) : wave + 4 * i;
-        a_sub[i] = ii / SH::A_CHUNKS;
-        a_inst[i] = ii - a_sub[i] * SH::A_CHUNKS;
+        // 10 chunks; 0..7 are dealt round-robin, 8 and 9 are each written by two waves (same data), which keeps the
+        // number of outstanding LDS-DMA instructions per stage the same for every wave (s_waitcnt vmcnt below)
+        a_inst[i] = i < 2 ? wave + 4 * i : 8 + (wave & 1);
         const int pos = a_inst[i] * 64 + lane;
         const int cell = pos >> 1;
         const int phase = cell / PHASE, sidx = cell - phase * PHASE;
@@ -167,47 +156,36 @@ __global__ __launch_bounds__(256, (WwShape<ROWS, KSPLIT>::BLOCKS_PER_CU)) void w
         const int hi = (pos & 1) ^ ((cell >> 3) & 1);
         if (row < SH::AROWS && src >= 0 && src < rows) a_bits |= 1u << i;
         a_bits |= (unsigned)hi << (4 + i);
-        a_voff[i] = 4u * (unsigned)(min(max(src, 0), rows - 1) * p.ldx + 8 * a_sub[i] + 4 * hi);
+        a_voff[i] = 4u * (unsigned)(min(max(src, 0), rows - 1) * p.ldx + 4 * hi);
     }
     // interior blocks (every staged row exists, whole stage fills): uniform base + per-lane byte offset, no selects
     // (C = 340: every stage fill but the last one is whole, so only that one takes the masked path)
     const bool fast_rows = p.fast_dma && m0 >= WW_HALO && m0 + ROWS + WW_HALO <= rows;
-    const int whole_fills = p.cin / (WW_BK * KSPLIT);
+    const int whole_fills = p.cin / WW_BK;
     const float *wtile = p.w + (long long)nt * nk8 * WW_B_FLOATS;
     const unsigned b_voff = 16u * (unsigned)lane;
-    // LDS-DMA of stage fill st (channels 8 KSPLIT st ..) into a stage: 3 A + 3 KSPLIT B instructions per wave
+    // LDS-DMA of slice st into a stage: 3 A + 3 B instructions per wave
     auto issue = [&](int st, int stage) {
-        const int ci0 = st * WW_BK * KSPLIT;
+        const int ci0 = st * WW_BK;
         const unsigned sdst = lds_base + 4u * (unsigned)(stage * STAGE);
         if (fast_rows && st < whole_fills) {
             const float *abase = xb + ci0;
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-                ww_lds_dma16_s(abase, a_voff[i], sdst + 4u * (unsigned)(a_sub[i] * SUB) + 1024u * (unsigned)a_inst[i]);
+            for (int i = 0; i < 3; ++i) ww_lds_dma16_s(abase, a_voff[i], sdst + 1024u * (unsigned)a_inst[i]);
+        } else {
 #pragma unroll
-            for (int i = 0; i < SH::B_INST; ++i) {
-                const int ii = wave + 4 * i;                              // 0 .. 12 KSPLIT - 1
-                const int sub = ii / 12, k = ii - 12 * sub;
-                ww_lds_dma16_s(wtile + (long long)(KSPLIT * st + sub) * WW_B_FLOATS + k * 256, b_voff,
-                               sdst + 4u * (unsigned)(sub * SUB + A_FLOATS) + 1024u * (unsigned)k);
+            for (int i = 0; i < 3; ++i) {
+                const int ci = ci0 + 4 * (int)((a_bits >> (4 + i)) & 1u);
+                const bool ok = ((a_bits >> i) & 1u) & (ci < p.cin);
+                const float *src = reinterpret_cast<const float *>(reinterpret_cast<const char *>(xb + ci0) + a_voff[i]);
+                ww_lds_dma16(ok ? src : p.zeros, sdst + 1024u * (unsigned)a_inst[i]);
             }
-            return;
         }
+        const float *bsrc = wtile + (long long)st * WW_B_FLOATS;         // st < nk8: the image has nk8 slices
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int ci = ci0 + 8 * a_sub[i] + 4 * (int)((a_bits >> (4 + i)) & 1u);
-            const bool ok = ((a_bits >> i) & 1u) & (ci < p.cin);
-            const float *src = reinterpret_cast<const float *>(reinterpret_cast<const char *>(xb + ci0) + a_voff[i]);
-            ww_lds_dma16(ok ? src : p.zeros, sdst + 4u * (unsigned)(a_sub[i] * SUB) + 1024u * (unsigned)a_inst[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < SH::B_INST; ++i) {
-            const int ii = wave + 4 * i;
-            const int sub = ii / 12, k = ii - 12 * sub;
-            const int kt8 = KSPLIT * st + sub;
-            const float *src = reinterpret_cast<const float *>(
-                reinterpret_cast<const char *>(wtile + (long long)kt8 * WW_B_FLOATS + k * 256) + b_voff);
-            ww_lds_dma16(kt8 < nk8 ? src : p.zeros, sdst + 4u * (unsigned)(sub * SUB + A_FLOATS) + 1024u * (unsigned)k);
+            const int k = wave + 4 * i;
+            ww_lds_dma16_s(bsrc + k * 256, b_voff, sdst + 4u * (unsigned)A_FLOATS + 1024u * (unsigned)k);
         }
     };
     // ---- conditioning rows of this block (COND_ROWS x (32 tanh | 32 sigmoid) columns): requested first, so every later
@@ -240,8 +218,8 @@ __global__ __launch_bounds__(256, (WwShape<ROWS, KSPLIT>::BLOCKS_PER_CU)) void w
     for (int j = 0; j < 6; ++j)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            // m1 enters y[t] .. y[t+3d] with coefficient 1: its accumulators (of channel half 0) start from the bias
-            const float bv = (j == 1 && kh == 0 && p.bias && ch_ok) ? p.bias[(c & 1) * C + n0 + 2 * r16 + (c >> 1)] : 0.f;
+            // m1 enters y[t] .. y[t+3d] with coefficient 1: its accumulators start from the bias
+            const float bv = (j == 1 && p.bias && ch_ok) ? p.bias[(c & 1) * C + n0 + 2 * r16 + (c >> 1)] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[j][c][r] = bv;
         }
@@ -261,13 +239,13 @@ __global__ __launch_bounds__(256, (WwShape<ROWS, KSPLIT>::BLOCKS_PER_CU)) void w
 
     // A operand: group of this lane Q = 16*rw + r16 -> t = m0 + 4 d (Q >> log2d) + (Q & (d-1)); channels 2 kq, 2 kq + 1
     const int grp = 16 * rw + r16;
-    const float *xptr[6];     // LDS addresses (stage 0, this wave's channel half) of h[t-d] .. h[t+4d]
+    const float *xptr[6];     // LDS addresses (stage 0) of h[t-d] .. h[t+4d]
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
         const int cell = (q & 3) * PHASE + grp + ((q >> 2) << log2d);
-        xptr[q] = lds + kh * SUB + 8 * cell + 4 * ((kq >> 1) ^ ((cell >> 3) & 1)) + 2 * (kq & 1);
+        xptr[q] = lds + 8 * cell + 4 * ((kq >> 1) ^ ((cell >> 3) & 1)) + 2 * (kq & 1);
     }
-    const float *bptr = lds + kh * SUB + A_FLOATS + lane * 4;
+    const float *bptr = lds + A_FLOATS + lane * 4;
 
     float2 x[6];              // raw activation rows of the slice whose combinations are being formed
     float2 u[2];              // input combination of product j in u[j & 1]
@@ -341,13 +319,8 @@ __global__ __launch_bounds__(256, (WwShape<ROWS, KSPLIT>::BLOCKS_PER_CU)) void w
         phase(sc, ww_int<2>());
         phase(sc, ww_int<3>());
         phase(sc, ww_int<4>());
-        // ---- product 5 behind the barrier; fill st+1 must have landed: only fill st+2 (three stages) may be in flight
-        if (NSTAGE == 3 && st + 2 < nst) {
-            if (SH::DMA_PER_STAGE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // ---- product 5 behind the barrier; fill st+1 must have landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (st + NSTAGE < nst) issue(st + NSTAGE, S);
         load_x(ns);
@@ -359,62 +332,19 @@ __global__ __launch_bounds__(256, (WwShape<ROWS, KSPLIT>::BLOCKS_PER_CU)) void w
         WW_FENCE();
     };
 
-    // ---- the first fill has landed (the launchers guarantee nst >= NSTAGE)
-    if (NSTAGE == 3) {
-        if (SH::DMA_PER_STAGE == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-    } else {
-        if (SH::DMA_PER_STAGE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    }
+    // ---- the first fill has landed (the launcher guarantees nst >= NSTAGE); the second one may still be in flight
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __syncthreads();
     load_x(ww_int<0>());
     load_b(ww_int<0>(), ww_int<0>());
     comb(ww_int<0>());
     {
         int st = 0;
-        if constexpr (NSTAGE == 3) {
-            for (; st + 3 <= nst; st += 3) {
-                fill(ww_int<0>(), st);
-                fill(ww_int<1>(), st + 1);
-                fill(ww_int<2>(), st + 2);
-            }
-            if (st < nst) {
-                fill(ww_int<0>(), st);
-                if (st + 1 < nst) fill(ww_int<1>(), st + 1);
-            }
-        } else {
-            for (; st + 2 <= nst; st += 2) {
-                fill(ww_int<0>(), st);
-                fill(ww_int<1>(), st + 1);
-            }
-            if (st < nst) fill(ww_int<0>(), st);
+        for (; st + 2 <= nst; st += 2) {
+            fill(ww_int<0>(), st);
+            fill(ww_int<1>(), st + 1);
         }
-    }
-
-    // ---- <128,2>: the two channel halves of a row part meet: wave kh keeps the rows v in {2 kh, 2 kh + 1} of every
-    // accumulator tile and hands the other two to its partner (through the stage memory: 4 waves x 12 KB)
-    constexpr int NV = 4 / KSPLIT;                   // rows per accumulator tile this wave finishes
-    const int v0 = KSPLIT == 2 ? 2 * kh : 0;
-    if (KSPLIT == 2) {
-        __syncthreads();                             // all LDS operand reads are done
-        float2 *mine = reinterpret_cast<float2 *>(lds) + wave * 1536 + lane;
-#pragma unroll
-        for (int j = 0; j < 6; ++j)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                mine[(j * 4 + c) * 64] = kh ? make_float2(acc[j][c][0], acc[j][c][1]) : make_float2(acc[j][c][2], acc[j][c][3]);
-        __syncthreads();
-        const float2 *theirs = reinterpret_cast<const float2 *>(lds) + (wave ^ 1) * 1536 + lane;
-#pragma unroll
-        for (int j = 0; j < 6; ++j)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float2 t = theirs[(j * 4 + c) * 64];
-                // the kept rows move to registers 0, 1 of the tile
-                acc[j][c][0] = (kh ? acc[j][c][2] : acc[j][c][0]) + t.x;
-                acc[j][c][1] = (kh ? acc[j][c][3] : acc[j][c][1]) + t.y;
-            }
+        if (st < nst) fill(ww_int<0>(), st);
     }
 
     // ---- epilogue: combine the six products, add the conditioning, gate, store the four outputs of the group
@@ -424,8 +354,8 @@ __global__ __launch_bounds__(256, (WwShape<ROWS, KSPLIT>::BLOCKS_PER_CU)) void w
     // everything up to the store is unconditional (every table and conditioning address is valid), so the LDS reads of
     // all rows can be in flight together; only the store is predicated
 #pragma unroll
-    for (int vi = 0; vi < NV; ++vi) {
-        const int gi = 16 * rw + 4 * kq + v0 + vi;                               // group held by this register
+    for (int vi = 0; vi < 4; ++vi) {
+        const int gi = 16 * rw + 4 * kq + vi;                                    // group held by this register
         const int lr0 = ((gi >> log2d) << (log2d + 2)) + (gi & (d - 1));         // its first row, relative to m0
         float y[4][4];                                                           // [column tile][output]
 #pragma unroll
@@ -454,18 +384,315 @@ __global__ __launch_bounds__(256, (WwShape<ROWS, KSPLIT>::BLOCKS_PER_CU)) void w
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// <128 rows, products split>: the shape for launches of a few blocks per CU (one utterance).  Such a launch is bound by
+// how evenly its wave tiles divide over the 1 024 SIMDs: a 10 s utterance is 2 500 wave tiles of 16 groups x 64 columns
+// = 2.44 per SIMD, so a third of the SIMDs work 3 tiles while the rest wait (0.82).  Here a 128-row block has waves = 2
+// row halves x 2 PRODUCT halves: wave (rw, ph) multiplies the products 3 ph .. 3 ph + 2 of its 16 groups over ALL input
+// channels -- half a wave tile of work, 5 000 units = 4.88 per SIMD (0.98) -- and the two product halves of a row half
+// meet once, in front of the epilogue: the wave with m0, m1, m2 hands (m1 + m2, m1 - m2) over and finishes y[t], y[t+d],
+// the wave with m3, m4, m5 hands (m3 + m4, m3 - m4) over and finishes y[t+2d], y[t+3d].  Every sum is formed in the order
+// of the 256-row shape, so both shapes give the SAME bits.  All four waves read the same stage (A: 6 KB, B: 12 KB per 8-channel slice, two stages):
+// 41.5 KB of LDS with the conditioning tile -> 3 blocks per CU.
+struct WpShape {
+    static constexpr int ROWS = 128;
+    static constexpr int AROWS = ROWS + 2 * WW_HALO;
+    static constexpr int PHASE = ROWS / 4 + WW_HALO;            // 48
+    static constexpr int CELLS = 4 * PHASE;                     // 192
+    static constexpr int A_FLOATS = CELLS * WW_BK;              // 1536
+    static constexpr int A_CHUNKS = A_FLOATS / 256;             // 6
+    static constexpr int STAGE = A_FLOATS + WW_B_FLOATS;        // 4608 floats = 18 KB
+    static constexpr int NSTAGE = 2;                            // (three stages at two blocks per CU measured 111 against 100 us)
+    static constexpr int DMA_PER_STAGE = 5;                     // 2 (A: chunks 4, 5 are requested twice) + 3 (B)
+    static constexpr int COND_ROWS = 16;
+    static constexpr int COND = NSTAGE * STAGE;
+    static constexpr int TAB = COND + COND_ROWS * 64;
+    static constexpr int LERP = TAB + ROWS;
+    static constexpr int LDS_FLOATS = LERP + 128;               // 9216 + 1024 + 128 + 128 = 10496 floats = 41 984 bytes
+};
+
+template <int J>
+__device__ __forceinline__ void wp_comb(int PH, const float2 (&x)[6], float2 (&u)[2], float2 &ca, float2 &cb) {
+    // product 3 PH + J of this wave (PH is wave-uniform: a scalar branch); the combination goes to u[J & 1]
+    constexpr int j = J;
+    if (PH == 0) {
+        if (j == 0) u[0] = ww_fma(4.f, x[0], ww_fma(-5.f, x[2], x[4]));
+        if (j == 1) {
+            ca = ww_fma(-4.f, x[2], x[4]);
+            cb = ww_fma(-4.f, x[1], x[3]);
+            u[1] = ww_add(ca, cb);
+        }
+        if (j == 2) u[0] = ww_sub(ca, cb);
+    } else {
+        if (j == 0) {
+            ca = ww_sub(x[4], x[2]);
+            cb = ww_sub(x[3], x[1]);
+            u[0] = ww_fma(2.f, cb, ca);
+        }
+        if (j == 1) u[1] = ww_fma(-2.f, cb, ca);
+        if (j == 2) u[0] = ww_fma(4.f, x[1], ww_fma(-5.f, x[3], x[5]));
+    }
+}
+
+__global__ __launch_bounds__(256, 3) void wn_gate_winograd4p_kernel(ConvArgs p, int log2d) {
+    using SH = WpShape;
+    constexpr int ROWS = SH::ROWS, NSTAGE = SH::NSTAGE, STAGE = SH::STAGE, A_FLOATS = SH::A_FLOATS, PHASE = SH::PHASE;
+    typedef __attribute__((address_space(3))) float lds_float;
+    __shared__ __attribute__((aligned(16))) float lds[SH::LDS_FLOATS];
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float *)lds);
+
+    const int id = blockIdx.x;
+    const int l = id >> 3;
+    const int g_ = (l / p.n_tiles) * 8 + (id & 7);
+    const int nt = l % p.n_tiles;
+    if (g_ >= p.m_tiles_total) return;
+    const int b = g_ / p.m_tiles_per_item;
+    const int mt = g_ - b * p.m_tiles_per_item;
+    const int rows = p.n_frames ? p.n_frames[b] * p.rows_per_frame : p.max_rows;
+    const int m0 = mt * ROWS;
+    if (m0 >= rows) return;
+    const int C = p.channels;
+    const int n0 = nt * 32;
+    const int d = 1 << log2d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rw = wave >> 1, ph = wave & 1;                // row half and product half of this wave
+    const int r16 = lane & 15, kq = lane >> 4;
+    const float *xb = p.x + (long long)b * p.x_bstride;
+    const int nk8 = (p.cin + WW_BK - 1) / WW_BK;
+
+    // ---- per-lane DMA sources of the activation rows (see wn_gate_winograd4w_kernel)
+    unsigned a_voff[2];
+    unsigned a_bits = 0;
+    int a_inst[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        a_inst[i] = i == 0 ? wave : 4 + (wave & 1);         // chunks 4, 5: written by two waves each (same data)
+        const int pos = a_inst[i] * 64 + lane;
+        const int cell = pos >> 1;
+        const int phase = cell / PHASE, sidx = cell - phase * PHASE;
+        const int m = 4 * (sidx >> log2d) + phase;
+        const int row = (m << log2d) + (sidx & (d - 1)) + WW_HALO - d;
+        const int src = m0 - WW_HALO + row;
+        const int hi = (pos & 1) ^ ((cell >> 3) & 1);
+        if (row < SH::AROWS && src >= 0 && src < rows) a_bits |= 1u << i;
+        a_bits |= (unsigned)hi << (4 + i);
+        a_voff[i] = 4u * (unsigned)(min(max(src, 0), rows - 1) * p.ldx + 4 * hi);
+    }
+    const bool fast_rows = p.fast_dma && m0 >= WW_HALO && m0 + ROWS + WW_HALO <= rows;
+    const int whole_fills = p.cin / WW_BK;
+    const float *wtile = p.w + (long long)nt * nk8 * WW_B_FLOATS;
+    const unsigned b_voff = 16u * (unsigned)lane;
+    auto issue = [&](int st, int stage) {
+        const int ci0 = st * WW_BK;
+        const unsigned sdst = lds_base + 4u * (unsigned)(stage * STAGE);
+        if (fast_rows && st < whole_fills) {
+            const float *abase = xb + ci0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) ww_lds_dma16_s(abase, a_voff[i], sdst + 1024u * (unsigned)a_inst[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ci = ci0 + 4 * (int)((a_bits >> (4 + i)) & 1u);
+                const bool ok = ((a_bits >> i) & 1u) & (ci < p.cin);
+                const float *src = reinterpret_cast<const float *>(reinterpret_cast<const char *>(xb + ci0) + a_voff[i]);
+                ww_lds_dma16(ok ? src : p.zeros, sdst + 1024u * (unsigned)a_inst[i]);
+            }
+        }
+        const float *bsrc = wtile + (long long)st * WW_B_FLOATS;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int k = wave + 4 * i;
+            ww_lds_dma16_s(bsrc + k * 256, b_voff, sdst + 4u * (unsigned)A_FLOATS + 1024u * (unsigned)k);
+        }
+    };
+    // ---- conditioning rows of this block (16 x (32 tanh | 32 sigmoid) columns): one request per wave, in front of the stages
+    const int cond_up = p.cond_up;
+    const int t2base = m0 / cond_up;
+    {
+        const int n2 = rows / cond_up;
+        const float *cbase = p.cond + (long long)b * p.cond_bstride;
+        const int pos = wave * 64 + lane;
+        const int crow = pos >> 4, cq = pos & 15;
+        const int chn = n0 + 4 * (cq & 7);
+        const int t = min(t2base + crow, n2 - 1);
+        ww_lds_dma16(chn < C ? cbase + (long long)t * (2 * C) + (cq >> 3) * C + chn : p.zeros,
+                     lds_base + 4u * (unsigned)SH::COND + 1024u * (unsigned)wave);
+    }
+#pragma unroll
+    for (int s0 = 0; s0 < NSTAGE; ++s0)
+        if (s0 < nk8) issue(s0, s0);
+
+    const bool ch_ok = n0 + 2 * r16 < C;
+    f32x4 acc[3][4];          // [product 3 ph + j][column tile: 2 e + (0 tanh | 1 sigmoid)]
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            // m1 enters all four outputs with coefficient 1: its accumulators start from the bias
+            const float bv = (j == 1 && ph == 0 && p.bias && ch_ok) ? p.bias[(c & 1) * C + n0 + 2 * r16 + (c >> 1)] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[j][c][r] = bv;
+        }
+    if (tid < ROWS) {
+        const int row = m0 + tid;
+        const int t2 = row / cond_up;
+        const int u = row - t2 * cond_up;
+        reinterpret_cast<int *>(lds + SH::TAB)[tid] = (((t2 - t2base) * 64) << 8) | u;
+    }
+    if (tid < 64) {
+        lds[SH::LERP + tid] = tid < cond_up ? p.lerp_w0[tid] : 0.f;
+        lds[SH::LERP + 64 + tid] = tid < cond_up ? p.lerp_w1[tid] : 0.f;
+    }
+
+    const int grp = 16 * rw + r16;
+    const float *xptr[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int cell = (q & 3) * PHASE + grp + ((q >> 2) << log2d);
+        xptr[q] = lds + 8 * cell + 4 * ((kq >> 1) ^ ((cell >> 3) & 1)) + 2 * (kq & 1);
+    }
+    const float *bptr = lds + A_FLOATS + (ph * 6) * 256 + lane * 4;      // this wave's three products
+
+    float2 x[6];
+    float2 u[2];
+    float4 bw[3][2];          // weights of this wave's product j in bw[j]: the next slice's product 0 is requested while product 2 waits
+    float2 ca, cb;
+
+    auto load_x = [&](auto sc) {
+        constexpr int S = decltype(sc)::value;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) x[q] = *reinterpret_cast<const float2 *>(xptr[q] + S * STAGE);
+    };
+    auto load_b = [&](auto sc, auto jc) {
+        constexpr int S = decltype(sc)::value, J = decltype(jc)::value;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            bw[J][e] = *reinterpret_cast<const float4 *>(bptr + S * STAGE + (J * 2 + e) * 256);
+    };
+    auto mfma8 = [&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        f32x4 *ac = acc[J];
+        const float2 uu = u[J & 1];
+        const float4 b0 = bw[J][0], b1 = bw[J][1];
+        ac[0] = WW_MFMA(uu.x, b0.x, ac[0]);
+        ac[1] = WW_MFMA(uu.x, b0.z, ac[1]);
+        ac[2] = WW_MFMA(uu.x, b1.x, ac[2]);
+        ac[3] = WW_MFMA(uu.x, b1.z, ac[3]);
+        ac[0] = WW_MFMA(uu.y, b0.y, ac[0]);
+        ac[1] = WW_MFMA(uu.y, b0.w, ac[1]);
+        ac[2] = WW_MFMA(uu.y, b1.y, ac[2]);
+        ac[3] = WW_MFMA(uu.y, b1.w, ac[3]);
+    };
+    // One slice = three phases of 8 MFMAs (one product each); the barrier that publishes slice st+1 sits in front of the
+    // last one.  In: u[0], bw[0] of this wave's first product.  Out: those of the next slice.
+    auto fill = [&](auto sc, int st) {
+        constexpr int S = decltype(sc)::value;
+        ww_int<(S + 1) % NSTAGE> ns;
+        load_b(sc, ww_int<1>());
+        WW_FENCE();
+        wp_comb<1>(ph, x, u, ca, cb);
+        mfma8(ww_int<0>());
+        WW_FENCE();
+        load_b(sc, ww_int<2>());
+        WW_FENCE();
+        wp_comb<2>(ph, x, u, ca, cb);
+        mfma8(ww_int<1>());
+        WW_FENCE();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (st + NSTAGE < nk8) issue(st + NSTAGE, S);
+        load_x(ns);
+        load_b(ns, ww_int<0>());
+        WW_FENCE();
+        mfma8(ww_int<2>());
+        WW_FENCE();
+        wp_comb<0>(ph, x, u, ca, cb);
+        WW_FENCE();
+    };
+
+    // ---- the first slice and the conditioning tile have landed; the later slices may still be in flight
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    __syncthreads();
+    load_x(ww_int<0>());
+    load_b(ww_int<0>(), ww_int<0>());
+    wp_comb<0>(ph, x, u, ca, cb);
+    {
+        int st = 0;
+        for (; st + 2 <= nk8; st += 2) {
+            fill(ww_int<0>(), st);
+            fill(ww_int<1>(), st + 1);
+        }
+        if (st < nk8) fill(ww_int<0>(), st);
+    }
+
+    // ---- the product halves of a row half meet (through the stage memory: 4 waves x 8 KB): every wave hands over the sum
+    // and the difference of its two symmetric products and keeps what it needs of its own
+    __syncthreads();                                 // all LDS operand reads are done
+    float sv[4][4], dv[4][4];                        // [column tile][row v]: s12 / d12 (ph 0) or s34 / d34 (ph 1)
+    {
+        float2 *mine = reinterpret_cast<float2 *>(lds) + wave * 1024 + lane;
+        const int ja = ph == 0 ? 1 : 0, jb = ph == 0 ? 2 : 1;          // m1, m2 | m3, m4 in this wave's accumulators
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                sv[c][v] = acc[ja][c][v] + acc[jb][c][v];
+                dv[c][v] = acc[ja][c][v] - acc[jb][c][v];
+                mine[(c * 4 + v) * 64] = make_float2(sv[c][v], dv[c][v]);
+            }
+    }
+    __syncthreads();
+    const float2 *theirs = reinterpret_cast<const float2 *>(lds) + (wave ^ 1) * 1024 + lane;
+    const float *cl = lds + SH::COND;
+    float *obase = p.out + (long long)b * p.out_bstride + n0 + 2 * r16;
+    const float *clane = cl + 2 * r16;
+#pragma unroll
+    for (int vi = 0; vi < 4; ++vi) {
+        const int gi = 16 * rw + 4 * kq + vi;                                    // group held by this register
+        const int lr0 = ((gi >> log2d) << (log2d + 2)) + (gi & (d - 1));         // its first row, relative to m0
+        float y[4][2];                                                           // [column tile][this wave's two outputs]
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float2 t = theirs[(c * 4 + vi) * 64];                          // (s, d) of the other product half
+            if (ph == 0) {
+                y[c][0] = (acc[0][c][vi] + sv[c][vi]) + t.x;                     // (m0 + s12) + s34
+                y[c][1] = fmaf(2.f, t.y, dv[c][vi]);                             // d12 + 2 d34
+            } else {
+                y[c][0] = fmaf(4.f, sv[c][vi], t.x);                             // s12 + 4 s34
+                y[c][1] = fmaf(8.f, dv[c][vi], t.y) + acc[2][c][vi];             // d12 + 8 d34 + m5
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int lr = lr0 + ((2 * ph + o) << log2d);
+            const int row = m0 + lr;
+            const int e = reinterpret_cast<const int *>(lds + SH::TAB)[lr];
+            const float2 w = make_float2(lds[SH::LERP + (e & 255)], lds[SH::LERP + 64 + (e & 255)]);
+            const float *c0 = clane + (e >> 8);
+            const float2 ct0 = *reinterpret_cast<const float2 *>(c0), ct1 = *reinterpret_cast<const float2 *>(c0 + 64);
+            const float2 cs0 = *reinterpret_cast<const float2 *>(c0 + 32), cs1 = *reinterpret_cast<const float2 *>(c0 + 96);
+            float2 res;
+            res.x = ww_gate_act(y[0][o] + (ct0.x * w.x + ct1.x * w.y), y[1][o] + (cs0.x * w.x + cs1.x * w.y));
+            res.y = ww_gate_act(y[2][o] + (ct0.y * w.x + ct1.y * w.y), y[3][o] + (cs0.y * w.x + cs1.y * w.y));
+            if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res;
+        }
+    }
+}
+
 // a.w must point at the host-packed F(4,3) weights (ceil(C/32), ceil(C/8), 3072) of engine.pack_winograd4w_weights;
-// small = the 128-row shape whose waves split the input channels; returns false if the layer does not fit
-bool launch_wn_gate_winograd4w(const ConvArgs &a, bool small, hipStream_t stream) {
+// split = the 128-row shape whose waves split the six products (same bits as the 256-row shape).  Returns false if the
+// layer does not fit.
+bool launch_wn_gate_winograd4w(const ConvArgs &a, bool split, hipStream_t stream) {
     int log2d = 0;
     while ((1 << log2d) < a.dil) ++log2d;
-    const int rows_blk = small ? 128 : 256;
+    const int rows_blk = split ? 128 : 256;
     const int nk8 = (a.cin + WW_BK - 1) / WW_BK;
     const bool ok = a.ks == 3 && (1 << log2d) == a.dil && a.dil <= WW_HALO && nk8 >= 4 && a.pad_l == a.dil && a.pad_mode == 0 &&
                     a.cin % 4 == 0 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 && a.channels % 4 == 0 &&
                     a.cout == 2 * a.channels && (uintptr_t)a.x % 16 == 0 && (uintptr_t)a.w % 16 == 0 && a.zeros &&
                     a.cond && (uintptr_t)a.cond % 16 == 0 && a.cond_bstride % 4 == 0 && a.cond_up >= 1 &&
-                    a.cond_up <= 64 && (rows_blk + a.cond_up - 2) / a.cond_up + 2 <= (small ? 16 : 28) && a.lerp_w0 && a.lerp_w1 && a.max_rows < (1 << 24);
+                    a.cond_up <= 64 && (rows_blk + a.cond_up - 2) / a.cond_up + 2 <= (split ? 16 : 28) && a.lerp_w0 && a.lerp_w1 && a.max_rows < (1 << 24);
     if (!ok) return false;
     ConvArgs r = a;
     r.fast_dma = (long long)a.max_rows * a.ldx * 4 < (1LL << 32);
@@ -473,8 +700,8 @@ bool launch_wn_gate_winograd4w(const ConvArgs &a, bool small, hipStream_t stream
     r.m_tiles_per_item = (a.max_rows + rows_blk - 1) / rows_blk;
     r.m_tiles_total = r.m_tiles_per_item * a.batch;
     const long long blocks = 8LL * ((r.m_tiles_total + 7) / 8) * r.n_tiles;
-    if (small) hipLaunchKernelGGL((wn_gate_winograd4w_kernel<128, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, r, log2d);
-    else hipLaunchKernelGGL((wn_gate_winograd4w_kernel<256, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, r, log2d);
+    if (split) hipLaunchKernelGGL(wn_gate_winograd4p_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, r, log2d);
+    else hipLaunchKernelGGL(wn_gate_winograd4w_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, r, log2d);
     return true;
 }
 

@@ -747,19 +747,25 @@ class MBExWNEngine:
 
     def gate_form(self, batch, max_frames):
         """Which implementation of the dilated convolution a forward of this size runs (mirror of the policy in
-        csrc/mbx_api.hip: MBX_WINOGRAD, read by mbx_create, default 4 = F(4,3), with 256-row blocks once they fill the
-        512 resident slots and 128-row channel-split blocks below; streams always run F(2,3)):
-        "direct", "winograd_f23", "winograd_f43" or "winograd_f43_small"."""
+        csrc/mbx_api.hip: MBX_WINOGRAD, read by mbx_create, default 4 = F(4,3), with 256-row blocks, or 128-row blocks
+        whose waves split the six products where those spread the work clearly more evenly over the SIMDs; streams always
+        run F(2,3)): "direct", "winograd_f23", "winograd_f43" or "winograd_f43_psplit"."""
         mode = int(os.environ.get("MBX_WINOGRAD", "4"))
         if mode == 0 or self.dims.wn_kernel_size != 3:
             return "direct"
         if mode not in (4, 44):
             return "winograd_f23"
         rows = max_frames * self.dims.steps_per_frame
-        full_blocks = ((rows + 255) // 256) * batch * ((self.dims.wn_channels + 31) // 32)
-        if mode == 44 or full_blocks >= 512:
+        tiles = (self.dims.wn_channels + 31) // 32
+        full_blocks = ((rows + 255) // 256) * batch * tiles
+        half_blocks = ((rows + 127) // 128) * batch * tiles
+        if mode == 44:
             return "winograd_f43"
-        return "winograd_f43_small"
+        small = os.environ.get("MBX_WG_SMALL")
+        if small is not None and full_blocks < 4 * 768:
+            return "winograd_f43" if small == "0" else "winograd_f43_psplit"
+        load_full, load_half = (full_blocks + 255) // 256, 0.5 * ((half_blocks + 255) // 256)
+        return "winograd_f43_psplit" if full_blocks <= 1024 and load_half <= load_full else "winograd_f43"
 
     @property
     def folds_start(self):

@@ -154,6 +154,7 @@ class StreamingSynthesizer:
         # a constant of the capture, and one graph launch stands for the ~30 kernel launches of a tick.  This is the
         # practical form of BASELINE config 5's "persistent-kernel path": the launch sequence persists, not a kernel.
         self.use_graph = True
+        self._inputs_changed = True
         self._steady = None               # what the last steady tick of the launch-by-launch path left behind
         self._graph = None                # the captured tick and its fixed buffers
         self.graph_ticks = 0              # ticks served by a graph replay
@@ -245,6 +246,7 @@ class StreamingSynthesizer:
             self._in_noise[st.slot, col:col + n] = noise
         st.have += n
         st.closed = st.closed or last
+        self._inputs_changed = True       # cached per-stream vectors of a run of replayed ticks are stale
 
     def _ready(self, st):
         have = st.have
@@ -476,10 +478,14 @@ class StreamingSynthesizer:
         the engine call is unchanged."""
         ctx = self._steady
         streams, B = ctx["streams"], ctx["B"]
-        have = np.fromiter((st.have for st in streams), np.int64, B)
-        closed = np.fromiter((st.closed for st in streams), np.int64, B)
+        if self._inputs_changed or "need_v" not in ctx:
+            # frames received (+ whether the stream is closed: its last frame must then lie behind the window) and the
+            # column of absolute frame 0 in the shared input rows; only push() changes them
+            ctx["need_v"] = np.fromiter((st.have - st.closed for st in streams), np.int64, B)
+            ctx["base_v"] = np.fromiter((st.base for st in streams), np.int64, B)
+            self._inputs_changed = False
         emitted = ctx["emitted_v"]
-        if np.any(have < emitted + (self.chunk + self.right) + closed):
+        if int((ctx["need_v"] - emitted).min()) < self.chunk + self.right:
             return False
         ws = np.maximum(0, ((emitted - self.left) // self.align) * self.align)
         if np.any(emitted - ws != ctx["rel0"]):
@@ -547,7 +553,7 @@ class StreamingSynthesizer:
         hop, B = dims.hop_size, ctx["B"]
         stage = gg["stage_np"]
         emitted, slots = ctx["emitted_v"], ctx["slots"]
-        base = np.fromiter((st.base for st in ctx["streams"]), np.int64, B)
+        base = ctx["base_v"]
         # the frames the windows gain: [emitted + right, emitted + right + chunk) of every stream
         cols = (emitted + self.right - base)[:, None] + gg["arange"]
         np.copyto(stage[:gg["n_mel"]].reshape(B, chunk, dims.mel_channels), self._in_mel[slots[:, None], cols])

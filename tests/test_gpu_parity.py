@@ -321,7 +321,7 @@ def test_engine_without_weight_images_runs_the_generic_kernels(torch):
 @pytest.mark.parametrize("batch", [16, 1])
 def test_full_size_gate_forms_agree(torch, monkeypatch, batch):
     """BASELINE config 3 / config 2 sizes (16 x 10 s, 1 x 10 s): the default picks the F(4,3) kernel with 256-row
-    blocks / with channel-split 128-row blocks; its result must agree with the F(2,3) form of the same engine to
+    blocks / with product-split 128-row blocks; its result must agree with the F(2,3) form of the same engine to
     float32 rounding (size-independent property: two algebraically identical evaluations)."""
     from mbexwn_vocoder_amd.engine import MBExWNEngine
     cfg, raw, wt = build_case(*CANON)
@@ -335,6 +335,34 @@ def test_full_size_gate_forms_agree(torch, monkeypatch, batch):
     assert np.all(np.isfinite(outs["4"]))
     assert _maxdiff(outs["4"], outs["2"]) <= 2e-5 * max(1.0, float(np.abs(outs["2"]).max()))
     assert not np.array_equal(outs["4"], outs["2"])       # the default really took the other kernel
+
+
+@pytest.mark.parametrize("voice", ["SPEECH", "VOICE"])
+def test_f43_block_shapes_give_the_same_bits(torch, monkeypatch, voice):
+    """The two block shapes of the F(4,3) gate kernel (MBX_WG_SMALL pins the one small launches take): 256-row blocks and
+    128-row blocks whose waves split the six PRODUCTS form every sum in the same order -> identical audio.  C = 320 and
+    C = 340 (partial column tile, partial last slice), ragged batch of two with an item that ends inside a block; the
+    short item is held to the oracle."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    cfg, raw, wt = build_case(voice, {})
+    lengths = [240, 133]
+    mel, noise = synthetic_inputs(77, 2, 240)
+    nf = torch.as_tensor(lengths, dtype=torch.int32).cuda()
+    outs = {}
+    for shape in ("0", "1"):
+        monkeypatch.setenv("MBX_WG_SMALL", shape)
+        eng = MBExWNEngine(cfg, raw, wt)
+        assert eng.gate_form(2, 240) == {"0": "winograd_f43", "1": "winograd_f43_psplit"}[shape]
+        outs[shape] = eng.forward(dev(torch, mel), n_frames=nf, noise=dev(torch, noise)).cpu().numpy()
+        del eng
+    assert np.array_equal(outs["0"], outs["1"]), "the product-split blocks must give the bits of the 256-row blocks"
+    ref = orc.OracleModel(cfg, raw, wt).forward(mel[1:2, :133], noise[1:2, :133 * 20])[0]
+    assert _maxdiff(outs["1"][1, :133 * 300], ref) <= _tol(ref, E2E_TOL)
+    # the default policy picks one of the two equivalent shapes by how the work divides over the SIMDs
+    monkeypatch.delenv("MBX_WG_SMALL")
+    eng = MBExWNEngine(cfg, raw, wt)
+    assert eng.gate_form(2, 240) in ("winograd_f43", "winograd_f43_psplit")
+    assert np.array_equal(eng.forward(dev(torch, mel), n_frames=nf, noise=dev(torch, noise)).cpu().numpy(), outs["1"])
 
 
 def test_padded_batch_equals_one_at_a_time(torch):
