@@ -61,13 +61,16 @@ __global__ __launch_bounds__(64) void phase_chunk_kernel(const float *__restrict
     for (int i = threadIdx.x; i < padded; i += 64) vin[i] = i < len ? fb[begin + i] / pulse_rate : 0.f;
     __syncthreads();
     if (threadIdx.x == 0) {
-        // separate input / output images and 16 values per trip: the LDS reads of the next values are in flight
-        // while the dependent chain of float32 adds (the only serial part) advances
+        // separate input / output images, 16 values per trip, and the 16 values of the NEXT trip requested from LDS before
+        // the dependent chain of float32 adds (the only serial part) of this trip starts: the chain never waits for a read
         float acc = acc0;
-        for (int i = 0; i < padded; i += 16) {
-            float4 q[4];
+        float4 q[4], nx[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const float4 *>(&vin[i + 4 * u]);
+        for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const float4 *>(&vin[4 * u]);
+        for (int i = 0; i < padded; i += 16) {
+            const int ni = min(i + 16, padded - 16);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) nx[u] = *reinterpret_cast<const float4 *>(&vin[ni + 4 * u]);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 acc = acc + q[u].x; q[u].x = acc;
@@ -76,6 +79,8 @@ __global__ __launch_bounds__(64) void phase_chunk_kernel(const float *__restrict
                 acc = acc + q[u].w; q[u].w = acc;
                 *reinterpret_cast<float4 *>(&vout[i + 4 * u]) = q[u];
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = nx[u];
         }
         chunk_last[(long long)b * chunks_max + c] = acc;   // adding the padding zeros leaves the sum unchanged
     }
@@ -83,10 +88,16 @@ __global__ __launch_bounds__(64) void phase_chunk_kernel(const float *__restrict
     for (int i = threadIdx.x; i < len; i += 64) cb[begin + i] = vout[i];
 }
 
-// (2)+(3) one thread per sample
+// (2)+(3) one thread per sample.  The offset of chunk c = (sum_{j < c} (last_j mod 1)) mod 1, summed in chunk order
+// (tf_wavetable.py:476-483), is the same for every sample of the chunk: each block forms the offsets of the item's chunks
+// once (one lane walks the chain out of LDS; <= WT_MAX_CHUNKS chunks, i.e. 128 s of audio at the 8 kHz pulse rate --
+// longer items sum per sample) instead of every sample walking up to its chunk.
+constexpr int WT_MAX_CHUNKS = 1024;
+
 __global__ void wavetable_kernel(WaveTableConsts k, const float *f0, long long bstride, const int *n_frames,
                                  int samples_per_frame, int n_max, const float *cum, const float *chunk_last,
                                  int chunks_max, float *pulse, float *phase_out, const StreamState *st) {
+    __shared__ float offs[WT_MAX_CHUNKS];
     const int b = blockIdx.y;
     const int n = n_frames ? n_frames[b] * samples_per_frame : n_max;
     const float *fb = f0 + (long long)b * bstride;
@@ -96,6 +107,23 @@ __global__ void wavetable_kernel(WaveTableConsts k, const float *f0, long long b
     const int start = st ? st[b].start_sample : 0;
     const int first_len = st ? k.chunk - st[b].pos_in_chunk : k.chunk;
     const float off0 = st ? st[b].offset_sum : 0.f;
+    // chunks this block's samples can fall into: 0 .. c_hi
+    const int i_last = min(n, n_max) - 1;
+    const int c_hi = i_last < start + first_len ? 0 : 1 + (i_last - start - first_len) / k.chunk;
+    const bool table = c_hi < WT_MAX_CHUNKS;
+    if (table) {
+        for (int j = threadIdx.x; j < c_hi; j += blockDim.x) offs[j + 1] = mod1(lb[j]);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float off = off0;
+            offs[0] = mod1(off);
+            for (int j = 1; j <= c_hi; ++j) {
+                off = off + offs[j];
+                offs[j] = mod1(off);
+            }
+        }
+        __syncthreads();
+    }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         if (i < start) {          // streaming: samples in front of the carried state are not reproducible
             pb[i] = 0.f;
@@ -104,10 +132,14 @@ __global__ void wavetable_kernel(WaveTableConsts k, const float *f0, long long b
         }
         const int rel = i - start;
         const int c = rel < first_len ? 0 : 1 + (rel - first_len) / k.chunk;
-        // offset of chunk c = (sum_{j < c} (last_j mod 1)) mod 1, summed in chunk order (tf_wavetable.py:476-483)
-        float off = off0;
-        for (int j = 0; j < c; ++j) off = off + mod1(lb[j]);
-        off = mod1(off);
+        float off;
+        if (table) {
+            off = offs[c];
+        } else {
+            off = off0;
+            for (int j = 0; j < c; ++j) off = off + mod1(lb[j]);
+            off = mod1(off);
+        }
         const float phase = mod1(cb[i] + off);
         if (phase_out) phase_out[(long long)b * bstride + i] = phase;
         // linear table lookup (tf_wavetable.py:619-638)
