@@ -74,6 +74,10 @@ typedef struct {
 
 /* Model topology: the integers MBExWN.__init__ derives from mbexwn_config / preprocess_config
  * (reference custom_pulsed_generator.py:155-504). */
+#define MBX_GATE_GTU 0
+#define MBX_GATE_GFU 1
+#define MBX_GATE_GSU 2
+
 typedef struct {
     int32_t struct_size;     /* sizeof(mbx_config), checked by mbx_create */
     int32_t abi_version;     /* MBX_ABI_VERSION */
@@ -108,6 +112,10 @@ typedef struct {
     float nm_rms_floor;          /* 1 / max_norm_fact, 0 => none */
     float nm_compressor_exp;
     float nm_lin_amp_scale, nm_lin_amp_off, nm_mel_amp_scale;
+    /* gate of the WaveNet layers (pp_mod_subnet.activation, reference custom_AE_layers.py:312-321): the first half of a
+     * layer's channels goes through MBX_GATE_GTU tanh(z), MBX_GATE_GFU z / (1 + |z|) or MBX_GATE_GSU z / (1 + sqrt|z|),
+     * and is multiplied by the sigmoid of the second half */
+    int32_t wn_gate_activation;
 } mbx_config;
 
 /* A named HOST tensor handed over at creation (weights already weight-norm folded, tables).

@@ -252,13 +252,12 @@ class ModelDims:
             # reference custom_AE_layers.py:165-166; the groups run as block-diagonal dense layers (weights.merge_channel_groups)
             raise RuntimeError(f"WaveNetAE::error::n_channels parameter {self.wn_channels} has to be a multiple of chanel "
                                f"groups parameter {self.wn_groups}")
-        if self.wn_activation != "gtu":
-            raise NotImplementedError("only the gtu (tanh*sigmoid) gate is supported")
+        if self.wn_activation not in ("gtu", "gfu", "gsu"):
+            # reference custom_AE_layers.py:312-318 knows exactly these three
+            raise NotImplementedError(f"WaveNetAE activation {self.wn_activation}: gtu, gfu and gsu are supported")
         # keys of WaveNetAE.__init__ (reference custom_AE_layers.py:120-131) that change the arithmetic and are not built:
         # silently ignoring them would load a valid model and produce wrong audio
-        if wn.get("use_equalized_lr", False):
-            raise NotImplementedError("pp_mod_subnet.use_equalized_lr (W = g v / sqrt(mean v^2), reference "
-                                      "conv_layers.py:151) is not supported")
+        self.wn_equalized_lr = bool(wn.get("use_equalized_lr", False))    # folded on the host (weights.fold_weights)
         if wn.get("pre_cond_layer_channels", None):
             raise NotImplementedError("pp_mod_subnet.pre_cond_layer_channels is not supported")
         if wn.get("disable_conditioning", False):

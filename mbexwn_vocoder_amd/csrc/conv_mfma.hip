@@ -51,7 +51,8 @@ __device__ __forceinline__ int map_row(int s, int n, int mode) {
 //   tanh(x) = 1 - 2 / (1 + e^{2x}),  sigmoid(x) = 1 / (1 + e^{-x})
 // absolute error of the product <= ~3e-7 (v_exp_f32 / v_rcp_f32 are 1 ulp), well inside the stage budget of
 // 2e-5; saturates correctly (e^{2x} = inf -> 1, 0 -> -1).
-__device__ __forceinline__ float gate_act(float zt, float zs) {
+__device__ __forceinline__ float gate_act(int kind, float zt, float zs) {
+    if (kind != 0) return wn_gate_act(kind, zt, zs);          // gfu / gsu (mbx_kernels.h)
     const float e2 = __expf(2.0f * zt);
     const float e1 = __expf(-zs);
     const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e2);
@@ -110,7 +111,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x16 (&acc)[T
                         const float *c1 = cb + t3 * (2 * C);
                         const float zt = (acc[i][0][r] + bt) + (c0[0] * w0 + c1[0] * w1);
                         const float zs = (acc[i][1][r] + bsg) + (c0[C] * w0 + c1[C] * w1);
-                        ob[row * p.ldo] = gate_act(zt, zs);
+                        ob[row * p.ldo] = gate_act(p.gate_act, zt, zs);
                     }
                 }
             }

@@ -435,6 +435,8 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
         return fail(MBX_ERR_INVALID_ARGUMENT, "wn_in_channels must be pulse_channels (+1 with noise)");
     if (c.pqmf_taps % 2) return fail(MBX_ERR_INVALID_ARGUMENT, "PQMF taps must be even");
     if (c.phase_chunk < 1 || c.phase_chunk > 1024) return fail(MBX_ERR_INVALID_ARGUMENT, "phase_chunk must be in [1, 1024]");
+    if (c.wn_gate_activation < MBX_GATE_GTU || c.wn_gate_activation > MBX_GATE_GSU)
+        return fail(MBX_ERR_INVALID_ARGUMENT, "wn_gate_activation must be MBX_GATE_GTU, MBX_GATE_GFU or MBX_GATE_GSU");
 
     mbx_handle *hd = new mbx_handle();
     hd->cfg = c;
@@ -959,6 +961,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         g.lerp_w0 = lerp.first;
         g.lerp_w1 = lerp.second;
         g.channels = C;
+        g.gate_act = c.wn_gate_activation;
         g.zeros = hd->zeros;
         if (l == 0 && fold_start) {
             // start convolution folded into the layer: a K = 24 contraction of the excitation (wn_gate0.hip)
@@ -977,6 +980,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
             g0.w = find(hd, "wn.conv1D_0.start_fold")->ptr;
             g0.bias = g.bias;
             g0.channels = C;
+            g0.gate_act = c.wn_gate_activation;
             g0.dil = d;
             g0.cond = g.cond;
             g0.cond_bstride = g.cond_bstride;

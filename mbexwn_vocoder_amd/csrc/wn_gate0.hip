@@ -29,13 +29,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int G0_ROWS = 256;
 
-__device__ __forceinline__ float g0_gate_act(float zt, float zs) {      // see ww_gate_act (wn_winograd4w.hip)
-    const float t = __builtin_amdgcn_exp2f(fminf(zt, 15.f) * 2.885390081777927f);
-    const float sg = __builtin_amdgcn_exp2f(zs * -1.4426950408889634f);
-    const float tp = t + 1.0f;
-    return (t - 1.0f) * __builtin_amdgcn_rcpf(fmaf(sg, tp, tp));
-}
-
 constexpr int G0_MAX_DIL = 16;
 constexpr int G0_XROWS = G0_ROWS + 2 * G0_MAX_DIL;      // staged rows of x'
 constexpr int G0_COND_ROWS = 32;
@@ -151,8 +144,8 @@ __global__ __launch_bounds__(256) void wn_gate0_kernel(Gate0Args p) {
             const float2 ct0 = *reinterpret_cast<const float2 *>(c0), ct1 = *reinterpret_cast<const float2 *>(c0 + 64);
             const float2 cs0 = *reinterpret_cast<const float2 *>(c0 + 32), cs1 = *reinterpret_cast<const float2 *>(c0 + 96);
             float2 res;
-            res.x = g0_gate_act(acc[0][v] + (ct0.x * w.x + ct1.x * w.y), acc[1][v] + (cs0.x * w.x + cs1.x * w.y));
-            res.y = g0_gate_act(acc[2][v] + (ct0.y * w.x + ct1.y * w.y), acc[3][v] + (cs0.y * w.x + cs1.y * w.y));
+            res.x = wn_gate_act(p.gate_act, acc[0][v] + (ct0.x * w.x + ct1.x * w.y), acc[1][v] + (cs0.x * w.x + cs1.x * w.y));
+            res.y = wn_gate_act(p.gate_act, acc[2][v] + (ct0.y * w.x + ct1.y * w.y), acc[3][v] + (cs0.y * w.x + cs1.y * w.y));
             if (ch_ok && row < rows) *reinterpret_cast<float2 *>(ob + (long long)row * p.ldo + n0 + 2 * r16) = res;
         }
         // x' (8 channels, padded to 16) behind the C gate channels of the rows of this tile: lane -> row lane / 4, 4 floats

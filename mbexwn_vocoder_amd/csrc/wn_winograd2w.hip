@@ -69,14 +69,6 @@ __device__ __forceinline__ void w2_lds_dma16_s(const float *sbase, unsigned voff
                  : "memory", "m0");
 }
 
-// tanh(zt) * sigmoid(zs) = (t - 1) / ((t + 1)(1 + s)), t = e^(2 zt), s = e^(-zs) (see wn_winograd4w.hip)
-__device__ __forceinline__ float w2_gate_act(float zt, float zs) {
-    const float t = __builtin_amdgcn_exp2f(fminf(zt, 15.f) * 2.885390081777927f);
-    const float sg = __builtin_amdgcn_exp2f(zs * -1.4426950408889634f);
-    const float tp = t + 1.0f;
-    return (t - 1.0f) * __builtin_amdgcn_rcpf(fmaf(sg, tp, tp));
-}
-
 #define W2_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
 #define W2_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define W2_SG_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
@@ -351,8 +343,8 @@ __global__ __launch_bounds__(256, (W2Shape<NSTAGE>::WAVES_PER_SIMD)) void wn_gat
             const float2 ct0 = *reinterpret_cast<const float2 *>(c0), ct1 = *reinterpret_cast<const float2 *>(c0 + 64);
             const float2 cs0 = *reinterpret_cast<const float2 *>(c0 + 32), cs1 = *reinterpret_cast<const float2 *>(c0 + 96);
             float2 res;
-            res.x = w2_gate_act(y[0][o] + (ct0.x * w0 + ct1.x * w1), y[1][o] + (cs0.x * w0 + cs1.x * w1));
-            res.y = w2_gate_act(y[2][o] + (ct0.y * w0 + ct1.y * w1), y[3][o] + (cs0.y * w0 + cs1.y * w1));
+            res.x = wn_gate_act(p.gate_act, y[0][o] + (ct0.x * w0 + ct1.x * w1), y[1][o] + (cs0.x * w0 + cs1.x * w1));
+            res.y = wn_gate_act(p.gate_act, y[2][o] + (ct0.y * w0 + ct1.y * w1), y[3][o] + (cs0.y * w0 + cs1.y * w1));
             if (ch_ok && row < out_hi) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res;
         }
     }

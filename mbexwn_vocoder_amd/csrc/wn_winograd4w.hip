@@ -88,15 +88,6 @@ __device__ __forceinline__ void ww_lds_dma16_s(const float *sbase, unsigned voff
                  : "memory", "m0");
 }
 
-// tanh(zt) * sigmoid(zs) = (t - 1) / ((t + 1)(1 + s)), t = e^(2 zt), s = e^(-zs): two exponentials and one reciprocal
-// (zt is clamped where tanh is 1 in float32, so t stays finite; s = inf gives 0, as it should)
-__device__ __forceinline__ float ww_gate_act(float zt, float zs) {
-    const float t = __builtin_amdgcn_exp2f(fminf(zt, 15.f) * 2.885390081777927f);
-    const float sg = __builtin_amdgcn_exp2f(zs * -1.4426950408889634f);
-    const float tp = t + 1.0f;
-    return (t - 1.0f) * __builtin_amdgcn_rcpf(fmaf(sg, tp, tp));
-}
-
 __device__ __forceinline__ float2 ww_fma(float s, float2 a, float2 b) { return make_float2(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y)); }
 __device__ __forceinline__ float2 ww_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 ww_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -377,8 +368,8 @@ __global__ __launch_bounds__(256, 3) void wn_gate_winograd4w_kernel(ConvArgs p, 
             const float2 ct0 = *reinterpret_cast<const float2 *>(c0), ct1 = *reinterpret_cast<const float2 *>(c0 + 64);
             const float2 cs0 = *reinterpret_cast<const float2 *>(c0 + 32), cs1 = *reinterpret_cast<const float2 *>(c0 + 96);
             float2 res;
-            res.x = ww_gate_act(y[0][o] + (ct0.x * w.x + ct1.x * w.y), y[1][o] + (cs0.x * w.x + cs1.x * w.y));
-            res.y = ww_gate_act(y[2][o] + (ct0.y * w.x + ct1.y * w.y), y[3][o] + (cs0.y * w.x + cs1.y * w.y));
+            res.x = wn_gate_act(p.gate_act, y[0][o] + (ct0.x * w.x + ct1.x * w.y), y[1][o] + (cs0.x * w.x + cs1.x * w.y));
+            res.y = wn_gate_act(p.gate_act, y[2][o] + (ct0.y * w.x + ct1.y * w.y), y[3][o] + (cs0.y * w.x + cs1.y * w.y));
             if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res;
         }
     }
@@ -673,8 +664,8 @@ __global__ __launch_bounds__(256, 3) void wn_gate_winograd4p_kernel(ConvArgs p, 
             const float2 ct0 = *reinterpret_cast<const float2 *>(c0), ct1 = *reinterpret_cast<const float2 *>(c0 + 64);
             const float2 cs0 = *reinterpret_cast<const float2 *>(c0 + 32), cs1 = *reinterpret_cast<const float2 *>(c0 + 96);
             float2 res;
-            res.x = ww_gate_act(y[0][o] + (ct0.x * w.x + ct1.x * w.y), y[1][o] + (cs0.x * w.x + cs1.x * w.y));
-            res.y = ww_gate_act(y[2][o] + (ct0.y * w.x + ct1.y * w.y), y[3][o] + (cs0.y * w.x + cs1.y * w.y));
+            res.x = wn_gate_act(p.gate_act, y[0][o] + (ct0.x * w.x + ct1.x * w.y), y[1][o] + (cs0.x * w.x + cs1.x * w.y));
+            res.y = wn_gate_act(p.gate_act, y[2][o] + (ct0.y * w.x + ct1.y * w.y), y[3][o] + (cs0.y * w.x + cs1.y * w.y));
             if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res;
         }
     }

@@ -60,7 +60,7 @@ class mbx_config(ctypes.Structure):
                 ("nm_use_max_limit", ctypes.c_int32), ("nm_rms_norm_fact", ctypes.c_float),
                 ("nm_rms_floor", ctypes.c_float), ("nm_compressor_exp", ctypes.c_float),
                 ("nm_lin_amp_scale", ctypes.c_float), ("nm_lin_amp_off", ctypes.c_float),
-                ("nm_mel_amp_scale", ctypes.c_float)]
+                ("nm_mel_amp_scale", ctypes.c_float), ("wn_gate_activation", ctypes.c_int32)]
 
 
 class mbx_forward_options(ctypes.Structure):
@@ -229,6 +229,7 @@ def make_config(config, wavetables):
     cc.wt_max_transposition = float(wavetables.max_transposition)
     cc.wt_grid_norm = float(wavetables.grid_norm)
     cc.phase_chunk = 1000
+    cc.wn_gate_activation = {"gtu": 0, "gfu": 1, "gsu": 2}[dims.wn_activation]
     f0_ops, vtf_ops = subnet_ops(config)
     cc.n_f0_ops = _fill_ops(cc.f0_ops, f0_ops)
     cc.n_vtf_ops = _fill_ops(cc.vtf_ops, vtf_ops)
@@ -458,7 +459,8 @@ def tensor_table(config, raw_weights, wavetables):
     mb = config["mbexwn_config"]
     mbc = mb["multi_band_config"]
     wn_norm = mb.get("pp_mod_subnet", {}).get("use_weight_norm", None)
-    out = dict(merge_channel_groups(fold_weights(raw_weights, wavenet_weight_norm=wn_norm), dims))
+    out = dict(merge_channel_groups(fold_weights(raw_weights, wavenet_weight_norm=wn_norm,
+                                                 wavenet_equalized_lr=dims.wn_equalized_lr), dims))
     _, syn = tb.pqmf_filters(int(mbc["subbands"]), int(mbc["taps"]), float(mbc["cutoff_ratio"]), float(mbc["beta"]),
                              mbc.get("max_band", None))
     out["table.pqmf_syn"] = syn

@@ -481,10 +481,12 @@ def to_reference_variables(raw, model_scope="mb_ex_wn"):
 
 
 def _uses_weight_norm(config, layer):
-    """WaveNet layers follow pp_mod_subnet.use_weight_norm (reference custom_AE_layers.py:123 default False); the
+    """True when the layer's checkpoint holds a gain g.  WaveNet layers follow pp_mod_subnet.use_weight_norm /
+    use_equalized_lr (reference custom_AE_layers.py:123 default False; conv_layers.py:79-119: either option adds g); the
     sub-nets and the post-net are always weight-normed (custom_pulsed_generator.py:100-148, 490-493)."""
     if layer.startswith("wn."):
-        return bool(config["mbexwn_config"]["pp_mod_subnet"].get("use_weight_norm", False))
+        wn = config["mbexwn_config"]["pp_mod_subnet"]
+        return bool(wn.get("use_weight_norm", False)) or bool(wn.get("use_equalized_lr", False))
     return True
 
 

@@ -62,10 +62,17 @@ def synthetic_weights(config, seed=1234, bias_std=0.0, alpha_jitter=0.0):
     rng = np.random.default_rng(seed)
     convs, prelus = layer_table(config)
     alpha0 = float(config["mbexwn_config"].get("alpha", 0.2))
+    wn_cfg = config["mbexwn_config"]["pp_mod_subnet"]
+    eq_norm = bool(wn_cfg.get("use_equalized_lr", False)) and bool(wn_cfg.get("use_weight_norm", False))
     raw = {}
     for name, ks, cin, cout in convs:
         raw[name + ".v"] = rng.normal(0.0, 0.02, size=(ks, cin, cout)).astype(np.float32)
-        raw[name + ".g"] = np.full((cout,), _SYNTH_GAIN.get(name, 1.0), dtype=np.float32)
+        gain = _SYNTH_GAIN.get(name, 1.0)
+        if eq_norm and name.startswith("wn."):
+            # use_equalized_lr normalises the kernel to unit variance instead of unit norm (W = g v / sqrt(mean v^2)): the
+            # gain takes the 1 / sqrt(fan-in) that keeps the activations at the scale of the weight-normed model
+            gain = gain / np.sqrt(ks * cin)
+        raw[name + ".g"] = np.full((cout,), gain, dtype=np.float32)
         raw[name + ".bias"] = (rng.normal(0.0, 1.0, size=(cout,)) * bias_std).astype(np.float32)
     for name, channels in prelus:
         raw[name + ".alpha"] = (alpha0 + alpha_jitter * rng.uniform(-1, 1, size=(channels,))).astype(np.float32)
@@ -87,19 +94,36 @@ def fold_weight_norm(v, g):
 _PLAIN_KERNEL_PREFIXES = ("wn.",)
 
 
-def fold_weights(raw, wavenet_weight_norm=None):
+def fold_weights(raw, wavenet_weight_norm=None, wavenet_equalized_lr=False):
     """raw variables -> {'<layer>.w': (ks,cin,cout) f32, '<layer>.b': (cout,) f32, '<act>.alpha': ...}.
 
     A layer without a gain ``<layer>.g`` is taken as built with use_weight_norm=False (the kernel is the weight,
     reference conv_layers.py:157-165) only where the reference can build it that way: the ``wn.*`` layers, and only when
     ``wavenet_weight_norm`` is False or unknown (None: raw dicts of tests / converted checkpoints).  A missing gain on any
     other layer -- or on a WaveNet layer of a model configured with weight normalisation -- raises KeyError instead of
-    silently using the un-normalised direction as the weight."""
+    silently using the un-normalised direction as the weight.
+
+    ``wavenet_equalized_lr`` (pp_mod_subnet.use_equalized_lr: every convolution of the WaveNet, reference
+    custom_AE_layers.py:177-260 -> conv_layers.py:133-153): with weight norm W = g v / sqrt(mean_{k,ci} v^2); without it
+    the layer multiplies its whole output by g, i.e. W = g K and b = g bias."""
     out = {}
     for key, val in raw.items():
         if key.endswith(".v"):
             name = key[:-2]
-            if name + ".g" in raw:
+            bias = np.asarray(raw[name + ".bias"], dtype=np.float32)
+            eq = wavenet_equalized_lr and name.startswith(_PLAIN_KERNEL_PREFIXES)
+            if eq:
+                if name + ".g" not in raw:
+                    raise KeyError(f"{name}.g is missing: layers built with use_equalized_lr always hold a gain")
+                v = np.asarray(val, dtype=np.float32)
+                g = np.asarray(raw[name + ".g"], dtype=np.float32)
+                if wavenet_weight_norm:      # conv_layers.py:151: g * v / sqrt(reduce_mean(square(v), axes [0, 1]))
+                    ms = np.mean(np.square(v), axis=(0, 1), keepdims=True, dtype=np.float32)
+                    out[name + ".w"] = ((g * v) / np.sqrt(ms)).astype(np.float32)
+                else:                        # conv_layers.py:135-136: act = g * conv(x) (bias included)
+                    out[name + ".w"] = (g * v).astype(np.float32)
+                    bias = (g * bias).astype(np.float32)
+            elif name + ".g" in raw:
                 out[name + ".w"] = fold_weight_norm(val, raw[name + ".g"])
             else:
                 plain_ok = name.startswith(_PLAIN_KERNEL_PREFIXES) and wavenet_weight_norm is not True
@@ -107,7 +131,7 @@ def fold_weights(raw, wavenet_weight_norm=None):
                     raise KeyError(f"{name}.g is missing: the reference builds this layer with weight normalisation, "
                                    f"so its checkpoint holds a gain (refusing to use {name}.v as the weight)")
                 out[name + ".w"] = np.asarray(val, dtype=np.float32)
-            out[name + ".b"] = np.asarray(raw[name + ".bias"], dtype=np.float32)
+            out[name + ".b"] = bias
         elif key.endswith(".alpha"):
             out[key] = np.asarray(val, dtype=np.float32)
     return out

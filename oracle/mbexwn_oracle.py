@@ -209,10 +209,24 @@ class OracleModel:
         self.f0_smooth = (sw / np.sum(sw)).astype(self.f32)
 
     def weight(self, name):
-        """folded (W, b) of a weight-normed conv layer, cached."""
+        """folded (W, b) of a conv layer, cached.  conv_layers.py:133-153: weight norm W = g v / ||v||; with
+        use_equalized_lr (WaveNetAE layers only, custom_AE_layers.py:177-260) W = g v / sqrt(mean_{k,ci} v^2), or -- without
+        weight norm -- the whole layer output is multiplied by g: W = g K, b = g bias."""
         if name not in self._w:
-            w = fold_weight_norm(self.raw[name + ".v"], self.raw[name + ".g"], self.dtype)
+            v = np.asarray(self.raw[name + ".v"], dtype=np.float64)
             b = np.asarray(self.raw[name + ".bias"]).astype(self.dtype)
+            eq = name.startswith("wn.") and bool(self.wn.get("use_equalized_lr", False))
+            if eq and self.wn.get("use_weight_norm", False):
+                g = np.asarray(self.raw[name + ".g"], dtype=np.float64)
+                w = (g * v / np.sqrt(np.mean(v * v, axis=(0, 1), keepdims=True))).astype(self.dtype)
+            elif eq:
+                g = np.asarray(self.raw[name + ".g"], dtype=np.float64)
+                w = (g * v).astype(self.dtype)
+                b = (g * np.asarray(self.raw[name + ".bias"], dtype=np.float64)).astype(self.dtype)
+            elif name + ".g" in self.raw:
+                w = fold_weight_norm(v, self.raw[name + ".g"], self.dtype)
+            else:                              # a WaveNet layer built without weight norm: the kernel is the weight
+                w = v.astype(self.dtype)
             self._w[name] = (w, b)
         return self._w[name]
 
@@ -330,7 +344,7 @@ class OracleModel:
         return lin_interp(c, lin_up, self.f32)
 
     def wavenet(self, x, mel, return_layers=False):
-        """custom_AE_layers.py:273-346 (WaveNetAE.call), activation gtu; n_ch_groups independent channel groups between
+        """custom_AE_layers.py:273-346 (WaveNetAE.call), activation gtu / gfu / gsu; n_ch_groups independent channel groups between
         the shared start and end convolutions (:303-340; layers of group g > 0 are named "<layer>g<g>", :249,260)."""
         C = self.wn["n_channels"]
         L = self.wn.get("n_layers", 12)
@@ -347,7 +361,17 @@ class OracleModel:
                 sfx = f"g{gg}" if gg else ""
                 w, b = self.weight(f"wn.conv1D_{ll}{sfx}")
                 z = conv1d_same_zero(started[gg], w, b, dilation=self.dilation(ll)) + cond[gg]   # :307-309
-                a = np.tanh(z[..., :Cg]) * (1 / (1 + np.exp(-z[..., Cg:])))       # :312-321
+                zt = z[..., :Cg]
+                act = self.wn.get("activation", "gtu")
+                if act == "gtu":                                                  # :312-318
+                    half = np.tanh(zt)
+                elif act == "gfu":
+                    half = zt / (1 + np.abs(zt))
+                elif act == "gsu":
+                    half = zt / (1 + np.sqrt(np.abs(zt)))
+                else:
+                    raise NotImplementedError(f"WaveNetAE activation {act}")
+                a = half * (1 / (1 + np.exp(-z[..., Cg:])))                       # :320-321
                 w, b = self.weight(f"wn.res_skip_{ll}{sfx}")
                 r = conv1d_valid(a, w, b)                                         # :324
                 if ll < L - 1:

@@ -40,13 +40,24 @@ CASES = {
     # two independent channel groups between the shared start and end convolutions (reference custom_AE_layers.py:303-340)
     "groups": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
                           "mbexwn_config:pp_mod_subnet:n_ch_groups": 2}, 2, 9),
+    # the other two gates of WaveNetAE (reference custom_AE_layers.py:312-318) and use_equalized_lr (conv_layers.py:133-153),
+    # with weight norm (W = g v / sqrt(mean v^2)) and without it (the layer output is multiplied by g)
+    "gfu": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                       "mbexwn_config:pp_mod_subnet:activation": "gfu"}, 2, 9),
+    "gsu_eqlr": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                            "mbexwn_config:pp_mod_subnet:activation": "gsu",
+                            "mbexwn_config:pp_mod_subnet:use_equalized_lr": True}, 2, 9),
+    "eqlr_plain": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                              "mbexwn_config:pp_mod_subnet:use_weight_norm": False,
+                              "mbexwn_config:pp_mod_subnet:use_equalized_lr": True}, 2, 9),
 }
 # the long cases keep the small stage outputs only (the full conditioning / envelope tensors would be megabytes)
-LEAN = {"canon60", "voice", "grammar", "groups"}
+LEAN = {"canon60", "voice", "grammar", "groups", "gfu", "gsu_eqlr", "eqlr_plain"}
 
 
 def assign_conv(layer, raw, name):
-    layer.v.assign(raw[name + ".v"])
+    # a layer built with use_equalized_lr but without weight norm keeps its kernel in the Keras layer and only adds g
+    (layer.v if hasattr(layer, "v") else layer.conv1d_layer.kernel).assign(raw[name + ".v"])
     layer.g.assign(raw[name + ".g"])
     layer.conv1d_layer.bias.assign(raw[name + ".bias"])
 

@@ -17,8 +17,16 @@ GOLDEN_CASES = {
                            "mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3}, 2, 9),
     "groups": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
                           "mbexwn_config:pp_mod_subnet:n_ch_groups": 2}, 2, 9),
+    "gfu": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                       "mbexwn_config:pp_mod_subnet:activation": "gfu"}, 2, 9),
+    "gsu_eqlr": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                            "mbexwn_config:pp_mod_subnet:activation": "gsu",
+                            "mbexwn_config:pp_mod_subnet:use_equalized_lr": True}, 2, 9),
+    "eqlr_plain": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                              "mbexwn_config:pp_mod_subnet:use_weight_norm": False,
+                              "mbexwn_config:pp_mod_subnet:use_equalized_lr": True}, 2, 9),
 }
-LEAN_GOLDEN_CASES = {"canon60", "voice", "grammar", "groups"}     # cond subsampled [:, ::37], no envelope / wavetables (see the generator)
+LEAN_GOLDEN_CASES = {"canon60", "voice", "grammar", "groups", "gfu", "gsu_eqlr", "eqlr_plain"}     # cond subsampled [:, ::37], no envelope / wavetables (see the generator)
 
 
 @functools.lru_cache(maxsize=None)

@@ -303,3 +303,42 @@ def test_norm_mel_inside_forward_matches_oracle(torch):
         from mbexwn_vocoder_amd.streaming import pack_state
         st = torch.as_tensor(np.stack([pack_state() for _ in range(2)])).cuda()
         eng.forward(dev(torch, mel), noise=dev(torch, noise), stream_state=st)
+
+
+# ------------------------------------------------------------------------------------------------
+# WaveNet options: the gfu / gsu gates and use_equalized_lr
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["gfu", "gsu_eqlr", "eqlr_plain"])
+def test_gate_variants_and_equalized_lr_vs_reference_goldens(torch, golden_dir, case):
+    """pp_mod_subnet.activation = gfu / gsu (reference custom_AE_layers.py:312-318) and use_equalized_lr with and without
+    weight norm (conv_layers.py:133-153), against the float32 run of the reference's own MBExWN.call and the oracle."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    gold = np.load(os.path.join(golden_dir, "reference_forward_f32.npz"))
+    voice, overrides, batch, frames = GOLDEN_CASES[case]
+    cfg, raw, wt = build_case(voice, overrides)
+    eng = MBExWNEngine(cfg, raw, wt)
+    mel, noise = gold[f"{case}/mell"], gold[f"{case}/noise"]
+    got = eng.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
+    assert _maxdiff(got, gold[f"{case}/audio"]) <= _tol(gold[f"{case}/audio"])
+    assert _maxdiff(eng.stage("excitation").cpu().numpy(), gold[f"{case}/excitation"]) <= _tol(gold[f"{case}/excitation"])
+    ref = orc.OracleModel(cfg, raw, wt).forward(mel, noise)
+    assert _maxdiff(got, ref) <= _tol(ref)
+
+
+@pytest.mark.parametrize("act", ["gfu", "gsu"])
+def test_gate_variants_at_full_width(torch, monkeypatch, act):
+    """The other two gates through every gate kernel of the canonical geometry (C = 320): the folded first layer, F(4,3) in
+    both block shapes, F(2,3) (MBX_WINOGRAD=2) and the direct form (MBX_WINOGRAD=0), each against the float64 oracle."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    cfg, raw, wt = build_case("SPEECH", {"mbexwn_config:pp_mod_subnet:activation": act})
+    mel, noise = synthetic_inputs(55, 2, 60)
+    ref = orc.OracleModel(cfg, raw, wt).forward(mel, noise)
+    for env in ({}, {"MBX_WG_SMALL": "0"}, {"MBX_WINOGRAD": "2"}, {"MBX_WINOGRAD": "0"}):
+        for kk in ("MBX_WG_SMALL", "MBX_WINOGRAD"):
+            monkeypatch.delenv(kk, raising=False)
+        for kk, vv in env.items():
+            monkeypatch.setenv(kk, vv)
+        eng = MBExWNEngine(cfg, raw, wt)
+        got = eng.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
+        assert _maxdiff(got, ref) <= _tol(ref), f"{act} {env}"
+        del eng

@@ -322,3 +322,25 @@ def test_resskip_wave_image_is_a_permutation_of_the_weights():
                         else:
                             assert val == 0.0
     assert seen == K * cout and np.array_equal(got, w[0])
+
+
+def test_equalized_lr_folds():
+    """pp_mod_subnet.use_equalized_lr (reference conv_layers.py:133-153): with weight norm W = g v / sqrt(mean v^2) per
+    output channel; without it the layer multiplies its output -- bias included -- by g.  Only WaveNet layers."""
+    from mbexwn_vocoder_amd.weights import fold_weights
+    rng = np.random.default_rng(2)
+    raw = {}
+    for name in ("wn.conv1D_0", "post"):
+        raw[name + ".v"] = rng.normal(size=(3, 4, 6)).astype(np.float32)
+        raw[name + ".g"] = rng.uniform(0.5, 2.0, size=6).astype(np.float32)
+        raw[name + ".bias"] = rng.normal(size=6).astype(np.float32)
+    v, g, b = (raw["wn.conv1D_0" + sfx].astype(np.float64) for sfx in (".v", ".g", ".bias"))
+    normed = fold_weights(raw, wavenet_weight_norm=True, wavenet_equalized_lr=True)
+    np.testing.assert_allclose(normed["wn.conv1D_0.w"], g * v / np.sqrt(np.mean(v * v, axis=(0, 1), keepdims=True)), rtol=2e-6)
+    np.testing.assert_array_equal(normed["wn.conv1D_0.b"], raw["wn.conv1D_0.bias"])
+    plain = fold_weights(raw, wavenet_weight_norm=False, wavenet_equalized_lr=True)
+    np.testing.assert_allclose(plain["wn.conv1D_0.w"], g * v, rtol=2e-6)
+    np.testing.assert_allclose(plain["wn.conv1D_0.b"], g * b, rtol=2e-6)
+    # the post-net is not a WaveNetAE layer: weight norm as always
+    ref = fold_weights(raw)["post.w"]
+    assert np.array_equal(normed["post.w"], ref) and np.array_equal(plain["post.w"], ref)
