@@ -132,11 +132,14 @@ def test_wavenet_without_weight_norm_loads_and_folds(tmp_path):
 def test_unbuilt_wavenet_options_raise():
     """Keys of WaveNetAE.__init__ that change the arithmetic and are not built must not be ignored silently."""
     from mbexwn_vocoder_amd.config import ModelDims
-    for key, value in (("use_equalized_lr", True), ("pre_cond_layer_channels", [64]), ("disable_conditioning", True),
-                       ("padding", "VALID")):
+    for key, value in (("pre_cond_layer_channels", [64]), ("disable_conditioning", True), ("padding", "VALID"),
+                       ("activation", "relu")):
         cfg = canonical_config("SPEECH", **{f"mbexwn_config:pp_mod_subnet:{key}": value})
         with pytest.raises(NotImplementedError):
             ModelDims(cfg)
+    # built since round 3: the gfu / gsu gates and use_equalized_lr (folded on the host)
+    assert ModelDims(canonical_config("SPEECH", **{"mbexwn_config:pp_mod_subnet:use_equalized_lr": True})).wn_equalized_lr
+    assert ModelDims(canonical_config("SPEECH", **{"mbexwn_config:pp_mod_subnet:activation": "gsu"})).wn_activation == "gsu"
     # channel groups are built (block-diagonal dense layers); the reference's divisibility check stays
     assert ModelDims(canonical_config("SPEECH", **{"mbexwn_config:pp_mod_subnet:n_ch_groups": 2})).wn_groups == 2
     with pytest.raises(RuntimeError, match="multiple of chanel groups"):
