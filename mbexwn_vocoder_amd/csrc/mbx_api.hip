@@ -780,9 +780,9 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     // is multiplied onto the audio at the end (reference wavegen_1d.py:506-507)
     const float *nm_gain_src = nullptr;
     if (c.nm_iters > 0) {
-        if (st_in || st_out)
-            return fail(MBX_ERR_UNSUPPORTED, "streaming windows cannot carry the RMS normalisation (its smoothing "
-                                             "spans the utterance edges)");
+        // (streaming windows: the smoothing treats the window edges as item edges, so the frames within the smoothing's
+        // reach of a window edge differ from the whole-utterance run -- the caller's margins cover that reach,
+        // streaming.py::norm_reach)
         ScopedEvents ev(hd, PROF_NORM_MEL, stream);
         nm_gain_src = mbx::launch_norm_mel(norm_mel_consts(hd), mel, (long long)T * c.mel_channels, n_frames, T, B,
                                            w.nm_a, w.nm_b, w.mel_norm, stream);

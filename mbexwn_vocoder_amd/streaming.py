@@ -28,9 +28,21 @@ def pack_state(cum=0.0, offset_sum=0.0, pos_in_chunk=0, start_sample=0, save_sam
     return np.asarray([ff[0], ff[1], pos_in_chunk, start_sample, save_sample, 0], dtype=np.int32)
 
 
+def norm_reach(dims, config):
+    """Reach in mel frames of the optional RMS normalisation of the mel input (reference wavegen_1d.py:697-726): every
+    smoothing iteration overlap-adds the per-frame RMS with the smoothing window and re-estimates it through the analysis
+    window, i.e. frame t then depends on the frames within (smooth_win + win) / (2 hop) of it; 0 without normalisation."""
+    if not dims.normalize_rms_from_mell:
+        return 0
+    from .norm_mel import NormMel
+    nm = NormMel(config)
+    return nm.iters * ((nm.smooth_win_size + nm.win) // (2 * nm.hop))
+
+
 def stream_margins(dims, config):
     """(left, right, pulse_lead, act_left, act_right, wn_reach) in mel frames, from the layer geometry of the model."""
     mb = config["mbexwn_config"]
+    nr = norm_reach(dims, config)      # the normalised mel of a window is reproducible nr frames inside its edges only
 
     def subnet_reach(specs):
         left = right = 0
@@ -54,12 +66,12 @@ def stream_margins(dims, config):
     pqmf_frames = -(-(int(mb["multi_band_config"]["taps"]) // 2) // dims.hop_size)
     cond_r = (dims.cond_kernel_size - 1) // 2 + 1
     stft_l, stft_r = 3, 4                                  # frame t reaches excitation frames t-3 .. t+4
-    pulse_lead = f0_l + 1                                  # first window frame with reproducible F0 / phase
+    pulse_lead = nr + f0_l + 1                             # first window frame with reproducible F0 / phase
     left = pulse_lead + wn_frames + pqmf_frames + stft_l
-    right = max(f0_r, cond_r) + wn_frames + pqmf_frames + stft_r
+    right = nr + max(f0_r, cond_r) + wn_frames + pqmf_frames + stft_r
     smooth = 3                                             # F0 smoother of the lifter selection: +-3 frames of valid F0
     left = max(left, pulse_lead + smooth + 1)
-    right = max(right, f0_r + smooth + 2)
+    right = max(right, nr + f0_r + smooth + 2)
     # margins of the stages from the WaveNet on (the active region of a window, mbx_forward_options.active_begin)
     act_left = wn_frames + pqmf_frames + stft_l
     act_right = wn_frames + pqmf_frames + stft_r

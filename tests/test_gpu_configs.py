@@ -299,10 +299,41 @@ def test_norm_mel_inside_forward_matches_oracle(torch):
     assert _maxdiff(got, ref) <= _tol(ref)
     f0, exc, env, rms = eng.infer_components(mel, synth_length=19 * 300, noise=noise)
     np.testing.assert_allclose(rms, gain, rtol=2e-5)
-    with pytest.raises(NotImplementedError):                # streaming windows cannot carry the smoothing
-        from mbexwn_vocoder_amd.streaming import pack_state
-        st = torch.as_tensor(np.stack([pack_state() for _ in range(2)])).cuda()
-        eng.forward(dev(torch, mel), noise=dev(torch, noise), stream_state=st)
+
+
+def test_streaming_with_rms_normalisation(torch, monkeypatch):
+    """A model with normalize_rms_from_mell streams: the smoothing of the RMS contour reaches norm_reach frames, which the
+    window margins cover (streaming.py::stream_margins), so the stream is bit-equal to the offline synthesis (F(2,3) form)
+    although every window normalises its own frames; steady ticks replay the captured graph."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    from mbexwn_vocoder_amd.streaming import StreamingSynthesizer, norm_reach, stream_margins
+    monkeypatch.setenv("MBX_WINOGRAD", "2")
+    cfg, raw, wt, _ = _norm_engine(NORM_CASES["iters2_comp"])
+    eng = MBExWNEngine(cfg, raw, wt)
+    assert eng.normalizes_rms and norm_reach(eng.dims, cfg) == 8
+    import copy
+    plain = copy.deepcopy(cfg)
+    plain["mbexwn_config"]["normalize_rms_from_mell"] = False
+    from mbexwn_vocoder_amd.config import ModelDims
+    base = stream_margins(ModelDims(plain), plain)
+    assert stream_margins(eng.dims, cfg)[:3] == (base[0] + 8, base[1] + 8, base[2] + 8)
+    syn = StreamingSynthesizer(eng, chunk_frames=8)
+    assert not syn.fe_carry                                  # the front-end ring is not used with the normalisation
+    lengths = [150, 97]
+    offline, got = {}, {0: [], 1: []}
+    for sid, ll in enumerate(lengths):
+        mel, noise = synthetic_inputs(700 + sid, 1, ll)
+        offline[sid] = eng.infer(mel, synth_length=ll * 300, noise=noise).numpy()[0]
+        syn.open(sid)
+        syn.push(sid, mel[0], noise[0], last=True)
+    for _ in range(60):
+        for sid, audio in syn.tick().items():
+            got[sid].append(np.array(audio))
+        if all(syn.finished(sid) for sid in offline):
+            break
+    assert syn.graph_ticks >= 3
+    for sid in offline:
+        assert np.array_equal(np.concatenate(got[sid]), offline[sid]), f"stream {sid}"
 
 
 # ------------------------------------------------------------------------------------------------
