@@ -23,24 +23,22 @@ from mbexwn_vocoder_amd.fileio import load_var  # noqa: E402
 
 
 def write_audio(outfile, data, rate, format):
+    """reference bin/resynth_mel.py:104-105 (sndio.write): libsndfile through soundfile where it is installed, else the
+    built-in writers -- flac (mbexwn_vocoder_amd/flac.py: 16-bit, uncompressed sub-frames) and wav (float32)."""
     try:
         import soundfile
         soundfile.write(outfile, data, rate, format=format.upper())
         return outfile
     except ImportError:
-        if format.lower() != "wav":
-            raise RuntimeError(f"cannot write format {format}: soundfile is not installed, only wav is available")
+        pass
+    if format.lower() == "flac":
+        from mbexwn_vocoder_amd import flac
+        return flac.write(outfile, data, rate)
+    if format.lower() == "wav":
         from scipy.io import wavfile
         wavfile.write(outfile, rate, np.asarray(data, dtype=np.float32))
         return outfile
-
-
-def default_format():
-    try:
-        import soundfile  # noqa: F401
-        return "flac"
-    except ImportError:
-        return "wav"
+    raise RuntimeError(f"cannot write format {format}: soundfile is not installed, only flac and wav are built in")
 
 
 def main(model_id, input_mell_files, output_dir, use_gpu=False, sigma=None, format=None, verbose=False, seed=42,
@@ -52,7 +50,14 @@ def main(model_id, input_mell_files, output_dir, use_gpu=False, sigma=None, form
     if not use_gpu and not quiet:
         print("resynth_mel::note:: running on the MI355X HIP path (this build has no CPU path, -g is implied)",
               file=sys.stderr)
-    format = format or default_format()
+    format = format or "flac"                                   # the reference's default (bin/resynth_mel.py:119)
+    if num_threads:                                           # -nt: host threads (numpy / torch CPU work around the HIP path)
+        torch.set_num_threads(max(1, int(num_threads)))
+        try:
+            from threadpoolctl import threadpool_limits
+            threadpool_limits(limits=max(1, int(num_threads)))
+        except ImportError:
+            pass
     if seed >= 0:                                  # reference :65-67
         np.random.seed(seed)
         torch.manual_seed(seed)
@@ -96,9 +101,9 @@ if __name__ == "__main__":
                              "model names; the first model whose DOMAIN/name contains the identifier is used.")
     parser.add_argument("-i", "--input_mell_files", nargs="+", help="list of mell spectra stored in pickle files")
     parser.add_argument("-o", "--output_dir", help="output directory where synthetic sounds will be stored")
-    parser.add_argument("--format", default=None, help="file format for generated audio files "
-                                                       "(Def: flac if soundfile is installed, else wav)")
-    parser.add_argument("-nt", "--num_threads", default=2, type=int, help="accepted for compatibility (ignored)")
+    parser.add_argument("--format", default="flac", help="file format for generated audio files (Def: %(default)s)")
+    parser.add_argument("-nt", "--num_threads", default=2, type=int,
+                        help="number of cpu threads of the host-side work (Def: %(default)s)")
     parser.add_argument("-g", "--use_gpu", action="store_true", help="run on gpu (implied)")
     parser.add_argument("-v", "--verbose", action="store_true", help="display verbose progress info")
     parser.add_argument("-q", "--quiet", action="store_true", help="dont display progress")

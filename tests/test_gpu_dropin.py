@@ -82,6 +82,12 @@ def test_cli_round_trip(model_dir, tmp_path):
     for ii, frames in enumerate((12, 31)):
         rate, data = wavfile.read(os.path.join(out_dir, f"syn_utt{ii}.wav"))
         assert rate == 24000 and data.shape == (frames * 300,) and np.all(np.isfinite(data))
+    # the reference's defaults: --format flac (built-in writer when libsndfile is absent), -nt host threads
+    res = subprocess.run([sys.executable, cli, model_dir, "-i", files[0], "-o", out_dir, "-nt", "1", "-q"],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    stream = open(os.path.join(out_dir, "syn_utt0.flac"), "rb").read()
+    assert stream[:4] == b"fLaC" and int.from_bytes(stream[18:26], "big") & ((1 << 36) - 1) == 12 * 300
     listing = subprocess.run([sys.executable, cli], capture_output=True, text=True, timeout=120)
     assert " - SPEECH/MBExWN_SIIConv_V71g_SPEECH" in listing.stdout
 
