@@ -7,8 +7,8 @@
 TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-for WL in config2_sp_b1_10s config3_si_b16_10s; do
-  STEPS=20; [ $WL = config3_si_b16_10s ] && STEPS=5
+for WL in config2_sp_b1_10s config3_si_b16_10s config5_sp_stream64; do
+  STEPS=20; [ $WL = config3_si_b16_10s ] && STEPS=5; [ $WL = config5_sp_stream64 ] && STEPS=30
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_trace_$WL -- \
       python3 $R/bench.py --workload $WL --steps $STEPS --warmup 3 --no-cpu-baseline --no-secondary > $R/gpurun_out/${TAG}_trace_$WL.log 2>&1
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_pmc_fetch_$WL -- \

@@ -21,12 +21,12 @@ summary = {}
 def short(name):
     if "wn_gate_winograd" in name or ("conv1d_mfma_dma_kernel" in name and ", 1>" in name):
         return "gate"
-    if "wn_resskip_kernel" in name or "wn_resskip_wide_kernel" in name or ("conv1d_mfma_kernel" in name and ", 2, true" in name):
+    if "wn_resskip_kernel" in name or "wn_resskip_wide_kernel" in name or "wn_resskip_wave_kernel" in name or ("conv1d_mfma_kernel" in name and ", 2, true" in name):
         return "res_skip"
     return None
 
 
-for wl in ("config2_sp_b1_10s", "config3_si_b16_10s"):
+for wl in ("config2_sp_b1_10s", "config3_si_b16_10s", "config5_sp_stream64"):
     entry = {}
     stats = sorted(glob.glob(os.path.join(src, f"{tag}_trace_{wl}", "*", "*kernel_stats.csv")), key=os.path.getmtime,
                    reverse=True)
