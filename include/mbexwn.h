@@ -24,8 +24,14 @@
  *   MBX_FOLD_SKIP=0      keep the un-folded skip path (C -> 2C res/skip layers, stage "wn_skip")
  *   MBX_FOLD_START=0     keep the start convolution and the full first layer (default: start convolution folded into
  *                        layer 0, a K = 24 contraction of the excitation; needs the folded skip path)
+ *   MBX_WG_SMALL=0|1     measurements / tests: pins the F(4,3) block shape of launches below 4 x 768 full blocks
+ *                        (0: 256-row blocks, 1: 128-row product-split blocks; both give the same bits)
+ *   MBX_RV_TILES=n       measurements: under the default policy, res/skip launches of at most n 16-row tiles run the
+ *                        wave-tiled kernel (default 2048; 0 = never)
+ *   MBX_RV_SPLIT=1|2|3   measurements: pins the column split of the wave-tiled res/skip kernel (default: by launch size)
  * The optional operand-order images of the weights ("*.wino2w", "*.wino4w", "*.packed", "*.fold",
- * "*.fold_wide", "*.start_fold", "*.fold_start", "*.fold_start_wide", "wn.tail.fold", "wn.end.packed";
+ * "*.fold_wide", "*.fold_wave", "*.start_fold", "*.fold_start", "*.fold_start_wide", "*.fold_start_wave",
+ * "wn.tail.fold", "wn.end.packed";
  * engine.tensor_table builds them) select the specialised kernels; a handle created from the plain folded weights
  * alone runs the generic ones.
  */

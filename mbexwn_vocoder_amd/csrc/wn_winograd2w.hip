@@ -32,8 +32,8 @@
 // (i & 1) * 32 + P + (i >> 1) * d for its four rows i -- consecutive lanes, consecutive cells, conflict free with the
 // chunk swizzle.  The block stages the weights of the slice: 4 products x 8 channels x 64 columns in MFMA operand order
 // [product j][channel parity e][lane][tanh step 0, tanh step 1, sigmoid step 0, sigmoid step 1] (one ds_read_b128 = the
-// weight operands of four MFMAs).  LDS: NSTAGE x (4 x 2 KB + 8 KB) + the four conditioning tiles (8 rows x 64 floats
-// each): 40 KB with two stages -> 4 blocks per CU = 4 waves per SIMD, which is what hides the LDS-DMA latency and the
+// weight operands of four MFMAs).  LDS: two stages x (4 x 2 KB + 8 KB) + the four conditioning tiles (8 rows x 64 floats
+// each): 40 KB -> 4 blocks per CU = 4 waves per SIMD, which is what hides the LDS-DMA latency and the
 // prologue / epilogue of these short blocks.
 #include <cstdlib>
 #include <type_traits>
@@ -52,12 +52,9 @@ constexpr int W2_B_FLOATS = 4 * W2_BK * 64;            // 2048: packed weights o
 constexpr int W2_STAGE = 4 * W2_A_FLOATS + W2_B_FLOATS;   // 4096 floats = 16 KB
 constexpr int W2_COND_ROWS = 8;                        // conditioning rows of a wave tile (64 floats each)
 
-template <int NSTAGE>
-struct W2Shape {
-    static constexpr int COND = NSTAGE * W2_STAGE;
-    static constexpr int LDS_FLOATS = COND + 4 * W2_COND_ROWS * 64;      // 40 KB | 56 KB
-    static constexpr int WAVES_PER_SIMD = LDS_FLOATS * 4 * 4 <= 160 * 1024 ? 4 : (LDS_FLOATS * 4 * 3 <= 160 * 1024 ? 3 : 2);
-};
+constexpr int W2_NSTAGE = 2;                           // (three stages at 3 blocks per CU: 0.834 against 0.811 ms per 64-stream tick)
+constexpr int W2_COND = W2_NSTAGE * W2_STAGE;
+constexpr int W2_LDS_FLOATS = W2_COND + 4 * W2_COND_ROWS * 64;            // 40 KB: 4 blocks per CU
 
 __device__ __forceinline__ void w2_lds_dma16(const float *src, unsigned lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(src) : "memory", "m0");
@@ -76,11 +73,10 @@ __device__ __forceinline__ void w2_lds_dma16_s(const float *sbase, unsigned voff
 template <int N>
 using w2_int = std::integral_constant<int, N>;
 
-template <int NSTAGE>
-__global__ __launch_bounds__(256, (W2Shape<NSTAGE>::WAVES_PER_SIMD)) void wn_gate_winograd2w_kernel(ConvArgs p, int log2d) {
-    using SH = W2Shape<NSTAGE>;
+__global__ __launch_bounds__(256, 4) void wn_gate_winograd2w_kernel(ConvArgs p, int log2d) {
+    constexpr int NSTAGE = W2_NSTAGE;
     typedef __attribute__((address_space(3))) float lds_float;
-    __shared__ __attribute__((aligned(16))) float lds[SH::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[W2_LDS_FLOATS];
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float *)lds);
 
     // XCD-aware decode (see decode_tile in conv_mfma.hip): a row group = four wave tiles; its column tiles run back to back
@@ -181,7 +177,7 @@ __global__ __launch_bounds__(256, (W2Shape<NSTAGE>::WAVES_PER_SIMD)) void wn_gat
             const int chn = n0 + 4 * (cq & 7);
             const int t = min(t2base + crow, n2 - 1);
             w2_lds_dma16((active && chn < C) ? cbase + (long long)t * (2 * C) + (cq >> 3) * C + chn : p.zeros,
-                         lds_base + 4u * (unsigned)(SH::COND + wave * (W2_COND_ROWS * 64)) + 1024u * (unsigned)i);
+                         lds_base + 4u * (unsigned)(W2_COND + wave * (W2_COND_ROWS * 64)) + 1024u * (unsigned)i);
         }
     }
     // ---- prologue: every stage requested
@@ -267,9 +263,8 @@ __global__ __launch_bounds__(256, (W2Shape<NSTAGE>::WAVES_PER_SIMD)) void wn_gat
             phase(sc, w2_int<1>());
             phase(sc, w2_int<2>());
         }
-        // ---- product 3 behind the barrier; slice st+1 must have landed: only slice st+2 (three stages) may be in flight
-        if (NSTAGE == 3 && st + 2 < nk8) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ---- product 3 behind the barrier; slice st+1 must have landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (st + NSTAGE < nk8) issue(st + NSTAGE, S);
         if (active) {
@@ -283,10 +278,9 @@ __global__ __launch_bounds__(256, (W2Shape<NSTAGE>::WAVES_PER_SIMD)) void wn_gat
         }
     };
 
-    // ---- the first slice (and the conditioning tile, requested in front of it) has landed; the launcher guarantees
-    // nk8 >= NSTAGE
-    if (NSTAGE == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // ---- the first slice (and the conditioning tile, requested in front of it) has landed, the second one may still be in
+    // flight; the launcher guarantees nk8 >= NSTAGE
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __syncthreads();
     if (active) {
         load_x(w2_int<0>());
@@ -295,29 +289,17 @@ __global__ __launch_bounds__(256, (W2Shape<NSTAGE>::WAVES_PER_SIMD)) void wn_gat
     }
     {
         int st = 0;
-        if constexpr (NSTAGE == 3) {
-            for (; st + 3 <= nk8; st += 3) {
-                fill(w2_int<0>(), st);
-                fill(w2_int<1>(), st + 1);
-                fill(w2_int<2>(), st + 2);
-            }
-            if (st < nk8) {
-                fill(w2_int<0>(), st);
-                if (st + 1 < nk8) fill(w2_int<1>(), st + 1);
-            }
-        } else {
-            for (; st + 2 <= nk8; st += 2) {
-                fill(w2_int<0>(), st);
-                fill(w2_int<1>(), st + 1);
-            }
-            if (st < nk8) fill(w2_int<0>(), st);
+        for (; st + 2 <= nk8; st += 2) {
+            fill(w2_int<0>(), st);
+            fill(w2_int<1>(), st + 1);
         }
+        if (st < nk8) fill(w2_int<0>(), st);
     }
     if (!active) return;
 
     // ---- epilogue: combine the four products, add the conditioning, gate, store the two outputs of every pair.
     // Everything up to the store is unconditional (every conditioning address is valid); only the store is predicated.
-    const float *cl = lds + SH::COND + wave * (W2_COND_ROWS * 64) + 2 * r16;
+    const float *cl = lds + W2_COND + wave * (W2_COND_ROWS * 64) + 2 * r16;
     float *obase = p.out + (long long)b * p.out_bstride + n0 + 2 * r16;
     const float inv_up = 1.0f / (float)cond_up;
 #pragma unroll
@@ -357,11 +339,6 @@ bool launch_wn_gate_winograd2w(const ConvArgs &a, hipStream_t stream) {
     int log2d = 0;
     while ((1 << log2d) < a.dil) ++log2d;
     const int nk8 = (a.cin + W2_BK - 1) / W2_BK;
-    static const int stages = []() {
-        const char *sv = getenv("MBX_W2_STAGES");
-        const int v = sv ? atoi(sv) : 2;
-        return v == 3 ? 3 : 2;
-    }();
     const bool ok = a.ks == 3 && (1 << log2d) == a.dil && a.dil <= W2_HALO && nk8 >= 3 && a.pad_l == a.dil && a.pad_mode == 0 &&
                     a.cin % 4 == 0 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 && a.channels % 4 == 0 &&
                     a.cout == 2 * a.channels && (uintptr_t)a.x % 16 == 0 && (uintptr_t)a.w % 16 == 0 && a.zeros &&
@@ -380,8 +357,7 @@ bool launch_wn_gate_winograd2w(const ConvArgs &a, hipStream_t stream) {
     r.m_tiles_total = r.m_tiles_per_item * a.batch;
     const long long groups = (r.m_tiles_total + 3) / 4;
     const long long blocks = 8LL * ((groups + 7) / 8) * r.n_tiles;
-    if (stages == 3) hipLaunchKernelGGL((wn_gate_winograd2w_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, stream, r, log2d);
-    else hipLaunchKernelGGL((wn_gate_winograd2w_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, stream, r, log2d);
+    hipLaunchKernelGGL(wn_gate_winograd2w_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, r, log2d);
     return true;
 }
 
