@@ -534,7 +534,9 @@ class StreamingSynthesizer:
         mel_win, noise_win = ctx["mel_d"], ctx["noise_d"] if use_noise else None
         graph = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(dev)
-        with torch.cuda.graph(graph):
+        # thread_local: another thread of the process (the RCCL watchdog of a multi-rank job) may touch the runtime while
+        # this one captures
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             stage_dev.copy_(stage_host, non_blocking=True)
             eng.window_advance(mel_win, mel_new, noise_win, noise_new)
             eng.forward(mel_win, n_frames=ints["nfr"], noise=noise_win, stream_state=states_d,

@@ -122,10 +122,6 @@ PATCHES = {
         ('        const float4 a = in_row ? *reinterpret_cast<const float4 *>(xr + 8 * c) : make_float4(0.f, 0.f, 0.f, 0.f);',
          '        const float4 a = make_float4(1.f, 2.f, (float)c, 0.f);'),
     ],
-    # wn_winograd.hip: 256-row blocks (NS = 1) already from 512 blocks on (streaming ticks: 640 blocks)
-    'f23_big512': [
-        ('    const bool split = w_split && (uintptr_t)w_split % 16 == 0 && full_blocks < 4 * 512;', '    const bool split = w_split && (uintptr_t)w_split % 16 == 0 && full_blocks < 512;'),
-    ],
     'base': [],
     # wn_winograd4w.hip
     'nodma': [
@@ -134,13 +130,33 @@ PATCHES = {
     ],
     # wn_winograd4w.hip
     'nobar': [
-        ('        if (NSTAGE == 3 && st + 2 < nst) {\n            if (SH::DMA_PER_STAGE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");\n            else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");\n        } else {\n            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n        }\n        __syncthreads();\n',
+        ('        // ---- product 5 behind the barrier; fill st+1 must have landed\n        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n        __syncthreads();\n',
          ''),
     ],
-    # wn_winograd4w.hip
-    'nowait': [
-        ('        } else {\n            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n        }\n        __syncthreads();',
-         '        } else {\n        }\n        __syncthreads();'),
+    # wn_resskip_wave.hip
+    'rv_nopre': [
+        ('            const float2 old = *reinterpret_cast<const float2 *>(src + (long long)min(row0 + v, row_last) * ld);',
+         '            const float2 old = make_float2(0.f, 0.f);'),
+    ],
+    # wn_resskip_wave.hip
+    'rv_nostore': [
+        ('            if (row < rows) *reinterpret_cast<float2 *>(dst + (long long)row * ld) = make_float2(acc[2 * pr][v], acc[2 * pr + 1][v]);',
+         '            if (row < rows && acc[2 * pr][v] == 123.456f) *reinterpret_cast<float2 *>(dst + (long long)row * ld) = make_float2(acc[2 * pr][v], acc[2 * pr + 1][v]);'),
+    ],
+    # wn_resskip_wave.hip
+    'rv_nodma': [
+        ('        if (kt + NSTAGE < nk) issue(kt + NSTAGE, S);\n',
+         ''),
+    ],
+    # wn_resskip_wave.hip
+    'rv_nobar': [
+        ('        else rv_wait_vm<0>();\n        __syncthreads();\n',
+         '        else {}\n'),
+    ],
+    # wn_resskip_wave.hip: half of the matrix work (every second pair skipped)
+    'rv_halfmfma': [
+        ('        const float4 we = bw[P % 3][0], wo = bw[P % 3][1];\n',
+         '        const float4 we = bw[P % 3][0], wo = bw[P % 3][1];\n        if (P % 2 == 1) return;\n'),
     ],
     # wn_winograd4w.hip
     'noepi': [
@@ -148,10 +164,6 @@ PATCHES = {
          '    {\n        float ssum = 0.f;\n#pragma unroll\n        for (int j = 0; j < 6; ++j)\n#pragma unroll\n            for (int c = 0; c < 4; ++c)\n#pragma unroll\n                for (int r = 0; r < 4; ++r) ssum += acc[j][c][r];\n        if (ssum == 123.456f) p.out[tid] = ssum;\n        return;\n    }\n    // ---- epilogue: combine the six products, add the conditioning'),
     ],
     # wn_winograd4w.hip
-    'noexch': [
-        ('    if (KSPLIT == 2) {\n        __syncthreads();                             // all LDS operand reads are done',
-         '    if (false) {\n        __syncthreads();'),
-    ],
     # wn_winograd4w.hip
     'nocomb': [
         ('        constexpr int J = decltype(jc)::value;\n        if (J == 0) u[0] = ww_fma(4.f, x[0]',
