@@ -134,3 +134,23 @@ def test_bench_counts_gpus_without_touching_them(monkeypatch):
     assert bench.visible_gpu_count() == 2
     monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "")
     assert bench.visible_gpu_count() == 0
+
+
+@pytest.mark.timeout(180)
+def test_bench_parent_ends_the_other_ranks_when_one_fails(monkeypatch):
+    """`bench.py --gpus 2` without a launcher: the parent starts the ranks as fresh child processes and polls them.  Here
+    (no GPU) every rank exits with an error right after start: the parent must come back with a non-zero status instead of
+    waiting on the survivors, without having touched a GPU itself."""
+    import argparse
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    monkeypatch.setattr(bench, "visible_gpu_count", lambda: 2)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
+    for kk in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        monkeypatch.delenv(kk, raising=False)
+    t0 = time.time()
+    with pytest.raises(SystemExit) as exc:
+        bench.spawn_ranks(argparse.Namespace(gpus=2, master_port=0))
+    assert exc.value.code not in (0, None)
+    assert time.time() - t0 < 120
