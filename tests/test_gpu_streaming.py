@@ -269,3 +269,51 @@ def test_window_advance(engine):
     assert np.array_equal(mel_d.cpu().numpy()[:, -step:], mel_new)
     with pytest.raises(ValueError):
         engine.window_advance(mel_d, torch.as_tensor(mel_new[:, :, :40]).cuda())
+
+
+def test_frontend_ring_equals_whole_window_and_checks_its_arguments(engine):
+    """mbx_forward_options.fe_store: a call that computes only the last fe_new + fe_margin frames of the front end and
+    takes the frames in front of them from the ring must give the conditioning rows / cepstrum / F0 contour (and the
+    audio) of the call that computed the whole window; malformed options are refused."""
+    import torch
+    from mbexwn_vocoder_amd.streaming import pack_state
+    assert engine.frontend_carry_supported
+    B, T, ring_frames = 2, 40, 64
+    mel, noise = synthetic_inputs(61, B, T + 8)
+    # the phase starts at frame 4 of the window: the F0 contour in front of it feels the window's left edge in a
+    # whole-window call and does not in a carried one
+    st = torch.as_tensor(np.stack([pack_state(0.0, 0.0, 0, 4 * 100, -1)] * B)).cuda()
+    act = torch.full((B,), T - 12, dtype=torch.int32, device="cuda")
+    store = torch.zeros((4, 8, 15), dtype=torch.float32, device="cuda")
+    desc = torch.tensor([[2, 0, 0, 0, 0], [1, 0, 0, 0, 0]], dtype=torch.int32, device="cuda")        # slots 2 and 1
+    ring = torch.zeros((4, ring_frames, engine.frontend_frame_floats), dtype=torch.float32, device="cuda")
+
+    def window(first):
+        return (torch.as_tensor(mel[:, first:first + T]).cuda(), torch.as_tensor(noise[:, first * 20:(first + T) * 20]).cuda())
+
+    def run(first, frontend):
+        mel_d, noise_d = window(first)
+        audio, _ = engine.forward(mel_d, noise=noise_d, stream_state=st, active=(8, act, T - 12), carry=(store, desc),
+                                  frontend=frontend)
+        return audio.cpu().numpy(), {kk: engine.stage(kk).cpu().numpy() for kk in ("cond", "cepstrum", "f0")}
+
+    pos0 = torch.tensor([10, 50], dtype=torch.int32, device="cuda")          # ring frames of window frame 0 (one wraps)
+    run(0, (ring, pos0, 0, 0))                                               # window [0, 40): every frame goes to the ring
+    want_audio, want = run(8, None)                                          # window [8, 48) computed as a whole
+    pos8 = torch.tensor([18, 58], dtype=torch.int32, device="cuda")
+    got_audio, got = run(8, (ring, pos8, 8 + 5, 3))                          # the same window: 16 frames computed, 27 carried
+    for kk in want:
+        per = want[kk].shape[1] // T
+        # frames 4 .. T - 5: exact in both calls (the first frames of a window feel its left edge, the last ones its right edge)
+        lo, hi = 4 * per, (T - 5) * per
+        assert np.array_equal(got[kk][:, lo:hi], want[kk][:, lo:hi]), kk
+    assert np.array_equal(got_audio[:, 12 * 300:(T - 12) * 300], want_audio[:, 12 * 300:(T - 12) * 300])
+    mel_d, noise_d = window(8)
+    with pytest.raises(ValueError):                                          # ring shorter than the window
+        engine.forward(mel_d, noise=noise_d, stream_state=st, active=(8, act, T - 12), carry=(store, desc),
+                       frontend=(ring[:, :32].contiguous(), pos8, 13, 3))
+    with pytest.raises(ValueError):                                          # more new + margin frames than the window has
+        engine.forward(mel_d, noise=noise_d, stream_state=st, active=(8, act, T - 12), carry=(store, desc),
+                       frontend=(ring, pos8, 38, 3))
+    with pytest.raises(ValueError):                                          # the slots come from the carry descriptors
+        engine.forward(mel_d, noise=noise_d, stream_state=st, active=(8, act, T - 12), frontend=(ring, pos8, 13, 3))
