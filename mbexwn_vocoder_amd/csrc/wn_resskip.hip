@@ -4,7 +4,7 @@
 //
 // Same layer as conv1d_mfma_kernel<EPI_RESSKIP> (reference MBExWN_NVoc/vocoder/model/custom_AE_layers.py:322-336:
 // res_skip = res_skip_l(acts); x = x + res_skip[:C]; skip_out (+)= res_skip[C:]), restructured like the Winograd gate
-// kernel (wn_winograd.hip) for large row counts:
+// kernels (wn_winograd4w.hip) for large row counts:
 //   block = 2 x 2 waves, (64 MT) rows x 128 columns, wave tile (32 MT) x 64; MT = 2 (128-row blocks, 3 per CU) for
 //   large launches, MT = 1 (64-row blocks, finer granularity) for small ones
 //   A: gate output rows [m0, m0+64 MT) x 16 channels per slice through LDS-DMA, chunk (row, c) at 4*row + (c ^ ((row>>2)&3))

@@ -106,7 +106,7 @@ def canon_case():
 
 def test_canon_ragged_batch_of_16(torch, monkeypatch, canon_case):
     """the DEFAULT policy at config-3 size (C = 320, 16 x 800 frames padded) -- the kernels of the
-    driver's bench line: wn_gate_winograd4w_kernel<256,1>, wn_resskip_wide_kernel<11>, conv1d_mel_group_kernel<2> -- held
+    driver's bench line: wn_gate_winograd4w_kernel (256-row blocks), wn_resskip_wide_kernel<11>, conv1d_mel_group_kernel<2> -- held
     to the float64 oracle on the two short items, to the prefix property on the longest, and every item to its
     one-at-a-time run (which takes the small-launch kernels: equal to float32 rounding)."""
     from mbexwn_vocoder_amd.engine import MBExWNEngine
