@@ -122,6 +122,49 @@ PATCHES = {
         ('        const float4 a = in_row ? *reinterpret_cast<const float4 *>(xr + 8 * c) : make_float4(0.f, 0.f, 0.f, 0.f);',
          '        const float4 a = make_float4(1.f, 2.f, (float)c, 0.f);'),
     ],
+    # wn_gate0.hip: gate kind as a compile-time constant (no wave-uniform branch around every activation)
+    'g0_kind0': [
+        ('res.x = wn_gate_act(p.gate_act,', 'res.x = wn_gate_act(0,'),
+        ('res.y = wn_gate_act(p.gate_act,', 'res.y = wn_gate_act(0,'),
+    ],
+    # wn_gate0.hip: no matrix work
+    'g0_nomfma': [
+        ('#pragma unroll\n        for (int t = 0; t < 3; ++t) {\n            acc[0] =', '        for (int t = 0; t < p.write_inputs - 7; ++t) {\n            acc[0] ='),
+    ],
+    # wn_gate0.hip: no conditioning, no activation
+    'g0_noepi': [
+        ('            res.x = wn_gate_act(p.gate_act, acc[0][v] + (ct0.x * w.x + ct1.x * w.y), acc[1][v] + (cs0.x * w.x + cs1.x * w.y));\n            res.y = wn_gate_act(p.gate_act, acc[2][v] + (ct0.y * w.x + ct1.y * w.y), acc[3][v] + (cs0.y * w.x + cs1.y * w.y));',
+         '            res.x = acc[0][v] + acc[1][v];\n            res.y = acc[2][v] + acc[3][v];'),
+    ],
+    # wn_winograd4w.hip (256-row kernel): block order in panels of R row tiles per XCD, one column tile after the other
+    'order_p96': [
+        ('    const int l = id >> 3;\n    const int g_ = (l / p.n_tiles) * 8 + (id & 7);\n    const int nt = l % p.n_tiles;\n',
+         '    const int l = id >> 3;\n    const int G_ = (p.m_tiles_total + 7) >> 3;\n    constexpr int R_ = 96;\n    const int panel_ = l / (R_ * p.n_tiles), w_ = l - panel_ * (R_ * p.n_tiles);\n    const int rip_ = min(R_, G_ - panel_ * R_);\n    const int nt = w_ / rip_;\n    const int g_ = (panel_ * R_ + w_ % rip_) * 8 + (id & 7);\n'),
+    ],
+    'order_p24': [
+        ('    const int l = id >> 3;\n    const int g_ = (l / p.n_tiles) * 8 + (id & 7);\n    const int nt = l % p.n_tiles;\n',
+         '    const int l = id >> 3;\n    const int G_ = (p.m_tiles_total + 7) >> 3;\n    constexpr int R_ = 24;\n    const int panel_ = l / (R_ * p.n_tiles), w_ = l - panel_ * (R_ * p.n_tiles);\n    const int rip_ = min(R_, G_ - panel_ * R_);\n    const int nt = w_ / rip_;\n    const int g_ = (panel_ * R_ + w_ % rip_) * 8 + (id & 7);\n'),
+    ],
+    # two passes over the row tiles, five column tiles each (n_tiles == 10 only)
+    'order_h5': [
+        ('    const int l = id >> 3;\n    const int g_ = (l / p.n_tiles) * 8 + (id & 7);\n    const int nt = l % p.n_tiles;\n',
+         '    const int l = id >> 3;\n    const int G_ = (p.m_tiles_total + 7) >> 3;\n    const int pass_ = l / (G_ * 5), w_ = l - pass_ * (G_ * 5);\n    const int nt = pass_ * 5 + w_ % 5;\n    const int g_ = (w_ / 5) * 8 + (id & 7);\n'),
+    ],
+    'order_colmajor': [
+        ('    const int l = id >> 3;\n    const int g_ = (l / p.n_tiles) * 8 + (id & 7);\n    const int nt = l % p.n_tiles;\n',
+         '    const int l = id >> 3;\n    const int G_ = (p.m_tiles_total + 7) >> 3;\n    const int nt = l / G_;\n    const int g_ = (l - nt * G_) * 8 + (id & 7);\n'),
+    ],
+    # wn_gate0.hip (round-3 kernel): what the block's prologue, its main loop and its stores cost
+    'g0n_nostore': [
+        ('        if (row < rows) {\n            float *orow', '        if (row < rows && o[0] == 123.456f) {\n            float *orow'),
+        ('        if (p.write_inputs && nt == 0) {', '        if (p.write_inputs && nt == 0 && o[1] == 123.456f) {'),
+    ],
+    'g0n_nomain': [
+        ('#pragma unroll\n    for (int i = 0; i < 4; ++i) {\n        cond_load(i, cr);', '    for (int i = 0; i < p.write_inputs - 1; ++i) {\n        cond_load(i, cr);'),
+    ],
+    'g0n_onetile': [
+        ('#pragma unroll\n    for (int i = 0; i < 4; ++i) {\n        cond_load(i, cr);', '#pragma unroll\n    for (int i = 0; i < 1; ++i) {\n        cond_load(i, cr);'),
+    ],
     'base': [],
     # wn_winograd4w.hip
     'nodma': [
