@@ -45,9 +45,10 @@
 extern "C" {
 #endif
 
-#define MBX_ABI_VERSION 5
+#define MBX_ABI_VERSION 6
 #define MBX_MAX_SUBNET_OPS 32
 #define MBX_MAX_WN_LAYERS 64
+#define MBX_MAX_PRECOND 8
 #define MBX_NAME_LEN 64
 
 typedef enum {
@@ -83,6 +84,7 @@ typedef struct {
 #define MBX_GATE_GTU 0
 #define MBX_GATE_GFU 1
 #define MBX_GATE_GSU 2
+#define MBX_GATE_GLU 3
 
 typedef struct {
     int32_t struct_size;     /* sizeof(mbx_config), checked by mbx_create */
@@ -119,9 +121,21 @@ typedef struct {
     float nm_compressor_exp;
     float nm_lin_amp_scale, nm_lin_amp_off, nm_mel_amp_scale;
     /* gate of the WaveNet layers (pp_mod_subnet.activation, reference custom_AE_layers.py:312-321): the first half of a
-     * layer's channels goes through MBX_GATE_GTU tanh(z), MBX_GATE_GFU z / (1 + |z|) or MBX_GATE_GSU z / (1 + sqrt|z|),
-     * and is multiplied by the sigmoid of the second half */
+     * layer's channels goes through MBX_GATE_GTU tanh(z), MBX_GATE_GFU z / (1 + |z|), MBX_GATE_GSU z / (1 + sqrt|z|) or
+     * MBX_GATE_GLU z (the reference accepts "glu" at :156 and leaves the half linear), and is multiplied by the sigmoid
+     * of the second half */
     int32_t wn_gate_activation;
+    /* pp_mod_subnet.disable_conditioning (reference custom_AE_layers.py:203-204,293-294): no conditioning layer, the
+     * gates see zeros; the tensors "wn.cond.*" are not needed */
+    int32_t wn_disable_conditioning;
+    /* pp_mod_subnet.pre_cond_layer_channels (reference custom_AE_layers.py:190-201,283-285): n_precond convolutions
+     * "wn.precond_<i>" (kernel size cond_kernel_size, zero SAME padding, no activation) of the mel input in front of the
+     * conditioning layer, whose input then has precond_channels[n_precond - 1] channels */
+    int32_t n_precond;
+    int32_t precond_channels[MBX_MAX_PRECOND];
+    /* spect_filters_preserve_energy (reference custom_pulsed_generator.py:817-849): the cepstrum keeps its coefficient
+     * 0 and every frame's filter is divided by the root of its mean squared magnitude over the fft_size/2 + 1 bins */
+    int32_t spect_preserve_energy;
 } mbx_config;
 
 /* A named HOST tensor handed over at creation (weights already weight-norm folded, tables).

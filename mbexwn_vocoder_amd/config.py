@@ -252,16 +252,17 @@ class ModelDims:
             # reference custom_AE_layers.py:165-166; the groups run as block-diagonal dense layers (weights.merge_channel_groups)
             raise RuntimeError(f"WaveNetAE::error::n_channels parameter {self.wn_channels} has to be a multiple of chanel "
                                f"groups parameter {self.wn_groups}")
-        if self.wn_activation not in ("gtu", "gfu", "gsu"):
-            # reference custom_AE_layers.py:312-318 knows exactly these three
-            raise NotImplementedError(f"WaveNetAE activation {self.wn_activation}: gtu, gfu and gsu are supported")
+        if self.wn_activation not in ("gtu", "glu", "gfu", "gsu"):
+            # reference custom_AE_layers.py:156-158 (glu passes the check and has no branch at :312-318: the half stays linear)
+            raise RuntimeError(f"WaveNetAE::error::unsupported wavenet activation {self.wn_activation} selected. "
+                               f"For gated units please select one of gtu, gfu, gsu, or glu.")
         # keys of WaveNetAE.__init__ (reference custom_AE_layers.py:120-131) that change the arithmetic and are not built:
         # silently ignoring them would load a valid model and produce wrong audio
         self.wn_equalized_lr = bool(wn.get("use_equalized_lr", False))    # folded on the host (weights.fold_weights)
-        if wn.get("pre_cond_layer_channels", None):
-            raise NotImplementedError("pp_mod_subnet.pre_cond_layer_channels is not supported")
-        if wn.get("disable_conditioning", False):
-            raise NotImplementedError("pp_mod_subnet.disable_conditioning is not supported")
+        # convolutions of the mel input in front of the conditioning layer (reference custom_AE_layers.py:190-201,283-285)
+        self.wn_pre_cond_channels = [int(cc) for cc in (wn.get("pre_cond_layer_channels", None) or [])]
+        # no conditioning layer at all: the gates see zeros (reference custom_AE_layers.py:203-204,293-294)
+        self.wn_disable_conditioning = bool(wn.get("disable_conditioning", False))
         if str(wn.get("padding", "SAME")).upper() != "SAME":
             raise NotImplementedError("pp_mod_subnet.padding other than SAME is not supported")
         self.wn_use_weight_norm = bool(wn.get("use_weight_norm", False))
@@ -289,9 +290,8 @@ class ModelDims:
         self.ps_env_order_scale = mb.get("ps_env_order_scale", None)
         fr = mb.get("filter_max_db_range", None)
         self.filter_max_log_range = (fr / (20 * np.log10(np.exp(1)))) if fr else 0.0
+        # cepstral coefficient 0 kept, every frame's filter divided by its rms magnitude (custom_pulsed_generator.py:817-849)
         self.preserve_energy = bool(mb.get("spect_filters_preserve_energy", False))
-        if self.preserve_energy:
-            raise NotImplementedError("spect_filters_preserve_energy is not supported")
         if not mb.get("ps_use_stft", True) or mb.get("ps_off", False):
             raise NotImplementedError("only the STFT-domain envelope filter path (ps_use_stft) is supported")
         if mb.get("pulse_channels_use_pqmf", False) or not mb.get("pp_mod_subnet_use_pqmf", True):

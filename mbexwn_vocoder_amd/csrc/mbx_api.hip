@@ -89,6 +89,8 @@ struct mbx_handle {
     // derived
     int f0_time_factor = 1, vtf_time_factor = 1;
     long long subnet_buf_per_frame = 0;   // floats per frame of one ping-pong buffer
+    std::vector<mbx_subnet_op> cond_ops;  // pre-conditioning convolutions + the conditioning layer (empty: conditioning disabled)
+    long long cond_buf_per_frame = 0;     // floats per frame of a ping-pong buffer of that chain (0: no pre-conditioning layers)
     bool fold_skip = false;      // skip path folded into the end convolution (needs the *.fold tensors)
     bool fold_start = false;     // start convolution folded into layer 0 (needs fold_skip and the *.start_fold / *.fold_start tensors)
     bool winograd4_always = false;   // MBX_WINOGRAD=44: F(4,3) at every size (tests)
@@ -133,7 +135,7 @@ mbx_status analyse_subnet(const mbx_subnet_op *ops, int n_ops, int cin, long lon
 
 struct Workspace {
     float *mel_norm, *nm_a, *nm_b;
-    float *sub0, *sub1, *sub2, *sub3, *f0_wide, *f0, *cum, *chunk_last, *pulse, *cond, *h, *a, *skip, *wn_out, *sub, *exc, *ceps, *frames;
+    float *sub0, *sub1, *sub2, *sub3, *sub4, *sub5, *f0_wide, *f0, *cum, *chunk_last, *pulse, *cond, *h, *a, *skip, *wn_out, *sub, *exc, *ceps, *frames;
     int *ceps_index;
     size_t total;
 };
@@ -158,6 +160,8 @@ Workspace carve(const mbx_handle *hd, char *base, int B, int T) {
     w.sub1 = take(BT * hd->subnet_buf_per_frame);
     w.sub2 = take(BT * hd->subnet_buf_per_frame);   // VTF-net ping-pong (its convolutions share launches with the F0-net's)
     w.sub3 = take(BT * hd->subnet_buf_per_frame);
+    w.sub4 = take(BT * hd->cond_buf_per_frame);     // pre-conditioning layers (usually none: zero floats)
+    w.sub5 = take(BT * hd->cond_buf_per_frame);
     // an F0-net with a bare ["L", up] entry runs at a multiple of the pulse rate and is cut to it (reference
     // custom_pulsed_generator.py:57-60, 787): the uncut contour lives here
     w.f0_wide = take(hd->f0_time_factor > c.pulse_per_frame ? BT * hd->f0_time_factor : 0);
@@ -397,6 +401,7 @@ mbx::StftConsts stft_consts(const mbx_handle *hd) {
     k.n_ceps = c.n_ceps;
     k.n_ceps_windows = c.n_ceps_windows;
     k.max_log_range = c.filter_max_log_range;
+    k.preserve_energy = c.spect_preserve_energy;
     k.hann = find(hd, "table.hann")->ptr;
     k.inv_win = find(hd, "table.inv_win")->ptr;
     k.twiddle = hd->twiddle;
@@ -435,8 +440,11 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
         return fail(MBX_ERR_INVALID_ARGUMENT, "wn_in_channels must be pulse_channels (+1 with noise)");
     if (c.pqmf_taps % 2) return fail(MBX_ERR_INVALID_ARGUMENT, "PQMF taps must be even");
     if (c.phase_chunk < 1 || c.phase_chunk > 1024) return fail(MBX_ERR_INVALID_ARGUMENT, "phase_chunk must be in [1, 1024]");
-    if (c.wn_gate_activation < MBX_GATE_GTU || c.wn_gate_activation > MBX_GATE_GSU)
-        return fail(MBX_ERR_INVALID_ARGUMENT, "wn_gate_activation must be MBX_GATE_GTU, MBX_GATE_GFU or MBX_GATE_GSU");
+    if (c.wn_gate_activation < MBX_GATE_GTU || c.wn_gate_activation > MBX_GATE_GLU)
+        return fail(MBX_ERR_INVALID_ARGUMENT, "wn_gate_activation must be MBX_GATE_GTU, MBX_GATE_GFU, MBX_GATE_GSU or MBX_GATE_GLU");
+    if (c.n_precond < 0 || c.n_precond > MBX_MAX_PRECOND) return fail(MBX_ERR_INVALID_ARGUMENT, "n_precond out of range");
+    for (int i = 0; i < c.n_precond; ++i)
+        if (c.precond_channels[i] < 1) return fail(MBX_ERR_INVALID_ARGUMENT, "precond_channels must be positive");
 
     mbx_handle *hd = new mbx_handle();
     hd->cfg = c;
@@ -542,7 +550,33 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
 
     // required tensors
     std::vector<std::string> need = {"table.hann", "table.inv_win", "table.wavetables", "wn.start.w", "wn.start.b",
-                                     "wn.cond.w", "wn.cond.b", "wn.end.w", "wn.end.b", "post.w", "post.b"};
+                                     "wn.end.w", "wn.end.b", "post.w", "post.b"};
+    // conditioning chain (reference custom_AE_layers.py:190-227,283-289): pre-conditioning convolutions, then the
+    // conditioning layer; all with kernel size cond_kernel_size and zero SAME padding, no activation in between
+    if (!c.wn_disable_conditioning) {
+        int chan = c.mel_channels;
+        auto add = [&](const std::string &nm, int cout) {
+            mbx_subnet_op op{};
+            op.kind = MBX_OP_CONV;
+            op.ks = c.cond_kernel_size;
+            op.cin = chan;
+            op.cout = cout;
+            op.pad_l = (c.cond_kernel_size - 1) / 2;
+            op.pad_r = c.cond_kernel_size - 1 - op.pad_l;
+            op.pad_mode = MBX_PAD_ZERO;
+            op.up = 1;
+            std::snprintf(op.name, MBX_NAME_LEN, "%s", nm.c_str());
+            hd->cond_ops.push_back(op);
+            need.push_back(nm + ".w");
+            need.push_back(nm + ".b");
+            chan = cout;
+        };
+        for (int i = 0; i < c.n_precond; ++i) {
+            add("wn.precond_" + std::to_string(i), c.precond_channels[i]);
+            hd->cond_buf_per_frame = std::max<long long>(hd->cond_buf_per_frame, c.precond_channels[i]);
+        }
+        add("wn.cond", 2 * c.wn_channels * c.cond_conv_upsampling);
+    }
     if (c.nm_iters > 0) {
         if (c.nm_smooth_win < c.hop_size || c.nm_smooth_win % 2 || !(c.nm_rms_norm_fact > 0.f))
             return bail(fail(MBX_ERR_INVALID_ARGUMENT, "RMS normalisation: bad smoothing window / norm factor"));
@@ -569,10 +603,11 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
     };
     const int C = c.wn_channels;
     bool ok = expect("wn.start.w", (long long)c.wn_in_channels * C) &&
-              expect("wn.cond.w", (long long)c.cond_kernel_size * c.mel_channels * 2 * C * c.cond_conv_upsampling) &&
               expect("wn.end.w", (long long)C * c.wn_out_channels) && expect("post.w", (long long)c.wn_out_channels * M) &&
               expect("table.hann", c.stft_win) && expect("table.inv_win", c.stft_win) &&
               expect("table.wavetables", (long long)(c.wt_n_period + 1) * c.wt_n_tables);
+    for (const mbx_subnet_op &op : hd->cond_ops)
+        ok = ok && expect(std::string(op.name) + ".w", (long long)op.ks * op.cin * op.cout) && expect(std::string(op.name) + ".b", op.cout);
     for (int l = 0; l < c.wn_layers && ok; ++l) {
         ok = expect("wn.conv1D_" + std::to_string(l) + ".w", (long long)c.wn_kernel_size * C * 2 * C) &&
              expect("wn.res_skip_" + std::to_string(l) + ".w", (long long)C * (l < c.wn_layers - 1 ? 2 * C : C));
@@ -788,7 +823,6 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                                            w.nm_a, w.nm_b, w.mel_norm, stream);
         mel = w.mel_norm;
     }
-    const DevTensor *cw = find(hd, "wn.cond.w"), *cbias = find(hd, "wn.cond.b");
     const int cond_cout = 2 * C * c.cond_conv_upsampling;
     mbx::StftConsts sc = stft_consts(hd);
     // ---- conditioning conv (reference custom_AE_layers.py:214-227,287), VTF-net -> cepstrum (reference
@@ -803,10 +837,13 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         const long long f_off = T - Tf;
         const int32_t *nf_fe = fe_frames ? nullptr : n_frames;
         const float *mel_fe = mel + f_off * c.mel_channels;
-        mbx::ConvArgs cond_conv = conv_args(mel_fe, (long long)T * c.mel_channels, c.mel_channels, nf_fe, 1, Tf, B, cw,
-                                            cbias, c.cond_kernel_size, c.mel_channels, cond_cout, 1,
-                                            (c.cond_kernel_size - 1) / 2, MBX_PAD_ZERO, w.cond + f_off * cond_cout,
-                                            (long long)T * cond_cout, cond_cout);
+        SubnetRun cond(hd, hd->cond_ops.data(), (int)hd->cond_ops.size(), mel_fe, c.mel_channels, nf_fe, B, Tf, w.sub4,
+                       w.sub5, w.cond + f_off * cond_cout, false, 1.f, 0.f, stream);
+        if (hd->cond_ops.empty()) {   // disable_conditioning: cond_layers = zeros (reference custom_AE_layers.py:293-294)
+            cond.finished = true;
+            if (hipMemsetAsync(w.cond, 0, (size_t)B * T * cond_cout * sizeof(float), stream) != hipSuccess)
+                return fail(MBX_ERR_HIP, "hipMemsetAsync of the conditioning rows failed");
+        }
         SubnetRun vtf(hd, c.vtf_ops, c.n_vtf_ops, mel_fe, c.mel_channels, nf_fe, B, Tf, w.sub2, w.sub3,
                       w.ceps + f_off * c.n_ceps, false, 1.f, 0.f, stream);
         const bool f0_wide = hd->f0_time_factor > c.pulse_per_frame;
@@ -815,23 +852,21 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         if (fe_frames) {
             vtf.window_stride(T, c.mel_channels);
             f0.window_stride(T, c.mel_channels);
+            cond.window_stride(T, c.mel_channels);
         }
         if (f0_in) f0.finished = true;
-        bool cond_pending = true;
         for (;;) {
             mbx::ConvArgs group[3];
             int n = 0;
             if (f0.next_conv(group[n])) ++n;
             if (vtf.next_conv(group[n])) ++n;
-            if (cond_pending) {
-                group[n++] = cond_conv;
-                cond_pending = false;
-            }
+            if (cond.next_conv(group[n])) ++n;
             if (!n) break;
             mbx::launch_conv1d_group(group, n, stream);
         }
         if (vtf.status != MBX_OK) return vtf.status;
         if (f0.status != MBX_OK) return f0.status;
+        if (cond.status != MBX_OK) return cond.status;
         if (f0_wide && !f0_in)   // pulse_frequency[:, :T * pulse_per_frame] (reference custom_pulsed_generator.py:787)
             mbx::launch_activation(w.f0_wide, (long long)T * hd->f0_time_factor, n_frames, c.pulse_per_frame, (int)npulse,
                                    B, 1, MBX_ACT_LINEAR, 1.f, 0.f, w.f0, npulse, stream);

@@ -6,9 +6,10 @@
 namespace mbx {
 
 // Gate of a WaveNet layer (reference custom_AE_layers.py:312-321): act(zt) * sigmoid(zs) with act = tanh (kind 0, gtu),
-// z / (1 + |z|) (1, gfu) or z / (1 + sqrt|z|) (2, gsu).  One reciprocal for the whole product:
+// z / (1 + |z|) (1, gfu), z / (1 + sqrt|z|) (2, gsu) or z itself (3, glu: accepted at :156, no branch at :312-318).  One
+// reciprocal for the whole product:
 //   tanh(zt) sigmoid(zs) = (t - 1) / ((t + 1)(1 + s)),  t = e^(2 zt), s = e^(-zs)   (zt is clamped where tanh is 1 in
-//   float32, so t stays finite; s = inf gives 0, as it should);   zt / ((1 + |zt|)(1 + s)) for the other two.
+//   float32, so t stays finite; s = inf gives 0, as it should);   zt / ((1 + |zt|)(1 + s)) etc. for the others.
 // `kind` is a kernel argument: the branch is wave-uniform.
 #if defined(__HIPCC__)
 __device__ __forceinline__ float wn_gate_act(int kind, float zt, float zs) {
@@ -18,6 +19,7 @@ __device__ __forceinline__ float wn_gate_act(int kind, float zt, float zs) {
         const float tp = t + 1.0f;
         return (t - 1.0f) * __builtin_amdgcn_rcpf(fmaf(sg, tp, tp));
     }
+    if (kind == 3) return zt * __builtin_amdgcn_rcpf(1.0f + sg);
     const float az = fabsf(zt);
     const float den = 1.0f + (kind == 1 ? az : __builtin_amdgcn_sqrtf(az));
     return zt * __builtin_amdgcn_rcpf(fmaf(sg, den, den));
@@ -62,7 +64,7 @@ struct ConvArgs {
     int cond_phase;           // item row r sits at conditioning-rate position r + cond_phase (0 <= cond_phase < cond_up; F(2,3) gate kernel only)
     const float *lerp_w0, *lerp_w1;   // (cond_up) float32 interpolation weights
     int channels;             // C (gate: cout == 2C, out has C columns; res/skip: split point)
-    int gate_act;             // EPI_GATE and the gate kernels: 0 gtu, 1 gfu, 2 gsu (wn_gate_act)
+    int gate_act;             // EPI_GATE and the gate kernels: 0 gtu, 1 gfu, 2 gsu, 3 glu (wn_gate_act)
     // EPI_RESSKIP extras
     float *h;                 // (batch, rows, C) updated in place
     float *skip;              // (batch, rows, skip_ld)
@@ -107,7 +109,7 @@ struct Gate0Args {
     long long cond_bstride;
     int cond_up;
     const float *lerp_w0, *lerp_w1;
-    int gate_act;             // 0 gtu, 1 gfu, 2 gsu (wn_gate_act)
+    int gate_act;             // 0 gtu, 1 gfu, 2 gsu, 3 glu (wn_gate_act)
     float *out;               // (batch, rows, ldo): C gate channels, then x' padded to 16 channels if write_inputs
     long long out_bstride;
     int ldo, write_inputs;
@@ -226,6 +228,7 @@ void launch_pqmf(const float *x, long long x_bstride, const int *n_frames, int s
 // ---------------------------------------------------------------------------------------------
 struct StftConsts {
     int hop, win, fft_size, n_ceps, n_ceps_windows;
+    int preserve_energy;              // spect_filters_preserve_energy: cepstral coefficient 0 kept, H / rms_k |H|
     float max_log_range;
     const float *hann, *inv_win;      // (win)
     const float *twiddle;             // (fft_size/2, 2)

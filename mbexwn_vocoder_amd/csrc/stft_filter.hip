@@ -97,7 +97,9 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_filter_kernel(StftConsts c, 
     }
     __syncthreads();
 
-    // ---- 2. one-sided cepstrum [0, c1*l1 .. c_{n_ceps-1}*l_{n_ceps-1}, 0 ...] -> log spectrum
+    // ---- 2. one-sided cepstrum [0, c1*l1 .. c_{n_ceps-1}*l_{n_ceps-1}, 0 ...] -> log spectrum (coefficient 0 is the
+    // noise gain's business unless the filters preserve the energy, reference custom_pulsed_generator.py:817-826)
+    const int first_ceps = c.preserve_energy ? 0 : 1;
     const float *cb = ceps + (long long)b * ceps_bstride + (long long)t * c.n_ceps;
     const float *lw = nullptr;
     if (c.n_ceps_windows > 0 && index) lw = c.ceps_windows + (long long)index[(long long)b * max_frames + t] * c.n_ceps;
@@ -108,24 +110,46 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_filter_kernel(StftConsts c, 
         for (int q = 0; q < 2; ++q) {
             const int i = 2 * m + q;
             v[q] = 0.f;
-            if (i >= 1 && i < c.n_ceps) v[q] = lw ? cb[i] * lw[i] : cb[i];
+            if (i >= first_ceps && i < c.n_ceps) v[q] = lw ? cb[i] * lw[i] : cb[i];
         }
         bufa[m] = make_float2(v[0], v[1]);
     }
     __syncthreads();
     res = fft_lds<false>(bufa, bufb, tw, nc, tid);
     // ---- 3. H = exp(R * tanh(Re S) + j Im S) ; Y = X * H
+    float2 hk[MAX_BINS_PER_THREAD];
+    float h2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MAX_BINS_PER_THREAD; ++i) {
         const int k = tid + i * FFT_THREADS;
+        hk[i] = make_float2(0.f, 0.f);
         if (k <= nc) {
             const float2 s = real_bin(res, tw, k, nc);
             const float re = (c.max_log_range > 0.f) ? c.max_log_range * tanhf(s.x) : s.x;
             const float mag = expf(re);
             float sn, cs;
             sincosf(s.y, &sn, &cs);
-            xk[i] = cmul(xk[i], make_float2(mag * cs, mag * sn));
+            hk[i] = make_float2(mag * cs, mag * sn);
+            if (c.preserve_energy) h2 += hk[i].x * hk[i].x + hk[i].y * hk[i].y;
         }
+    }
+    float inv_gain = 1.f;
+    if (c.preserve_energy) {
+        // filter_gain = sqrt(mean_k |H_k|^2) over the fft_size / 2 + 1 bins of the frame (reference :838-839); H /= gain
+        __shared__ float s_h2[FFT_THREADS / 64];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) h2 += __shfl_xor(h2, o);
+        if ((tid & 63) == 0) s_h2[tid >> 6] = h2;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < FFT_THREADS / 64; ++q) tot += s_h2[q];
+        inv_gain = 1.f / sqrtf(tot / (float)(nc + 1));
+    }
+#pragma unroll
+    for (int i = 0; i < MAX_BINS_PER_THREAD; ++i) {
+        const int k = tid + i * FFT_THREADS;
+        if (k <= nc) xk[i] = cmul(xk[i], make_float2(hk[i].x * inv_gain, hk[i].y * inv_gain));
     }
     __syncthreads();
     // Y[0..nc) to LDS; a real inverse transform ignores Im Y[0] and Im Y[nc], so Re Y[nc] travels in Im of entry 0

@@ -278,7 +278,8 @@ bool launch_wn_gate0(const Gate0Args &a, hipStream_t stream) {
     const long long blocks = (long long)r.m_tiles_per_item * a.batch * r.n_tiles;
     if (a.gate_act == 0) hipLaunchKernelGGL(wn_gate0_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, r);
     else if (a.gate_act == 1) hipLaunchKernelGGL(wn_gate0_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, r);
-    else hipLaunchKernelGGL(wn_gate0_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, r);
+    else if (a.gate_act == 2) hipLaunchKernelGGL(wn_gate0_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, r);
+    else hipLaunchKernelGGL(wn_gate0_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, stream, r);
     return true;
 }
 

@@ -19,9 +19,10 @@ from .config import ModelDims
 from .subnet import build_subnet
 from .weights import fold_weights, merge_channel_groups
 
-MBX_ABI_VERSION = 5
+MBX_ABI_VERSION = 6
 MBX_MAX_SUBNET_OPS = 32
 MBX_MAX_WN_LAYERS = 64
+MBX_MAX_PRECOND = 8
 MBX_NAME_LEN = 64
 
 _OP_KIND = {"conv": 0, "lin": 1, "prelu": 2, "leaky": 3, "act": 4}
@@ -60,7 +61,9 @@ class mbx_config(ctypes.Structure):
                 ("nm_use_max_limit", ctypes.c_int32), ("nm_rms_norm_fact", ctypes.c_float),
                 ("nm_rms_floor", ctypes.c_float), ("nm_compressor_exp", ctypes.c_float),
                 ("nm_lin_amp_scale", ctypes.c_float), ("nm_lin_amp_off", ctypes.c_float),
-                ("nm_mel_amp_scale", ctypes.c_float), ("wn_gate_activation", ctypes.c_int32)]
+                ("nm_mel_amp_scale", ctypes.c_float), ("wn_gate_activation", ctypes.c_int32),
+                ("wn_disable_conditioning", ctypes.c_int32), ("n_precond", ctypes.c_int32),
+                ("precond_channels", ctypes.c_int32 * MBX_MAX_PRECOND), ("spect_preserve_energy", ctypes.c_int32)]
 
 
 class mbx_forward_options(ctypes.Structure):
@@ -229,7 +232,14 @@ def make_config(config, wavetables):
     cc.wt_max_transposition = float(wavetables.max_transposition)
     cc.wt_grid_norm = float(wavetables.grid_norm)
     cc.phase_chunk = 1000
-    cc.wn_gate_activation = {"gtu": 0, "gfu": 1, "gsu": 2}[dims.wn_activation]
+    cc.wn_gate_activation = {"gtu": 0, "gfu": 1, "gsu": 2, "glu": 3}[dims.wn_activation]
+    cc.wn_disable_conditioning = int(dims.wn_disable_conditioning)
+    if len(dims.wn_pre_cond_channels) > MBX_MAX_PRECOND:
+        raise ValueError("too many pre-conditioning layers for the engine")
+    cc.n_precond = len(dims.wn_pre_cond_channels)
+    for ii, chans in enumerate(dims.wn_pre_cond_channels):
+        cc.precond_channels[ii] = chans
+    cc.spect_preserve_energy = int(dims.preserve_energy)
     f0_ops, vtf_ops = subnet_ops(config)
     cc.n_f0_ops = _fill_ops(cc.f0_ops, f0_ops)
     cc.n_vtf_ops = _fill_ops(cc.vtf_ops, vtf_ops)

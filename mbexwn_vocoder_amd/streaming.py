@@ -95,7 +95,8 @@ def frontend_reach(dims, config):
 
     f0_l, f0_r = reach(mb["pp_subnet"])
     vt_l, vt_r = reach(mb["ps_subnet"])
-    ck = (dims.cond_kernel_size - 1) // 2
+    # the conditioning layer and the pre-conditioning convolutions in front of it (same kernel size, zero SAME padding)
+    ck = ((dims.cond_kernel_size - 1) // 2) * (1 + len(dims.wn_pre_cond_channels))
     # + 1: the interpolators (F0 contour, conditioning rows) reach the next frame
     return max(f0_l, vt_l, ck), max(f0_r, vt_r, ck) + 1
 

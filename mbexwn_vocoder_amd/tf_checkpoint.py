@@ -415,7 +415,7 @@ _WAVENET_LAYERS = {"start": "wn.start", "end": "wn.end", "cond_": "wn.cond"}
 def _engine_layer_name(layer):
     if layer in _WAVENET_LAYERS:
         return _WAVENET_LAYERS[layer]
-    if re.fullmatch(r"(conv1D|res_skip)_\d+(g\d+)?", layer):
+    if re.fullmatch(r"(conv1D|res_skip)_\d+(g\d+)?", layer) or re.fullmatch(r"precond_\d+", layer):
         return "wn." + layer
     if layer.endswith("_PaNMPulseWaveNet_Post"):
         return "post"

@@ -36,7 +36,12 @@ def layer_table(config):
             prelus.append((op["name"], op["channels"]))
     C, L = dims.wn_channels, dims.wn_layers
     convs.append(("wn.start", 1, dims.wn_in_channels, C))
-    convs.append(("wn.cond", dims.cond_kernel_size, dims.mel_channels, 2 * C * dims.cond_conv_upsampling))
+    if not dims.wn_disable_conditioning:
+        cond_in = dims.mel_channels
+        for ii, chans in enumerate(dims.wn_pre_cond_channels):          # reference custom_AE_layers.py:192-201
+            convs.append((f"wn.precond_{ii}", dims.cond_kernel_size, cond_in, chans))
+            cond_in = chans
+        convs.append(("wn.cond", dims.cond_kernel_size, cond_in, 2 * C * dims.cond_conv_upsampling))
     # n_ch_groups independent channel groups, each with its own layers "conv1D_<l>", "conv1D_<l>g1", ...
     # (reference custom_AE_layers.py:235-260)
     G = dims.wn_groups
@@ -181,10 +186,11 @@ def merge_channel_groups(folded, dims):
         out[f"wn.conv1D_{ll}.w"], out[f"wn.conv1D_{ll}.b"] = wc, bc
         out[f"wn.res_skip_{ll}.w"], out[f"wn.res_skip_{ll}.b"] = wr, br
     # conditioning: new column (u, [tanh | sigmoid], g, i) <- old column (u, g, [tanh | sigmoid], i)
-    up = dims.cond_conv_upsampling
-    perm = np.arange(up * 2 * C).reshape(up, G, 2, Cg).transpose(0, 2, 1, 3).reshape(-1)
-    out["wn.cond.w"] = np.ascontiguousarray(folded["wn.cond.w"][:, :, perm])
-    out["wn.cond.b"] = np.ascontiguousarray(folded["wn.cond.b"][perm])
+    if "wn.cond.w" in folded:                                 # absent with disable_conditioning
+        up = dims.cond_conv_upsampling
+        perm = np.arange(up * 2 * C).reshape(up, G, 2, Cg).transpose(0, 2, 1, 3).reshape(-1)
+        out["wn.cond.w"] = np.ascontiguousarray(folded["wn.cond.w"][:, :, perm])
+        out["wn.cond.b"] = np.ascontiguousarray(folded["wn.cond.b"][perm])
     return out
 
 

@@ -150,6 +150,7 @@ class OracleModel:
         self.use_ceps_constraint = mb.get("psns_use_cepstral_loss_constraint", False)
         rng_db = mb.get("filter_max_db_range", None)
         self.max_log_range = rng_db / LOG_TO_DB if rng_db is not None else None      # :371
+        self.preserve_energy = bool(mb.get("spect_filters_preserve_energy", False))     # :817-849
         self.stft_win = 4 * self.hop                                                # :396
         fft_size = 16
         while fft_size < self.stft_win:
@@ -339,12 +340,16 @@ class OracleModel:
         """custom_AE_layers.py:214-227,287-289: sub-pixel conv (factor cond_conv_upsampling) then LinInterp."""
         lin_up = self.wn.get("cond_lin_upsampling", 16)
         conv_up = int((self.pulse_rate / self.pulse_channels) // ((self.sample_rate / self.hop) * lin_up))
+        x = mel
+        for ii in range(len(self.wn.get("pre_cond_layer_channels", None) or [])):    # :192-201, 283-285: plain convolutions
+            w, b = self.weight(f"wn.precond_{ii}")
+            x = conv1d_same_zero(x, w, b)
         w, b = self.weight("wn.cond")
-        c = depth_to_time(conv1d_same_zero(mel, w, b), conv_up)
+        c = depth_to_time(conv1d_same_zero(x, w, b), conv_up)
         return lin_interp(c, lin_up, self.f32)
 
     def wavenet(self, x, mel, return_layers=False):
-        """custom_AE_layers.py:273-346 (WaveNetAE.call), activation gtu / gfu / gsu; n_ch_groups independent channel groups between
+        """custom_AE_layers.py:273-346 (WaveNetAE.call), activation gtu / gfu / gsu / glu; n_ch_groups independent channel groups between
         the shared start and end convolutions (:303-340; layers of group g > 0 are named "<layer>g<g>", :249,260)."""
         C = self.wn["n_channels"]
         L = self.wn.get("n_layers", 12)
@@ -353,7 +358,10 @@ class OracleModel:
         w, b = self.weight("wn.start")
         started = np.split(conv1d_valid(x, w, b), G, axis=-1)                     # :280, :303-304
         started = [np.array(ss) for ss in started]
-        cond = np.split(self.conditioning(mel), G, axis=-1)                       # :287-289
+        if self.wn.get("disable_conditioning", False):                            # :293-294: zeros
+            cond = [np.zeros((), dtype=self.dtype)] * G
+        else:
+            cond = np.split(self.conditioning(mel), G, axis=-1)                   # :287-289
         output = [None] * G
         acts = []
         for ll in range(L):
@@ -369,6 +377,8 @@ class OracleModel:
                     half = zt / (1 + np.abs(zt))
                 elif act == "gsu":
                     half = zt / (1 + np.sqrt(np.abs(zt)))
+                elif act == "glu":                                                # accepted at :156, no branch: linear half
+                    half = zt
                 else:
                     raise NotImplementedError(f"WaveNetAE activation {act}")
                 a = half * (1 / (1 + np.exp(-z[..., Cg:])))                       # :320-321
@@ -447,11 +457,16 @@ class OracleModel:
                 window_index = self.cepstral_window_index(f0)
             x = x * self.ceps_windows[window_index]                               # :813
         ceps = np.zeros(x.shape[:2] + (self.fft_size,), dtype=self.dtype)
-        ceps[:, :, 1:self.n_ceps] = x[:, :, 1:]                                   # :820-821
+        first = 0 if self.preserve_energy else 1                                  # :817-826
+        ceps[:, :, first:self.n_ceps] = x[:, :, first:]
         spec = np.fft.rfft(ceps, axis=-1)                                         # :829
         if self.max_log_range:
-            return np.exp(self.max_log_range * np.tanh(spec.real) + 1j * spec.imag)   # :831-834
-        return np.exp(spec)
+            filt = np.exp(self.max_log_range * np.tanh(spec.real) + 1j * spec.imag)   # :831-834
+        else:
+            filt = np.exp(spec)
+        if self.preserve_energy:                                                  # :838-843
+            filt = filt / np.sqrt(np.mean(np.square(np.abs(filt)), axis=-1, keepdims=True))
+        return filt
 
     # ------------------------------------------------------------------ STFT filter (A11,A13)
     def stft(self, exc, n_frames):

@@ -50,9 +50,20 @@ CASES = {
     "eqlr_plain": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
                               "mbexwn_config:pp_mod_subnet:use_weight_norm": False,
                               "mbexwn_config:pp_mod_subnet:use_equalized_lr": True}, 2, 9),
+    # "glu" (accepted at custom_AE_layers.py:156, no branch at :312-318: linear half x sigmoid), pre-conditioning
+    # convolutions (:190-201,283-285), a WaveNet without conditioning (:203-204,293-294) and energy preserving spectral
+    # filters (custom_pulsed_generator.py:817-849)
+    "glu": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                       "mbexwn_config:pp_mod_subnet:activation": "glu"}, 2, 9),
+    "precond": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                           "mbexwn_config:pp_mod_subnet:pre_cond_layer_channels": [48, 40]}, 2, 9),
+    "nocond": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                          "mbexwn_config:pp_mod_subnet:disable_conditioning": True}, 2, 9),
+    "energy": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                          "mbexwn_config:spect_filters_preserve_energy": True}, 2, 9),
 }
 # the long cases keep the small stage outputs only (the full conditioning / envelope tensors would be megabytes)
-LEAN = {"canon60", "voice", "grammar", "groups", "gfu", "gsu_eqlr", "eqlr_plain"}
+LEAN = {"canon60", "voice", "grammar", "groups", "gfu", "gsu_eqlr", "eqlr_plain", "glu", "precond", "nocond", "energy"}
 
 
 def assign_conv(layer, raw, name):
@@ -74,7 +85,9 @@ def load_into_reference(model, raw):
                 ll.alpha.assign(np.reshape(raw[ll.name + ".alpha"], ll.alpha.shape))
                 used.add(ll.name + ".alpha")
     wn = model.pp_waveNetBlocks[0].wavenet
-    pairs = [(wn.start, "wn.start"), (wn.end, "wn.end"), (wn.cond_layer, "wn.cond"), (model.wn_post_net[0], "post")]
+    pairs = [(wn.start, "wn.start"), (wn.end, "wn.end"), (model.wn_post_net[0], "post")]
+    if wn.cond_layer is not None:
+        pairs += [(wn.cond_layer, "wn.cond")] + [(ll, f"wn.precond_{ii}") for ii, ll in enumerate(wn.pre_cond_layers)]
     # layer list index = layer * n_ch_groups + group; group g > 0 is named "<layer>g<g>" (reference custom_AE_layers.py:249,260)
     ng = wn.n_ch_groups
 
@@ -116,8 +129,11 @@ def run_case(voice, overrides, batch, frames, float_type):
     out["phase"] = np.asarray(model.pulse_generator.stable_cumsum_and_wrap(f0 / model.pulse_generator.sample_rate))
     out["pulse"] = np.asarray(model.pulse_generator(f0))[:, :, 0]
     wn = model.pp_waveNetBlocks[0].wavenet
-    cond = wn.cond_lin_upsampling_layer(wn.cond_layer(mel_t))
-    out["cond"] = np.asarray(cond)
+    if wn.cond_layer is not None:
+        cond_in = mel_t
+        for ll in wn.pre_cond_layers:
+            cond_in = ll(cond_in)
+        out["cond"] = np.asarray(wn.cond_lin_upsampling_layer(wn.cond_layer(cond_in)))
     shim.INJECTED_NOISE["normal"] = noise
     out["excitation"] = np.asarray(model.generate_excitation(mel_t, pulse_frequency=f0))
     env = model.generate_specenv(mel=mel_t, pulse_frequency=f0, training=False)
@@ -145,7 +161,8 @@ def main():
         for name, (voice, overrides, batch, frames) in CASES.items():
             res = run_case(voice, overrides, batch, frames, float_type)
             if name in LEAN:
-                res["cond"] = np.asarray(res["cond"])[:, ::37]
+                if "cond" in res:
+                    res["cond"] = np.asarray(res["cond"])[:, ::37]
                 for kk in ("envelope_re", "envelope_im", "wavetables"):
                     res.pop(kk)
                 if tag == "f64":

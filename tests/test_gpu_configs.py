@@ -339,10 +339,12 @@ def test_streaming_with_rms_normalisation(torch, monkeypatch):
 # ------------------------------------------------------------------------------------------------
 # WaveNet options: the gfu / gsu gates and use_equalized_lr
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("case", ["gfu", "gsu_eqlr", "eqlr_plain"])
+@pytest.mark.parametrize("case", ["gfu", "gsu_eqlr", "eqlr_plain", "glu", "precond", "nocond", "energy"])
 def test_gate_variants_and_equalized_lr_vs_reference_goldens(torch, golden_dir, case):
-    """pp_mod_subnet.activation = gfu / gsu (reference custom_AE_layers.py:312-318) and use_equalized_lr with and without
-    weight norm (conv_layers.py:133-153), against the float32 run of the reference's own MBExWN.call and the oracle."""
+    """pp_mod_subnet.activation = gfu / gsu / glu (reference custom_AE_layers.py:156,312-318), use_equalized_lr with and
+    without weight norm (conv_layers.py:133-153), pre_cond_layer_channels (:190-201,283-285), disable_conditioning
+    (:203-204,293-294) and spect_filters_preserve_energy (custom_pulsed_generator.py:817-849), against the float32 run of
+    the reference's own MBExWN.call and the oracle."""
     from mbexwn_vocoder_amd.engine import MBExWNEngine
     gold = np.load(os.path.join(golden_dir, "reference_forward_f32.npz"))
     voice, overrides, batch, frames = GOLDEN_CASES[case]
@@ -356,7 +358,7 @@ def test_gate_variants_and_equalized_lr_vs_reference_goldens(torch, golden_dir, 
     assert _maxdiff(got, ref) <= _tol(ref)
 
 
-@pytest.mark.parametrize("act", ["gfu", "gsu"])
+@pytest.mark.parametrize("act", ["gfu", "gsu", "glu"])
 def test_gate_variants_at_full_width(torch, monkeypatch, act):
     """The other two gates through every gate kernel of the canonical geometry (C = 320): the folded first layer, F(4,3) in
     both block shapes, F(2,3) (MBX_WINOGRAD=2) and the direct form (MBX_WINOGRAD=0), each against the float64 oracle."""

@@ -163,6 +163,45 @@ def test_streaming_without_layer_state(monkeypatch):
     assert np.array_equal(np.concatenate(got), offline)
 
 
+@pytest.mark.parametrize("extra", [{"mbexwn_config:pp_mod_subnet:pre_cond_layer_channels": [48, 40]},
+                                   {"mbexwn_config:pp_mod_subnet:disable_conditioning": True},
+                                   {"mbexwn_config:spect_filters_preserve_energy": True,
+                                    "mbexwn_config:pp_mod_subnet:activation": "glu"}])
+def test_streaming_with_the_second_batch_of_options(monkeypatch, extra):
+    """Streams of models with pre-conditioning layers (the mel-rate front end reaches two more frames per layer: margins
+    and the carried front end follow streaming.frontend_reach), without conditioning, and with energy preserving
+    filters + the glu gate: bit-equal to the offline synthesis in the streams' convolution form, steady ticks included."""
+    import torch
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    from mbexwn_vocoder_amd.streaming import StreamingSynthesizer, frontend_reach
+    monkeypatch.setenv("MBX_WINOGRAD", "2")
+    cfg, raw, wt = build_case("SPEECH", dict(SMALL, **extra))
+    eng = MBExWNEngine(cfg, raw, wt)
+    if "mbexwn_config:pp_mod_subnet:pre_cond_layer_channels" in extra:
+        base_cfg, _, _ = build_case("SPEECH", SMALL)
+        from mbexwn_vocoder_amd.config import ModelDims
+        assert frontend_reach(ModelDims(cfg), cfg)[0] >= 3 > (ModelDims(base_cfg).cond_kernel_size - 1) // 2
+    syn = StreamingSynthesizer(eng, chunk_frames=8)
+    offline, got = {}, {}
+    for sid, ll in enumerate([97, 33]):
+        mel, noise = synthetic_inputs(300 + sid, 1, ll)
+        offline[sid] = eng.forward(torch.as_tensor(mel).cuda(), noise=torch.as_tensor(noise).cuda()).cpu().numpy()[0]
+        got[sid] = []
+        syn.open(sid)
+        syn.push(sid, mel[0], noise[0], last=True)
+    steady = 0
+    for _ in range(60):
+        out = syn.tick()
+        steady += syn.last_tick_layer_rows > 0
+        for sid, audio in out.items():
+            got[sid].append(np.array(audio))
+        if all(syn.finished(sid) for sid in offline):
+            break
+    assert steady >= 3
+    for sid in offline:
+        assert np.array_equal(np.concatenate(got[sid]), offline[sid]), f"stream {sid}"
+
+
 def test_streaming_dilation_cycle_model(monkeypatch):
     """Per-layer state with a dilation cycle (7 layers: 1 2 4 1 2 4 1): the staircase of exact rows has repeated steps,
     two inner layers of dilation 1 whose reach is rounded up to 2 rows; 15 rows of reach + 9 rows of conditioning clamp = 2 frames.  Steady ticks must occur and the stream must be

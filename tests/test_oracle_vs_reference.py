@@ -58,8 +58,9 @@ def test_float32_emulation(golden_dir, case):
     assert _maxdiff(st["excitation"], gold[f"{case}/excitation"]) < 1e-4
     assert _maxdiff(audio, gold[f"{case}/audio"]) < 1e-4
     if case in LEAN_GOLDEN_CASES:
-        cond = om.conditioning(mel.astype(np.float64))[:, ::37]
-        assert _maxdiff(cond, gold[f"{case}/cond"]) < 1e-5
+        if f"{case}/cond" in gold.files:                            # absent with disable_conditioning
+            cond = om.conditioning(mel.astype(np.float64))[:, ::37]
+            assert _maxdiff(cond, gold[f"{case}/cond"]) < 1e-5
         if case in ("canon60", "voice"):                           # several phase chunks and the offset chain are pinned
             assert (frames * 100 + 999) // 1000 >= 5
     if f"{case}/ceps_window_sum" in gold.files:

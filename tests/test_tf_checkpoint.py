@@ -129,14 +129,41 @@ def test_wavenet_without_weight_norm_loads_and_folds(tmp_path):
         tfc.load_reference_checkpoint(prefix, cfg_wn)
 
 
+def test_pre_conditioning_layers_and_missing_conditioning_round_trip(tmp_path):
+    """`precond_<i>` layers (reference custom_AE_layers.py:192-201) map to "wn.precond_<i>"; a model built with
+    disable_conditioning has no `cond_` layer at all (:203-204)."""
+    for extra, present, absent in (({"mbexwn_config:pp_mod_subnet:pre_cond_layer_channels": [48, 40]}, "wn.precond_1.v", None),
+                                   ({"mbexwn_config:pp_mod_subnet:disable_conditioning": True}, "wn.start.v", "wn.cond.v")):
+        cfg = canonical_config("SPEECH", **dict({"mbexwn_config:pp_mod_subnet:n_channels": 32}, **extra))
+        raw = synthetic_weights(cfg, seed=11)
+        assert present in raw and (absent is None or absent not in raw)
+        if "wn.precond_1.v" in raw:
+            assert raw["wn.precond_0.v"].shape == (3, 80, 48) and raw["wn.precond_1.v"].shape == (3, 48, 40)
+            assert raw["wn.cond.v"].shape[1] == 40
+        prefix = str(tmp_path / ("w" + str(len(raw))))
+        named = _reference_names(raw)
+        if "wn.precond_1.v" in raw:
+            assert any(kk.endswith("wave_net_ae/precond_1/kernel") for kk in named)
+        tfc.write_checkpoint(prefix, named)
+        got = tfc.load_reference_checkpoint(prefix, cfg)
+        assert sorted(got) == sorted(raw)
+        for name in raw:
+            assert np.array_equal(got[name], raw[name]), name
+
+
 def test_unbuilt_wavenet_options_raise():
     """Keys of WaveNetAE.__init__ that change the arithmetic and are not built must not be ignored silently."""
     from mbexwn_vocoder_amd.config import ModelDims
-    for key, value in (("pre_cond_layer_channels", [64]), ("disable_conditioning", True), ("padding", "VALID"),
-                       ("activation", "relu")):
-        cfg = canonical_config("SPEECH", **{f"mbexwn_config:pp_mod_subnet:{key}": value})
-        with pytest.raises(NotImplementedError):
-            ModelDims(cfg)
+    with pytest.raises(NotImplementedError):
+        ModelDims(canonical_config("SPEECH", **{"mbexwn_config:pp_mod_subnet:padding": "VALID"}))
+    with pytest.raises(RuntimeError, match="unsupported wavenet activation"):   # the reference's own check and message
+        ModelDims(canonical_config("SPEECH", **{"mbexwn_config:pp_mod_subnet:activation": "relu"}))
+    # built since round 3 (second batch): pre-conditioning layers, a WaveNet without conditioning, the glu gate
+    dims = ModelDims(canonical_config("SPEECH", **{"mbexwn_config:pp_mod_subnet:pre_cond_layer_channels": [64, 48]}))
+    assert dims.wn_pre_cond_channels == [64, 48]
+    assert ModelDims(canonical_config("SPEECH", **{"mbexwn_config:pp_mod_subnet:disable_conditioning": True})).wn_disable_conditioning
+    assert ModelDims(canonical_config("SPEECH", **{"mbexwn_config:pp_mod_subnet:activation": "glu"})).wn_activation == "glu"
+    assert ModelDims(canonical_config("SPEECH", **{"mbexwn_config:spect_filters_preserve_energy": True})).preserve_energy
     # built since round 3: the gfu / gsu gates and use_equalized_lr (folded on the host)
     assert ModelDims(canonical_config("SPEECH", **{"mbexwn_config:pp_mod_subnet:use_equalized_lr": True})).wn_equalized_lr
     assert ModelDims(canonical_config("SPEECH", **{"mbexwn_config:pp_mod_subnet:activation": "gsu"})).wn_activation == "gsu"
