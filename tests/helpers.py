@@ -33,8 +33,22 @@ GOLDEN_CASES = {
                           "mbexwn_config:pp_mod_subnet:disable_conditioning": True}, 2, 9),
     "energy": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
                           "mbexwn_config:spect_filters_preserve_energy": True}, 2, 9),
+    "mixed_a": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 5,
+                           "mbexwn_config:pp_mod_subnet:dilation_rate_step": 2,
+                           "mbexwn_config:pp_mod_subnet:max_log2_dilation_rate": 2,
+                           "mbexwn_config:pp_mod_subnet:cond_kernel_size": 1,
+                           "mbexwn_config:pp_mod_subnet_noise_channel_sigma": 0,
+                           "mbexwn_config:filter_max_db_range": None,
+                           "mbexwn_config:ps_env_order_scale": None}, 2, 9),
+    "mixed_b": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                           "mbexwn_config:use_prelu": False, "mbexwn_config:alpha": 0.1,
+                           "mbexwn_config:pp_subnet_use_valid_padding": True,
+                           "mbexwn_config:ps_subnet_use_valid_padding": True,
+                           "mbexwn_config:psns_use_cepstral_loss_constraint": True,
+                           "mbexwn_config:filter_max_db_range": 12.0,
+                           "mbexwn_config:pp_mod_subnet:cond_lin_upsampling": 20}, 2, 9),
 }
-LEAN_GOLDEN_CASES = {"canon60", "voice", "grammar", "groups", "gfu", "gsu_eqlr", "eqlr_plain", "glu", "precond", "nocond", "energy"}     # cond subsampled [:, ::37], no envelope / wavetables (see the generator)
+LEAN_GOLDEN_CASES = {"canon60", "voice", "grammar", "groups", "gfu", "gsu_eqlr", "eqlr_plain", "glu", "precond", "nocond", "energy", "mixed_a", "mixed_b"}     # cond subsampled [:, ::37], no envelope / wavetables (see the generator)
 
 
 @functools.lru_cache(maxsize=None)

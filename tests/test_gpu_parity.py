@@ -223,7 +223,7 @@ def test_forward_matches_reference_goldens(torch, golden_dir, case):
     pulse_from_ref_f0, phase = eng.wavetable(dev(torch, gold[f"{case}/f0"]))
     assert np.array_equal(phase.cpu().numpy(), gold[f"{case}/phase"])
     assert _maxdiff(pulse_from_ref_f0.cpu().numpy(), gold[f"{case}/pulse"]) <= 2e-6
-    assert cond.shape[1] == frames * 2 * 2 * eng.dims.wn_channels
+    assert cond.shape[1] == frames * eng.dims.cond_conv_upsampling * 2 * eng.dims.wn_channels
 
 
 @pytest.mark.parametrize("form", ["0", "2", "44"])
