@@ -136,6 +136,13 @@ typedef struct {
     /* spect_filters_preserve_energy (reference custom_pulsed_generator.py:817-849): the cepstrum keeps its coefficient
      * 0 and every frame's filter is divided by the root of its mean squared magnitude over the fft_size/2 + 1 bins */
     int32_t spect_preserve_energy;
+    /* wavetable_config.add_subharm_chans (reference tf_wavetable.py:520-559): n extra excitation channels
+     * sin(2 pi phase / ii), ii = 2 .. n + 1, next to the pulse: the pulse tensor is (samples, 1 + n), a WaveNet row folds
+     * pulse_channels samples = pulse_channels * (1 + n) channels (custom_pulsed_generator.py:893), and wn_in_channels
+     * counts them.  wt_sinusoid_as_fun (use_sinusoid_as_fun, tf_wavetable.py:522-523): the pulse itself is
+     * sin(2 pi phase) * 0.5 * (1 - cos(2 pi phase)) instead of the table lookup */
+    int32_t wt_subharm_channels;
+    int32_t wt_sinusoid_as_fun;
 } mbx_config;
 
 /* A named HOST tensor handed over at creation (weights already weight-norm folded, tables).
@@ -322,7 +329,7 @@ mbx_status mbx_conv1d(mbx_handle *handle, const float *x, int32_t batch, int32_t
 mbx_status mbx_lin_interp(mbx_handle *handle, const float *x, int32_t batch, int32_t n_rows, int32_t channels,
                           int32_t up, float *y, void *hip_stream);
 
-/* PulseWaveTable.call (reference tf_wavetable.py:495-552): f0 (batch, n) Hz -> pulse (batch, n);
+/* PulseWaveTable.call (reference tf_wavetable.py:495-552): f0 (batch, n) Hz -> pulse (batch, n, 1 + wt_subharm_channels);
  * phase (batch, n) optional output of stable_cumsum_and_wrap (may be NULL). scratch >= batch*(n + n/chunk + 3) floats. */
 mbx_status mbx_wavetable(mbx_handle *handle, const float *f0, int32_t batch, int32_t n, float *pulse, float *phase,
                          float *scratch, void *hip_stream);

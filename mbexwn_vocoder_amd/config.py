@@ -277,7 +277,13 @@ class ModelDims:
                                f"{self.cond_lin_upsampling}")
         self.cond_conv_upsampling = int(conv_up)
         self.noise_sigma = float(mb.get("pp_mod_subnet_noise_channel_sigma", 0.5) or 0.0)
-        self.wn_in_channels = self.pulse_channels + (1 if self.noise_sigma else 0)
+        # wavetable options that change the excitation tensor (reference tf_wavetable.py:520-559,
+        # custom_pulsed_generator.py:893): n sub-harmonic sinusoid channels next to the pulse; the pulse as a function
+        wtc = mb.get("wavetable_config", {}) or {}
+        self.wt_subharm = int(wtc.get("add_subharm_chans", 0) or 0)
+        self.wt_sinusoid_as_fun = bool(wtc.get("use_sinusoid_as_fun", False))
+        self.pulse_channels_eff = self.pulse_channels * (1 + self.wt_subharm)
+        self.wn_in_channels = self.pulse_channels_eff + (1 if self.noise_sigma else 0)
         self.f0_min = float(mb.get("pp_min_frequency", 40.0))
         self.f0_max = float(mb.get("pp_max_frequency", 600.0))
         win_s = mb.get("internal_win_size_s", None)

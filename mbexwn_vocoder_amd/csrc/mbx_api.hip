@@ -168,7 +168,7 @@ Workspace carve(const mbx_handle *hd, char *base, int B, int T) {
     w.f0 = take(B * npulse);
     w.cum = take(B * npulse);
     w.chunk_last = take((size_t)B * chunks);
-    w.pulse = take(B * npulse);
+    w.pulse = take(B * npulse * (1 + c.wt_subharm_channels));
     w.cond = take(BT * 2 * c.wn_channels * c.cond_conv_upsampling);
     w.h = take(B * nsteps * c.wn_channels);
     w.a = take(B * nsteps * (c.wn_channels + 16));   // layer 0 appends the excitation channels to its rows (wn_gate0.hip)
@@ -366,6 +366,8 @@ mbx::WaveTableConsts wavetable_consts(const mbx_handle *hd) {
     k.max_tf = c.wt_max_transposition;
     k.grid_norm = c.wt_grid_norm;
     k.chunk = c.phase_chunk;
+    k.n_sub = c.wt_subharm_channels;
+    k.sin_fun = c.wt_sinusoid_as_fun;
     return k;
 }
 
@@ -436,8 +438,9 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
         return fail(MBX_ERR_INVALID_ARGUMENT, "pulse_per_frame must be steps_per_frame * pulse_channels");
     if ((c.steps_per_frame % c.cond_lin_upsampling) || c.steps_per_frame / c.cond_lin_upsampling != c.cond_conv_upsampling)
         return fail(MBX_ERR_INVALID_ARGUMENT, "conditioning rates do not reach the WaveNet rate");
-    if (c.wn_in_channels != c.pulse_channels + (c.noise_sigma != 0.f ? 1 : 0))
-        return fail(MBX_ERR_INVALID_ARGUMENT, "wn_in_channels must be pulse_channels (+1 with noise)");
+    if (c.wt_subharm_channels < 0 || c.wt_subharm_channels > 8) return fail(MBX_ERR_INVALID_ARGUMENT, "wt_subharm_channels out of range");
+    if (c.wn_in_channels != c.pulse_channels * (1 + c.wt_subharm_channels) + (c.noise_sigma != 0.f ? 1 : 0))
+        return fail(MBX_ERR_INVALID_ARGUMENT, "wn_in_channels must be pulse_channels * (1 + wt_subharm_channels) (+1 with noise)");
     if (c.pqmf_taps % 2) return fail(MBX_ERR_INVALID_ARGUMENT, "PQMF taps must be even");
     if (c.phase_chunk < 1 || c.phase_chunk > 1024) return fail(MBX_ERR_INVALID_ARGUMENT, "phase_chunk must be in [1, 1024]");
     if (c.wn_gate_activation < MBX_GATE_GTU || c.wn_gate_activation > MBX_GATE_GLU)
@@ -645,7 +648,7 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
         // start convolution folded into layer 0 (wn_gate0.hip); MBX_FOLD_START=0 keeps the h0 tensor and the full layer
         const char *sv = getenv("MBX_FOLD_START");
         bool have0 = have && (!sv || atoi(sv) != 0) && c.wn_kernel_size == 3 &&
-                     mbx::wn_gate0_fits(C, c.pulse_channels, c.wn_dilations[0], c.cond_lin_upsampling) &&
+                     mbx::wn_gate0_fits(C, c.pulse_channels * (1 + c.wt_subharm_channels), c.wn_dilations[0], c.cond_lin_upsampling) &&
                      expect("wn.conv1D_0.start_fold", (long long)((C + 31) / 32) * 1536);
         if (have0 && c.wn_layers > 1)
             have0 = expect("wn.res_skip_0.fold_start", nct * ((C + 16 + 15) / 16) * 2048);
@@ -969,13 +972,14 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         }
         tail_sp = res_sp[L - 1];
     }
-    const int ppr = c.pulse_per_frame / spf;                   // excitation samples per WaveNet row
+    const int nsub1 = 1 + c.wt_subharm_channels;              // floats per excitation sample (pulse + sub-harmonic sinusoids)
+    const int ppr = c.pulse_per_frame / spf * nsub1;           // excitation floats per WaveNet row
     if (c.pulse_per_frame % spf != 0) return fail(MBX_ERR_INVALID_ARGUMENT, "pulse_per_frame must be a multiple of steps_per_frame");
     if (!fold_start) {
         ScopedEvents ev(hd, PROF_START, stream);
         const Span &sp = region;
-        mbx::launch_wn_start(w.pulse + sp.row0 * ppr, npulse, c.noise_sigma != 0.f ? noise + sp.row0 : nullptr, nsteps, c.noise_sigma,
-                             sp.nf, sp.rpf, sp.max_rows, B, c.pulse_channels, find(hd, "wn.start.w")->ptr,
+        mbx::launch_wn_start(w.pulse + sp.row0 * ppr, npulse * nsub1, c.noise_sigma != 0.f ? noise + sp.row0 : nullptr, nsteps, c.noise_sigma,
+                             sp.nf, sp.rpf, sp.max_rows, B, c.pulse_channels * nsub1, find(hd, "wn.start.w")->ptr,
                              find(hd, "wn.start.b")->ptr, C, w.h + sp.row0 * C, nsteps * C, stream);
     }
     auto lerp = hd->lerp[cond_up];
@@ -1003,11 +1007,11 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
             ScopedEvents ev(hd, PROF_GATE0, stream);
             mbx::Gate0Args g0{};
             g0.pulse = w.pulse + gs.row0 * ppr;
-            g0.pulse_bstride = npulse;
+            g0.pulse_bstride = npulse * nsub1;
             g0.noise = c.noise_sigma != 0.f ? noise + gs.row0 : nullptr;
             g0.noise_bstride = nsteps;
             g0.sigma = c.noise_sigma;
-            g0.pulse_channels = c.pulse_channels;
+            g0.pulse_channels = c.pulse_channels * nsub1;
             g0.n_frames = gs.nf;
             g0.rows_per_frame = gs.rpf;
             g0.max_rows = gs.max_rows;
@@ -1238,7 +1242,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     if (nm_gain_src) sg["mel_norm"] = {w_base.mel_norm, (long long)T * c.mel_channels, (long long)T * c.mel_channels};
     else sg.erase("mel_norm");
     sg["f0"] = {w_base.f0, npulse, npulse};
-    sg["pulse"] = {w_base.pulse, npulse, npulse};
+    sg["pulse"] = {w_base.pulse, npulse * (1 + c.wt_subharm_channels), npulse * (1 + c.wt_subharm_channels)};
     sg["cond"] = {w_base.cond, (long long)T * cond_cout, (long long)T * cond_cout};
     sg["wn_hidden"] = {w_base.h, nsteps * C, nsteps * C};
     if (!hd->fold_skip) sg["wn_skip"] = {w_base.skip, nsteps * C, nsteps * C};

@@ -199,6 +199,8 @@ struct WaveTableConsts {
     int n_period, n_tables;
     float pulse_rate, nominal_f0, min_tf, max_tf, grid_norm;
     int chunk;
+    int n_sub;             // add_subharm_chans: extra channels sin(2 pi phase / ii), ii = 2 .. n_sub + 1, behind the pulse
+    int sin_fun;           // use_sinusoid_as_fun: pulse = sin(2 pi phase) * 0.5 * (1 - cos(2 pi phase)), no table lookup
 };
 // carried phase-accumulator state of a stream (== mbx_stream_state of include/mbexwn.h)
 struct StreamState {
@@ -209,7 +211,7 @@ struct StreamState {
     int save_sample;      // window-relative pulse sample whose state is written to the output (< start: none)
     int reserved;
 };
-// f0 (B, n_max) -> pulse (B, n_max); cum / chunk_last are scratch: cum (B, n_max), chunk_last (B, n_chunks_max + 1)
+// f0 (B, n_max) -> pulse (B, n_max, 1 + n_sub); cum / chunk_last are scratch: cum (B, n_max), chunk_last (B, n_chunks_max + 1)
 void launch_wavetable(const WaveTableConsts &c, const float *f0, long long bstride, const int *n_frames,
                       int samples_per_frame, int n_max, int batch, float *pulse, float *phase_out, float *cum,
                       float *chunk_last, const StreamState *st_in, StreamState *st_out, hipStream_t stream);

@@ -1,4 +1,4 @@
-// Wavetable oscillator: F0 -> wrapped phase -> band-limited LF pulse.
+// Wavetable oscillator: F0 -> wrapped phase -> band-limited LF pulse (+ optional sub-harmonic sinusoid channels).
 //
 // restates PulseWaveTable.call                 reference MBExWN_NVoc/vocoder/model/tf_wavetable.py:495-552
 //          stable_cumsum_and_wrap               reference tf_wavetable.py:429-492
@@ -103,7 +103,8 @@ __global__ void wavetable_kernel(WaveTableConsts k, const float *f0, long long b
     const float *fb = f0 + (long long)b * bstride;
     const float *cb = cum + (long long)b * bstride;
     const float *lb = chunk_last + (long long)b * chunks_max;
-    float *pb = pulse + (long long)b * bstride;
+    const int nch = 1 + k.n_sub;                              // channels per sample: pulse, then the sub-harmonic sinusoids
+    float *pb = pulse + (long long)b * bstride * nch;
     const int start = st ? st[b].start_sample : 0;
     const int first_len = st ? k.chunk - st[b].pos_in_chunk : k.chunk;
     const float off0 = st ? st[b].offset_sum : 0.f;
@@ -126,7 +127,7 @@ __global__ void wavetable_kernel(WaveTableConsts k, const float *f0, long long b
     }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         if (i < start) {          // streaming: samples in front of the carried state are not reproducible
-            pb[i] = 0.f;
+            for (int ch = 0; ch < nch; ++ch) pb[(long long)i * nch + ch] = 0.f;
             if (phase_out) phase_out[(long long)b * bstride + i] = 0.f;
             continue;
         }
@@ -142,6 +143,13 @@ __global__ void wavetable_kernel(WaveTableConsts k, const float *f0, long long b
         }
         const float phase = mod1(cb[i] + off);
         if (phase_out) phase_out[(long long)b * bstride + i] = phase;
+        // wrapped_phase * 2 * pi in float32, left to right (tf_wavetable.py:521)
+        const float w2pi = (phase * 2.f) * 3.14159265358979323846f;
+        for (int ii = 2; ii < nch + 1; ++ii) pb[(long long)i * nch + ii - 1] = sinf(w2pi / (float)ii);   // :554-557
+        if (k.sin_fun) {          // :522-523
+            pb[(long long)i * nch] = (sinf(w2pi) * 0.5f) * (1.f - cosf(w2pi));
+            continue;
+        }
         // linear table lookup (tf_wavetable.py:619-638)
         const float pos = phase * (float)k.n_period;
         const float base = floorf(pos);
@@ -165,7 +173,7 @@ __global__ void wavetable_kernel(WaveTableConsts k, const float *f0, long long b
             const float w1 = fmaxf(1.0f - fabsf(q - (float)r1), 0.f);
             out = out + s1 * w1;
         }
-        pb[i] = out;
+        pb[(long long)i * nch] = out;
     }
 }
 

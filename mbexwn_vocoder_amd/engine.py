@@ -63,7 +63,8 @@ class mbx_config(ctypes.Structure):
                 ("nm_lin_amp_scale", ctypes.c_float), ("nm_lin_amp_off", ctypes.c_float),
                 ("nm_mel_amp_scale", ctypes.c_float), ("wn_gate_activation", ctypes.c_int32),
                 ("wn_disable_conditioning", ctypes.c_int32), ("n_precond", ctypes.c_int32),
-                ("precond_channels", ctypes.c_int32 * MBX_MAX_PRECOND), ("spect_preserve_energy", ctypes.c_int32)]
+                ("precond_channels", ctypes.c_int32 * MBX_MAX_PRECOND), ("spect_preserve_energy", ctypes.c_int32),
+                ("wt_subharm_channels", ctypes.c_int32), ("wt_sinusoid_as_fun", ctypes.c_int32)]
 
 
 class mbx_forward_options(ctypes.Structure):
@@ -240,6 +241,8 @@ def make_config(config, wavetables):
     for ii, chans in enumerate(dims.wn_pre_cond_channels):
         cc.precond_channels[ii] = chans
     cc.spect_preserve_energy = int(dims.preserve_energy)
+    cc.wt_subharm_channels = dims.wt_subharm
+    cc.wt_sinusoid_as_fun = int(dims.wt_sinusoid_as_fun)
     f0_ops, vtf_ops = subnet_ops(config)
     cc.n_f0_ops = _fill_ops(cc.f0_ops, f0_ops)
     cc.n_vtf_ops = _fill_ops(cc.vtf_ops, vtf_ops)
@@ -434,11 +437,11 @@ def fold_start_weights(folded, dims, fold_skip):
     ws = np.asarray(folded["wn.start.w"], dtype=np.float64)
     w0 = np.asarray(folded["wn.conv1D_0.w"], dtype=np.float64)
     cin = dims.wn_in_channels
-    if ws.shape != (1, cin, C) or w0.shape != (3, C, 2 * C) or cin + 1 > 8 or dims.pulse_channels + 2 > 8:
+    if ws.shape != (1, cin, C) or w0.shape != (3, C, 2 * C) or cin + 1 > 8 or dims.pulse_channels_eff + 2 > 8:
         return {}
     wsp = np.zeros((8, C))
     wsp[:cin] = ws[0]
-    wsp[dims.pulse_channels + 1] = np.asarray(folded["wn.start.b"], dtype=np.float64)   # the constant channel
+    wsp[dims.pulse_channels_eff + 1] = np.asarray(folded["wn.start.b"], dtype=np.float64)   # the constant channel
     prod = np.einsum("kc,tcn->tkn", wsp, w0)                       # (3, 8, 2C)
     nt = (C + 31) // 32
     wp = np.zeros((3, 8, 2, nt * 32))
@@ -784,7 +787,7 @@ class MBExWNEngine:
         """True when layer 0 runs with the start convolution folded in (csrc/wn_gate0.hip): mirror of mbx_create's
         policy (MBX_FOLD_SKIP / MBX_FOLD_START not 0, the folded tensors exist and the layer fits the kernel)."""
         cu = self.dims.cond_lin_upsampling
-        fits = ((256 + cu - 2) // cu + 2 <= 32 and self.dims.wn_dilation(0) <= 16 and self.dims.pulse_channels + 2 <= 8 and
+        fits = ((256 + cu - 2) // cu + 2 <= 32 and self.dims.wn_dilation(0) <= 16 and self.dims.pulse_channels_eff + 2 <= 8 and
                 self.dims.wn_kernel_size == 3)                     # wn_gate0_fits (csrc/wn_gate0.hip)
         return (int(os.environ.get("MBX_FOLD_SKIP", "1")) != 0 and int(os.environ.get("MBX_FOLD_START", "1")) != 0 and fits and
                 "wn.conv1D_0.start_fold" in self._tensors and
@@ -939,7 +942,8 @@ class MBExWNEngine:
         torch = self._torch
         f0 = f0.contiguous()
         B, N = f0.shape
-        pulse = torch.empty_like(f0)
+        nch = 1 + self.dims.wt_subharm                       # pulse + sub-harmonic sinusoid channels per sample
+        pulse = torch.empty((B, N, nch) if nch > 1 else (B, N), dtype=torch.float32, device=self.device)
         phase = torch.empty_like(f0)
         scratch = torch.empty(B * (N + N // 1000 + 3), dtype=torch.float32, device=self.device)
         _check(self._lib.mbx_wavetable(self._handle, f0.data_ptr(), B, N, pulse.data_ptr(), phase.data_ptr(),

@@ -180,8 +180,13 @@ def lf_pulse(n_wavetable, oq=0.5, am=0.7, rta=0.1, pul_bw=0.1, use_deriv=False, 
 
 
 def normed_pulse(Oq, target_nominalF0, nominalBandWidth, sample_rate, am=0.8, rta=0.1, use_radiation=False,
-                 bandWidthReductionFactor=1.0, wt_oversampling=1):
-    """reference tf_wavetable.py:309-410 (create_normed_pulse, LF branch). Returns (table, realised F0)."""
+                 bandWidthReductionFactor=1.0, wt_oversampling=1, use_sinusoid=False):
+    """reference tf_wavetable.py:309-410 (create_normed_pulse: LF branch, or one Hann-weighted sine period with
+    use_sinusoid, :387-390). Returns (table, realised F0)."""
+    if use_sinusoid:
+        period = int(wt_oversampling * np.floor(sample_rate / target_nominalF0))
+        res = np.sin(np.arange(period) / period * np.pi * 2) * ss.get_window("hann", period, fftbins=True)
+        return res, wt_oversampling * sample_rate / period
     res = lf_pulse(int(np.ceil(wt_oversampling * sample_rate / target_nominalF0)), oq=Oq, am=am, rta=rta,
                    pul_bw=nominalBandWidth / (bandWidthReductionFactor * wt_oversampling),
                    transition_width=0.1 / wt_oversampling, use_deriv=use_radiation)
@@ -191,33 +196,43 @@ def normed_pulse(Oq, target_nominalF0, nominalBandWidth, sample_rate, am=0.8, rt
 class WaveTables:
     """The runtime constants of the wavetable oscillator.
 
-    reference tf_wavetable.py:181-306 (PulseWaveTable.__init__), LF-pulse branch only
-    (use_sinusoid / white pulse / sub-harmonic channels are not part of the mel-inversion models).
+    reference tf_wavetable.py:181-306 (PulseWaveTable.__init__): the LF-pulse tables, or the single sine table of
+    use_sinusoid / use_sinusoid_as_fun (:239,254-259).  add_subharm_chans and use_sinusoid_as_fun change what the
+    oscillator emits, not the tables (config.ModelDims carries them to the kernel).  Not built: white pulse, no_interp,
+    pulse-synchronous gains.
     """
 
     def __init__(self, sample_rate, nominalF0, Oq=0.5, am=0.8, rta=0.05, use_radiation=False, F0GridFactor=1.25,
-                 numF0InGrid=5, maxF0=None, wt_oversampling=2, nominalBandWidth=None, **unsupported):
-        for kk in ("use_sinusoid", "use_sinusoid_as_fun", "use_white_pulse", "add_subharm_chans", "no_interp",
-                   "pulse_sync_gain_avg"):
+                 numF0InGrid=5, maxF0=None, wt_oversampling=2, nominalBandWidth=None, use_sinusoid=False,
+                 use_sinusoid_as_fun=False, add_subharm_chans=0, **unsupported):
+        for kk in ("use_white_pulse", "no_interp", "pulse_sync_gain_avg"):
             if unsupported.get(kk, False):
                 raise NotImplementedError(f"wavetable_config option {kk} is not supported")
+        self.add_subharm_chans = int(add_subharm_chans or 0)
+        self.use_sinusoid_as_fun = bool(use_sinusoid_as_fun)
+        # reference :239,250,275: the tables are built with the constructor argument use_sinusoid; use_sinusoid_as_fun
+        # alone keeps the LF tables (they are then not looked up)
+        use_sinusoid = bool(use_sinusoid)
         self.sample_rate = float(sample_rate)
         grid = float(F0GridFactor)
         # first pass only to learn which nominal F0 a power-of-two table realises (reference :244-254)
         band = 0.5 / grid
         ref_f0 = maxF0 if maxF0 is not None else nominalF0 * grid ** numF0InGrid
         _, nominal = normed_pulse(Oq, nominalF0, band, sample_rate, am=am, rta=rta, use_radiation=use_radiation,
-                                  bandWidthReductionFactor=ref_f0 / nominalF0, wt_oversampling=wt_oversampling)
+                                  bandWidthReductionFactor=ref_f0 / nominalF0, wt_oversampling=wt_oversampling,
+                                  use_sinusoid=use_sinusoid)
         self.nominalF0 = float(nominal)
         n_grid = int(numF0InGrid)
         if maxF0 is not None:
             n_grid = int(np.ceil(np.log(maxF0 / self.nominalF0) / np.log(grid)))
+        if use_sinusoid:                                           # reference :254-259: one table
+            n_grid = 0
         tables = []
         self.F0_list = []
         for ir in range(n_grid + 1):
             rs = grid ** ir if ir > 0 else 1
             tab, _ = normed_pulse(Oq, self.nominalF0, 0.5, sample_rate, am=am, rta=rta, use_radiation=use_radiation,
-                                  bandWidthReductionFactor=rs, wt_oversampling=wt_oversampling)
+                                  bandWidthReductionFactor=rs, wt_oversampling=wt_oversampling, use_sinusoid=use_sinusoid)
             tab = tab.astype(np.float32)
             self.F0_list.append(self.nominalF0 * rs)
             # first sample appended for the interpolation across the period boundary (reference :278-280)

@@ -139,6 +139,7 @@ class OracleModel:
         self.M = mb["multi_band_config"]["subbands"]
         self.pulse_rate = self.sample_rate / mb["pulse_rate_factor"]
         self.pulse_channels = mb["pulse_channels"]
+        self.wt_cfg = mb.get("wavetable_config", {}) or {}
         self.steps_per_frame = self.hop // self.M                                   # :265
         self.pulse_per_frame = self.steps_per_frame * self.pulse_channels           # :266
         self.sigma = mb.get("pp_mod_subnet_noise_channel_sigma", 0.5)
@@ -315,6 +316,19 @@ class OracleModel:
         ft = self.f32
         f0_32 = np.asarray(f0, dtype=ft)
         phase = self.phase_from_f0(f0_32)
+        n_sub = int(self.wt_cfg.get("add_subharm_chans", 0) or 0)
+        if self.wt_cfg.get("use_sinusoid_as_fun", False) or n_sub:
+            w2pi = ((phase * ft(2)) * ft(np.pi)).astype(ft)                         # :521, float32 left to right
+        if n_sub:                                                                  # :554-559: (B, N, 1 + n_sub)
+            subs = [np.sin((w2pi / ft(ii)).astype(ft).astype(dt)) for ii in range(2, n_sub + 2)]
+            return np.stack([self._pulse_channel(f0_32, phase, w2pi if self.wt_cfg.get("use_sinusoid_as_fun", False) else None)] + subs, axis=-1)
+        return self._pulse_channel(f0_32, phase, w2pi if self.wt_cfg.get("use_sinusoid_as_fun", False) else None)
+
+    def _pulse_channel(self, f0_32, phase, w2pi):
+        dt, ft = self.dtype, self.f32
+        if w2pi is not None:                                                       # :522-523 use_sinusoid_as_fun
+            w = w2pi.astype(dt)
+            return np.sin(w) * 0.5 * (1.0 - np.cos(w))
         pos = (phase * ft(self.wt.n_period)).astype(ft)                            # :619
         base = np.floor(pos)
         rem = (pos - base).astype(ft).astype(dt)                                   # :630
@@ -420,7 +434,8 @@ class OracleModel:
     def generate_excitation(self, mel, f0, noise):
         """custom_pulsed_generator.py:886-925 ; noise (B, T*steps_per_frame) ~ N(0,1) or None (sigma=0)."""
         pulse = self.wavetable(f0)                                                # :889
-        x = pulse.reshape(pulse.shape[0], -1, self.pulse_channels).astype(self.dtype)   # :893
+        n_sub = int(self.wt_cfg.get("add_subharm_chans", 0) or 0)
+        x = pulse.reshape(pulse.shape[0], -1, self.pulse_channels * (1 + n_sub)).astype(self.dtype)   # :893
         if self.sigma:
             if noise is None:
                 raise ValueError("noise must be given when pp_mod_subnet_noise_channel_sigma != 0")

@@ -78,9 +78,16 @@ CASES = {
                            "mbexwn_config:psns_use_cepstral_loss_constraint": True,
                            "mbexwn_config:filter_max_db_range": 12.0,
                            "mbexwn_config:pp_mod_subnet:cond_lin_upsampling": 20}, 2, 9),
+    # wavetable options that change the excitation tensor (reference tf_wavetable.py:520-559, custom_pulsed_generator.py:893):
+    # one sub-harmonic sinusoid channel next to the LF pulse; the pulse as sin * (1 - cos) / 2 with two of them
+    "subharm": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                           "mbexwn_config:wavetable_config:add_subharm_chans": 1}, 2, 9),
+    "sinfun": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                          "mbexwn_config:wavetable_config:use_sinusoid_as_fun": True,
+                          "mbexwn_config:wavetable_config:add_subharm_chans": 2}, 2, 9),
 }
 # the long cases keep the small stage outputs only (the full conditioning / envelope tensors would be megabytes)
-LEAN = {"canon60", "voice", "grammar", "groups", "gfu", "gsu_eqlr", "eqlr_plain", "glu", "precond", "nocond", "energy", "mixed_a", "mixed_b"}
+LEAN = {"canon60", "voice", "grammar", "groups", "gfu", "gsu_eqlr", "eqlr_plain", "glu", "precond", "nocond", "energy", "mixed_a", "mixed_b", "subharm", "sinfun"}
 
 
 def assign_conv(layer, raw, name):
@@ -144,7 +151,8 @@ def run_case(voice, overrides, batch, frames, float_type):
     f0 = model.generate_f0(mel_t)
     out["f0"] = np.asarray(f0)
     out["phase"] = np.asarray(model.pulse_generator.stable_cumsum_and_wrap(f0 / model.pulse_generator.sample_rate))
-    out["pulse"] = np.asarray(model.pulse_generator(f0))[:, :, 0]
+    pulse = np.asarray(model.pulse_generator(f0))            # (B, N, 1 + add_subharm_chans)
+    out["pulse"] = pulse[:, :, 0] if pulse.shape[2] == 1 else pulse
     wn = model.pp_waveNetBlocks[0].wavenet
     if wn.cond_layer is not None:
         cond_in = mel_t

@@ -47,8 +47,13 @@ GOLDEN_CASES = {
                            "mbexwn_config:psns_use_cepstral_loss_constraint": True,
                            "mbexwn_config:filter_max_db_range": 12.0,
                            "mbexwn_config:pp_mod_subnet:cond_lin_upsampling": 20}, 2, 9),
+    "subharm": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                           "mbexwn_config:wavetable_config:add_subharm_chans": 1}, 2, 9),
+    "sinfun": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                          "mbexwn_config:wavetable_config:use_sinusoid_as_fun": True,
+                          "mbexwn_config:wavetable_config:add_subharm_chans": 2}, 2, 9),
 }
-LEAN_GOLDEN_CASES = {"canon60", "voice", "grammar", "groups", "gfu", "gsu_eqlr", "eqlr_plain", "glu", "precond", "nocond", "energy", "mixed_a", "mixed_b"}     # cond subsampled [:, ::37], no envelope / wavetables (see the generator)
+LEAN_GOLDEN_CASES = {"canon60", "voice", "grammar", "groups", "gfu", "gsu_eqlr", "eqlr_plain", "glu", "precond", "nocond", "energy", "mixed_a", "mixed_b", "subharm", "sinfun"}     # cond subsampled [:, ::37], no envelope / wavetables (see the generator)
 
 
 @functools.lru_cache(maxsize=None)

@@ -217,7 +217,8 @@ def test_forward_matches_reference_goldens(torch, golden_dir, case):
     ref = gold[f"{case}/audio"]
     assert _maxdiff(got, ref) <= _tol(ref, E2E_TOL)
     assert _maxdiff(eng.stage("excitation").cpu().numpy(), gold[f"{case}/excitation"]) <= _tol(gold[f"{case}/excitation"], E2E_TOL)
-    assert _maxdiff(eng.stage("pulse").cpu().numpy(), gold[f"{case}/pulse"]) <= 5e-4     # F0 rounding moves the phase
+    # (with sub-harmonic channels the pulse tensor is (B, N, 1 + n): the stage is its flat image)
+    assert _maxdiff(eng.stage("pulse").cpu().numpy(), gold[f"{case}/pulse"].reshape(batch, -1)) <= 5e-4     # F0 rounding moves the phase
     cond = eng.stage("cond").cpu().numpy().reshape(batch, -1)
     # the engine keeps the conditioning at the sub-pixel rate (2T, 2C) and interpolates on the fly
     pulse_from_ref_f0, phase = eng.wavetable(dev(torch, gold[f"{case}/f0"]))
@@ -301,6 +302,35 @@ def test_other_wavenet_geometries(torch, overrides):
         assert _maxdiff(got, ref) <= _tol(ref, E2E_TOL)
     with pytest.raises(ValueError, match="multiple of 4"):
         MBExWNEngine(*build_case("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 34}))
+
+
+def test_subharmonic_channels_through_the_folded_first_layer(torch):
+    """add_subharm_chans with 3 folded samples per row (pulse rate 4 800 Hz): 6 excitation channels + noise + the constant
+    channel = the 8 channels of wn_gate0_kernel, so the sub-harmonic sinusoids go through the folded first layer; the
+    canonical 5 x 2 channels (golden case "subharm") take the un-folded start convolution instead."""
+    from mbexwn_vocoder_amd.config import ModelDims, canonical_config
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    from mbexwn_vocoder_amd.tables import WaveTables
+    from mbexwn_vocoder_amd.weights import synthetic_weights
+    cfg = canonical_config("SPEECH", **{"mbexwn_config:pulse_rate_factor": 5, "mbexwn_config:pulse_channels": 3,
+                                        "mbexwn_config:wavetable_config:add_subharm_chans": 1,
+                                        "mbexwn_config:pp_mod_subnet:n_channels": 64, "mbexwn_config:pp_mod_subnet:n_layers": 3})
+    dims = ModelDims(cfg)
+    assert dims.pulse_channels_eff == 6 and dims.wn_in_channels == 7 and dims.pulse_per_frame == 60
+    raw = synthetic_weights(cfg, seed=21, bias_std=0.05, alpha_jitter=0.05)
+    wt = WaveTables(sample_rate=dims.pulse_rate, **cfg["mbexwn_config"]["wavetable_config"])
+    eng, om = MBExWNEngine(cfg, raw, wt), orc.OracleModel(cfg, raw, wt)
+    assert "wn.conv1D_0.start_fold" in eng._tensors
+    mel, noise = synthetic_inputs(9, 2, 25)
+    got = eng.forward(dev(torch, mel), noise=dev(torch, noise),
+                      n_frames=torch.tensor([25, 11], dtype=torch.int32, device="cuda")).cpu().numpy()
+    for ii, ll in enumerate((25, 11)):
+        ref = om.forward(mel[ii:ii + 1, :ll], noise[ii:ii + 1, :ll * 20])[0]
+        assert _maxdiff(got[ii, :ll * 300], ref) <= _tol(ref, E2E_TOL)
+    pulse, phase = eng.wavetable(eng.stage("f0"))
+    assert pulse.shape == (2, 25 * 60, 2)
+    sub = np.sin((phase.cpu().numpy().astype(np.float32) * np.float32(2)) * np.float32(np.pi) / np.float32(2))
+    assert _maxdiff(pulse[..., 1].cpu().numpy(), sub) <= 2e-6
 
 
 def test_engine_without_weight_images_runs_the_generic_kernels(torch):

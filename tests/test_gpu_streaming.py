@@ -166,7 +166,9 @@ def test_streaming_without_layer_state(monkeypatch):
 @pytest.mark.parametrize("extra", [{"mbexwn_config:pp_mod_subnet:pre_cond_layer_channels": [48, 40]},
                                    {"mbexwn_config:pp_mod_subnet:disable_conditioning": True},
                                    {"mbexwn_config:spect_filters_preserve_energy": True,
-                                    "mbexwn_config:pp_mod_subnet:activation": "glu"}])
+                                    "mbexwn_config:pp_mod_subnet:activation": "glu"},
+                                   {"mbexwn_config:wavetable_config:add_subharm_chans": 1},
+                                   {"mbexwn_config:wavetable_config:use_sinusoid_as_fun": True}])
 def test_streaming_with_the_second_batch_of_options(monkeypatch, extra):
     """Streams of models with pre-conditioning layers (the mel-rate front end reaches two more frames per layer: margins
     and the carried front end follow streaming.frontend_reach), without conditioning, and with energy preserving
@@ -197,7 +199,10 @@ def test_streaming_with_the_second_batch_of_options(monkeypatch, extra):
             got[sid].append(np.array(audio))
         if all(syn.finished(sid) for sid in offline):
             break
-    assert steady >= 3
+    # (10 excitation channels do not fit the folded first layer: such a handle carries no per-layer state and every tick
+    # runs the WaveNet on its whole region)
+    assert steady >= 3 or not syn.layer_carry
+    assert syn.layer_carry or "mbexwn_config:wavetable_config:add_subharm_chans" in extra
     for sid in offline:
         assert np.array_equal(np.concatenate(got[sid]), offline[sid]), f"stream {sid}"
 

@@ -180,7 +180,7 @@ def test_start_convolution_folds_into_layer_0_including_the_item_edges():
     from types import SimpleNamespace
     rng = np.random.default_rng(11)
     C, pc, n_out, T = 40, 5, 30, 37
-    dims = SimpleNamespace(wn_channels=C, wn_layers=2, wn_in_channels=pc + 1, pulse_channels=pc, wn_out_channels=n_out)
+    dims = SimpleNamespace(wn_channels=C, wn_layers=2, wn_in_channels=pc + 1, pulse_channels=pc, pulse_channels_eff=pc, wn_out_channels=n_out)
     folded = {"wn.start.w": rng.normal(size=(1, pc + 1, C)), "wn.start.b": rng.normal(size=C),
               "wn.conv1D_0.w": rng.normal(size=(3, C, 2 * C)),
               "wn.res_skip_0.w": rng.normal(size=(1, C, 2 * C)), "wn.res_skip_0.b": rng.normal(size=2 * C)}

@@ -107,6 +107,29 @@ def test_full_wavetable_grid(gold):
     assert np.array_equal(wt.tables[-1], wt.tables[0])
 
 
+def test_wavetable_options():
+    """use_sinusoid: one table = one sine period under a periodic Hann window (reference tf_wavetable.py:254-259,387-390;
+    unpinned: that branch calls scipy.signal.hanning, which the scipy of this image no longer has, so the reference cannot
+    run it here).  add_subharm_chans / use_sinusoid_as_fun leave the tables alone; the unbuilt options still raise."""
+    cfg = canonical_config("SPEECH")
+    dims = ModelDims(cfg)
+    base = dict(cfg["mbexwn_config"]["wavetable_config"])
+    wt = tables.WaveTables(sample_rate=dims.pulse_rate, **dict(base, use_sinusoid=True))
+    period = 2 * int(np.floor(dims.pulse_rate / base["nominalF0"]))
+    assert wt.tables.shape == (period + 1, 1) and wt.n_tables == 1 and wt.nominalF0 == 2 * dims.pulse_rate / period
+    assert float(wt.min_transposition) == float(wt.max_transposition) == 1.0 and wt.tables.min() == -1.0
+    want = np.sin(2 * np.pi * np.arange(period) / period) * (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(period) / period))
+    np.testing.assert_allclose(wt.tables[:-1, 0], want / -want.min(), rtol=0, atol=1e-6)
+    ref = tables.WaveTables(sample_rate=dims.pulse_rate, **base)
+    for extra in ({"add_subharm_chans": 2}, {"use_sinusoid_as_fun": True}):
+        assert np.array_equal(tables.WaveTables(sample_rate=dims.pulse_rate, **dict(base, **extra)).tables, ref.tables)
+    over = canonical_config("SPEECH", **{"mbexwn_config:wavetable_config:add_subharm_chans": 2})
+    assert ModelDims(over).wn_in_channels == 5 * 3 + 1 and ModelDims(over).pulse_channels_eff == 15
+    for kk in ("use_white_pulse", "no_interp", "pulse_sync_gain_avg"):
+        with pytest.raises(NotImplementedError):
+            tables.WaveTables(sample_rate=dims.pulse_rate, **dict(base, **{kk: True}))
+
+
 def test_cepstral_windows_and_smoother():
     logs, rows = tables.cepstral_windows(1.0, 24000, 40.0, 600.0, 240)
     assert rows.shape == (30, 240) and logs.shape == (30,)
