@@ -143,6 +143,11 @@ typedef struct {
      * sin(2 pi phase) * 0.5 * (1 - cos(2 pi phase)) instead of the table lookup */
     int32_t wt_subharm_channels;
     int32_t wt_sinusoid_as_fun;
+    /* ps_off (reference custom_pulsed_generator.py:663-672): no VTF-net and no STFT-domain filter, the audio is the
+     * excitation itself (n_vtf_ops == 0).  no_pqmf (pp_mod_subnet_use_pqmf: false, :920-923): the sub-band rows are
+     * not run through the PQMF synthesis bank but laid out one after the other (a reshape of the post-net output) */
+    int32_t ps_off;
+    int32_t no_pqmf;
 } mbx_config;
 
 /* A named HOST tensor handed over at creation (weights already weight-norm folded, tables).

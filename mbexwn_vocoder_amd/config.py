@@ -298,10 +298,14 @@ class ModelDims:
         self.filter_max_log_range = (fr / (20 * np.log10(np.exp(1)))) if fr else 0.0
         # cepstral coefficient 0 kept, every frame's filter divided by its rms magnitude (custom_pulsed_generator.py:817-849)
         self.preserve_energy = bool(mb.get("spect_filters_preserve_energy", False))
-        if not mb.get("ps_use_stft", True) or mb.get("ps_off", False):
-            raise NotImplementedError("only the STFT-domain envelope filter path (ps_use_stft) is supported")
-        if mb.get("pulse_channels_use_pqmf", False) or not mb.get("pp_mod_subnet_use_pqmf", True):
-            raise NotImplementedError("pulse_channels_use_pqmf / no-PQMF variants are not supported")
+        # ps_off: no VTF-net, no STFT-domain filter, the audio is the excitation (reference custom_pulsed_generator.py:663-672)
+        self.ps_off = bool(mb.get("ps_off", False))
+        if not mb.get("ps_use_stft", True) and not self.ps_off:
+            raise NotImplementedError("the sub-band gain variant of the envelope filter (ps_use_stft: false) is not supported")
+        # pp_mod_subnet_use_pqmf: false -- the sub-band rows are laid out one after the other instead (reference :920-923)
+        self.no_pqmf = not mb.get("pp_mod_subnet_use_pqmf", True)
+        if mb.get("pulse_channels_use_pqmf", False):
+            raise NotImplementedError("pulse_channels_use_pqmf (PQMF analysis of the pulse signal) is not supported")
         self.alpha = float(mb.get("alpha", 0.2))
         # NormMelComponents (reference wavegen_1d.py:578-769, row A14): device kernels csrc/norm_mel.hip, tables norm_mel.py
         self.normalize_rms_from_mell = bool(mb.get("normalize_rms_from_mell", False))

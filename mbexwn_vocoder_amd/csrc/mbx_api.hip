@@ -427,8 +427,9 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
         return fail(MBX_ERR_INVALID_ARGUMENT, "mbx_config ABI mismatch (struct_size / abi_version)");
     const mbx_config &c = *config;
     if (c.wn_layers < 1 || c.wn_layers > MBX_MAX_WN_LAYERS) return fail(MBX_ERR_INVALID_ARGUMENT, "wn_layers out of range");
-    if (c.n_f0_ops < 1 || c.n_f0_ops > MBX_MAX_SUBNET_OPS || c.n_vtf_ops < 1 || c.n_vtf_ops > MBX_MAX_SUBNET_OPS)
-        return fail(MBX_ERR_INVALID_ARGUMENT, "sub-net op count out of range");
+    if (c.n_f0_ops < 1 || c.n_f0_ops > MBX_MAX_SUBNET_OPS || c.n_vtf_ops < (c.ps_off ? 0 : 1) || c.n_vtf_ops > MBX_MAX_SUBNET_OPS ||
+        (c.ps_off && c.n_vtf_ops != 0))
+        return fail(MBX_ERR_INVALID_ARGUMENT, "sub-net op count out of range (ps_off: no VTF-net)");
     if (c.wn_channels % 4 || c.wn_kernel_size % 2 != 1) return fail(MBX_ERR_INVALID_ARGUMENT, "wn_channels must be a multiple of 4, kernel size odd");
     if (c.fft_size > 2048 || (c.fft_size & (c.fft_size - 1)) || c.stft_win > c.fft_size || c.stft_win != 4 * c.hop_size)
         return fail(MBX_ERR_UNSUPPORTED, "STFT geometry: need power-of-two fft_size <= 2048 and win == 4*hop");
@@ -627,11 +628,13 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
     int f0_out = 0, vtf_out = 0;
     mbx_status st = analyse_subnet(c.f0_ops, c.n_f0_ops, c.mel_channels, &pf0, &hd->f0_time_factor, &f0_out);
     if (st != MBX_OK) return bail(st);
-    st = analyse_subnet(c.vtf_ops, c.n_vtf_ops, c.mel_channels, &pvtf, &hd->vtf_time_factor, &vtf_out);
-    if (st != MBX_OK) return bail(st);
+    if (!c.ps_off) {
+        st = analyse_subnet(c.vtf_ops, c.n_vtf_ops, c.mel_channels, &pvtf, &hd->vtf_time_factor, &vtf_out);
+        if (st != MBX_OK) return bail(st);
+    }
     if (hd->f0_time_factor < c.pulse_per_frame || f0_out != 1)
         return bail(fail(MBX_ERR_INVALID_ARGUMENT, "F0 sub-net must end with 1 channel at >= pulse_per_frame samples per frame"));
-    if (hd->vtf_time_factor != 1 || vtf_out != c.n_ceps)
+    if (!c.ps_off && (hd->vtf_time_factor != 1 || vtf_out != c.n_ceps))
         return bail(fail(MBX_ERR_INVALID_ARGUMENT, "VTF sub-net must end with n_ceps channels at the mel frame rate"));
     hd->subnet_buf_per_frame = std::max(pf0, pvtf);
     {
@@ -852,6 +855,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         const bool f0_wide = hd->f0_time_factor > c.pulse_per_frame;
         SubnetRun f0(hd, c.f0_ops, c.n_f0_ops, mel_fe, c.mel_channels, nf_fe, B, Tf, w.sub0, w.sub1,
                      f0_wide ? w.f0_wide : w.f0 + f_off * c.pulse_per_frame, true, c.f0_max - c.f0_min, c.f0_min, stream);
+        if (c.ps_off) vtf.finished = true;             // no VTF-net (the cepstrum buffer stays unused)
         if (fe_frames) {
             vtf.window_stride(T, c.mel_channels);
             f0.window_stride(T, c.mel_channels);
@@ -1215,9 +1219,21 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     // ---- PQMF synthesis (reference :920-921)
     {
         ScopedEvents ev(hd, PROF_PQMF, stream);
-        mbx::launch_pqmf(sub_act, nsteps * M, n_frames_act, c.steps_per_frame, act_frames_max * c.steps_per_frame, B, M, hd->poly, hd->poly_t, hd->poly_ndm,
-                         hd->poly_dm_min, exc_act, (long long)T * c.hop_size, stream);
+        if (c.no_pqmf)   // pp_mod_subnet_use_pqmf: false -- source_signal = reshape(x, (B, rows * M)) (reference :922-923)
+            mbx::launch_activation(sub_act, nsteps * M, n_frames_act, c.hop_size, act_frames_max * c.hop_size, B, 1, MBX_ACT_LINEAR,
+                                   1.f, 0.f, exc_act, (long long)T * c.hop_size, stream);
+        else
+            mbx::launch_pqmf(sub_act, nsteps * M, n_frames_act, c.steps_per_frame, act_frames_max * c.steps_per_frame, B, M, hd->poly, hd->poly_t, hd->poly_ndm,
+                             hd->poly_dm_min, exc_act, (long long)T * c.hop_size, stream);
     }
+    if (c.ps_off) {
+        // ps_off: signal = generate_excitation(...) (reference :663-672); samples behind an item's own length are zero
+        ScopedEvents ev(hd, PROF_OVERLAP_ADD, stream);
+        if (hipMemsetAsync(audio, 0, (size_t)B * T * c.hop_size * sizeof(float), stream) != hipSuccess)
+            return fail(MBX_ERR_HIP, "hipMemsetAsync of the audio failed");
+        mbx::launch_activation(exc_act, (long long)T * c.hop_size, n_frames_act, c.hop_size, act_frames_max * c.hop_size, B, 1,
+                               MBX_ACT_LINEAR, 1.f, 0.f, audio_act, (long long)T * c.hop_size, stream);
+    } else {
     // ---- STFT-domain filtering with the spectral envelope (reference :681-724, 801-855)
     // (the lifter row of a frame is selected from the F0 contour inside the kernel, reference :507-525)
     {
@@ -1229,6 +1245,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     {
         ScopedEvents ev(hd, PROF_OVERLAP_ADD, stream);
         mbx::launch_overlap_add(sc, frames_act, n_frames_act, T, T - (int)act0, B, audio_act, (long long)T * c.hop_size, stream);
+    }
     }
     if (nm_gain_src) {
         ScopedEvents ev(hd, PROF_NORM_MEL, stream);

@@ -64,7 +64,8 @@ class mbx_config(ctypes.Structure):
                 ("nm_mel_amp_scale", ctypes.c_float), ("wn_gate_activation", ctypes.c_int32),
                 ("wn_disable_conditioning", ctypes.c_int32), ("n_precond", ctypes.c_int32),
                 ("precond_channels", ctypes.c_int32 * MBX_MAX_PRECOND), ("spect_preserve_energy", ctypes.c_int32),
-                ("wt_subharm_channels", ctypes.c_int32), ("wt_sinusoid_as_fun", ctypes.c_int32)]
+                ("wt_subharm_channels", ctypes.c_int32), ("wt_sinusoid_as_fun", ctypes.c_int32),
+                ("ps_off", ctypes.c_int32), ("no_pqmf", ctypes.c_int32)]
 
 
 class mbx_forward_options(ctypes.Structure):
@@ -172,10 +173,12 @@ def subnet_ops(config):
                                 pad_to_valid=mb.get("pp_subnet_use_valid_padding", False),
                                 remove_inactive_pad_layers=mb.get("remove_inactive_pad_layers", False),
                                 use_prelu=use_prelu, alpha=dims.alpha, force_causal=mb.get("force_causal", False))
-    vtf_ops, _, _ = build_subnet(mb["ps_subnet"], "PS", dims.mel_channels, dims.n_ceps, 1, None,
-                                 pad_to_valid=mb.get("ps_subnet_use_valid_padding", False),
-                                 remove_inactive_pad_layers=mb.get("remove_inactive_pad_layers", False),
-                                 use_prelu=use_prelu, alpha=dims.alpha, force_causal=mb.get("force_causal", False))
+    vtf_ops = []
+    if not dims.ps_off:
+        vtf_ops, _, _ = build_subnet(mb["ps_subnet"], "PS", dims.mel_channels, dims.n_ceps, 1, None,
+                                     pad_to_valid=mb.get("ps_subnet_use_valid_padding", False),
+                                     remove_inactive_pad_layers=mb.get("remove_inactive_pad_layers", False),
+                                     use_prelu=use_prelu, alpha=dims.alpha, force_causal=mb.get("force_causal", False))
     return f0_ops, vtf_ops
 
 
@@ -243,6 +246,7 @@ def make_config(config, wavetables):
     cc.spect_preserve_energy = int(dims.preserve_energy)
     cc.wt_subharm_channels = dims.wt_subharm
     cc.wt_sinusoid_as_fun = int(dims.wt_sinusoid_as_fun)
+    cc.ps_off, cc.no_pqmf = int(dims.ps_off), int(dims.no_pqmf)
     f0_ops, vtf_ops = subnet_ops(config)
     cc.n_f0_ops = _fill_ops(cc.f0_ops, f0_ops)
     cc.n_vtf_ops = _fill_ops(cc.vtf_ops, vtf_ops)
@@ -866,9 +870,10 @@ class MBExWNEngine:
         B, T = int(mel.shape[0]), int(mel.shape[1])
         rate = int(self.dims.sample_rate // self.dims.pulse_rate)
         f0 = self.stage("f0")[:, :audio.shape[1]:rate]               # the reference's own slice (:757)
-        params = [["F0", _HostTensor(f0[:, :synth_length])],
-                  ["PSig", _HostTensor(self.stage("excitation")[:, :audio.shape[1]][:, :synth_length])],
-                  ["PS", _HostTensor(np.abs(self._envelope(B, T))[:, :synth_length])]]
+        params = [["F0", _HostTensor(f0[:, :synth_length])]]
+        if not self.dims.ps_off:     # ps_off: neither excitation_signal nor source_filter_stft exist (reference :756-767)
+            params += [["PSig", _HostTensor(self.stage("excitation")[:, :audio.shape[1]][:, :synth_length])],
+                       ["PS", _HostTensor(np.abs(self._envelope(B, T))[:, :synth_length])]]
         return (signals, params) if return_components else (signals[0], params)
 
     def infer_components(self, spect, synth_length=0, F0=None, transposition_factor=None, noise=None):
@@ -879,6 +884,9 @@ class MBExWNEngine:
         last mel frame is repeated and how long ``upsampled_rms`` is.
         Additionally the (transposed) synthesis itself is available as ``self.last_audio`` (device tensor)."""
         torch = self._torch
+        if self.dims.ps_off:
+            raise NotImplementedError("infer_components(): a ps_off model has no spectral envelope (the reference's "
+                                      "generate_specenv has no VTF-net to run)")
         synth_length = int(synth_length) if F0 is None else int(np.asarray(F0).shape[1])
         mel, noise = self._prepare(spect, synth_length, noise)
         hop, ppf = self.dims.hop_size, self.dims.pulse_per_frame

@@ -26,9 +26,11 @@ def layer_table(config):
                                 mb.get("pp_activation", "soft_sigmoid"), target_ups=dims.pulse_per_frame,
                                 pad_to_valid=mb.get("pp_subnet_use_valid_padding", False), use_prelu=use_prelu,
                                 alpha=dims.alpha)
-    vtf_ops, _, _ = build_subnet(mb["ps_subnet"], "PS", dims.mel_channels, dims.n_ceps, 1, None,
-                                 pad_to_valid=mb.get("ps_subnet_use_valid_padding", False), use_prelu=use_prelu,
-                                 alpha=dims.alpha)
+    vtf_ops = []
+    if not dims.ps_off:                                       # ps_off builds no VTF-net (reference custom_pulsed_generator.py:413)
+        vtf_ops, _, _ = build_subnet(mb["ps_subnet"], "PS", dims.mel_channels, dims.n_ceps, 1, None,
+                                     pad_to_valid=mb.get("ps_subnet_use_valid_padding", False), use_prelu=use_prelu,
+                                     alpha=dims.alpha)
     for op in f0_ops + vtf_ops:
         if op["kind"] == "conv":
             convs.append((op["name"], op["ks"], op["cin"], op["cout"]))

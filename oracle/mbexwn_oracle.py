@@ -132,6 +132,7 @@ class OracleModel:
         self.f32 = np.float32 if float32_constants else np.float64
         self.cfg = config
         mb = config["mbexwn_config"]
+        self.mb = mb
         pp = config["preprocess_config"]
         self.sample_rate = pp["sample_rate"]
         self.hop = pp["hop_size"]
@@ -444,6 +445,8 @@ class OracleModel:
         y = self.wavenet(x, mel)                                                  # :908-910
         w, b = self.weight("post")
         y = conv1d_valid(y, w, b)                                                 # :913-914
+        if not self.mb.get("pp_mod_subnet_use_pqmf", True):                       # :922-923: no PQMF, a reshape
+            return y.reshape(y.shape[0], y.shape[1] * y.shape[2])
         return self.pqmf_synthesis(y)                                             # :920-921
 
     # ------------------------------------------------------------------ envelope (A12)
@@ -512,6 +515,9 @@ class OracleModel:
         T = mel.shape[1]
         f0 = self.generate_f0(mel)                                                # :567
         exc = self.generate_excitation(mel, f0, noise)                            # :676
+        if self.mb.get("ps_off", False):                                          # :663-672: the signal is the excitation
+            audio = exc[:, :T * self.hop]
+            return (audio, {"f0": f0, "excitation": exc}) if return_stages else audio
         src = self.stft(exc, T)                                                   # :681-694
         env = self.generate_specenv(mel, f0)                                      # :704
         out_len = f0.shape[1] * int(self.sample_rate // self.pulse_rate)

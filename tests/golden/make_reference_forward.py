@@ -85,9 +85,15 @@ CASES = {
     "sinfun": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
                           "mbexwn_config:wavetable_config:use_sinusoid_as_fun": True,
                           "mbexwn_config:wavetable_config:add_subharm_chans": 2}, 2, 9),
+    # no STFT-domain filter (and no VTF-net): the audio is the excitation; no PQMF bank: the sub-band rows laid out one
+    # after the other (reference custom_pulsed_generator.py:663-672, 920-923)
+    "psoff": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                         "mbexwn_config:ps_off": True}, 2, 9),
+    "nopqmf": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                          "mbexwn_config:pp_mod_subnet_use_pqmf": False}, 2, 9),
 }
 # the long cases keep the small stage outputs only (the full conditioning / envelope tensors would be megabytes)
-LEAN = {"canon60", "voice", "grammar", "groups", "gfu", "gsu_eqlr", "eqlr_plain", "glu", "precond", "nocond", "energy", "mixed_a", "mixed_b", "subharm", "sinfun"}
+LEAN = {"canon60", "voice", "grammar", "groups", "gfu", "gsu_eqlr", "eqlr_plain", "glu", "precond", "nocond", "energy", "mixed_a", "mixed_b", "subharm", "sinfun", "psoff", "nopqmf"}
 
 
 def assign_conv(layer, raw, name):
@@ -161,10 +167,11 @@ def run_case(voice, overrides, batch, frames, float_type):
         out["cond"] = np.asarray(wn.cond_lin_upsampling_layer(wn.cond_layer(cond_in)))
     shim.INJECTED_NOISE["normal"] = noise
     out["excitation"] = np.asarray(model.generate_excitation(mel_t, pulse_frequency=f0))
-    env = model.generate_specenv(mel=mel_t, pulse_frequency=f0, training=False)
-    out["envelope_re"] = np.asarray(env).real
-    out["envelope_im"] = np.asarray(env).imag
-    if model.ps_env_order_scale:
+    if not model.ps_off:
+        env = model.generate_specenv(mel=mel_t, pulse_frequency=f0, training=False)
+        out["envelope_re"] = np.asarray(env).real
+        out["envelope_im"] = np.asarray(env).imag
+    if model.ps_env_order_scale and not model.ps_off:
         win = model._get_cepstral_windows(f0, model.ps_cepstral_windows_log10f0, model.ps_cepstral_windows,
                                           smooth_stride=model.spect_to_pulse_upsampling_factor)
         out["ceps_window_sum"] = np.asarray(win).sum(axis=-1)
@@ -189,7 +196,7 @@ def main():
                 if "cond" in res:
                     res["cond"] = np.asarray(res["cond"])[:, ::37]
                 for kk in ("envelope_re", "envelope_im", "wavetables"):
-                    res.pop(kk)
+                    res.pop(kk, None)
                 if tag == "f64":
                     res = {kk: res[kk] for kk in ("mell", "noise", "f0", "excitation", "audio")}
             for kk, vv in res.items():

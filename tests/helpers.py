@@ -52,8 +52,12 @@ GOLDEN_CASES = {
     "sinfun": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
                           "mbexwn_config:wavetable_config:use_sinusoid_as_fun": True,
                           "mbexwn_config:wavetable_config:add_subharm_chans": 2}, 2, 9),
+    "psoff": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                         "mbexwn_config:ps_off": True}, 2, 9),
+    "nopqmf": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                          "mbexwn_config:pp_mod_subnet_use_pqmf": False}, 2, 9),
 }
-LEAN_GOLDEN_CASES = {"canon60", "voice", "grammar", "groups", "gfu", "gsu_eqlr", "eqlr_plain", "glu", "precond", "nocond", "energy", "mixed_a", "mixed_b", "subharm", "sinfun"}     # cond subsampled [:, ::37], no envelope / wavetables (see the generator)
+LEAN_GOLDEN_CASES = {"canon60", "voice", "grammar", "groups", "gfu", "gsu_eqlr", "eqlr_plain", "glu", "precond", "nocond", "energy", "mixed_a", "mixed_b", "subharm", "sinfun", "psoff", "nopqmf"}     # cond subsampled [:, ::37], no envelope / wavetables (see the generator)
 
 
 @functools.lru_cache(maxsize=None)

@@ -358,6 +358,27 @@ def test_gate_variants_and_equalized_lr_vs_reference_goldens(torch, golden_dir, 
     assert _maxdiff(got, ref) <= _tol(ref)
 
 
+def test_ps_off_model_returns_only_the_f0_parameter(torch):
+    """ps_off: MBExWN.call returns the excitation as the signal and only ["F0", .] as parameter (neither PSig nor PS exist,
+    reference custom_pulsed_generator.py:663-672, 756-767); infer_components has no envelope to return."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    cfg, raw, wt = build_case(*GOLDEN_CASES["psoff"][:2])
+    assert not any(kk.startswith("PS_") for kk in raw)
+    eng = MBExWNEngine(cfg, raw, wt)
+    mel, noise = synthetic_inputs(31, 2, 12)
+    audio, params = eng.infer(mel, synth_length=12 * 300 - 7, return_F0=True, noise=noise)
+    assert [pp[0] for pp in params] == ["F0"] and audio.numpy().shape == (2, 12 * 300 - 7)
+    assert np.array_equal(audio.numpy(), eng.stage("excitation").cpu().numpy()[:, :12 * 300 - 7])
+    ref = orc.OracleModel(cfg, raw, wt).forward(mel, noise)
+    assert _maxdiff(audio.numpy(), ref[:, :12 * 300 - 7]) <= _tol(ref)
+    with pytest.raises(NotImplementedError):
+        eng.infer_components(mel, synth_length=12 * 300, noise=noise)
+    # a ragged batch: samples behind an item's own length are zero
+    nf = torch.tensor([12, 5], dtype=torch.int32, device="cuda")
+    got = eng.forward(dev(torch, mel), n_frames=nf, noise=dev(torch, noise)).cpu().numpy()
+    assert np.all(got[1, 5 * 300:] == 0.0) and np.any(got[1, :5 * 300] != 0.0)
+
+
 @pytest.mark.parametrize("act", ["gfu", "gsu", "glu"])
 def test_gate_variants_at_full_width(torch, monkeypatch, act):
     """The other two gates through every gate kernel of the canonical geometry (C = 320): the folded first layer, F(4,3) in

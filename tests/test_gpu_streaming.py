@@ -168,7 +168,9 @@ def test_streaming_without_layer_state(monkeypatch):
                                    {"mbexwn_config:spect_filters_preserve_energy": True,
                                     "mbexwn_config:pp_mod_subnet:activation": "glu"},
                                    {"mbexwn_config:wavetable_config:add_subharm_chans": 1},
-                                   {"mbexwn_config:wavetable_config:use_sinusoid_as_fun": True}])
+                                   {"mbexwn_config:wavetable_config:use_sinusoid_as_fun": True},
+                                   {"mbexwn_config:ps_off": True},
+                                   {"mbexwn_config:pp_mod_subnet_use_pqmf": False}])
 def test_streaming_with_the_second_batch_of_options(monkeypatch, extra):
     """Streams of models with pre-conditioning layers (the mel-rate front end reaches two more frames per layer: margins
     and the carried front end follow streaming.frontend_reach), without conditioning, and with energy preserving
