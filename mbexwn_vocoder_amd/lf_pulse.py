@@ -162,14 +162,31 @@ def pulse_lowpass(pass_band_edge, stop_att_db=70.0, trans_width_normed=0.1):
                      window=("kaiser", beta), pass_zero=True, fs=1.0)
 
 
-def lf_pulse(n_wavetable, oq=0.5, am=0.7, rta=0.1, pul_bw=0.1, use_deriv=False, transition_width=0.1):
+def min_phase_spectrum(log_magnitude):
+    """Minimum-phase spectrum of a log magnitude through the folded real cepstrum (reference tf_wavetable.py:82-89)."""
+    fft_size = log_magnitude.shape[-1] * 2 - 2
+    real_cepst = np.fft.irfft(np.fmax(log_magnitude, np.finfo(log_magnitude.dtype).eps), n=fft_size)
+    mask = np.concatenate(([1.0], 2 * np.ones(fft_size // 2 - 1), [1.0]), axis=0)
+    return np.exp(np.fft.rfft(real_cepst[:mask.shape[0]] * mask, n=fft_size))
+
+
+def lf_pulse(n_wavetable, oq=0.5, am=0.7, rta=0.1, pul_bw=0.1, use_deriv=False, transition_width=0.1, white_pulse=False):
     """One band-limited LF pulse period of power-of-two length >= n_wavetable.
-    reference tf_wavetable.py:93-162 (white_pulse / norm options are not used by the model)."""
+    reference tf_wavetable.py:93-162; white_pulse (:110-120): the spectrum above its maximum is flattened up to the
+    band edge by a minimum-phase filter (the norm option is not used by the model)."""
     fft_size = 16
     while fft_size < n_wavetable:
         fft_size *= 2
     freqs = np.arange(fft_size // 2 + 1) / fft_size
     spec = lf_spectrum(freqs * n_wavetable, oq=oq, am=am, ta=rta * (1 - oq), derivative=use_deriv)
+    if white_pulse:
+        n_max = int(np.argmax(spec))                              # of the complex spectrum, as the reference takes it
+        n_white = int(np.fmax(n_max, int(fft_size * (pul_bw - 0.5 * transition_width))))
+        if n_max < n_white:
+            wfilt = np.ones(spec.shape)
+            wfilt[n_max:n_white] = np.abs(spec[n_max]) / np.abs(spec[n_max:n_white])
+            wfilt[n_white:] = np.abs(spec[n_max]) / np.abs(spec[n_white])
+            spec = spec * min_phase_spectrum(np.log(wfilt))
     fcoef = pulse_lowpass(pul_bw, stop_att_db=70, trans_width_normed=min(pul_bw / 2.0, transition_width))
     over = 1
     while fcoef.shape[0] > fft_size * over:
@@ -180,7 +197,7 @@ def lf_pulse(n_wavetable, oq=0.5, am=0.7, rta=0.1, pul_bw=0.1, use_deriv=False, 
 
 
 def normed_pulse(Oq, target_nominalF0, nominalBandWidth, sample_rate, am=0.8, rta=0.1, use_radiation=False,
-                 bandWidthReductionFactor=1.0, wt_oversampling=1, use_sinusoid=False):
+                 bandWidthReductionFactor=1.0, wt_oversampling=1, use_sinusoid=False, use_white_pulse=False):
     """reference tf_wavetable.py:309-410 (create_normed_pulse: LF branch, or one Hann-weighted sine period with
     use_sinusoid, :387-390). Returns (table, realised F0)."""
     if use_sinusoid:
@@ -189,7 +206,7 @@ def normed_pulse(Oq, target_nominalF0, nominalBandWidth, sample_rate, am=0.8, rt
         return res, wt_oversampling * sample_rate / period
     res = lf_pulse(int(np.ceil(wt_oversampling * sample_rate / target_nominalF0)), oq=Oq, am=am, rta=rta,
                    pul_bw=nominalBandWidth / (bandWidthReductionFactor * wt_oversampling),
-                   transition_width=0.1 / wt_oversampling, use_deriv=use_radiation)
+                   transition_width=0.1 / wt_oversampling, use_deriv=use_radiation, white_pulse=use_white_pulse)
     return res, wt_oversampling * sample_rate / res.shape[0]
 
 
@@ -198,14 +215,16 @@ class WaveTables:
 
     reference tf_wavetable.py:181-306 (PulseWaveTable.__init__): the LF-pulse tables, or the single sine table of
     use_sinusoid / use_sinusoid_as_fun (:239,254-259).  add_subharm_chans and use_sinusoid_as_fun change what the
-    oscillator emits, not the tables (config.ModelDims carries them to the kernel).  Not built: white pulse, no_interp,
-    pulse-synchronous gains.
+    oscillator emits, not the tables (config.ModelDims carries them to the kernel); use_white_pulse whitens the LF
+    tables (:110-120).  Not built: no_interp, pulse-synchronous gains.
     """
 
     def __init__(self, sample_rate, nominalF0, Oq=0.5, am=0.8, rta=0.05, use_radiation=False, F0GridFactor=1.25,
                  numF0InGrid=5, maxF0=None, wt_oversampling=2, nominalBandWidth=None, use_sinusoid=False,
-                 use_sinusoid_as_fun=False, add_subharm_chans=0, **unsupported):
-        for kk in ("use_white_pulse", "no_interp", "pulse_sync_gain_avg"):
+                 use_sinusoid_as_fun=False, add_subharm_chans=0, use_white_pulse=False, **unsupported):
+        # no_interp: the reference's own branch (tf_wavetable.py:623-629) gathers with batch_dims=1 from the un-batched
+        # tables and cannot run; pulse_sync_gain_avg needs the gain inputs of another model family
+        for kk in ("no_interp", "pulse_sync_gain_avg"):
             if unsupported.get(kk, False):
                 raise NotImplementedError(f"wavetable_config option {kk} is not supported")
         self.add_subharm_chans = int(add_subharm_chans or 0)
@@ -220,7 +239,7 @@ class WaveTables:
         ref_f0 = maxF0 if maxF0 is not None else nominalF0 * grid ** numF0InGrid
         _, nominal = normed_pulse(Oq, nominalF0, band, sample_rate, am=am, rta=rta, use_radiation=use_radiation,
                                   bandWidthReductionFactor=ref_f0 / nominalF0, wt_oversampling=wt_oversampling,
-                                  use_sinusoid=use_sinusoid)
+                                  use_sinusoid=use_sinusoid, use_white_pulse=use_white_pulse)
         self.nominalF0 = float(nominal)
         n_grid = int(numF0InGrid)
         if maxF0 is not None:
@@ -232,7 +251,8 @@ class WaveTables:
         for ir in range(n_grid + 1):
             rs = grid ** ir if ir > 0 else 1
             tab, _ = normed_pulse(Oq, self.nominalF0, 0.5, sample_rate, am=am, rta=rta, use_radiation=use_radiation,
-                                  bandWidthReductionFactor=rs, wt_oversampling=wt_oversampling, use_sinusoid=use_sinusoid)
+                                  bandWidthReductionFactor=rs, wt_oversampling=wt_oversampling, use_sinusoid=use_sinusoid,
+                                  use_white_pulse=use_white_pulse)
             tab = tab.astype(np.float32)
             self.F0_list.append(self.nominalF0 * rs)
             # first sample appended for the interpolation across the period boundary (reference :278-280)

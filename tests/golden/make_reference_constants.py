@@ -57,6 +57,16 @@ def main():
         0.5, target_nominalF0=40.0, nominalBandWidth=0.4, sample_rate=8000.0, am=0.8, rta=0.05, use_radiation=True,
         bandWidthReductionFactor=15.0, wt_oversampling=2, return_nominal_f0=True, quiet=True)
     out["wt/adapted_nominalF0"] = np.asarray(f0)
+    # whitened LF pulse (get_LFpulse white_pulse branch, tf_wavetable.py:110-120), single entries and the whole grid
+    for ii, (rs, rad) in enumerate([(1.0, True), (1.25 ** 4, False)]):
+        out[f"wt/white/{ii}/params"] = np.asarray([rs, float(rad)])
+        out[f"wt/white/{ii}/table"] = tf_wavetable.PulseWaveTable.create_normed_pulse(
+            0.5, target_nominalF0=31.25, nominalBandWidth=0.5, sample_rate=8000.0, am=0.8, rta=0.05,
+            use_radiation=rad, bandWidthReductionFactor=rs, wt_oversampling=2, quiet=True, use_white_pulse=True)
+    white = tf_wavetable.PulseWaveTable(sample_rate=8000.0, nominalF0=40.0, maxF0=600.0, F0GridFactor=1.25,
+                                        wt_oversampling=2, Oq=0.5, am=0.8, rta=0.05, use_radiation=True, quiet=True,
+                                        use_white_pulse=True)
+    out["wt/white/full/tables"] = np.asarray(white.wavetables)
     out["wt/lowpass_0p2"] = tf_wavetable.get_pulse_lowpass_kaiser(0.2, stop_att_db=70, trans_width_normed=0.05)
     full = tf_wavetable.PulseWaveTable(sample_rate=8000.0, nominalF0=40.0, maxF0=600.0, F0GridFactor=1.25,
                                        wt_oversampling=2, Oq=0.5, am=0.8, rta=0.05, use_radiation=True, quiet=True)

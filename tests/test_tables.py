@@ -107,6 +107,23 @@ def test_full_wavetable_grid(gold):
     assert np.array_equal(wt.tables[-1], wt.tables[0])
 
 
+def test_white_pulse_tables(gold):
+    """use_white_pulse (get_LFpulse's white_pulse branch, reference tf_wavetable.py:110-120): single entries and the whole
+    table grid against the reference's own output."""
+    for ii in range(2):
+        rs, rad = gold[f"wt/white/{ii}/params"]
+        tab, _ = lf_pulse.normed_pulse(0.5, 31.25, 0.5, 8000.0, am=0.8, rta=0.05, use_radiation=bool(rad),
+                                       bandWidthReductionFactor=rs, wt_oversampling=2, use_white_pulse=True)
+        np.testing.assert_allclose(tab, gold[f"wt/white/{ii}/table"], rtol=0, atol=1e-14)
+        plain, _ = lf_pulse.normed_pulse(0.5, 31.25, 0.5, 8000.0, am=0.8, rta=0.05, use_radiation=bool(rad),
+                                         bandWidthReductionFactor=rs, wt_oversampling=2)
+        assert np.max(np.abs(plain - tab)) > 1e-3                  # it is a different pulse
+    cfg = canonical_config("SPEECH")
+    dims = ModelDims(cfg)
+    wt = tables.WaveTables(sample_rate=dims.pulse_rate, **dict(cfg["mbexwn_config"]["wavetable_config"], use_white_pulse=True))
+    assert np.array_equal(wt.tables, gold["wt/white/full/tables"])
+
+
 def test_wavetable_options():
     """use_sinusoid: one table = one sine period under a periodic Hann window (reference tf_wavetable.py:254-259,387-390;
     unpinned: that branch calls scipy.signal.hanning, which the scipy of this image no longer has, so the reference cannot
@@ -125,7 +142,7 @@ def test_wavetable_options():
         assert np.array_equal(tables.WaveTables(sample_rate=dims.pulse_rate, **dict(base, **extra)).tables, ref.tables)
     over = canonical_config("SPEECH", **{"mbexwn_config:wavetable_config:add_subharm_chans": 2})
     assert ModelDims(over).wn_in_channels == 5 * 3 + 1 and ModelDims(over).pulse_channels_eff == 15
-    for kk in ("use_white_pulse", "no_interp", "pulse_sync_gain_avg"):
+    for kk in ("no_interp", "pulse_sync_gain_avg"):
         with pytest.raises(NotImplementedError):
             tables.WaveTables(sample_rate=dims.pulse_rate, **dict(base, **{kk: True}))
 
