@@ -49,6 +49,7 @@ extern "C" {
 #define MBX_MAX_SUBNET_OPS 32
 #define MBX_MAX_WN_LAYERS 64
 #define MBX_MAX_PRECOND 8
+#define MBX_MAX_WN_BLOCKS 4
 #define MBX_NAME_LEN 64
 
 typedef enum {
@@ -148,6 +149,17 @@ typedef struct {
      * not run through the PQMF synthesis bank but laid out one after the other (a reshape of the post-net output) */
     int32_t ps_off;
     int32_t no_pqmf;
+    /* several WaveNet blocks with in-block upsampling (pp_mod_subnet_upsampling_factors / _channel_factors, reference
+     * custom_pulsed_generator.py:456-488, custom_AE_layers.py:457-582).  n_wn_blocks == 0: one block without upsampling,
+     * the fields above describe it.  n_wn_blocks >= 1: block b has wn_block_channels[b] channels (block 0: == wn_channels) and is followed
+     * by a sub-pixel convolution "up<b>" (kernel size 3, wn_out_channels -> wn_out_channels * wn_block_ups[b], depth ->
+     * time) when wn_block_ups[b] > 1; block b runs at steps_per_frame / prod(wn_block_ups[b:]) rows per frame
+     * (steps_per_frame stays the sub-band rate, pulse_per_frame and cond_conv_upsampling describe block 0); its tensors
+     * are "wn<b>.start", "wn<b>.cond", "wn<b>.conv1D_<l>", ... ("wn." for block 0).  Such a handle runs the generic
+     * kernels and does not stream. */
+    int32_t n_wn_blocks;
+    int32_t wn_block_channels[MBX_MAX_WN_BLOCKS];
+    int32_t wn_block_ups[MBX_MAX_WN_BLOCKS];
 } mbx_config;
 
 /* A named HOST tensor handed over at creation (weights already weight-norm folded, tables).

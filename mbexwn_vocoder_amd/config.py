@@ -225,11 +225,13 @@ class ModelDims:
         self.pulse_rate_factor = int(mb.get("pulse_rate_factor", 2))
         self.pulse_rate = self.sample_rate / self.pulse_rate_factor
         self.pulse_channels = int(mb.get("pulse_channels", 8))
+        # one WaveNet block per entry, block b with n_channels * channel_factors[b] channels and an up-sampling convolution
+        # of factor upsampling_factors[b] behind it (reference custom_pulsed_generator.py:456-488)
         ups = [int(uu) for uu in mb["pp_mod_subnet_upsampling_factors"]]
-        chf = mb["pp_mod_subnet_channel_factors"]
-        if ups != [1] or list(chf) != [1]:
-            raise NotImplementedError("only a single WaveNet block without in-block upsampling "
-                                      "(pp_mod_subnet_upsampling_factors == [1]) is supported")
+        chf = list(mb["pp_mod_subnet_channel_factors"])
+        if len(ups) != len(chf) or not ups or any(uu < 1 for uu in ups):
+            raise RuntimeError("MBExWN::config_error::pp_mod_subnet_upsampling_factors / _channel_factors must be non-empty "
+                               "lists of the same length")
         self.steps_per_frame = self.hop_size // self.subbands
         self.pulse_per_frame = (self.steps_per_frame * self.pulse_channels) // int(np.prod(ups))
         self.f0_down_sampling_factor = int(self.sample_rate // self.pulse_rate)
@@ -237,7 +239,16 @@ class ModelDims:
         if gen_rate != self.sample_rate:
             raise RuntimeError(f"MBExWN::config_error::the generated sample rate {gen_rate} != {self.sample_rate}")
         wn = mb["pp_mod_subnet"]
-        self.wn_channels = int(wn["n_channels"])
+        self.wn_channels = int(int(wn["n_channels"]) * chf[0])             # the first block (reference :479)
+        self.wn_block_channels = [int(int(wn["n_channels"]) * ff) for ff in chf]
+        self.wn_block_ups = ups
+        self.n_wn_blocks = len(ups)
+        self.wn_multi = len(ups) > 1 or ups[0] > 1                # several blocks / in-block upsampling: the generic path
+        # rows per frame of the first block; the noise channel has one value per such row
+        self.wn_in_rows_per_frame = self.steps_per_frame // int(np.prod(ups))
+        if self.wn_in_rows_per_frame * int(np.prod(ups)) != self.steps_per_frame:
+            raise RuntimeError("MBExWN::config_error::the product of pp_mod_subnet_upsampling_factors must divide the "
+                               "sub-band rows per frame")
         self.wn_layers = int(wn.get("n_layers", 12))
         self.wn_kernel_size = int(wn.get("kernel_size", 3))
         self.wn_out_channels = int(wn["n_out_channels"])
@@ -252,6 +263,8 @@ class ModelDims:
             # reference custom_AE_layers.py:165-166; the groups run as block-diagonal dense layers (weights.merge_channel_groups)
             raise RuntimeError(f"WaveNetAE::error::n_channels parameter {self.wn_channels} has to be a multiple of chanel "
                                f"groups parameter {self.wn_groups}")
+        if self.wn_multi and self.wn_groups > 1:
+            raise NotImplementedError("n_ch_groups > 1 together with several WaveNet blocks is not supported")
         if self.wn_activation not in ("gtu", "glu", "gfu", "gsu"):
             # reference custom_AE_layers.py:156-158 (glu passes the check and has no branch at :312-318: the half stays linear)
             raise RuntimeError(f"WaveNetAE::error::unsupported wavenet activation {self.wn_activation} selected. "
@@ -276,6 +289,13 @@ class ModelDims:
                                f"integer usampling of spectrum rate {spect_rate} with linear up "
                                f"{self.cond_lin_upsampling}")
         self.cond_conv_upsampling = int(conv_up)
+        rate = curr_rate
+        for uu in ups:                                             # every block's rate must be reachable (reference :469-472)
+            if rate != (rate // (spect_rate * self.cond_lin_upsampling)) * spect_rate * self.cond_lin_upsampling:
+                raise RuntimeError(f"MBExWN::config_error:: cannot achieve conditioning rate {rate} by means of "
+                                   f"integer usampling of spectrum rate {spect_rate} with linear up "
+                                   f"{self.cond_lin_upsampling}")
+            rate *= uu
         self.noise_sigma = float(mb.get("pp_mod_subnet_noise_channel_sigma", 0.5) or 0.0)
         # wavetable options that change the excitation tensor (reference tf_wavetable.py:520-559,
         # custom_pulsed_generator.py:893): n sub-harmonic sinusoid channels next to the pulse; the pulse as a function

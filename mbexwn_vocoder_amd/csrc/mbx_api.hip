@@ -91,6 +91,14 @@ struct mbx_handle {
     long long subnet_buf_per_frame = 0;   // floats per frame of one ping-pong buffer
     std::vector<mbx_subnet_op> cond_ops;  // pre-conditioning convolutions + the conditioning layer (empty: conditioning disabled)
     long long cond_buf_per_frame = 0;     // floats per frame of a ping-pong buffer of that chain (0: no pre-conditioning layers)
+    // several WaveNet blocks (mbx_config.n_wn_blocks > 1; empty: the single-block path)
+    struct WnBlock {
+        int C = 0, ups = 1, spf = 0, ccu = 0;      // channels, upsampling factor behind the block, rows per frame, conditioning rows per frame
+        std::string prefix;                        // "wn." | "wn1." ...
+        std::vector<mbx_subnet_op> cond_ops;       // its pre-conditioning + conditioning chain (empty: conditioning disabled)
+    };
+    std::vector<WnBlock> blocks;
+    long long mb_hc_per_frame = 0;                 // max over the blocks of rows per frame x channels
     bool fold_skip = false;      // skip path folded into the end convolution (needs the *.fold tensors)
     bool fold_start = false;     // start convolution folded into layer 0 (needs fold_skip and the *.start_fold / *.fold_start tensors)
     bool winograd4_always = false;   // MBX_WINOGRAD=44: F(4,3) at every size (tests)
@@ -136,6 +144,7 @@ mbx_status analyse_subnet(const mbx_subnet_op *ops, int n_ops, int cin, long lon
 struct Workspace {
     float *mel_norm, *nm_a, *nm_b;
     float *sub0, *sub1, *sub2, *sub3, *sub4, *sub5, *f0_wide, *f0, *cum, *chunk_last, *pulse, *cond, *h, *a, *skip, *wn_out, *sub, *exc, *ceps, *frames;
+    float *mb_h, *mb_a, *mb_skip, *mb_y0, *mb_y1, *mb_cond[MBX_MAX_WN_BLOCKS];   // several WaveNet blocks only
     int *ceps_index;
     size_t total;
 };
@@ -179,6 +188,14 @@ Workspace carve(const mbx_handle *hd, char *base, int B, int T) {
     w.ceps = take(BT * c.n_ceps);
     w.ceps_index = reinterpret_cast<int *>(take(BT));
     w.frames = take(BT * c.stft_win);
+    const bool mb = !hd->blocks.empty();
+    w.mb_h = take(mb ? BT * hd->mb_hc_per_frame : 0);
+    w.mb_a = take(mb ? BT * hd->mb_hc_per_frame : 0);
+    w.mb_skip = take(mb ? BT * hd->mb_hc_per_frame : 0);
+    w.mb_y0 = take(mb ? B * nsteps * c.wn_out_channels : 0);
+    w.mb_y1 = take(mb ? B * nsteps * c.wn_out_channels : 0);
+    for (int b = 0; b < MBX_MAX_WN_BLOCKS; ++b)
+        w.mb_cond[b] = take(mb && b >= 1 && b < (int)hd->blocks.size() ? BT * hd->blocks[b].ccu * 2 * hd->blocks[b].C : 0);
     w.total = off;
     return w;
 }
@@ -435,9 +452,20 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
         return fail(MBX_ERR_UNSUPPORTED, "STFT geometry: need power-of-two fft_size <= 2048 and win == 4*hop");
     if (c.hop_size % c.subbands || c.steps_per_frame * c.subbands != c.hop_size)
         return fail(MBX_ERR_INVALID_ARGUMENT, "hop_size must be steps_per_frame * subbands");
-    if (c.steps_per_frame * c.pulse_channels != c.pulse_per_frame)
-        return fail(MBX_ERR_INVALID_ARGUMENT, "pulse_per_frame must be steps_per_frame * pulse_channels");
-    if ((c.steps_per_frame % c.cond_lin_upsampling) || c.steps_per_frame / c.cond_lin_upsampling != c.cond_conv_upsampling)
+    // rows per frame of the first WaveNet block: the sub-band rate divided by the in-block upsampling factors
+    int spf0 = c.steps_per_frame;
+    if (c.n_wn_blocks > MBX_MAX_WN_BLOCKS || c.n_wn_blocks < 0) return fail(MBX_ERR_INVALID_ARGUMENT, "n_wn_blocks out of range");
+    if (c.n_wn_blocks >= 1) {
+        if (c.wn_block_channels[0] != c.wn_channels) return fail(MBX_ERR_INVALID_ARGUMENT, "wn_block_channels[0] must be wn_channels");
+        for (int b = 0; b < c.n_wn_blocks; ++b) {
+            if (c.wn_block_ups[b] < 1 || c.wn_block_channels[b] < 4 || c.wn_block_channels[b] % 4 || spf0 % c.wn_block_ups[b])
+                return fail(MBX_ERR_INVALID_ARGUMENT, "WaveNet blocks: channels must be multiples of 4, upsampling factors must divide steps_per_frame");
+            spf0 /= c.wn_block_ups[b];
+        }
+    }
+    if (spf0 * c.pulse_channels != c.pulse_per_frame)
+        return fail(MBX_ERR_INVALID_ARGUMENT, "pulse_per_frame must be (rows per frame of the first WaveNet block) * pulse_channels");
+    if ((spf0 % c.cond_lin_upsampling) || spf0 / c.cond_lin_upsampling != c.cond_conv_upsampling)
         return fail(MBX_ERR_INVALID_ARGUMENT, "conditioning rates do not reach the WaveNet rate");
     if (c.wt_subharm_channels < 0 || c.wt_subharm_channels > 8) return fail(MBX_ERR_INVALID_ARGUMENT, "wt_subharm_channels out of range");
     if (c.wn_in_channels != c.pulse_channels * (1 + c.wt_subharm_channels) + (c.noise_sigma != 0.f ? 1 : 0))
@@ -557,7 +585,8 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
                                      "wn.end.w", "wn.end.b", "post.w", "post.b"};
     // conditioning chain (reference custom_AE_layers.py:190-227,283-289): pre-conditioning convolutions, then the
     // conditioning layer; all with kernel size cond_kernel_size and zero SAME padding, no activation in between
-    if (!c.wn_disable_conditioning) {
+    auto cond_chain = [&](const std::string &prefix, int channels, int ccu, std::vector<mbx_subnet_op> &ops) {
+        if (c.wn_disable_conditioning) return;
         int chan = c.mel_channels;
         auto add = [&](const std::string &nm, int cout) {
             mbx_subnet_op op{};
@@ -570,16 +599,51 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
             op.pad_mode = MBX_PAD_ZERO;
             op.up = 1;
             std::snprintf(op.name, MBX_NAME_LEN, "%s", nm.c_str());
-            hd->cond_ops.push_back(op);
+            ops.push_back(op);
             need.push_back(nm + ".w");
             need.push_back(nm + ".b");
             chan = cout;
         };
         for (int i = 0; i < c.n_precond; ++i) {
-            add("wn.precond_" + std::to_string(i), c.precond_channels[i]);
+            add(prefix + "precond_" + std::to_string(i), c.precond_channels[i]);
             hd->cond_buf_per_frame = std::max<long long>(hd->cond_buf_per_frame, c.precond_channels[i]);
         }
-        add("wn.cond", 2 * c.wn_channels * c.cond_conv_upsampling);
+        add(prefix + "cond", 2 * channels * ccu);
+    };
+    cond_chain("wn.", c.wn_channels, c.cond_conv_upsampling, hd->cond_ops);
+    // several WaveNet blocks (reference custom_pulsed_generator.py:456-488): every block has its own start / conditioning
+    // / layer / end tensors; the up-sampling convolution "up<b>" sits behind block b
+    if (c.n_wn_blocks >= 1) {
+        int spf = spf0;
+        for (int b = 0; b < c.n_wn_blocks; ++b) {
+            mbx_handle::WnBlock blk;
+            blk.C = c.wn_block_channels[b];
+            blk.ups = c.wn_block_ups[b];
+            blk.spf = spf;
+            if (spf % c.cond_lin_upsampling) return bail(fail(MBX_ERR_INVALID_ARGUMENT, "a WaveNet block's rate is not a multiple of cond_lin_upsampling"));
+            blk.ccu = spf / c.cond_lin_upsampling;
+            blk.prefix = b == 0 ? "wn." : "wn" + std::to_string(b) + ".";
+            if (b == 0) blk.cond_ops = hd->cond_ops;
+            else cond_chain(blk.prefix, blk.C, blk.ccu, blk.cond_ops);
+            hd->mb_hc_per_frame = std::max<long long>(hd->mb_hc_per_frame, (long long)spf * blk.C);
+            if (b >= 1) {
+                need.push_back(blk.prefix + "start.w");
+                need.push_back(blk.prefix + "start.b");
+                need.push_back(blk.prefix + "end.w");
+                need.push_back(blk.prefix + "end.b");
+                for (int l = 0; l < c.wn_layers; ++l)
+                    for (const char *nm : {"conv1D_", "res_skip_"}) {
+                        need.push_back(blk.prefix + nm + std::to_string(l) + ".w");
+                        need.push_back(blk.prefix + nm + std::to_string(l) + ".b");
+                    }
+            }
+            if (blk.ups > 1) {
+                need.push_back("up" + std::to_string(b) + ".w");
+                need.push_back("up" + std::to_string(b) + ".b");
+            }
+            spf *= blk.ups;
+            hd->blocks.push_back(blk);
+        }
     }
     if (c.nm_iters > 0) {
         if (c.nm_smooth_win < c.hop_size || c.nm_smooth_win % 2 || !(c.nm_rms_norm_fact > 0.f))
@@ -612,6 +676,20 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
               expect("table.wavetables", (long long)(c.wt_n_period + 1) * c.wt_n_tables);
     for (const mbx_subnet_op &op : hd->cond_ops)
         ok = ok && expect(std::string(op.name) + ".w", (long long)op.ks * op.cin * op.cout) && expect(std::string(op.name) + ".b", op.cout);
+    for (size_t b = 0; b < hd->blocks.size(); ++b) {
+        const auto &blk = hd->blocks[b];
+        const long long Cb = blk.C;
+        if (b >= 1) {
+            for (const mbx_subnet_op &op : blk.cond_ops)
+                ok = ok && expect(std::string(op.name) + ".w", (long long)op.ks * op.cin * op.cout) && expect(std::string(op.name) + ".b", op.cout);
+            ok = ok && expect(blk.prefix + "start.w", (long long)c.wn_out_channels * Cb) && expect(blk.prefix + "end.w", Cb * c.wn_out_channels);
+            for (int l = 0; l < c.wn_layers && ok; ++l)
+                ok = expect(blk.prefix + "conv1D_" + std::to_string(l) + ".w", (long long)c.wn_kernel_size * Cb * 2 * Cb) &&
+                     expect(blk.prefix + "res_skip_" + std::to_string(l) + ".w", Cb * (l < c.wn_layers - 1 ? 2 * Cb : Cb));
+        }
+        if (blk.ups > 1)
+            ok = ok && expect("up" + std::to_string(b) + ".w", 3LL * c.wn_out_channels * c.wn_out_channels * blk.ups);
+    }
     for (int l = 0; l < c.wn_layers && ok; ++l) {
         ok = expect("wn.conv1D_" + std::to_string(l) + ".w", (long long)c.wn_kernel_size * C * 2 * C) &&
              expect("wn.res_skip_" + std::to_string(l) + ".w", (long long)C * (l < c.wn_layers - 1 ? 2 * C : C));
@@ -647,6 +725,7 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
             have = expect("wn.res_skip_" + std::to_string(l) + ".fold", nct * nk * 2048) &&
                    expect("wn.res_skip_" + std::to_string(l) + ".fold_b", C + c.wn_out_channels);
         have = have && expect("wn.tail.fold", (long long)((C + 7) / 8) * 256) && expect("wn.tail.fold_b", c.wn_out_channels);
+        if (c.n_wn_blocks >= 1) have = false;      // several blocks: generic kernels (run_wavenet_blocks)
         hd->fold_skip = have;
         // start convolution folded into layer 0 (wn_gate0.hip); MBX_FOLD_START=0 keeps the h0 tensor and the full layer
         const char *sv = getenv("MBX_FOLD_START");
@@ -769,6 +848,95 @@ struct ForwardExtras {
     const int32_t *fe_pos = nullptr;
 };
 
+// Several WaveNet blocks with in-block upsampling (reference custom_pulsed_generator.py:456-488, 908-914;
+// custom_AE_layers.py:273-346, 574-582), on the generic kernels: block b = start convolution (block 0: fold + noise
+// channel + start, wn_start_kernel) -> L x (dilated convolution + conditioning + gate, res/skip) -> end convolution ->
+// sub-pixel convolution "up<b>" (depth -> time).  The last block's output goes through the post-net into the sub-band
+// rows.  Whole items only (no stream regions).
+static mbx_status run_wavenet_blocks(mbx_handle *hd, const Workspace &w, int B, int T, const int32_t *n_frames,
+                                     const float *noise, hipStream_t stream) {
+    const mbx_config &c = hd->cfg;
+    const int L = c.wn_layers, n_out = c.wn_out_channels, M = c.subbands, cond_up = c.cond_lin_upsampling;
+    const long long npulse = (long long)T * c.pulse_per_frame;
+    const int nsub1 = 1 + c.wt_subharm_channels;
+    auto lerp = hd->lerp[cond_up];
+    const float *x_in = nullptr;                 // output of the previous block (B, rows, n_out)
+    for (size_t b = 0; b < hd->blocks.size(); ++b) {
+        const auto &blk = hd->blocks[b];
+        const int C = blk.C, spf = blk.spf;
+        const long long rows = (long long)T * spf;
+        const bool last_block = b + 1 == hd->blocks.size();
+        const float *cond = b == 0 ? w.cond : w.mb_cond[b];
+        const long long cond_bstride = (long long)T * blk.ccu * 2 * C;
+        const DevTensor *ws = find(hd, blk.prefix + "start.w"), *bs = find(hd, blk.prefix + "start.b");
+        if (b == 0) {
+            ScopedEvents ev(hd, PROF_START, stream);
+            mbx::launch_wn_start(w.pulse, npulse * nsub1, c.noise_sigma != 0.f ? noise : nullptr, rows, c.noise_sigma, n_frames, spf,
+                                 (int)rows, B, c.pulse_channels * nsub1, ws->ptr, bs->ptr, C, w.mb_h, rows * C, stream);
+        } else {
+            mbx::ConvArgs a = conv_args(x_in, rows * n_out, n_out, n_frames, spf, (int)rows, B, ws, bs, 1, n_out, C, 1, 0,
+                                        MBX_PAD_ZERO, w.mb_h, rows * C, C);
+            mbx::launch_conv1d(a, mbx::EPI_LINEAR, stream);
+        }
+        for (int l = 0; l < L; ++l) {
+            const std::string ls = std::to_string(l);
+            const int d = c.wn_dilations[l];
+            mbx::ConvArgs g = conv_args(w.mb_h, rows * C, C, n_frames, spf, (int)rows, B, find(hd, blk.prefix + "conv1D_" + ls + ".w"),
+                                        find(hd, blk.prefix + "conv1D_" + ls + ".b"), c.wn_kernel_size, C, 2 * C, d,
+                                        d * (c.wn_kernel_size - 1) / 2, MBX_PAD_ZERO, w.mb_a, rows * C, C);
+            g.cond = cond;
+            g.cond_bstride = cond_bstride;
+            g.cond_up = cond_up;
+            g.lerp_w0 = lerp.first;
+            g.lerp_w1 = lerp.second;
+            g.channels = C;
+            g.gate_act = c.wn_gate_activation;
+            g.zeros = hd->zeros;
+            {
+                ScopedEvents ev(hd, PROF_GATE, stream);
+                mbx::launch_conv1d(g, mbx::EPI_GATE, stream);
+            }
+            const bool last = l == L - 1;
+            mbx::ConvArgs r = conv_args(w.mb_a, rows * C, C, n_frames, spf, (int)rows, B, find(hd, blk.prefix + "res_skip_" + ls + ".w"),
+                                        find(hd, blk.prefix + "res_skip_" + ls + ".b"), 1, C, last ? C : 2 * C, 1, 0, MBX_PAD_ZERO,
+                                        nullptr, 0, 0);
+            r.channels = C;
+            r.zeros = hd->zeros;
+            r.h = w.mb_h;
+            r.skip = w.mb_skip;
+            r.hs_bstride = rows * C;
+            r.skip_init = (l == 0);
+            r.last_layer = last;
+            ScopedEvents ev(hd, PROF_RES_SKIP, stream);
+            mbx::launch_conv1d(r, mbx::EPI_RESSKIP, stream);
+        }
+        // end convolution (reference custom_AE_layers.py:337-340); the last block's output is the stage "wn_out" unless an
+        // up-sampling convolution follows it
+        ScopedEvents ev(hd, PROF_TAIL, stream);
+        float *y = (last_block && blk.ups == 1) ? w.wn_out : w.mb_y0;
+        mbx::ConvArgs e = conv_args(w.mb_skip, rows * C, C, n_frames, spf, (int)rows, B, find(hd, blk.prefix + "end.w"),
+                                    find(hd, blk.prefix + "end.b"), 1, C, n_out, 1, 0, MBX_PAD_ZERO, y, rows * n_out, n_out);
+        mbx::launch_conv1d(e, mbx::EPI_LINEAR, stream);
+        x_in = y;
+        if (blk.ups > 1) {
+            // Conv1DUpDownSample (reference conv_layers.py:177-261): k = 3 convolution to n_out * ups channels, zero SAME
+            // padding, then depth -> time: row r of the input becomes rows ups r .. ups r + ups - 1 (a reshape in memory)
+            const std::string un = "up" + std::to_string(b);
+            float *yu = last_block ? w.wn_out : w.mb_y1;
+            mbx::ConvArgs u = conv_args(y, rows * n_out, n_out, n_frames, spf, (int)rows, B, find(hd, un + ".w"), find(hd, un + ".b"), 3,
+                                        n_out, n_out * blk.ups, 1, 1, MBX_PAD_ZERO, yu, rows * n_out * blk.ups, n_out * blk.ups);
+            mbx::launch_conv1d(u, mbx::EPI_LINEAR, stream);
+            x_in = yu;
+        }
+    }
+    // post-net 1x1 (reference custom_pulsed_generator.py:490-493,913-914) at the sub-band rate
+    const long long nsteps = (long long)T * c.steps_per_frame;
+    mbx::ConvArgs pn = conv_args(x_in, nsteps * n_out, n_out, n_frames, c.steps_per_frame, (int)nsteps, B, find(hd, "post.w"),
+                                 find(hd, "post.b"), 1, n_out, M, 1, 0, MBX_PAD_ZERO, w.sub, nsteps * M, M);
+    mbx::launch_conv1d(pn, mbx::EPI_LINEAR, stream);
+    return MBX_OK;
+}
+
 static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *n_frames, int32_t batch,
                                int32_t max_frames, const float *noise, float *audio, void *workspace,
                                size_t workspace_bytes, void *hip_stream, const ForwardExtras &ex = ForwardExtras()) {
@@ -799,6 +967,8 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         if (ex.fe_new_frames > 0) fe_frames = ex.fe_new_frames + ex.fe_margin_frames;
     }
     if (batch <= 0 || max_frames <= 0) return fail(MBX_ERR_INVALID_ARGUMENT, "batch and max_frames must be positive");
+    if (!hd->blocks.empty() && (active_frames || st_in || st_out || sub_carry || ex.lay || fe_on))
+        return fail(MBX_ERR_UNSUPPORTED, "a model with several WaveNet blocks runs whole items only (no stream windows / state)");
     DeviceGuard guard(hd->device);
     if (!guard.ok) return fail(MBX_ERR_HIP, "cannot select the handle's device");
     const mbx_config &c = hd->cfg;
@@ -874,6 +1044,21 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         if (vtf.status != MBX_OK) return vtf.status;
         if (f0.status != MBX_OK) return f0.status;
         if (cond.status != MBX_OK) return cond.status;
+        // the conditioning chains of the WaveNet blocks behind the first one (each block has its own layer)
+        for (size_t bk = 1; bk < hd->blocks.size(); ++bk) {
+            const auto &blk = hd->blocks[bk];
+            const size_t floats = (size_t)B * T * blk.ccu * 2 * blk.C;
+            if (blk.cond_ops.empty()) {
+                if (hipMemsetAsync(w.mb_cond[bk], 0, floats * sizeof(float), stream) != hipSuccess)
+                    return fail(MBX_ERR_HIP, "hipMemsetAsync of the conditioning rows failed");
+                continue;
+            }
+            SubnetRun cb(hd, blk.cond_ops.data(), (int)blk.cond_ops.size(), mel, c.mel_channels, n_frames, B, T, w.sub4, w.sub5,
+                         w.mb_cond[bk], false, 1.f, 0.f, stream);
+            mbx::ConvArgs one;
+            while (cb.next_conv(one)) mbx::launch_conv1d_group(&one, 1, stream);
+            if (cb.status != MBX_OK) return cb.status;
+        }
         if (f0_wide && !f0_in)   // pulse_frequency[:, :T * pulse_per_frame] (reference custom_pulsed_generator.py:787)
             mbx::launch_activation(w.f0_wide, (long long)T * hd->f0_time_factor, n_frames, c.pulse_per_frame, (int)npulse,
                                    B, 1, MBX_ACT_LINEAR, 1.f, 0.f, w.f0, npulse, stream);
@@ -927,7 +1112,8 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     const int wn_rows = wn_frames_max * c.steps_per_frame;
     int act_frames_max = T - (int)act0;
     if (active_frames && active_max_frames > 0) act_frames_max = std::min(act_frames_max, active_max_frames);
-    // ---- WaveNet (reference custom_AE_layers.py:273-346)
+    // ---- WaveNet (reference custom_AE_layers.py:273-346): one block (the measured path) or several (generic kernels)
+    auto single_block = [&]() -> mbx_status {
     const bool fold_start = hd->fold_start;
     const bool fold = hd->fold_skip;
     const int n_out = c.wn_out_channels, spf = c.steps_per_frame, cond_up = c.cond_lin_upsampling;
@@ -1199,6 +1385,12 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                                          MBX_PAD_ZERO, sub_t, nsteps * M, M);
             mbx::launch_conv1d(pn, mbx::EPI_LINEAR, stream);
         }
+    }
+    return MBX_OK;
+    };
+    {
+        const mbx_status wst = hd->blocks.empty() ? single_block() : run_wavenet_blocks(hd, w, B, T, n_frames, noise, stream);
+        if (wst != MBX_OK) return wst;
     }
     // ---- sub-band rows carried between the ticks of a stream: rows in front of the WaveNet region come from the
     // caller's store (computed by the previous tick), the rows the next tick will need go there

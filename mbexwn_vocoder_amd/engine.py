@@ -23,6 +23,7 @@ MBX_ABI_VERSION = 6
 MBX_MAX_SUBNET_OPS = 32
 MBX_MAX_WN_LAYERS = 64
 MBX_MAX_PRECOND = 8
+MBX_MAX_WN_BLOCKS = 4
 MBX_NAME_LEN = 64
 
 _OP_KIND = {"conv": 0, "lin": 1, "prelu": 2, "leaky": 3, "act": 4}
@@ -65,7 +66,8 @@ class mbx_config(ctypes.Structure):
                 ("wn_disable_conditioning", ctypes.c_int32), ("n_precond", ctypes.c_int32),
                 ("precond_channels", ctypes.c_int32 * MBX_MAX_PRECOND), ("spect_preserve_energy", ctypes.c_int32),
                 ("wt_subharm_channels", ctypes.c_int32), ("wt_sinusoid_as_fun", ctypes.c_int32),
-                ("ps_off", ctypes.c_int32), ("no_pqmf", ctypes.c_int32)]
+                ("ps_off", ctypes.c_int32), ("no_pqmf", ctypes.c_int32), ("n_wn_blocks", ctypes.c_int32),
+                ("wn_block_channels", ctypes.c_int32 * MBX_MAX_WN_BLOCKS), ("wn_block_ups", ctypes.c_int32 * MBX_MAX_WN_BLOCKS)]
 
 
 class mbx_forward_options(ctypes.Structure):
@@ -247,6 +249,12 @@ def make_config(config, wavetables):
     cc.wt_subharm_channels = dims.wt_subharm
     cc.wt_sinusoid_as_fun = int(dims.wt_sinusoid_as_fun)
     cc.ps_off, cc.no_pqmf = int(dims.ps_off), int(dims.no_pqmf)
+    if dims.wn_multi:                 # several WaveNet blocks / in-block upsampling: the generic path of the library
+        if dims.n_wn_blocks > MBX_MAX_WN_BLOCKS:
+            raise ValueError("too many WaveNet blocks for the engine")
+        cc.n_wn_blocks = dims.n_wn_blocks
+        for bb in range(dims.n_wn_blocks):
+            cc.wn_block_channels[bb], cc.wn_block_ups[bb] = dims.wn_block_channels[bb], dims.wn_block_ups[bb]
     f0_ops, vtf_ops = subnet_ops(config)
     cc.n_f0_ops = _fill_ops(cc.f0_ops, f0_ops)
     cc.n_vtf_ops = _fill_ops(cc.vtf_ops, vtf_ops)
@@ -481,16 +489,17 @@ def tensor_table(config, raw_weights, wavetables):
     _, syn = tb.pqmf_filters(int(mbc["subbands"]), int(mbc["taps"]), float(mbc["cutoff_ratio"]), float(mbc["beta"]),
                              mbc.get("max_band", None))
     out["table.pqmf_syn"] = syn
-    if out["wn.end.w"].shape[0] == 1 and out["wn.end.w"].shape[2] <= 32:
+    # (several WaveNet blocks / in-block upsampling run the library's generic kernels: no operand-order images)
+    if not dims.wn_multi and out["wn.end.w"].shape[0] == 1 and out["wn.end.w"].shape[2] <= 32:
         out["wn.end.packed"] = pack_end_weights(out["wn.end.w"])
         fs = fold_skip_weights(out, dims.wn_layers, dims.wn_channels)
         if dims.wn_kernel_size == 3:
             out.update(fold_start_weights(out, dims, fs))
         fs.pop("__proj_0", None)
         out.update(fs)
-    for ll in range(dims.wn_layers):
+    for ll in range(0 if dims.wn_multi else dims.wn_layers):
         out[f"wn.res_skip_{ll}.packed"] = pack_resskip_weights(out[f"wn.res_skip_{ll}.w"])
-    if dims.wn_kernel_size == 3:
+    if dims.wn_kernel_size == 3 and not dims.wn_multi:
         for ll in range(dims.wn_layers):
             out[f"wn.conv1D_{ll}.wino4w"] = pack_winograd4w_weights(out[f"wn.conv1D_{ll}.w"])
             out[f"wn.conv1D_{ll}.wino2w"] = pack_winograd2w_weights(out[f"wn.conv1D_{ll}.w"])
@@ -617,7 +626,7 @@ class MBExWNEngine:
         B, T = int(mel.shape[0]), int(mel.shape[1])
         if B == 0 or T == 0:
             return torch.zeros((B, T * self.dims.hop_size), dtype=torch.float32, device=self.device)
-        steps = T * self.dims.steps_per_frame
+        steps = T * self.dims.wn_in_rows_per_frame            # one noise value per row of the (first) WaveNet block
         if self.dims.noise_sigma:
             if noise is None:
                 raise ValueError("noise is required (the noise channel is an explicit input, see SURVEY.md F7)")
@@ -821,7 +830,7 @@ class MBExWNEngine:
         mel = mel.contiguous()
         if noise is None and self.dims.noise_sigma:
             # the reference draws tf.random.normal here (custom_pulsed_generator.py:905-906)
-            noise = torch.randn((mel.shape[0], mel.shape[1] * self.dims.steps_per_frame), device=self.device,
+            noise = torch.randn((mel.shape[0], mel.shape[1] * self.dims.wn_in_rows_per_frame), device=self.device,
                                 dtype=torch.float32)
         elif noise is not None:
             noise = torch.as_tensor(noise).to(self.device, torch.float32).contiguous()

@@ -419,6 +419,9 @@ def _engine_layer_name(layer):
         return "wn." + layer
     if layer.endswith("_PaNMPulseWaveNet_Post"):
         return "post"
+    up = re.fullmatch(r"PP_waveNetBlock_ups\d+_(\d+)_WNBlock_UP_\d+", layer)     # custom_AE_layers.py:519-524
+    if up:
+        return "up" + up.group(1)
     if re.fullmatch(r"\w+_(Layer_(\d+|final)|ActLayer_\d+)", layer):
         return layer
     return None
@@ -439,6 +442,14 @@ def map_reference_variables(named_arrays):
             owner = owner[:-len("_base")]
         if leaf in ("kernel", "bias", "g") and owner:
             layer = _engine_layer_name(owner)
+            if layer and layer.startswith("wn."):
+                # the layers of the WaveNet blocks behind the first one: the block index is in the enclosing scope
+                # "PP_waveNetBlock_ups<u>_<i>" (reference custom_pulsed_generator.py:487)
+                for comp in parts[:-2]:
+                    blk = re.match(r"PP_waveNetBlock_ups\d+_(\d+)", comp)
+                    if blk and int(blk.group(1)) > 0:
+                        layer = f"wn{int(blk.group(1))}." + layer[3:]
+                        break
             if layer:
                 target = layer + "." + ("v" if leaf == "kernel" else leaf)
         elif leaf == "alpha":
@@ -461,8 +472,14 @@ def to_reference_variables(raw, model_scope="mb_ex_wn"):
     inverse = {vv: kk for kk, vv in _WAVENET_LAYERS.items()}
     for name, arr in raw.items():
         layer, kind = name.rsplit(".", 1)
-        if layer in inverse or layer.startswith("wn."):
-            ref, scope = inverse.get(layer, layer[3:]), f"{model_scope}/PP_waveNetBlock_ups1_0/wave_net_ae/"
+        blk = re.match(r"wn(\d*)\.(.*)", layer)
+        up = re.fullmatch(r"up(\d+)", layer)
+        if blk:
+            idx, inner = int(blk.group(1) or 0), "wn." + blk.group(2)
+            ref, scope = inverse.get(inner, blk.group(2)), f"{model_scope}/PP_waveNetBlock_ups1_{idx}/wave_net_ae/"
+        elif up:
+            ref = f"PP_waveNetBlock_ups1_{up.group(1)}_WNBlock_UP_2"
+            scope = f"{model_scope}/PP_waveNetBlock_ups1_{up.group(1)}/"
         elif layer == "post":
             ref, scope = f"{model_scope}_PaNMPulseWaveNet_Post", f"{model_scope}/"
         else:
@@ -484,7 +501,7 @@ def _uses_weight_norm(config, layer):
     """True when the layer's checkpoint holds a gain g.  WaveNet layers follow pp_mod_subnet.use_weight_norm /
     use_equalized_lr (reference custom_AE_layers.py:123 default False; conv_layers.py:79-119: either option adds g); the
     sub-nets and the post-net are always weight-normed (custom_pulsed_generator.py:100-148, 490-493)."""
-    if layer.startswith("wn."):
+    if re.match(r"wn\d*\.", layer):
         wn = config["mbexwn_config"]["pp_mod_subnet"]
         return bool(wn.get("use_weight_norm", False)) or bool(wn.get("use_equalized_lr", False))
     return True

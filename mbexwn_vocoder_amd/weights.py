@@ -10,10 +10,24 @@ The pretrained checkpoints are not in the reference tree; ``synth
 generates seeded weights of the exact architecture.
 A checkpoint saved with ``save_weights`` is a plain ``.npz`` of the raw variables.
 """
+import re
+
 import numpy as np
 
 from .config import ModelDims
 from .subnet import build_subnet
+
+
+def block_prefix(index):
+    """Tensor-name prefix of WaveNet block ``index``: "wn." for the first (and usually only) one, "wn1." ..."""
+    return "wn." if index == 0 else f"wn{index}."
+
+
+def is_wavenet_layer(name):
+    """Layers built with pp_mod_subnet's use_weight_norm / use_equalized_lr switches: everything inside a WaveNetAE
+    (reference custom_AE_layers.py:177-260), of any block; not the up-sampling convolutions behind the blocks."""
+    import re
+    return re.match(r"wn\d*\.", name) is not None
 
 
 def layer_table(config):
@@ -36,24 +50,31 @@ def layer_table(config):
             convs.append((op["name"], op["ks"], op["cin"], op["cout"]))
         elif op["kind"] == "prelu":
             prelus.append((op["name"], op["channels"]))
-    C, L = dims.wn_channels, dims.wn_layers
-    convs.append(("wn.start", 1, dims.wn_in_channels, C))
-    if not dims.wn_disable_conditioning:
-        cond_in = dims.mel_channels
-        for ii, chans in enumerate(dims.wn_pre_cond_channels):          # reference custom_AE_layers.py:192-201
-            convs.append((f"wn.precond_{ii}", dims.cond_kernel_size, cond_in, chans))
-            cond_in = chans
-        convs.append(("wn.cond", dims.cond_kernel_size, cond_in, 2 * C * dims.cond_conv_upsampling))
-    # n_ch_groups independent channel groups, each with its own layers "conv1D_<l>", "conv1D_<l>g1", ...
-    # (reference custom_AE_layers.py:235-260)
+    L = dims.wn_layers
     G = dims.wn_groups
-    Cg = C // G
-    for ll in range(L):
-        for gg in range(G):
-            sfx = f"g{gg}" if gg else ""
-            convs.append((f"wn.conv1D_{ll}{sfx}", dims.wn_kernel_size, Cg, 2 * Cg))
-            convs.append((f"wn.res_skip_{ll}{sfx}", 1, Cg, 2 * Cg if ll < L - 1 else Cg))
-    convs.append(("wn.end", 1, C, dims.wn_out_channels))
+    rows_per_frame = dims.wn_in_rows_per_frame
+    for bb, (C, ups) in enumerate(zip(dims.wn_block_channels, dims.wn_block_ups)):
+        # block b: "wn." (b = 0) / "wn<b>." ; its input: the folded excitation (b = 0) or the previous block's n_out channels
+        pre = block_prefix(bb)
+        convs.append((pre + "start", 1, dims.wn_in_channels if bb == 0 else dims.wn_out_channels, C))
+        if not dims.wn_disable_conditioning:
+            cond_in = dims.mel_channels
+            for ii, chans in enumerate(dims.wn_pre_cond_channels):      # reference custom_AE_layers.py:192-201
+                convs.append((f"{pre}precond_{ii}", dims.cond_kernel_size, cond_in, chans))
+                cond_in = chans
+            convs.append((pre + "cond", dims.cond_kernel_size, cond_in, 2 * C * (rows_per_frame // dims.cond_lin_upsampling)))
+        # n_ch_groups independent channel groups, each with its own layers "conv1D_<l>", "conv1D_<l>g1", ...
+        # (reference custom_AE_layers.py:235-260)
+        Cg = C // G
+        for ll in range(L):
+            for gg in range(G):
+                sfx = f"g{gg}" if gg else ""
+                convs.append((f"{pre}conv1D_{ll}{sfx}", dims.wn_kernel_size, Cg, 2 * Cg))
+                convs.append((f"{pre}res_skip_{ll}{sfx}", 1, Cg, 2 * Cg if ll < L - 1 else Cg))
+        convs.append((pre + "end", 1, C, dims.wn_out_channels))
+        if ups > 1:      # Conv1DUpDownSample behind the block: k = 3, n_out -> n_out * ups, depth -> time (conv_layers.py:177-261)
+            convs.append((f"up{bb}", 3, dims.wn_out_channels, dims.wn_out_channels * ups))
+        rows_per_frame *= ups
     convs.append(("post", 1, dims.wn_out_channels, dims.subbands))
     return convs, prelus
 
@@ -74,8 +95,8 @@ def synthetic_weights(config, seed=1234, bias_std=0.0, alpha_jitter=0.0):
     raw = {}
     for name, ks, cin, cout in convs:
         raw[name + ".v"] = rng.normal(0.0, 0.02, size=(ks, cin, cout)).astype(np.float32)
-        gain = _SYNTH_GAIN.get(name, 1.0)
-        if eq_norm and name.startswith("wn."):
+        gain = _SYNTH_GAIN.get(re.sub(r"^wn\d+\.", "wn.", name), 1.0)     # the blocks behind the first one like the first
+        if eq_norm and is_wavenet_layer(name):
             # use_equalized_lr normalises the kernel to unit variance instead of unit norm (W = g v / sqrt(mean v^2)): the
             # gain takes the 1 / sqrt(fan-in) that keeps the activations at the scale of the weight-normed model
             gain = gain / np.sqrt(ks * cin)
@@ -98,7 +119,6 @@ def fold_weight_norm(v, g):
 # layers the reference may build without weight normalisation: only the WaveNet's own (pp_mod_subnet.use_weight_norm,
 # reference custom_AE_layers.py:124,177-260); the F0 / VTF sub-nets and the post-net are always weight-normed
 # (reference custom_pulsed_generator.py:84-136, 491)
-_PLAIN_KERNEL_PREFIXES = ("wn.",)
 
 
 def fold_weights(raw, wavenet_weight_norm=None, wavenet_equalized_lr=False):
@@ -118,7 +138,7 @@ def fold_weights(raw, wavenet_weight_norm=None, wavenet_equalized_lr=False):
         if key.endswith(".v"):
             name = key[:-2]
             bias = np.asarray(raw[name + ".bias"], dtype=np.float32)
-            eq = wavenet_equalized_lr and name.startswith(_PLAIN_KERNEL_PREFIXES)
+            eq = wavenet_equalized_lr and is_wavenet_layer(name)
             if eq:
                 if name + ".g" not in raw:
                     raise KeyError(f"{name}.g is missing: layers built with use_equalized_lr always hold a gain")
@@ -133,7 +153,7 @@ def fold_weights(raw, wavenet_weight_norm=None, wavenet_equalized_lr=False):
             elif name + ".g" in raw:
                 out[name + ".w"] = fold_weight_norm(val, raw[name + ".g"])
             else:
-                plain_ok = name.startswith(_PLAIN_KERNEL_PREFIXES) and wavenet_weight_norm is not True
+                plain_ok = is_wavenet_layer(name) and wavenet_weight_norm is not True
                 if not plain_ok:
                     raise KeyError(f"{name}.g is missing: the reference builds this layer with weight normalisation, "
                                    f"so its checkpoint holds a gain (refusing to use {name}.v as the weight)")

@@ -24,6 +24,8 @@ PINNING STATUS
 The noise channel is an explicit input: TensorFlow's Philox stream cannot be
 reproduced, so parity is defined with injected noise.
 """
+import re
+
 import numpy as np
 
 LOG_TO_DB = 20 * np.log10(np.exp(1))
@@ -142,7 +144,7 @@ class OracleModel:
         self.pulse_channels = mb["pulse_channels"]
         self.wt_cfg = mb.get("wavetable_config", {}) or {}
         self.steps_per_frame = self.hop // self.M                                   # :265
-        self.pulse_per_frame = self.steps_per_frame * self.pulse_channels           # :266
+        self.pulse_per_frame = (self.steps_per_frame * self.pulse_channels) // int(np.prod(mb.get("pp_mod_subnet_upsampling_factors", [1])))   # :266
         self.sigma = mb.get("pp_mod_subnet_noise_channel_sigma", 0.5)
         self.f_min = mb.get("pp_min_frequency", 40.0)
         self.f_max = mb.get("pp_max_frequency", 600.0)
@@ -218,7 +220,7 @@ class OracleModel:
         if name not in self._w:
             v = np.asarray(self.raw[name + ".v"], dtype=np.float64)
             b = np.asarray(self.raw[name + ".bias"]).astype(self.dtype)
-            eq = name.startswith("wn.") and bool(self.wn.get("use_equalized_lr", False))
+            eq = re.match(r"wn\d*\.", name) is not None and bool(self.wn.get("use_equalized_lr", False))
             if eq and self.wn.get("use_weight_norm", False):
                 g = np.asarray(self.raw[name + ".g"], dtype=np.float64)
                 w = (g * v / np.sqrt(np.mean(v * v, axis=(0, 1), keepdims=True))).astype(self.dtype)
@@ -351,38 +353,39 @@ class OracleModel:
             return 2 ** (int(index // step) % mx)
         return 2 ** int(index // step)                                            # custom_AE_layers.py:229-233
 
-    def conditioning(self, mel):
-        """custom_AE_layers.py:214-227,287-289: sub-pixel conv (factor cond_conv_upsampling) then LinInterp."""
+    def conditioning(self, mel, prefix="wn.", rate_factor=1):
+        """custom_AE_layers.py:214-227,287-289: sub-pixel conv (factor cond_conv_upsampling) then LinInterp.  ``prefix`` /
+        ``rate_factor``: the block's tensors and its rate relative to the first block (custom_pulsed_generator.py:484,488)."""
         lin_up = self.wn.get("cond_lin_upsampling", 16)
-        conv_up = int((self.pulse_rate / self.pulse_channels) // ((self.sample_rate / self.hop) * lin_up))
+        conv_up = int((self.pulse_rate / self.pulse_channels * rate_factor) // ((self.sample_rate / self.hop) * lin_up))
         x = mel
         for ii in range(len(self.wn.get("pre_cond_layer_channels", None) or [])):    # :192-201, 283-285: plain convolutions
-            w, b = self.weight(f"wn.precond_{ii}")
+            w, b = self.weight(f"{prefix}precond_{ii}")
             x = conv1d_same_zero(x, w, b)
-        w, b = self.weight("wn.cond")
+        w, b = self.weight(prefix + "cond")
         c = depth_to_time(conv1d_same_zero(x, w, b), conv_up)
         return lin_interp(c, lin_up, self.f32)
 
-    def wavenet(self, x, mel, return_layers=False):
+    def wavenet(self, x, mel, return_layers=False, prefix="wn.", channels=None, rate_factor=1):
         """custom_AE_layers.py:273-346 (WaveNetAE.call), activation gtu / gfu / gsu / glu; n_ch_groups independent channel groups between
         the shared start and end convolutions (:303-340; layers of group g > 0 are named "<layer>g<g>", :249,260)."""
-        C = self.wn["n_channels"]
+        C = self.wn["n_channels"] if channels is None else channels
         L = self.wn.get("n_layers", 12)
         G = int(self.wn.get("n_ch_groups", 1))
         Cg = C // G
-        w, b = self.weight("wn.start")
+        w, b = self.weight(prefix + "start")
         started = np.split(conv1d_valid(x, w, b), G, axis=-1)                     # :280, :303-304
         started = [np.array(ss) for ss in started]
         if self.wn.get("disable_conditioning", False):                            # :293-294: zeros
             cond = [np.zeros((), dtype=self.dtype)] * G
         else:
-            cond = np.split(self.conditioning(mel), G, axis=-1)                   # :287-289
+            cond = np.split(self.conditioning(mel, prefix, rate_factor), G, axis=-1)   # :287-289
         output = [None] * G
         acts = []
         for ll in range(L):
             for gg in range(G):
                 sfx = f"g{gg}" if gg else ""
-                w, b = self.weight(f"wn.conv1D_{ll}{sfx}")
+                w, b = self.weight(f"{prefix}conv1D_{ll}{sfx}")
                 z = conv1d_same_zero(started[gg], w, b, dilation=self.dilation(ll)) + cond[gg]   # :307-309
                 zt = z[..., :Cg]
                 act = self.wn.get("activation", "gtu")
@@ -397,7 +400,7 @@ class OracleModel:
                 else:
                     raise NotImplementedError(f"WaveNetAE activation {act}")
                 a = half * (1 / (1 + np.exp(-z[..., Cg:])))                       # :320-321
-                w, b = self.weight(f"wn.res_skip_{ll}{sfx}")
+                w, b = self.weight(f"{prefix}res_skip_{ll}{sfx}")
                 r = conv1d_valid(a, w, b)                                         # :324
                 if ll < L - 1:
                     started[gg] = started[gg] + r[..., :Cg]                       # :326-328
@@ -408,7 +411,7 @@ class OracleModel:
                 if return_layers:
                     acts.append(a)
         skip = np.concatenate(output, axis=-1) if G > 1 else output[0]            # :337-340
-        w, b = self.weight("wn.end")
+        w, b = self.weight(prefix + "end")
         out = conv1d_valid(skip, w, b)
         if return_layers:
             h = np.concatenate(started, axis=-1) if G > 1 else started[0]
@@ -442,7 +445,18 @@ class OracleModel:
                 raise ValueError("noise must be given when pp_mod_subnet_noise_channel_sigma != 0")
             nz = np.asarray(noise).astype(self.dtype)[:, :x.shape[1], None]
             x = np.concatenate((x, self.sigma * nz), axis=-1)                     # :905-906
-        y = self.wavenet(x, mel)                                                  # :908-910
+        # :908-910, 456-488: one WaveNet block per up-sampling factor; block b has n_channels * channel_factors[b] channels
+        # and an up-sampling convolution (k = 3, SAME, depth -> time; custom_AE_layers.py:519-524, 574-582) behind it
+        ups = [int(uu) for uu in self.mb.get("pp_mod_subnet_upsampling_factors", [1])]
+        chf = list(self.mb.get("pp_mod_subnet_channel_factors", [1]))
+        y, rate = x, 1
+        for bb, (uu, ff) in enumerate(zip(ups, chf)):
+            prefix = "wn." if bb == 0 else f"wn{bb}."
+            y = self.wavenet(y, mel, prefix=prefix, channels=int(self.wn["n_channels"] * ff), rate_factor=rate)
+            if uu > 1:
+                w, b = self.weight(f"up{bb}")
+                y = depth_to_time(conv1d_same_zero(y, w, b), uu)
+            rate *= uu
         w, b = self.weight("post")
         y = conv1d_valid(y, w, b)                                                 # :913-914
         if not self.mb.get("pp_mod_subnet_use_pqmf", True):                       # :922-923: no PQMF, a reshape

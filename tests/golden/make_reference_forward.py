@@ -91,9 +91,16 @@ CASES = {
                          "mbexwn_config:ps_off": True}, 2, 9),
     "nopqmf": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
                           "mbexwn_config:pp_mod_subnet_use_pqmf": False}, 2, 9),
+    # two WaveNet blocks with in-block upsampling (reference custom_pulsed_generator.py:456-488, custom_AE_layers.py:457-582):
+    # 32 channels at 800 Hz (10 folded pulse samples per row), x2 sub-pixel convolution, 16 channels at 1 600 Hz
+    "blocks": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                          "mbexwn_config:pp_mod_subnet_upsampling_factors": [2, 1],
+                          "mbexwn_config:pp_mod_subnet_channel_factors": [1, 0.5],
+                          "mbexwn_config:pulse_channels": 10,
+                          "mbexwn_config:pp_mod_subnet:cond_lin_upsampling": 5}, 2, 9),
 }
 # the long cases keep the small stage outputs only (the full conditioning / envelope tensors would be megabytes)
-LEAN = {"canon60", "voice", "grammar", "groups", "gfu", "gsu_eqlr", "eqlr_plain", "glu", "precond", "nocond", "energy", "mixed_a", "mixed_b", "subharm", "sinfun", "psoff", "nopqmf"}
+LEAN = {"canon60", "voice", "grammar", "groups", "gfu", "gsu_eqlr", "eqlr_plain", "glu", "precond", "nocond", "energy", "mixed_a", "mixed_b", "subharm", "sinfun", "psoff", "nopqmf", "blocks"}
 
 
 def assign_conv(layer, raw, name):
@@ -114,17 +121,23 @@ def load_into_reference(model, raw):
             elif type(ll).__name__ == "PReLU":
                 ll.alpha.assign(np.reshape(raw[ll.name + ".alpha"], ll.alpha.shape))
                 used.add(ll.name + ".alpha")
-    wn = model.pp_waveNetBlocks[0].wavenet
-    pairs = [(wn.start, "wn.start"), (wn.end, "wn.end"), (model.wn_post_net[0], "post")]
-    if wn.cond_layer is not None:
-        pairs += [(wn.cond_layer, "wn.cond")] + [(ll, f"wn.precond_{ii}") for ii, ll in enumerate(wn.pre_cond_layers)]
-    # layer list index = layer * n_ch_groups + group; group g > 0 is named "<layer>g<g>" (reference custom_AE_layers.py:249,260)
-    ng = wn.n_ch_groups
+    pairs = [(model.wn_post_net[0], "post")]
+    # one WaveNetAEBlock per up-sampling factor (reference custom_pulsed_generator.py:456-488): "wn." / "wn1." ..., the
+    # up-sampling convolution behind block b is "up<b>"
+    for bb, block in enumerate(model.pp_waveNetBlocks):
+        wn, pre = block.wavenet, ("wn." if bb == 0 else f"wn{bb}.")
+        pairs += [(wn.start, pre + "start"), (wn.end, pre + "end")]
+        if wn.cond_layer is not None:
+            pairs += [(wn.cond_layer, pre + "cond")] + [(ll, f"{pre}precond_{ii}") for ii, ll in enumerate(wn.pre_cond_layers)]
+        # layer list index = layer * n_ch_groups + group; group g > 0 is named "<layer>g<g>" (reference custom_AE_layers.py:249,260)
+        ng = wn.n_ch_groups
 
-    def wn_name(base, ii):
-        return f"wn.{base}_{ii // ng}" + (f"g{ii % ng}" if ii % ng else "")
-    pairs += [(ll, wn_name("conv1D", ii)) for ii, ll in enumerate(wn.conv_layers)]
-    pairs += [(ll, wn_name("res_skip", ii)) for ii, ll in enumerate(wn.res_skip_layers)]
+        def wn_name(base, ii, pre=pre, ng=ng):
+            return f"{pre}{base}_{ii // ng}" + (f"g{ii % ng}" if ii % ng else "")
+        pairs += [(ll, wn_name("conv1D", ii)) for ii, ll in enumerate(wn.conv_layers)]
+        pairs += [(ll, wn_name("res_skip", ii)) for ii, ll in enumerate(wn.res_skip_layers)]
+        if block.up_down_sample is not None:
+            pairs.append((block.up_down_sample, f"up{bb}"))
     for layer, name in pairs:
         assign_conv(layer, raw, name)
         used.update({name + ".v", name + ".g", name + ".bias"})
@@ -148,7 +161,8 @@ def run_case(voice, overrides, batch, frames, float_type):
     rng = np.random.default_rng(42)
     mell = np.log(np.exp(rng.normal(-5.0, 2.0, size=(batch, frames, 80))) + 1e-5)
     mell = np.clip(mell, -11.5, 2.0).astype(np.float32)
-    steps = frames * model.spect_to_subband_upsampling_factor
+    # one noise value per row of the first WaveNet block (reference :905-906)
+    steps = frames * model.spect_to_pulse_upsampling_factor // model.pulse_channels
     noise = rng.normal(size=(batch, steps)).astype(np.float32)
 
     mel_t = shim.Tensor(mell.astype(float_type))

@@ -56,8 +56,13 @@ GOLDEN_CASES = {
                          "mbexwn_config:ps_off": True}, 2, 9),
     "nopqmf": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
                           "mbexwn_config:pp_mod_subnet_use_pqmf": False}, 2, 9),
+    "blocks": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                          "mbexwn_config:pp_mod_subnet_upsampling_factors": [2, 1],
+                          "mbexwn_config:pp_mod_subnet_channel_factors": [1, 0.5],
+                          "mbexwn_config:pulse_channels": 10,
+                          "mbexwn_config:pp_mod_subnet:cond_lin_upsampling": 5}, 2, 9),
 }
-LEAN_GOLDEN_CASES = {"canon60", "voice", "grammar", "groups", "gfu", "gsu_eqlr", "eqlr_plain", "glu", "precond", "nocond", "energy", "mixed_a", "mixed_b", "subharm", "sinfun", "psoff", "nopqmf"}     # cond subsampled [:, ::37], no envelope / wavetables (see the generator)
+LEAN_GOLDEN_CASES = {"canon60", "voice", "grammar", "groups", "gfu", "gsu_eqlr", "eqlr_plain", "glu", "precond", "nocond", "energy", "mixed_a", "mixed_b", "subharm", "sinfun", "psoff", "nopqmf", "blocks"}     # cond subsampled [:, ::37], no envelope / wavetables (see the generator)
 
 
 @functools.lru_cache(maxsize=None)

@@ -333,6 +333,50 @@ def test_subharmonic_channels_through_the_folded_first_layer(torch):
     assert _maxdiff(pulse[..., 1].cpu().numpy(), sub) <= 2e-6
 
 
+@pytest.mark.parametrize("overrides", [
+    {"mbexwn_config:pp_mod_subnet_upsampling_factors": [2, 1], "mbexwn_config:pp_mod_subnet_channel_factors": [1, 0.5],
+     "mbexwn_config:pulse_channels": 10, "mbexwn_config:pp_mod_subnet:cond_lin_upsampling": 5,
+     "mbexwn_config:pp_mod_subnet:n_channels": 64, "mbexwn_config:pp_mod_subnet:n_layers": 3},
+    {"mbexwn_config:pp_mod_subnet_upsampling_factors": [2], "mbexwn_config:pp_mod_subnet_channel_factors": [1],
+     "mbexwn_config:pulse_channels": 10, "mbexwn_config:pp_mod_subnet:cond_lin_upsampling": 10,
+     "mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 2},
+    {"mbexwn_config:pp_mod_subnet_upsampling_factors": [2, 2, 1], "mbexwn_config:pp_mod_subnet_channel_factors": [1, 0.75, 0.5],
+     "mbexwn_config:pulse_channels": 20, "mbexwn_config:pp_mod_subnet:cond_lin_upsampling": 5,
+     "mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 2,
+     "mbexwn_config:pp_mod_subnet:pre_cond_layer_channels": [24], "mbexwn_config:pp_mod_subnet:activation": "gfu"},
+    {"mbexwn_config:pp_mod_subnet_upsampling_factors": [1, 1], "mbexwn_config:pp_mod_subnet_channel_factors": [1, 2],
+     "mbexwn_config:pp_mod_subnet:n_channels": 16, "mbexwn_config:pp_mod_subnet:n_layers": 2,
+     "mbexwn_config:pp_mod_subnet:disable_conditioning": True},
+], ids=["2blocks_C64", "1block_up2", "3blocks_precond_gfu", "2blocks_noup_nocond"])
+def test_several_wavenet_blocks(torch, overrides):
+    """pp_mod_subnet_upsampling_factors / _channel_factors (reference custom_pulsed_generator.py:456-488): stacked WaveNet
+    blocks with sub-pixel up-sampling convolutions in between, each block with its own conditioning chain; ragged batch
+    against the oracle (which the golden case "blocks" pins to the reference).  Such a handle does not stream."""
+    from mbexwn_vocoder_amd.config import ModelDims
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    from mbexwn_vocoder_amd.streaming import StreamingSynthesizer
+    cfg, raw, wt = build_case("SPEECH", overrides)
+    dims = ModelDims(cfg)
+    assert dims.wn_multi and dims.wn_in_rows_per_frame * int(np.prod(dims.wn_block_ups)) == 20
+    eng, om = MBExWNEngine(cfg, raw, wt), orc.OracleModel(cfg, raw, wt)
+    rpf = dims.wn_in_rows_per_frame
+    mel, noise = synthetic_inputs(17, 2, 23, steps_per_frame=rpf)
+    lengths = (23, 7)
+    got = eng.forward(dev(torch, mel), noise=dev(torch, noise),
+                      n_frames=torch.tensor(lengths, dtype=torch.int32, device="cuda")).cpu().numpy()
+    for ii, ll in enumerate(lengths):
+        ref = om.forward(mel[ii:ii + 1, :ll], noise[ii:ii + 1, :ll * rpf])[0]
+        assert _maxdiff(got[ii, :ll * 300], ref) <= _tol(ref, E2E_TOL)
+        assert np.all(got[ii, ll * 300:] == 0.0)
+    assert eng.layer_state_info()[0] == 0
+    syn = StreamingSynthesizer(eng, chunk_frames=8)
+    syn.open(0)
+    with pytest.raises((NotImplementedError, ValueError)):
+        syn.push(0, mel[0], noise[0], last=True)
+        for _ in range(4):
+            syn.tick()
+
+
 def test_engine_without_weight_images_runs_the_generic_kernels(torch):
     """A handle created from the folded weights and tables alone (no operand-order images) must give the same audio
     through the generic convolution kernels (direct gate, C->2C res/skip with the skip tensor, separate end/post)."""

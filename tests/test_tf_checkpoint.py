@@ -151,6 +151,27 @@ def test_pre_conditioning_layers_and_missing_conditioning_round_trip(tmp_path):
             assert np.array_equal(got[name], raw[name]), name
 
 
+def test_several_wavenet_blocks_round_trip(tmp_path):
+    """Layers of the WaveNet blocks behind the first one carry the same names inside another "PP_waveNetBlock_ups<u>_<i>"
+    scope; the up-sampling convolution of block i is "<block>_WNBlock_UP_<factor>" (reference custom_pulsed_generator.py:487,
+    custom_AE_layers.py:519-524)."""
+    cfg = canonical_config("SPEECH", **{"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 2,
+                                        "mbexwn_config:pp_mod_subnet_upsampling_factors": [2, 1],
+                                        "mbexwn_config:pp_mod_subnet_channel_factors": [1, 0.5],
+                                        "mbexwn_config:pulse_channels": 10, "mbexwn_config:pp_mod_subnet:cond_lin_upsampling": 5})
+    raw = synthetic_weights(cfg, seed=13)
+    assert raw["wn1.start.v"].shape == (1, 30, 16) and raw["up0.v"].shape == (3, 30, 60) and raw["wn1.cond.v"].shape == (3, 80, 2 * 16 * 4)
+    named = _reference_names(raw)
+    assert any("PP_waveNetBlock_ups1_1/wave_net_ae/conv1D_0/kernel" in kk for kk in named)
+    assert any(kk.endswith("PP_waveNetBlock_ups1_0_WNBlock_UP_2/kernel") for kk in named)
+    prefix = str(tmp_path / "blocks")
+    tfc.write_checkpoint(prefix, named)
+    got = tfc.load_reference_checkpoint(prefix, cfg)
+    assert sorted(got) == sorted(raw)
+    for name in raw:
+        assert np.array_equal(got[name], raw[name]), name
+
+
 def test_unbuilt_wavenet_options_raise():
     """Keys of WaveNetAE.__init__ that change the arithmetic and are not built must not be ignored silently."""
     from mbexwn_vocoder_amd.config import ModelDims
