@@ -160,6 +160,11 @@ typedef struct {
     int32_t n_wn_blocks;
     int32_t wn_block_channels[MBX_MAX_WN_BLOCKS];
     int32_t wn_block_ups[MBX_MAX_WN_BLOCKS];
+    /* pulse_channels_use_pqmf (reference custom_pulsed_generator.py:499-501, 892-895): the WaveNet rows are not
+     * pulse_channels consecutive pulse samples but the pulse_channels sub-bands of a PQMF analysis of the pulse signal
+     * (TFPQMF.analysis, tf_preprocess.py:188-200): pulse_pqmf_taps > 0 = taps of that bank, tensor "table.pulse_ana"
+     * (pulse_pqmf_taps + 1, pulse_channels).  Whole items only; not together with wt_subharm_channels. */
+    int32_t pulse_pqmf_taps;
 } mbx_config;
 
 /* A named HOST tensor handed over at creation (weights already weight-norm folded, tables).

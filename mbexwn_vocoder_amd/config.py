@@ -324,8 +324,15 @@ class ModelDims:
             raise NotImplementedError("the sub-band gain variant of the envelope filter (ps_use_stft: false) is not supported")
         # pp_mod_subnet_use_pqmf: false -- the sub-band rows are laid out one after the other instead (reference :920-923)
         self.no_pqmf = not mb.get("pp_mod_subnet_use_pqmf", True)
+        # pulse_channels_use_pqmf: the WaveNet rows are the sub-bands of a PQMF analysis of the pulse signal instead of
+        # consecutive samples (reference custom_pulsed_generator.py:499-501, 892-895)
+        self.pulse_pqmf = None
         if mb.get("pulse_channels_use_pqmf", False):
-            raise NotImplementedError("pulse_channels_use_pqmf (PQMF analysis of the pulse signal) is not supported")
+            self.pulse_pqmf = dict(mb["pulse_channels_multi_band_config"])
+            if int(self.pulse_pqmf["subbands"]) != self.pulse_channels:
+                raise RuntimeError("MBExWN::config_error::pulse_channels_multi_band_config.subbands must equal pulse_channels")
+            if self.wt_subharm:
+                raise NotImplementedError("pulse_channels_use_pqmf together with add_subharm_chans is not supported")
         self.alpha = float(mb.get("alpha", 0.2))
         # NormMelComponents (reference wavegen_1d.py:578-769, row A14): device kernels csrc/norm_mel.hip, tables norm_mel.py
         self.normalize_rms_from_mell = bool(mb.get("normalize_rms_from_mell", False))

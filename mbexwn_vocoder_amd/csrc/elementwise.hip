@@ -99,6 +99,35 @@ void launch_prelu(float *x, long long x_bstride, const int *n_frames, int rows_p
                        rows_per_frame, max_rows, channels, alpha, leaky);
 }
 
+// PQMF analysis bank in front of the WaveNet (pulse_channels_use_pqmf, reference custom_pulsed_generator.py:892-895,
+// tf_preprocess.py:188-200): zero-pad taps/2 on both sides, cross-correlate with the K analysis filters, keep every K-th
+// sample.  One thread per output value; the bank (taps + 1, K) is a few hundred floats and stays in L1.
+__global__ void pulse_analysis_kernel(const float *pulse, long long bstride, const int *n_frames, int samples_per_frame,
+                                      int n_max, const float *ana, int taps, int K, float *out) {
+    const int b = blockIdx.y;
+    const int n = n_frames ? n_frames[b] * samples_per_frame : n_max;
+    const float *pb = pulse + (long long)b * bstride;
+    float *ob = out + (long long)b * bstride;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int r = i / K, k = i - r * K;
+        const int first = r * K - taps / 2;
+        float acc = 0.f;
+        for (int t = 0; t <= taps; ++t) {
+            const int src = first + t;
+            if (src >= 0 && src < n) acc = fmaf(ana[t * K + k], pb[src], acc);
+        }
+        ob[i] = acc;
+    }
+}
+
+void launch_pulse_analysis(const float *pulse, long long bstride, const int *n_frames, int samples_per_frame, int n_max,
+                           int batch, const float *ana, int taps, int K, float *out, hipStream_t stream) {
+    if (n_max <= 0 || batch <= 0) return;
+    const int blocks = (int)min((long long)(n_max + 255) / 256, (long long)2048);
+    hipLaunchKernelGGL(pulse_analysis_kernel, dim3(blocks, batch), dim3(256), 0, stream, pulse, bstride, n_frames,
+                       samples_per_frame, n_max, ana, taps, K, out);
+}
+
 // Excitation fold + noise channel + WaveNet "start" 1x1 convolution
 // (reference custom_pulsed_generator.py:893,905-906 and custom_AE_layers.py:280):
 //   x[s, c] = pulse[pc*s + c] (c < pc), x[s, pc] = sigma * noise[s]

@@ -145,6 +145,7 @@ struct Workspace {
     float *mel_norm, *nm_a, *nm_b;
     float *sub0, *sub1, *sub2, *sub3, *sub4, *sub5, *f0_wide, *f0, *cum, *chunk_last, *pulse, *cond, *h, *a, *skip, *wn_out, *sub, *exc, *ceps, *frames;
     float *mb_h, *mb_a, *mb_skip, *mb_y0, *mb_y1, *mb_cond[MBX_MAX_WN_BLOCKS];   // several WaveNet blocks only
+    float *pulse_ana;   // PQMF analysis of the pulse signal (pulse_pqmf_taps > 0): the WaveNet's excitation rows
     int *ceps_index;
     size_t total;
 };
@@ -178,6 +179,7 @@ Workspace carve(const mbx_handle *hd, char *base, int B, int T) {
     w.cum = take(B * npulse);
     w.chunk_last = take((size_t)B * chunks);
     w.pulse = take(B * npulse * (1 + c.wt_subharm_channels));
+    w.pulse_ana = take(c.pulse_pqmf_taps > 0 ? B * npulse : 0);
     w.cond = take(BT * 2 * c.wn_channels * c.cond_conv_upsampling);
     w.h = take(B * nsteps * c.wn_channels);
     w.a = take(B * nsteps * (c.wn_channels + 16));   // layer 0 appends the excitation channels to its rows (wn_gate0.hip)
@@ -471,6 +473,8 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
     if (c.wn_in_channels != c.pulse_channels * (1 + c.wt_subharm_channels) + (c.noise_sigma != 0.f ? 1 : 0))
         return fail(MBX_ERR_INVALID_ARGUMENT, "wn_in_channels must be pulse_channels * (1 + wt_subharm_channels) (+1 with noise)");
     if (c.pqmf_taps % 2) return fail(MBX_ERR_INVALID_ARGUMENT, "PQMF taps must be even");
+    if (c.pulse_pqmf_taps < 0 || c.pulse_pqmf_taps % 2 || (c.pulse_pqmf_taps > 0 && c.wt_subharm_channels))
+        return fail(MBX_ERR_INVALID_ARGUMENT, "pulse_pqmf_taps must be even and >= 0, and excludes wt_subharm_channels");
     if (c.phase_chunk < 1 || c.phase_chunk > 1024) return fail(MBX_ERR_INVALID_ARGUMENT, "phase_chunk must be in [1, 1024]");
     if (c.wn_gate_activation < MBX_GATE_GTU || c.wn_gate_activation > MBX_GATE_GLU)
         return fail(MBX_ERR_INVALID_ARGUMENT, "wn_gate_activation must be MBX_GATE_GTU, MBX_GATE_GFU, MBX_GATE_GSU or MBX_GATE_GLU");
@@ -652,6 +656,7 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
         need.push_back("table.nm_gwin");
         need.push_back("table.nm_smooth_win");
     }
+    if (c.pulse_pqmf_taps > 0) need.push_back("table.pulse_ana");
     if (c.n_ceps_windows) {
         need.push_back("table.ceps_windows");
         need.push_back("table.ceps_log10f0");
@@ -694,6 +699,7 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
         ok = expect("wn.conv1D_" + std::to_string(l) + ".w", (long long)c.wn_kernel_size * C * 2 * C) &&
              expect("wn.res_skip_" + std::to_string(l) + ".w", (long long)C * (l < c.wn_layers - 1 ? 2 * C : C));
     }
+    if (c.pulse_pqmf_taps > 0) ok = ok && expect("table.pulse_ana", (long long)(c.pulse_pqmf_taps + 1) * c.pulse_channels);
     if (c.n_ceps_windows)
         ok = ok && expect("table.ceps_windows", (long long)c.n_ceps_windows * c.n_ceps) &&
              expect("table.f0_smooth", 2 * c.hop_size + 1);
@@ -1095,6 +1101,15 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         mbx::launch_wavetable(wavetable_consts(hd), w.f0, npulse, n_frames, c.pulse_per_frame, (int)npulse, B, w.pulse,
                               nullptr, w.cum, w.chunk_last, st_in, st_out, stream);
     }
+    // ---- PQMF analysis of the pulse signal instead of folding consecutive samples (reference :892-895)
+    float *const pulse_osc = w.pulse;
+    if (c.pulse_pqmf_taps > 0) {
+        if (active_frames || st_in || st_out) return fail(MBX_ERR_UNSUPPORTED, "pulse_channels_use_pqmf models run whole items only");
+        ScopedEvents ev(hd, PROF_WAVETABLE, stream);
+        mbx::launch_pulse_analysis(w.pulse, npulse, n_frames, c.pulse_per_frame, (int)npulse, B, find(hd, "table.pulse_ana")->ptr,
+                                   c.pulse_pqmf_taps, c.pulse_channels, w.pulse_ana, stream);
+        w.pulse = w.pulse_ana;                   // what the WaveNet reads; the stage "pulse" stays the oscillator's output
+    }
     // ---- active region (streaming windows, mbx_forward_options): from here on every stage sees the frames
     // [active_begin, active_begin + active_frames[b]) of the window as the item.  All buffers are (batch, frames * k)
     // with the batch stride of the whole window, so a region is a row offset into every buffer plus per-item row counts.
@@ -1451,7 +1466,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     if (nm_gain_src) sg["mel_norm"] = {w_base.mel_norm, (long long)T * c.mel_channels, (long long)T * c.mel_channels};
     else sg.erase("mel_norm");
     sg["f0"] = {w_base.f0, npulse, npulse};
-    sg["pulse"] = {w_base.pulse, npulse * (1 + c.wt_subharm_channels), npulse * (1 + c.wt_subharm_channels)};
+    sg["pulse"] = {pulse_osc, npulse * (1 + c.wt_subharm_channels), npulse * (1 + c.wt_subharm_channels)};
     sg["cond"] = {w_base.cond, (long long)T * cond_cout, (long long)T * cond_cout};
     sg["wn_hidden"] = {w_base.h, nsteps * C, nsteps * C};
     if (!hd->fold_skip) sg["wn_skip"] = {w_base.skip, nsteps * C, nsteps * C};

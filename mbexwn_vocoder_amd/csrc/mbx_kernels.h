@@ -185,6 +185,10 @@ void launch_activation(const float *x, long long x_bstride, const int *n_frames,
 // PReLU / leaky in place (used when a conv is not directly followed by its activation)
 void launch_prelu(float *x, long long x_bstride, const int *n_frames, int rows_per_frame, int max_rows, int batch,
                   int channels, const float *alpha, float leaky, hipStream_t stream);
+// PQMF analysis of the pulse signal (reference tf_preprocess.py:188-200): pulse (B, n_max) -> out (B, n_max) viewed as
+// (rows, K): out[r, k] = sum_n ana[n, k] * pulse[r K + n - taps / 2], zero outside the item
+void launch_pulse_analysis(const float *pulse, long long bstride, const int *n_frames, int samples_per_frame, int n_max,
+                           int batch, const float *ana, int taps, int K, float *out, hipStream_t stream);
 // WaveNet input: fold pulse (B, steps*pc) + noise (B, steps) and apply the start 1x1 conv -> h (B, steps, C)
 void launch_wn_start(const float *pulse, long long pulse_bstride, const float *noise, long long noise_bstride,
                      float sigma, const int *n_frames, int steps_per_frame, int max_steps, int batch,

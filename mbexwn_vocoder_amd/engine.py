@@ -67,7 +67,8 @@ class mbx_config(ctypes.Structure):
                 ("precond_channels", ctypes.c_int32 * MBX_MAX_PRECOND), ("spect_preserve_energy", ctypes.c_int32),
                 ("wt_subharm_channels", ctypes.c_int32), ("wt_sinusoid_as_fun", ctypes.c_int32),
                 ("ps_off", ctypes.c_int32), ("no_pqmf", ctypes.c_int32), ("n_wn_blocks", ctypes.c_int32),
-                ("wn_block_channels", ctypes.c_int32 * MBX_MAX_WN_BLOCKS), ("wn_block_ups", ctypes.c_int32 * MBX_MAX_WN_BLOCKS)]
+                ("wn_block_channels", ctypes.c_int32 * MBX_MAX_WN_BLOCKS), ("wn_block_ups", ctypes.c_int32 * MBX_MAX_WN_BLOCKS),
+                ("pulse_pqmf_taps", ctypes.c_int32)]
 
 
 class mbx_forward_options(ctypes.Structure):
@@ -249,6 +250,7 @@ def make_config(config, wavetables):
     cc.wt_subharm_channels = dims.wt_subharm
     cc.wt_sinusoid_as_fun = int(dims.wt_sinusoid_as_fun)
     cc.ps_off, cc.no_pqmf = int(dims.ps_off), int(dims.no_pqmf)
+    cc.pulse_pqmf_taps = int(dims.pulse_pqmf["taps"]) if dims.pulse_pqmf else 0
     if dims.wn_multi:                 # several WaveNet blocks / in-block upsampling: the generic path of the library
         if dims.n_wn_blocks > MBX_MAX_WN_BLOCKS:
             raise ValueError("too many WaveNet blocks for the engine")
@@ -489,6 +491,10 @@ def tensor_table(config, raw_weights, wavetables):
     _, syn = tb.pqmf_filters(int(mbc["subbands"]), int(mbc["taps"]), float(mbc["cutoff_ratio"]), float(mbc["beta"]),
                              mbc.get("max_band", None))
     out["table.pqmf_syn"] = syn
+    if dims.pulse_pqmf:                                            # analysis bank in front of the WaveNet
+        pq = dims.pulse_pqmf
+        out["table.pulse_ana"] = tb.pqmf_filters(int(pq["subbands"]), int(pq["taps"]), float(pq["cutoff_ratio"]),
+                                                 float(pq["beta"]), pq.get("max_band", None))[0]
     # (several WaveNet blocks / in-block upsampling run the library's generic kernels: no operand-order images)
     if not dims.wn_multi and out["wn.end.w"].shape[0] == 1 and out["wn.end.w"].shape[2] <= 32:
         out["wn.end.packed"] = pack_end_weights(out["wn.end.w"])

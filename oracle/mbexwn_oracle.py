@@ -439,7 +439,15 @@ class OracleModel:
         """custom_pulsed_generator.py:886-925 ; noise (B, T*steps_per_frame) ~ N(0,1) or None (sigma=0)."""
         pulse = self.wavetable(f0)                                                # :889
         n_sub = int(self.wt_cfg.get("add_subharm_chans", 0) or 0)
-        x = pulse.reshape(pulse.shape[0], -1, self.pulse_channels * (1 + n_sub)).astype(self.dtype)   # :893
+        if self.mb.get("pulse_channels_use_pqmf", False):                         # :894-895, tf_preprocess.py:188-200
+            pq = self.mb["pulse_channels_multi_band_config"]
+            ana = pqmf_analysis_bank(pq["subbands"], pq["taps"], pq["cutoff_ratio"], pq["beta"]).astype(self.dtype)
+            K, taps = ana.shape[1], ana.shape[0] - 1
+            padded = np.pad(pulse.astype(self.dtype), ((0, 0), (taps // 2, taps // 2)))
+            x = np.stack([np.stack([np.correlate(padded[bb], ana[:, kk], mode="valid")[::K] for kk in range(K)], axis=-1)
+                          for bb in range(pulse.shape[0])], axis=0)
+        else:
+            x = pulse.reshape(pulse.shape[0], -1, self.pulse_channels * (1 + n_sub)).astype(self.dtype)   # :893
         if self.sigma:
             if noise is None:
                 raise ValueError("noise must be given when pp_mod_subnet_noise_channel_sigma != 0")
@@ -539,6 +547,18 @@ class OracleModel:
         if return_stages:
             return audio, {"f0": f0, "excitation": exc, "envelope": env}
         return audio
+
+
+def pqmf_analysis_bank(subbands, taps, cutoff, beta):
+    """Cosine-modulated analysis bank (taps + 1, subbands), float32 constants -- tf_preprocess.py:30-80,119-150."""
+    nn = np.arange(taps + 1) - 0.5 * taps
+    with np.errstate(invalid="ignore", divide="ignore"):
+        proto = np.sin(np.pi * cutoff * nn) / (np.pi * nn)
+    proto[taps // 2] = cutoff
+    proto = proto * np.kaiser(taps + 1, beta)
+    kk = np.arange(subbands)[:, None]
+    ana = 2 * proto[None, :] * np.cos((2 * kk + 1) * (np.pi / (2 * subbands)) * nn[None, :] + (-1.0) ** kk * np.pi / 4)
+    return ana.T.astype(np.float32)
 
 
 def synthetic_mel(rng, batch, frames, channels=80):

@@ -98,9 +98,15 @@ CASES = {
                           "mbexwn_config:pp_mod_subnet_channel_factors": [1, 0.5],
                           "mbexwn_config:pulse_channels": 10,
                           "mbexwn_config:pp_mod_subnet:cond_lin_upsampling": 5}, 2, 9),
+    # PQMF analysis of the pulse signal in front of the WaveNet instead of folding consecutive samples (reference
+    # custom_pulsed_generator.py:499-501, 892-895)
+    "pulsepqmf": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                             "mbexwn_config:pulse_channels_use_pqmf": True,
+                             "mbexwn_config:pulse_channels_multi_band_config": {"subbands": 5, "taps": 40,
+                                                                                "cutoff_ratio": 0.12, "beta": 9.0}}, 2, 9),
 }
 # the long cases keep the small stage outputs only (the full conditioning / envelope tensors would be megabytes)
-LEAN = {"canon60", "voice", "grammar", "groups", "gfu", "gsu_eqlr", "eqlr_plain", "glu", "precond", "nocond", "energy", "mixed_a", "mixed_b", "subharm", "sinfun", "psoff", "nopqmf", "blocks"}
+LEAN = {"canon60", "voice", "grammar", "groups", "gfu", "gsu_eqlr", "eqlr_plain", "glu", "precond", "nocond", "energy", "mixed_a", "mixed_b", "subharm", "sinfun", "psoff", "nopqmf", "blocks", "pulsepqmf"}
 
 
 def assign_conv(layer, raw, name):

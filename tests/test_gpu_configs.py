@@ -358,6 +358,31 @@ def test_gate_variants_and_equalized_lr_vs_reference_goldens(torch, golden_dir, 
     assert _maxdiff(got, ref) <= _tol(ref)
 
 
+def test_pulse_pqmf_model(torch):
+    """pulse_channels_use_pqmf: the excitation rows are the PQMF analysis of the pulse signal (reference
+    custom_pulsed_generator.py:892-895); ragged batch vs the oracle (pinned by the golden case "pulsepqmf"), the stage
+    "pulse" stays the oscillator's output, streams are refused."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    from mbexwn_vocoder_amd.streaming import StreamingSynthesizer
+    cfg, raw, wt = build_case(*GOLDEN_CASES["pulsepqmf"][:2])
+    eng, om = MBExWNEngine(cfg, raw, wt), orc.OracleModel(cfg, raw, wt)
+    mel, noise = synthetic_inputs(77, 2, 19)
+    lengths = (19, 6)
+    got = eng.forward(dev(torch, mel), noise=dev(torch, noise),
+                      n_frames=torch.tensor(lengths, dtype=torch.int32, device="cuda")).cpu().numpy()
+    for ii, ll in enumerate(lengths):
+        ref, st = om.forward(mel[ii:ii + 1, :ll], noise[ii:ii + 1, :ll * 20], return_stages=True)
+        assert _maxdiff(got[ii, :ll * 300], ref[0]) <= _tol(ref)
+    pulse = eng.stage("pulse").cpu().numpy()
+    assert _maxdiff(pulse[0], om.wavetable(eng.stage("f0").cpu().numpy()[:1])[0]) <= 5e-4
+    syn = StreamingSynthesizer(eng, chunk_frames=8)
+    syn.open(0)
+    with pytest.raises((NotImplementedError, ValueError)):
+        syn.push(0, mel[0], noise[0], last=True)
+        for _ in range(4):
+            syn.tick()
+
+
 def test_ps_off_model_returns_only_the_f0_parameter(torch):
     """ps_off: MBExWN.call returns the excitation as the signal and only ["F0", .] as parameter (neither PSig nor PS exist,
     reference custom_pulsed_generator.py:663-672, 756-767); infer_components has no envelope to return."""
