@@ -165,6 +165,12 @@ typedef struct {
      * (TFPQMF.analysis, tf_preprocess.py:188-200): pulse_pqmf_taps > 0 = taps of that bank, tensor "table.pulse_ana"
      * (pulse_pqmf_taps + 1, pulse_channels).  Whole items only; not together with wt_subharm_channels. */
     int32_t pulse_pqmf_taps;
+    /* ps_use_stft: false (reference custom_pulsed_generator.py:427,453,663-672,857-884,916-917): the VTF-net ends in one
+     * log gain per sub-band (n_ceps == subbands, mean over the bands removed with spect_preserve_energy); exp of it is
+     * linearly interpolated by hop_size -- i.e. to the SAMPLE rate -- and its first rows multiply the sub-band rows
+     * (the reference's own indexing, kept as it is); no STFT-domain filter, the audio is the excitation.  Whole items
+     * only. */
+    int32_t ps_subband_gain;
 } mbx_config;
 
 /* A named HOST tensor handed over at creation (weights already weight-norm folded, tables).

@@ -320,8 +320,12 @@ class ModelDims:
         self.preserve_energy = bool(mb.get("spect_filters_preserve_energy", False))
         # ps_off: no VTF-net, no STFT-domain filter, the audio is the excitation (reference custom_pulsed_generator.py:663-672)
         self.ps_off = bool(mb.get("ps_off", False))
-        if not mb.get("ps_use_stft", True) and not self.ps_off:
-            raise NotImplementedError("the sub-band gain variant of the envelope filter (ps_use_stft: false) is not supported")
+        # ps_use_stft: false -- the VTF-net ends in one log gain per sub-band; the gains multiply the sub-band rows and there
+        # is no STFT-domain filter (reference :427,453,663-672,857-884,916-917).  n_ceps then is the number of sub-bands.
+        self.ps_subband_gain = (not mb.get("ps_use_stft", True)) and not self.ps_off
+        if self.ps_subband_gain:
+            self.n_ceps = self.subbands
+        self.no_envelope = self.ps_off or self.ps_subband_gain     # neither PSig nor PS among the returned parameters
         # pp_mod_subnet_use_pqmf: false -- the sub-band rows are laid out one after the other instead (reference :920-923)
         self.no_pqmf = not mb.get("pp_mod_subnet_use_pqmf", True)
         # pulse_channels_use_pqmf: the WaveNet rows are the sub-bands of a PQMF analysis of the pulse signal instead of

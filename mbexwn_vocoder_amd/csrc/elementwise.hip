@@ -99,6 +99,45 @@ void launch_prelu(float *x, long long x_bstride, const int *n_frames, int rows_p
                        rows_per_frame, max_rows, channels, alpha, leaky);
 }
 
+// Sub-band gains (ps_use_stft: false).  The reference interpolates the per-frame gains with factor hop_size (one value per
+// audio sample, edge frame repeated) and multiplies the sub-band rows -- steps_per_frame per frame -- with the FIRST rows
+// of that tensor (custom_pulsed_generator.py:453,670,916-917): row r takes the gain at frame r / hop, phase r % hop.
+__global__ void subband_gain_kernel(float *sub, long long sub_bstride, const float *log_gain, long long gain_bstride,
+                                    const int *n_frames, int max_frames, int rows_per_frame, int M, int hop,
+                                    const float *w0, const float *w1, int remove_mean) {
+    const int b = blockIdx.y;
+    const int T = n_frames ? n_frames[b] : max_frames;
+    const long long total = (long long)T * rows_per_frame * M;
+    const float *gb = log_gain + (long long)b * gain_bstride;
+    float *sb = sub + (long long)b * sub_bstride;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / M), m = (int)(i - (long long)r * M);
+        const int f0 = r / hop, j = r - f0 * hop;
+        const int f1 = min(f0 + 1, T - 1);
+        float m0 = 0.f, m1 = 0.f;
+        if (remove_mean) {       // channel_log_gain -= reduce_mean(channel_log_gain, axis=-1) (:868-871)
+            for (int k = 0; k < M; ++k) {
+                m0 += gb[(long long)f0 * M + k];
+                m1 += gb[(long long)f1 * M + k];
+            }
+            m0 /= (float)M;
+            m1 /= (float)M;
+        }
+        const float g0 = expf(gb[(long long)f0 * M + m] - m0), g1 = expf(gb[(long long)f1 * M + m] - m1);
+        sb[i] *= g0 * w0[j] + g1 * w1[j];
+    }
+}
+
+void launch_subband_gain(float *sub, long long sub_bstride, const float *log_gain, long long gain_bstride, const int *n_frames,
+                         int max_frames, int rows_per_frame, int batch, int M, int hop, const float *w0, const float *w1,
+                         int remove_mean, hipStream_t stream) {
+    if (max_frames <= 0 || batch <= 0) return;
+    const long long total = (long long)max_frames * rows_per_frame * M;
+    const int blocks = (int)min((total + 255) / 256, (long long)2048);
+    hipLaunchKernelGGL(subband_gain_kernel, dim3(blocks, batch), dim3(256), 0, stream, sub, sub_bstride, log_gain, gain_bstride,
+                       n_frames, max_frames, rows_per_frame, M, hop, w0, w1, remove_mean);
+}
+
 // PQMF analysis bank in front of the WaveNet (pulse_channels_use_pqmf, reference custom_pulsed_generator.py:892-895,
 // tf_preprocess.py:188-200): zero-pad taps/2 on both sides, cross-correlate with the K analysis filters, keep every K-th
 // sample.  One thread per output value; the bank (taps + 1, K) is a few hundred floats and stays in L1.

@@ -472,6 +472,8 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
     if (c.wt_subharm_channels < 0 || c.wt_subharm_channels > 8) return fail(MBX_ERR_INVALID_ARGUMENT, "wt_subharm_channels out of range");
     if (c.wn_in_channels != c.pulse_channels * (1 + c.wt_subharm_channels) + (c.noise_sigma != 0.f ? 1 : 0))
         return fail(MBX_ERR_INVALID_ARGUMENT, "wn_in_channels must be pulse_channels * (1 + wt_subharm_channels) (+1 with noise)");
+    if (c.ps_subband_gain && (c.n_ceps != c.subbands || c.ps_off || c.n_ceps_windows))
+        return fail(MBX_ERR_INVALID_ARGUMENT, "ps_subband_gain: the VTF-net ends in one gain per sub-band (n_ceps == subbands), no lifter, not ps_off");
     if (c.pqmf_taps % 2) return fail(MBX_ERR_INVALID_ARGUMENT, "PQMF taps must be even");
     if (c.pulse_pqmf_taps < 0 || c.pulse_pqmf_taps % 2 || (c.pulse_pqmf_taps > 0 && c.wt_subharm_channels))
         return fail(MBX_ERR_INVALID_ARGUMENT, "pulse_pqmf_taps must be even and >= 0, and excludes wt_subharm_channels");
@@ -498,6 +500,7 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
 
     // interpolation factors in use
     std::vector<int> ups = {c.cond_lin_upsampling};
+    if (c.ps_subband_gain) ups.push_back(c.hop_size);     // the sub-band gains are interpolated by hop_size
     for (int i = 0; i < c.n_f0_ops; ++i)
         if (c.f0_ops[i].kind == MBX_OP_LIN) ups.push_back(c.f0_ops[i].up);
     for (int i = 0; i < c.n_vtf_ops; ++i)
@@ -1407,6 +1410,13 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         const mbx_status wst = hd->blocks.empty() ? single_block() : run_wavenet_blocks(hd, w, B, T, n_frames, noise, stream);
         if (wst != MBX_OK) return wst;
     }
+    // ---- sub-band gains instead of the STFT-domain filter (ps_use_stft: false; reference :857-884, 670, 916-917)
+    if (c.ps_subband_gain) {
+        if (active_frames || st_in || st_out) return fail(MBX_ERR_UNSUPPORTED, "ps_use_stft: false models run whole items only");
+        auto lh = hd->lerp[c.hop_size];
+        mbx::launch_subband_gain(w.sub, nsteps * M, w.ceps, (long long)T * c.n_ceps, n_frames, T, c.steps_per_frame, B, M, c.hop_size,
+                                 lh.first, lh.second, c.spect_preserve_energy, stream);
+    }
     // ---- sub-band rows carried between the ticks of a stream: rows in front of the WaveNet region come from the
     // caller's store (computed by the previous tick), the rows the next tick will need go there
     if (sub_carry) {
@@ -1433,8 +1443,8 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
             mbx::launch_pqmf(sub_act, nsteps * M, n_frames_act, c.steps_per_frame, act_frames_max * c.steps_per_frame, B, M, hd->poly, hd->poly_t, hd->poly_ndm,
                              hd->poly_dm_min, exc_act, (long long)T * c.hop_size, stream);
     }
-    if (c.ps_off) {
-        // ps_off: signal = generate_excitation(...) (reference :663-672); samples behind an item's own length are zero
+    if (c.ps_off || c.ps_subband_gain) {
+        // ps_off / sub-band gains: signal = generate_excitation(...) (reference :663-672); samples behind an item's own length are zero
         ScopedEvents ev(hd, PROF_OVERLAP_ADD, stream);
         if (hipMemsetAsync(audio, 0, (size_t)B * T * c.hop_size * sizeof(float), stream) != hipSuccess)
             return fail(MBX_ERR_HIP, "hipMemsetAsync of the audio failed");

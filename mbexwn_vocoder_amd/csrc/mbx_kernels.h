@@ -185,6 +185,11 @@ void launch_activation(const float *x, long long x_bstride, const int *n_frames,
 // PReLU / leaky in place (used when a conv is not directly followed by its activation)
 void launch_prelu(float *x, long long x_bstride, const int *n_frames, int rows_per_frame, int max_rows, int batch,
                   int channels, const float *alpha, float leaky, hipStream_t stream);
+// sub-band gains of the ps_use_stft: false variant (reference custom_pulsed_generator.py:857-884, 670, 916-917):
+// sub[b, r, m] *= lerp_{hop}(exp(log_gain[b, :, m] (- mean over m)))[r], log_gain (B, max_frames, M)
+void launch_subband_gain(float *sub, long long sub_bstride, const float *log_gain, long long gain_bstride, const int *n_frames,
+                         int max_frames, int rows_per_frame, int batch, int M, int hop, const float *w0, const float *w1,
+                         int remove_mean, hipStream_t stream);
 // PQMF analysis of the pulse signal (reference tf_preprocess.py:188-200): pulse (B, n_max) -> out (B, n_max) viewed as
 // (rows, K): out[r, k] = sum_n ana[n, k] * pulse[r K + n - taps / 2], zero outside the item
 void launch_pulse_analysis(const float *pulse, long long bstride, const int *n_frames, int samples_per_frame, int n_max,

@@ -68,7 +68,7 @@ class mbx_config(ctypes.Structure):
                 ("wt_subharm_channels", ctypes.c_int32), ("wt_sinusoid_as_fun", ctypes.c_int32),
                 ("ps_off", ctypes.c_int32), ("no_pqmf", ctypes.c_int32), ("n_wn_blocks", ctypes.c_int32),
                 ("wn_block_channels", ctypes.c_int32 * MBX_MAX_WN_BLOCKS), ("wn_block_ups", ctypes.c_int32 * MBX_MAX_WN_BLOCKS),
-                ("pulse_pqmf_taps", ctypes.c_int32)]
+                ("pulse_pqmf_taps", ctypes.c_int32), ("ps_subband_gain", ctypes.c_int32)]
 
 
 class mbx_forward_options(ctypes.Structure):
@@ -230,7 +230,8 @@ def make_config(config, wavetables):
     cc.cond_conv_upsampling = dims.cond_conv_upsampling
     cc.cond_lin_upsampling = dims.cond_lin_upsampling
     cc.stft_win, cc.fft_size, cc.n_ceps = dims.stft_win, dims.fft_size, dims.n_ceps
-    use_windows = bool(dims.ps_env_order_scale) and not mb.get("psns_use_cepstral_loss_constraint", False)
+    use_windows = (bool(dims.ps_env_order_scale) and not mb.get("psns_use_cepstral_loss_constraint", False) and
+                   not dims.no_envelope)
     cc.n_ceps_windows = 30 if use_windows else 0
     cc.filter_max_log_range = dims.filter_max_log_range
     cc.wt_n_period, cc.wt_n_tables = wavetables.n_period, wavetables.n_tables
@@ -251,6 +252,7 @@ def make_config(config, wavetables):
     cc.wt_sinusoid_as_fun = int(dims.wt_sinusoid_as_fun)
     cc.ps_off, cc.no_pqmf = int(dims.ps_off), int(dims.no_pqmf)
     cc.pulse_pqmf_taps = int(dims.pulse_pqmf["taps"]) if dims.pulse_pqmf else 0
+    cc.ps_subband_gain = int(dims.ps_subband_gain)
     if dims.wn_multi:                 # several WaveNet blocks / in-block upsampling: the generic path of the library
         if dims.n_wn_blocks > MBX_MAX_WN_BLOCKS:
             raise ValueError("too many WaveNet blocks for the engine")
@@ -512,7 +514,7 @@ def tensor_table(config, raw_weights, wavetables):
     out["table.hann"] = tb.hann_periodic_f32(dims.stft_win)
     out["table.inv_win"] = tb.inverse_stft_window_f32(dims.stft_win, dims.hop_size)
     out["table.wavetables"] = np.ascontiguousarray(wavetables.tables, dtype=np.float32)
-    if dims.ps_env_order_scale and not mb.get("psns_use_cepstral_loss_constraint", False):
+    if dims.ps_env_order_scale and not mb.get("psns_use_cepstral_loss_constraint", False) and not dims.no_envelope:
         logs, rows = tb.cepstral_windows(dims.ps_env_order_scale, dims.sample_rate, dims.f0_min, dims.f0_max, dims.n_ceps)
         out["table.ceps_windows"] = rows
         out["table.ceps_log10f0"] = logs
@@ -886,7 +888,7 @@ class MBExWNEngine:
         rate = int(self.dims.sample_rate // self.dims.pulse_rate)
         f0 = self.stage("f0")[:, :audio.shape[1]:rate]               # the reference's own slice (:757)
         params = [["F0", _HostTensor(f0[:, :synth_length])]]
-        if not self.dims.ps_off:     # ps_off: neither excitation_signal nor source_filter_stft exist (reference :756-767)
+        if not self.dims.no_envelope:     # ps_off / sub-band gains: neither excitation_signal nor source_filter_stft exist (reference :756-767)
             params += [["PSig", _HostTensor(self.stage("excitation")[:, :audio.shape[1]][:, :synth_length])],
                        ["PS", _HostTensor(np.abs(self._envelope(B, T))[:, :synth_length])]]
         return (signals, params) if return_components else (signals[0], params)
@@ -899,9 +901,9 @@ class MBExWNEngine:
         last mel frame is repeated and how long ``upsampled_rms`` is.
         Additionally the (transposed) synthesis itself is available as ``self.last_audio`` (device tensor)."""
         torch = self._torch
-        if self.dims.ps_off:
-            raise NotImplementedError("infer_components(): a ps_off model has no spectral envelope (the reference's "
-                                      "generate_specenv has no VTF-net to run)")
+        if self.dims.no_envelope:
+            raise NotImplementedError("infer_components(): a ps_off / ps_use_stft: false model has no spectral envelope "
+                                      "(the reference's generate_specenv has no cepstral VTF-net to run)")
         synth_length = int(synth_length) if F0 is None else int(np.asarray(F0).shape[1])
         mel, noise = self._prepare(spect, synth_length, noise)
         hop, ppf = self.dims.hop_size, self.dims.pulse_per_frame

@@ -467,6 +467,14 @@ class OracleModel:
             rate *= uu
         w, b = self.weight("post")
         y = conv1d_valid(y, w, b)                                                 # :913-914
+        if not self.mb.get("ps_use_stft", True) and not self.mb.get("ps_off", False):
+            # :857-884: one log gain per sub-band from the VTF-net (mean over the bands removed with preserve_energy), exp;
+            # :453,670: interpolated by hop_size (edge frame repeated); :916-917: its FIRST rows multiply the sub-band rows
+            lg = self.run_subnet(mel, self.ps_specs, "PS", self.M, 1, None, pad_to_valid=self.ps_valid)
+            if self.preserve_energy:
+                lg = lg - np.mean(lg, axis=-1, keepdims=True)
+            gain = lin_interp(np.exp(lg), self.hop, self.f32)
+            y = y * gain[:, :y.shape[1]]
         if not self.mb.get("pp_mod_subnet_use_pqmf", True):                       # :922-923: no PQMF, a reshape
             return y.reshape(y.shape[0], y.shape[1] * y.shape[2])
         return self.pqmf_synthesis(y)                                             # :920-921
@@ -537,7 +545,7 @@ class OracleModel:
         T = mel.shape[1]
         f0 = self.generate_f0(mel)                                                # :567
         exc = self.generate_excitation(mel, f0, noise)                            # :676
-        if self.mb.get("ps_off", False):                                          # :663-672: the signal is the excitation
+        if self.mb.get("ps_off", False) or not self.mb.get("ps_use_stft", True):  # :663-672: the signal is the excitation
             audio = exc[:, :T * self.hop]
             return (audio, {"f0": f0, "excitation": exc}) if return_stages else audio
         src = self.stft(exc, T)                                                   # :681-694

@@ -104,9 +104,15 @@ CASES = {
                              "mbexwn_config:pulse_channels_use_pqmf": True,
                              "mbexwn_config:pulse_channels_multi_band_config": {"subbands": 5, "taps": 40,
                                                                                 "cutoff_ratio": 0.12, "beta": 9.0}}, 2, 9),
+    # ps_use_stft: false: sub-band gains instead of the STFT-domain filter, with and without the mean removal of
+    # spect_filters_preserve_energy (reference custom_pulsed_generator.py:453,663-672,857-884,916-917)
+    "subgain": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                           "mbexwn_config:ps_use_stft": False}, 2, 9),
+    "subgain_e": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                             "mbexwn_config:ps_use_stft": False, "mbexwn_config:spect_filters_preserve_energy": True}, 1, 40),
 }
 # the long cases keep the small stage outputs only (the full conditioning / envelope tensors would be megabytes)
-LEAN = {"canon60", "voice", "grammar", "groups", "gfu", "gsu_eqlr", "eqlr_plain", "glu", "precond", "nocond", "energy", "mixed_a", "mixed_b", "subharm", "sinfun", "psoff", "nopqmf", "blocks", "pulsepqmf"}
+LEAN = {"canon60", "voice", "grammar", "groups", "gfu", "gsu_eqlr", "eqlr_plain", "glu", "precond", "nocond", "energy", "mixed_a", "mixed_b", "subharm", "sinfun", "psoff", "nopqmf", "blocks", "pulsepqmf", "subgain", "subgain_e"}
 
 
 def assign_conv(layer, raw, name):
@@ -186,12 +192,15 @@ def run_case(voice, overrides, batch, frames, float_type):
             cond_in = ll(cond_in)
         out["cond"] = np.asarray(wn.cond_lin_upsampling_layer(wn.cond_layer(cond_in)))
     shim.INJECTED_NOISE["normal"] = noise
-    out["excitation"] = np.asarray(model.generate_excitation(mel_t, pulse_frequency=f0))
-    if not model.ps_off:
+    mb_gain = None
+    if not model.ps_off and not model.ps_use_stft:      # the call path of the sub-band gain variant (reference :667-672)
+        mb_gain = model.ps_gain_interpolator(model.generate_multiband_gain(mel=mel_t, training=False))
+    out["excitation"] = np.asarray(model.generate_excitation(mel_t, pulse_frequency=f0, mb_gain=mb_gain))
+    if not model.ps_off and model.ps_use_stft:
         env = model.generate_specenv(mel=mel_t, pulse_frequency=f0, training=False)
         out["envelope_re"] = np.asarray(env).real
         out["envelope_im"] = np.asarray(env).imag
-    if model.ps_env_order_scale and not model.ps_off:
+    if model.ps_env_order_scale and not model.ps_off and model.ps_use_stft:
         win = model._get_cepstral_windows(f0, model.ps_cepstral_windows_log10f0, model.ps_cepstral_windows,
                                           smooth_stride=model.spect_to_pulse_upsampling_factor)
         out["ceps_window_sum"] = np.asarray(win).sum(axis=-1)

@@ -65,8 +65,12 @@ GOLDEN_CASES = {
                              "mbexwn_config:pulse_channels_use_pqmf": True,
                              "mbexwn_config:pulse_channels_multi_band_config": {"subbands": 5, "taps": 40,
                                                                                 "cutoff_ratio": 0.12, "beta": 9.0}}, 2, 9),
+    "subgain": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                           "mbexwn_config:ps_use_stft": False}, 2, 9),
+    "subgain_e": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                             "mbexwn_config:ps_use_stft": False, "mbexwn_config:spect_filters_preserve_energy": True}, 1, 40),
 }
-LEAN_GOLDEN_CASES = {"canon60", "voice", "grammar", "groups", "gfu", "gsu_eqlr", "eqlr_plain", "glu", "precond", "nocond", "energy", "mixed_a", "mixed_b", "subharm", "sinfun", "psoff", "nopqmf", "blocks", "pulsepqmf"}     # cond subsampled [:, ::37], no envelope / wavetables (see the generator)
+LEAN_GOLDEN_CASES = {"canon60", "voice", "grammar", "groups", "gfu", "gsu_eqlr", "eqlr_plain", "glu", "precond", "nocond", "energy", "mixed_a", "mixed_b", "subharm", "sinfun", "psoff", "nopqmf", "blocks", "pulsepqmf", "subgain", "subgain_e"}     # cond subsampled [:, ::37], no envelope / wavetables (see the generator)
 
 
 @functools.lru_cache(maxsize=None)

@@ -383,6 +383,29 @@ def test_pulse_pqmf_model(torch):
             syn.tick()
 
 
+@pytest.mark.parametrize("case", ["subgain", "subgain_e"])
+def test_subband_gain_model(torch, golden_dir, case):
+    """ps_use_stft: false -- sub-band gains, interpolated and indexed exactly as the reference does it (by hop_size, first
+    rows), against the reference's own run and the oracle; a ragged batch; only ["F0", .] among the parameters."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    gold = np.load(os.path.join(golden_dir, "reference_forward_f32.npz"))
+    voice, overrides, batch, frames = GOLDEN_CASES[case]
+    cfg, raw, wt = build_case(voice, overrides)
+    eng, om = MBExWNEngine(cfg, raw, wt), orc.OracleModel(cfg, raw, wt)
+    mel, noise = gold[f"{case}/mell"], gold[f"{case}/noise"]
+    got = eng.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
+    assert _maxdiff(got, gold[f"{case}/audio"]) <= _tol(gold[f"{case}/audio"])
+    mel2, noise2 = synthetic_inputs(5, 2, 47)
+    lengths = (47, 16)
+    got = eng.forward(dev(torch, mel2), noise=dev(torch, noise2),
+                      n_frames=torch.tensor(lengths, dtype=torch.int32, device="cuda")).cpu().numpy()
+    for ii, ll in enumerate(lengths):
+        ref = om.forward(mel2[ii:ii + 1, :ll], noise2[ii:ii + 1, :ll * 20])[0]
+        assert _maxdiff(got[ii, :ll * 300], ref) <= _tol(ref)
+    _, params = eng.infer(mel2, synth_length=47 * 300, return_F0=True, noise=noise2)
+    assert [pp[0] for pp in params] == ["F0"]
+
+
 def test_ps_off_model_returns_only_the_f0_parameter(torch):
     """ps_off: MBExWN.call returns the excitation as the signal and only ["F0", .] as parameter (neither PSig nor PS exist,
     reference custom_pulsed_generator.py:663-672, 756-767); infer_components has no envelope to return."""
