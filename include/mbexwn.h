@@ -171,6 +171,10 @@ typedef struct {
      * (the reference's own indexing, kept as it is); no STFT-domain filter, the audio is the excitation.  Whole items
      * only. */
     int32_t ps_subband_gain;
+    /* pp_mod_subnet.padding: CAUSAL (Keras "causal"): the dilated, pre-conditioning, conditioning and up-sampling
+     * convolutions of the WaveNet blocks pad dilation * (kernel size - 1) zeros in front and none behind.  Generic
+     * kernels, whole items only. */
+    int32_t wn_causal;
 } mbx_config;
 
 /* A named HOST tensor handed over at creation (weights already weight-norm folded, tables).

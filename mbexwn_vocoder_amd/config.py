@@ -276,8 +276,11 @@ class ModelDims:
         self.wn_pre_cond_channels = [int(cc) for cc in (wn.get("pre_cond_layer_channels", None) or [])]
         # no conditioning layer at all: the gates see zeros (reference custom_AE_layers.py:203-204,293-294)
         self.wn_disable_conditioning = bool(wn.get("disable_conditioning", False))
-        if str(wn.get("padding", "SAME")).upper() != "SAME":
-            raise NotImplementedError("pp_mod_subnet.padding other than SAME is not supported")
+        # Keras padding of the WaveNet's convolutions: SAME, or CAUSAL (all padding in front).  VALID shortens the dilated
+        # convolutions' output against the conditioning rows, which the reference's own graph cannot add up (:309)
+        self.wn_padding = str(wn.get("padding", "SAME")).upper()
+        if self.wn_padding not in ("SAME", "CAUSAL"):
+            raise NotImplementedError(f"pp_mod_subnet.padding {self.wn_padding}: SAME and CAUSAL are supported")
         self.wn_use_weight_norm = bool(wn.get("use_weight_norm", False))
         self.cond_lin_upsampling = int(wn.get("cond_lin_upsampling", 16))
         self.cond_kernel_size = int(wn.get("cond_kernel_size", 3))

@@ -601,7 +601,7 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
             op.ks = c.cond_kernel_size;
             op.cin = chan;
             op.cout = cout;
-            op.pad_l = (c.cond_kernel_size - 1) / 2;
+            op.pad_l = c.wn_causal ? c.cond_kernel_size - 1 : (c.cond_kernel_size - 1) / 2;
             op.pad_r = c.cond_kernel_size - 1 - op.pad_l;
             op.pad_mode = MBX_PAD_ZERO;
             op.up = 1;
@@ -735,10 +735,11 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
                    expect("wn.res_skip_" + std::to_string(l) + ".fold_b", C + c.wn_out_channels);
         have = have && expect("wn.tail.fold", (long long)((C + 7) / 8) * 256) && expect("wn.tail.fold_b", c.wn_out_channels);
         if (c.n_wn_blocks >= 1) have = false;      // several blocks: generic kernels (run_wavenet_blocks)
+        const bool sym = !c.wn_causal;              // the folded first layer and the Winograd forms assume SAME padding
         hd->fold_skip = have;
         // start convolution folded into layer 0 (wn_gate0.hip); MBX_FOLD_START=0 keeps the h0 tensor and the full layer
         const char *sv = getenv("MBX_FOLD_START");
-        bool have0 = have && (!sv || atoi(sv) != 0) && c.wn_kernel_size == 3 &&
+        bool have0 = have && sym && (!sv || atoi(sv) != 0) && c.wn_kernel_size == 3 &&
                      mbx::wn_gate0_fits(C, c.pulse_channels * (1 + c.wt_subharm_channels), c.wn_dilations[0], c.cond_lin_upsampling) &&
                      expect("wn.conv1D_0.start_fold", (long long)((C + 31) / 32) * 1536);
         if (have0 && c.wn_layers > 1)
@@ -748,6 +749,7 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
     {
         const char *wv = getenv("MBX_WINOGRAD");
         hd->winograd = wv ? atoi(wv) : 4;   // default F(4,3) / F(2,3) by size; MBX_WINOGRAD=2: F(2,3) only, 0: direct form
+        if (c.wn_causal) hd->winograd = 0;  // causal padding: the direct form (generic kernel)
         if (hd->winograd == 44) {
             hd->winograd = 4;
             hd->winograd4_always = true;
@@ -892,7 +894,7 @@ static mbx_status run_wavenet_blocks(mbx_handle *hd, const Workspace &w, int B, 
             const int d = c.wn_dilations[l];
             mbx::ConvArgs g = conv_args(w.mb_h, rows * C, C, n_frames, spf, (int)rows, B, find(hd, blk.prefix + "conv1D_" + ls + ".w"),
                                         find(hd, blk.prefix + "conv1D_" + ls + ".b"), c.wn_kernel_size, C, 2 * C, d,
-                                        d * (c.wn_kernel_size - 1) / 2, MBX_PAD_ZERO, w.mb_a, rows * C, C);
+                                        (c.wn_causal ? d * (c.wn_kernel_size - 1) : d * (c.wn_kernel_size - 1) / 2), MBX_PAD_ZERO, w.mb_a, rows * C, C);
             g.cond = cond;
             g.cond_bstride = cond_bstride;
             g.cond_up = cond_up;
@@ -933,7 +935,7 @@ static mbx_status run_wavenet_blocks(mbx_handle *hd, const Workspace &w, int B, 
             const std::string un = "up" + std::to_string(b);
             float *yu = last_block ? w.wn_out : w.mb_y1;
             mbx::ConvArgs u = conv_args(y, rows * n_out, n_out, n_frames, spf, (int)rows, B, find(hd, un + ".w"), find(hd, un + ".b"), 3,
-                                        n_out, n_out * blk.ups, 1, 1, MBX_PAD_ZERO, yu, rows * n_out * blk.ups, n_out * blk.ups);
+                                        n_out, n_out * blk.ups, 1, c.wn_causal ? 2 : 1, MBX_PAD_ZERO, yu, rows * n_out * blk.ups, n_out * blk.ups);
             mbx::launch_conv1d(u, mbx::EPI_LINEAR, stream);
             x_in = yu;
         }
@@ -976,8 +978,8 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         if (ex.fe_new_frames > 0) fe_frames = ex.fe_new_frames + ex.fe_margin_frames;
     }
     if (batch <= 0 || max_frames <= 0) return fail(MBX_ERR_INVALID_ARGUMENT, "batch and max_frames must be positive");
-    if (!hd->blocks.empty() && (active_frames || st_in || st_out || sub_carry || ex.lay || fe_on))
-        return fail(MBX_ERR_UNSUPPORTED, "a model with several WaveNet blocks runs whole items only (no stream windows / state)");
+    if ((!hd->blocks.empty() || hd->cfg.wn_causal) && (active_frames || st_in || st_out || sub_carry || ex.lay || fe_on))
+        return fail(MBX_ERR_UNSUPPORTED, "a model with several WaveNet blocks or causal padding runs whole items only (no stream windows / state)");
     DeviceGuard guard(hd->device);
     if (!guard.ok) return fail(MBX_ERR_HIP, "cannot select the handle's device");
     const mbx_config &c = hd->cfg;
@@ -1197,7 +1199,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         const Span &gs = gate_sp[l];
         mbx::ConvArgs g = conv_args(w.h + gs.row0 * C, nsteps * C, C, gs.nf, gs.rpf, gs.max_rows, B,
                                     find(hd, "wn.conv1D_" + ls + ".w"), find(hd, "wn.conv1D_" + ls + ".b"),
-                                    c.wn_kernel_size, C, 2 * C, d, d * (c.wn_kernel_size - 1) / 2, MBX_PAD_ZERO, w.a + gs.row0 * C,
+                                    c.wn_kernel_size, C, 2 * C, d, (c.wn_causal ? d * (c.wn_kernel_size - 1) : d * (c.wn_kernel_size - 1) / 2), MBX_PAD_ZERO, w.a + gs.row0 * C,
                                     nsteps * C, C);
         g.cond = w.cond + (gs.row0 / cond_up) * (2 * C);
         g.cond_bstride = (long long)T * cond_cout;

@@ -68,7 +68,8 @@ class mbx_config(ctypes.Structure):
                 ("wt_subharm_channels", ctypes.c_int32), ("wt_sinusoid_as_fun", ctypes.c_int32),
                 ("ps_off", ctypes.c_int32), ("no_pqmf", ctypes.c_int32), ("n_wn_blocks", ctypes.c_int32),
                 ("wn_block_channels", ctypes.c_int32 * MBX_MAX_WN_BLOCKS), ("wn_block_ups", ctypes.c_int32 * MBX_MAX_WN_BLOCKS),
-                ("pulse_pqmf_taps", ctypes.c_int32), ("ps_subband_gain", ctypes.c_int32)]
+                ("pulse_pqmf_taps", ctypes.c_int32), ("ps_subband_gain", ctypes.c_int32),
+                ("wn_causal", ctypes.c_int32)]
 
 
 class mbx_forward_options(ctypes.Structure):
@@ -253,6 +254,7 @@ def make_config(config, wavetables):
     cc.ps_off, cc.no_pqmf = int(dims.ps_off), int(dims.no_pqmf)
     cc.pulse_pqmf_taps = int(dims.pulse_pqmf["taps"]) if dims.pulse_pqmf else 0
     cc.ps_subband_gain = int(dims.ps_subband_gain)
+    cc.wn_causal = int(dims.wn_padding == "CAUSAL")
     if dims.wn_multi:                 # several WaveNet blocks / in-block upsampling: the generic path of the library
         if dims.n_wn_blocks > MBX_MAX_WN_BLOCKS:
             raise ValueError("too many WaveNet blocks for the engine")
@@ -809,7 +811,7 @@ class MBExWNEngine:
         policy (MBX_FOLD_SKIP / MBX_FOLD_START not 0, the folded tensors exist and the layer fits the kernel)."""
         cu = self.dims.cond_lin_upsampling
         fits = ((256 + cu - 2) // cu + 2 <= 32 and self.dims.wn_dilation(0) <= 16 and self.dims.pulse_channels_eff + 2 <= 8 and
-                self.dims.wn_kernel_size == 3)                     # wn_gate0_fits (csrc/wn_gate0.hip)
+                self.dims.wn_kernel_size == 3 and self.dims.wn_padding == "SAME" and not self.dims.wn_multi)   # wn_gate0_fits (csrc/wn_gate0.hip)
         return (int(os.environ.get("MBX_FOLD_SKIP", "1")) != 0 and int(os.environ.get("MBX_FOLD_START", "1")) != 0 and fits and
                 "wn.conv1D_0.start_fold" in self._tensors and
                 (self.dims.wn_layers == 1 or "wn.res_skip_0.fold_start" in self._tensors))

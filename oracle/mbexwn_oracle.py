@@ -73,6 +73,11 @@ def conv1d_same_zero(x, w, b=None, dilation=1):
     return conv1d_valid(xp, w, b, dilation)
 
 
+def conv1d_causal(x, w, b=None, dilation=1):
+    """Keras Conv1D padding="causal": d*(k-1) zeros in front, none behind (pp_mod_subnet.padding: CAUSAL)."""
+    return conv1d_valid(pad_time(x, (w.shape[0] - 1) * dilation, 0, "CONSTANT"), w, b, dilation)
+
+
 def lin_interp(x, up, weights_dtype=np.float32):
     """TF2C_LinInterpLayer(num_pad_end=1, drop_last=True): support_layers.py:19-27,99-121.
     out[t*U+u] = x[t]*(U-u)/U + x[min(t+1,T-1)]*u/U ; the two weight vectors are float32 constants."""
@@ -353,6 +358,12 @@ class OracleModel:
             return 2 ** (int(index // step) % mx)
         return 2 ** int(index // step)                                            # custom_AE_layers.py:229-233
 
+    def wn_conv(self, x, w, b=None, dilation=1):
+        """The convolutions that take pp_mod_subnet.padding (custom_AE_layers.py:192-260, 519-524): SAME or CAUSAL."""
+        if str(self.wn.get("padding", "SAME")).upper() == "CAUSAL":
+            return conv1d_causal(x, w, b, dilation)
+        return conv1d_same_zero(x, w, b, dilation)
+
     def conditioning(self, mel, prefix="wn.", rate_factor=1):
         """custom_AE_layers.py:214-227,287-289: sub-pixel conv (factor cond_conv_upsampling) then LinInterp.  ``prefix`` /
         ``rate_factor``: the block's tensors and its rate relative to the first block (custom_pulsed_generator.py:484,488)."""
@@ -361,9 +372,9 @@ class OracleModel:
         x = mel
         for ii in range(len(self.wn.get("pre_cond_layer_channels", None) or [])):    # :192-201, 283-285: plain convolutions
             w, b = self.weight(f"{prefix}precond_{ii}")
-            x = conv1d_same_zero(x, w, b)
+            x = self.wn_conv(x, w, b)
         w, b = self.weight(prefix + "cond")
-        c = depth_to_time(conv1d_same_zero(x, w, b), conv_up)
+        c = depth_to_time(self.wn_conv(x, w, b), conv_up)
         return lin_interp(c, lin_up, self.f32)
 
     def wavenet(self, x, mel, return_layers=False, prefix="wn.", channels=None, rate_factor=1):
@@ -386,7 +397,7 @@ class OracleModel:
             for gg in range(G):
                 sfx = f"g{gg}" if gg else ""
                 w, b = self.weight(f"{prefix}conv1D_{ll}{sfx}")
-                z = conv1d_same_zero(started[gg], w, b, dilation=self.dilation(ll)) + cond[gg]   # :307-309
+                z = self.wn_conv(started[gg], w, b, dilation=self.dilation(ll)) + cond[gg]   # :307-309
                 zt = z[..., :Cg]
                 act = self.wn.get("activation", "gtu")
                 if act == "gtu":                                                  # :312-318
@@ -463,7 +474,7 @@ class OracleModel:
             y = self.wavenet(y, mel, prefix=prefix, channels=int(self.wn["n_channels"] * ff), rate_factor=rate)
             if uu > 1:
                 w, b = self.weight(f"up{bb}")
-                y = depth_to_time(conv1d_same_zero(y, w, b), uu)
+                y = depth_to_time(self.wn_conv(y, w, b), uu)
             rate *= uu
         w, b = self.weight("post")
         y = conv1d_valid(y, w, b)                                                 # :913-914

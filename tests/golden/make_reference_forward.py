@@ -110,9 +110,19 @@ CASES = {
                            "mbexwn_config:ps_use_stft": False}, 2, 9),
     "subgain_e": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
                              "mbexwn_config:ps_use_stft": False, "mbexwn_config:spect_filters_preserve_energy": True}, 1, 40),
+    # pp_mod_subnet.padding: CAUSAL -- every padded convolution of the WaveNet blocks (dilated, conditioning, up-sampling)
+    # pads in front only (Keras "causal"); two blocks so that the up-sampling convolution is covered
+    "causal": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                          "mbexwn_config:pp_mod_subnet:padding": "CAUSAL",
+                          "mbexwn_config:pp_mod_subnet_upsampling_factors": [2, 1],
+                          "mbexwn_config:pp_mod_subnet_channel_factors": [1, 1],
+                          "mbexwn_config:pulse_channels": 10,
+                          "mbexwn_config:pp_mod_subnet:cond_lin_upsampling": 5}, 2, 9),
+    "causal1": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3,
+                           "mbexwn_config:pp_mod_subnet:padding": "CAUSAL"}, 2, 9),
 }
 # the long cases keep the small stage outputs only (the full conditioning / envelope tensors would be megabytes)
-LEAN = {"canon60", "voice", "grammar", "groups", "gfu", "gsu_eqlr", "eqlr_plain", "glu", "precond", "nocond", "energy", "mixed_a", "mixed_b", "subharm", "sinfun", "psoff", "nopqmf", "blocks", "pulsepqmf", "subgain", "subgain_e"}
+LEAN = {"canon60", "voice", "grammar", "groups", "gfu", "gsu_eqlr", "eqlr_plain", "glu", "precond", "nocond", "energy", "mixed_a", "mixed_b", "subharm", "sinfun", "psoff", "nopqmf", "blocks", "pulsepqmf", "subgain", "subgain_e", "causal", "causal1"}
 
 
 def assign_conv(layer, raw, name):

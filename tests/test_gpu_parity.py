@@ -286,7 +286,9 @@ def test_start_convolution_folded_into_layer_0_matches_the_unfolded_graph(torch,
      "mbexwn_config:pp_mod_subnet:cond_lin_upsampling": 5},                                            # 4 x 5 conditioning: un-folded first layer, generic gate
     {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 4,
      "mbexwn_config:pp_mod_subnet:cond_lin_upsampling": 20, "mbexwn_config:pp_mod_subnet:cond_kernel_size": 5},
-], ids=["C36_L3", "C24_L7_cycle", "C64_L1", "cond_4x5", "cond_1x20_k5"])
+    {"mbexwn_config:pp_mod_subnet:n_channels": 36, "mbexwn_config:pp_mod_subnet:n_layers": 4,
+     "mbexwn_config:pp_mod_subnet:padding": "CAUSAL", "mbexwn_config:pp_mod_subnet:cond_kernel_size": 5},   # all padding in front
+], ids=["C36_L3", "C24_L7_cycle", "C64_L1", "cond_4x5", "cond_1x20_k5", "causal_C36_k5"])
 def test_other_wavenet_geometries(torch, overrides):
     """Every size is configuration driven: partial channel tiles and slices, repeating dilation cycles, a single layer
     (the folded skip path then consists of the tail kernel alone), other splits of the conditioning up-sampling (x5

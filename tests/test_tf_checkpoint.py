@@ -175,8 +175,9 @@ def test_several_wavenet_blocks_round_trip(tmp_path):
 def test_unbuilt_wavenet_options_raise():
     """Keys of WaveNetAE.__init__ that change the arithmetic and are not built must not be ignored silently."""
     from mbexwn_vocoder_amd.config import ModelDims
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):    # VALID cannot add the conditioning rows up in the reference's own graph
         ModelDims(canonical_config("SPEECH", **{"mbexwn_config:pp_mod_subnet:padding": "VALID"}))
+    assert ModelDims(canonical_config("SPEECH", **{"mbexwn_config:pp_mod_subnet:padding": "causal"})).wn_padding == "CAUSAL"
     with pytest.raises(RuntimeError, match="unsupported wavenet activation"):   # the reference's own check and message
         ModelDims(canonical_config("SPEECH", **{"mbexwn_config:pp_mod_subnet:activation": "relu"}))
     # built since round 3 (second batch): pre-conditioning layers, a WaveNet without conditioning, the glu gate
