@@ -904,8 +904,18 @@ static mbx_status run_wavenet_blocks(mbx_handle *hd, const Workspace &w, int B, 
             g.gate_act = c.wn_gate_activation;
             g.zeros = hd->zeros;
             {
+                // the Winograd F(4,3) form when the host supplied the block's weight image and the layer fits (SAME padding,
+                // k = 3, power-of-two dilation <= 16), the direct form otherwise
                 ScopedEvents ev(hd, PROF_GATE, stream);
-                mbx::launch_conv1d(g, mbx::EPI_GATE, stream);
+                bool done = false;
+                const DevTensor *wino4 = (hd->winograd == 4 && !c.wn_causal) ? find(hd, blk.prefix + "conv1D_" + ls + ".wino4w") : nullptr;
+                if (wino4 && wino4->ndim == 3 && wino4->shape[0] == (C + 31) / 32 && wino4->shape[1] == (C + 7) / 8 &&
+                    wino4->shape[2] == 3072) {
+                    mbx::ConvArgs gw = g;
+                    gw.w = wino4->ptr;
+                    done = mbx::launch_wn_gate_winograd4w(gw, false, stream);
+                }
+                if (!done) mbx::launch_conv1d(g, mbx::EPI_GATE, stream);
             }
             const bool last = l == L - 1;
             mbx::ConvArgs r = conv_args(w.mb_a, rows * C, C, n_frames, spf, (int)rows, B, find(hd, blk.prefix + "res_skip_" + ls + ".w"),
@@ -919,7 +929,15 @@ static mbx_status run_wavenet_blocks(mbx_handle *hd, const Workspace &w, int B, 
             r.skip_init = (l == 0);
             r.last_layer = last;
             ScopedEvents ev(hd, PROF_RES_SKIP, stream);
-            mbx::launch_conv1d(r, mbx::EPI_RESSKIP, stream);
+            const DevTensor *pk = find(hd, blk.prefix + "res_skip_" + ls + ".packed");
+            const int cout_l = last ? C : 2 * C;
+            bool rdone = false;
+            if (pk && pk->ndim == 3 && pk->shape[0] == (cout_l + 127) / 128 && pk->shape[1] == (C + 15) / 16 && pk->shape[2] == 2048) {
+                mbx::ConvArgs rp = r;
+                rp.w = pk->ptr;
+                rdone = mbx::launch_wn_resskip(rp, stream);
+            }
+            if (!rdone) mbx::launch_conv1d(r, mbx::EPI_RESSKIP, stream);
         }
         // end convolution (reference custom_AE_layers.py:337-340); the last block's output is the stage "wn_out" unless an
         // up-sampling convolution follows it

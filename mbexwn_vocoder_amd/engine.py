@@ -513,6 +513,15 @@ def tensor_table(config, raw_weights, wavetables):
         for ll in range(dims.wn_layers):
             out[f"wn.conv1D_{ll}.wino4w"] = pack_winograd4w_weights(out[f"wn.conv1D_{ll}.w"])
             out[f"wn.conv1D_{ll}.wino2w"] = pack_winograd2w_weights(out[f"wn.conv1D_{ll}.w"])
+    if dims.wn_multi:
+        # several blocks: the library's block runner takes the packed res/skip weights and the F(4,3) images per block
+        from .weights import block_prefix
+        for bb in range(dims.n_wn_blocks):
+            pre = block_prefix(bb)
+            for ll in range(dims.wn_layers):
+                out[f"{pre}res_skip_{ll}.packed"] = pack_resskip_weights(out[f"{pre}res_skip_{ll}.w"])
+                if dims.wn_kernel_size == 3 and dims.wn_padding == "SAME":
+                    out[f"{pre}conv1D_{ll}.wino4w"] = pack_winograd4w_weights(out[f"{pre}conv1D_{ll}.w"])
     out["table.hann"] = tb.hann_periodic_f32(dims.stft_win)
     out["table.inv_win"] = tb.inverse_stft_window_f32(dims.stft_win, dims.hop_size)
     out["table.wavetables"] = np.ascontiguousarray(wavetables.tables, dtype=np.float32)
