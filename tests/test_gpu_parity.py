@@ -119,6 +119,19 @@ def test_wavetable_phase_bit_exact(torch, n):
     assert _maxdiff(pulse.cpu().numpy(), ref_pulse) <= 2e-6
 
 
+def test_wavetable_phase_beyond_the_chunk_offset_table(torch):
+    """More than 1 024 phase chunks (128 s of audio at the 8 kHz pulse rate): the kernel's per-block table of chunk
+    offsets does not hold them and every sample walks the chain itself -- still the reference's order of additions."""
+    eng, om = get_engine("small", *SMALL)[:2]
+    n = 1_030_500
+    rng = np.random.default_rng(3)
+    f0 = (60 + 500 * np.abs(np.sin(np.cumsum(rng.normal(0, 0.0005, size=(1, n)), axis=1)))).astype(np.float32)
+    pulse, phase = eng.wavetable(dev(torch, f0))
+    torch.cuda.synchronize()
+    assert np.array_equal(phase.cpu().numpy(), om.phase_from_f0(f0)), "phase accumulator must be bit exact"
+    assert float(pulse[:, n - 4000:].abs().max()) > 0.1            # (the lookup itself is covered at the small sizes)
+
+
 @pytest.mark.parametrize("steps", [1, 9, 64, 65, 333])
 def test_pqmf_synthesis(torch, steps):
     eng, om = get_engine("small", *SMALL)[:2]
