@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs p) {
     const int wave = tid >> 6;
     const int wr = wave / WN, wc = wave % WN;
 
-    const float *xb = p.x + (long long)b * p.x_bstride;
+    const float *xb = p.x + (long long)b * p.x_bstride + (long long)m0 * p.ldx;   // the block's first row: int row offsets stay small for any item length
     const int nkc = (p.cin + BK - 1) / BK;   // K slices per tap
     const int nk = p.ks * nkc;
 
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs p) {
         for (int i = 0; i < A_F4; ++i) {
             const int row = (tid + i * 256) / KQ;
             const int src = map_row(m0 + row - p.pad_l + tap * p.dil, rows, p.pad_mode);
-            a_off[i] = max(src, 0) * p.ldx;
+            a_off[i] = (max(src, 0) - m0) * p.ldx;
             if (src >= 0) a_rowok |= 1u << i;
         }
     };
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_dma_kernel(ConvArgs p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WN, wc = wave % WN;
-    const float *xb = p.x + (long long)b * p.x_bstride;
+    const float *xb = p.x + (long long)b * p.x_bstride + (long long)m0 * p.ldx;   // the block's first row: int row offsets stay small for any item length
     const int nkc = (p.cin + BK - 1) / BK;
     const int nk = p.ks * nkc;
 
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_dma_kernel(ConvArgs p) {
 #pragma unroll
         for (int i = 0; i < A_INST; ++i) {
             const int src = map_row(m0 + a_row[i] - p.pad_l + tap * p.dil, rows, p.pad_mode);
-            a_off[i] = max(src, 0) * p.ldx;
+            a_off[i] = (max(src, 0) - m0) * p.ldx;
             if (src >= 0) a_rowok |= 1u << i;
         }
     };

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 4) void wn_resskip_kernel(ConvAr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;
     const int lrow = lane & 31, lk = lane >> 5;
-    const float *xb = p.x + (long long)b * p.x_bstride;
+    const float *xb = p.x + (long long)b * p.x_bstride + (long long)m0 * p.ldx;   // the block's first row: 32-bit offsets stay small
     const int nk = (p.cin + RS_BK - 1) / RS_BK;
 
     // ---- per-lane DMA sources
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 4) void wn_resskip_kernel(ConvAr
         const int pos = (wave + 4 * i) * 64 + lane;
         const int row = pos >> 2;
         a_ch[i] = 4 * ((pos & 3) ^ ((row >> 2) & 3));
-        a_off[i] = min(m0 + row, rows - 1) * p.ldx;
+        a_off[i] = (min(m0 + row, rows - 1) - m0) * p.ldx;
         if (m0 + row < rows) a_ok |= 1u << i;
         a_voff[i] = 4u * (unsigned)(a_off[i] + a_ch[i]);
     }
@@ -245,7 +245,7 @@ bool launch_wn_resskip(const ConvArgs &a, hipStream_t stream) {
                     (a.skip_ld ? a.cout <= a.channels + a.skip_ld : a.cout == (a.last_layer ? a.channels : 2 * a.channels));
     if (!ok) return false;
     ConvArgs r = a;
-    r.fast_dma = (long long)a.max_rows * a.ldx * 4 < (1LL << 32);
+    r.fast_dma = 1;                 // byte offsets are relative to the block's first row
     r.n_tiles = (a.cout + 127) / 128;
     // 64-row blocks while the 128-row grid is less than three rounds of the 768 resident blocks (3 per CU x 256 CUs)
     const long long big_blocks = (long long)((a.max_rows + 127) / 128) * a.batch * r.n_tiles;

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256, (RvShape<NPW, NSTAGE>::WAVES_PER_SIMD)) void w
     if (!any) return;
     if (!active) m0 = 0;
     const int C = p.channels;
-    const float *xb = p.x + (long long)b * p.x_bstride;
+    const float *xb = p.x + (long long)b * p.x_bstride + (long long)m0 * p.ldx;   // the tile's first row: 32-bit offsets stay small
     const int nk = (p.cin + RV_BK - 1) / RV_BK;
 
     // ---- LDS-DMA requests of a slice: this wave's rows (1 KB) + B_INST of the 2 NPW weight kilobytes
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, (RvShape<NPW, NSTAGE>::WAVES_PER_SIMD)) void w
         const int row = lane >> 2;
         a_ch = 4 * ((lane & 3) ^ ((-(row >> 2)) & 3));
         a_ok = active && m0 + row < rows;
-        a_voff = 4u * (unsigned)(min(m0 + row, rows - 1) * p.ldx + a_ch);
+        a_voff = 4u * (unsigned)((min(m0 + row, rows - 1) - m0) * p.ldx + a_ch);
     }
     const bool fast_rows = active && p.fast_dma && m0 + 16 <= rows;
     const int whole_slices = p.cin / RV_BK;
@@ -307,7 +307,7 @@ bool launch_wn_resskip_wave(const ConvArgs &a, hipStream_t stream) {
                     a.h && a.skip;
     if (!ok) return false;
     ConvArgs r = a;
-    r.fast_dma = (long long)a.max_rows * a.ldx * 4 < (1LL << 32);
+    r.fast_dma = 1;                 // byte offsets are relative to the tile's first row
     r.m_tiles_per_item = (a.max_rows + 15) / 16;
     r.m_tiles_total = r.m_tiles_per_item * a.batch;
     const unsigned groups = (unsigned)((r.m_tiles_total + 3) / 4);

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(512, 4) void wn_resskip_wide_kernel(ConvArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
-    const float *xb = p.x + (long long)b * p.x_bstride;
+    const float *xb = p.x + (long long)b * p.x_bstride + (long long)m0 * p.ldx;   // the block's first row: 32-bit offsets stay small
     const int nk = (p.cin + RW_BK - 1) / RW_BK;
 
     // ---- LDS-DMA requests of a slice: 4 x 1 KB of activation rows + NP x 1 KB of weights = 15 / 16 chunks, two per wave
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(512, 4) void wn_resskip_wide_kernel(ConvArgs p) {
         const int row = pos >> 1;
         a_hi = ((pos & 1) ^ ((row >> 3) & 1)) != 0;
         a_ok = m0 + row < rows;
-        a_voff = 4u * (unsigned)(min(m0 + row, rows - 1) * p.ldx + 4 * (int)a_hi);
+        a_voff = 4u * (unsigned)((min(m0 + row, rows - 1) - m0) * p.ldx + 4 * (int)a_hi);
     }
     const bool fast_rows = p.fast_dma && m0 + RW_ROWS <= rows;     // (cin = 340: only the last, half slice takes the masked path)
     const int whole_slices = p.cin / RW_BK;
@@ -244,7 +244,7 @@ bool launch_wn_resskip_wide(const ConvArgs &a, hipStream_t stream) {
                     a.h && a.skip;
     if (!ok) return false;
     ConvArgs r = a;
-    r.fast_dma = (long long)a.max_rows * a.ldx * 4 < (1LL << 32);
+    r.fast_dma = 1;                 // byte offsets are relative to the block's first row
     r.m_tiles_per_item = (a.max_rows + RW_ROWS - 1) / RW_ROWS;
     const long long blocks = (long long)r.m_tiles_per_item * a.batch;
     // 11 pairs (C = 320): one block owns all columns of its rows.  12 pairs (C = 340) would need 96 accumulator registers

@@ -114,7 +114,9 @@ __global__ __launch_bounds__(256, 4) void wn_gate_winograd2w_kernel(ConvArgs p, 
     const int n0 = nt * 32;
     const int d = 1 << log2d;
     const int r16 = lane & 15, kq = lane >> 4;
-    const float *xb = p.x + (long long)b * p.x_bstride;
+    // rows are addressed relative to the tile's first staged row: 32-bit byte offsets stay small for any item length
+    const int xrow0 = max(m0 - d, 0);
+    const float *xb = p.x + (long long)b * p.x_bstride + (long long)xrow0 * p.ldx;
     const int nk8 = (p.cin + W2_BK - 1) / W2_BK;         // 8-channel slices of the weight image = stage fills
 
     // ---- per-lane DMA sources of this wave's rows (fixed except the channel offset): byte offset of (row, chunk) from
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256, 4) void wn_gate_winograd2w_kernel(ConvArgs p, 
         const int hi = (pos & 1) ^ ((cell >> 3) & 1);
         if (active && sidx < W2_TROWS / 2 + d && src >= 0 && src < rows) a_bits |= 1u << i;
         a_bits |= (unsigned)hi << (4 + i);
-        a_voff[i] = 4u * (unsigned)(min(max(src, 0), rows - 1) * p.ldx + 4 * hi);
+        a_voff[i] = 4u * (unsigned)((min(max(src, 0), rows - 1) - xrow0) * p.ldx + 4 * hi);
     }
     // interior tiles (every staged row exists, whole slices): uniform base + per-lane byte offset, no selects
     const bool fast_rows = active && p.fast_dma && m0 >= d && m0 + W2_TROWS + d <= rows;
@@ -349,7 +351,7 @@ bool launch_wn_gate_winograd2w(const ConvArgs &a, hipStream_t stream) {
                     (uintptr_t)a.out % 8 == 0;
     if (!ok) return false;
     ConvArgs r = a;
-    r.fast_dma = (long long)a.max_rows * a.ldx * 4 < (1LL << 32);
+    r.fast_dma = 1;                 // byte offsets are relative to the tile's window
     r.n_tiles = (a.channels + 31) / 32;
     const int span = a.out_rows > 0 ? std::min(a.out_rows, a.max_rows - a.out_row0) : a.max_rows - a.out_row0;
     if (span <= 0) return true;

@@ -124,7 +124,10 @@ __global__ __launch_bounds__(256, 3) void wn_gate_winograd4w_kernel(ConvArgs p, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rw = wave;                                    // row part of this wave
     const int r16 = lane & 15, kq = lane >> 4;
-    const float *xb = p.x + (long long)b * p.x_bstride;
+    // rows are addressed relative to the block's first staged row: 32-bit byte offsets never leave the block's window,
+    // however long the item is
+    const int xrow0 = max(m0 - WW_HALO, 0);
+    const float *xb = p.x + (long long)b * p.x_bstride + (long long)xrow0 * p.ldx;
     const int nk8 = (p.cin + WW_BK - 1) / WW_BK;            // 8-channel slices of the weight image = stage fills
     const int nst = nk8;
 
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256, 3) void wn_gate_winograd4w_kernel(ConvArgs p, 
         const int hi = (pos & 1) ^ ((cell >> 3) & 1);
         if (row < SH::AROWS && src >= 0 && src < rows) a_bits |= 1u << i;
         a_bits |= (unsigned)hi << (4 + i);
-        a_voff[i] = 4u * (unsigned)(min(max(src, 0), rows - 1) * p.ldx + 4 * hi);
+        a_voff[i] = 4u * (unsigned)((min(max(src, 0), rows - 1) - xrow0) * p.ldx + 4 * hi);
     }
     // interior blocks (every staged row exists, whole stage fills): uniform base + per-lane byte offset, no selects
     // (C = 340: every stage fill but the last one is whole, so only that one takes the masked path)
@@ -449,7 +452,10 @@ __global__ __launch_bounds__(256, 3) void wn_gate_winograd4p_kernel(ConvArgs p, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rw = wave >> 1, ph = wave & 1;                // row half and product half of this wave
     const int r16 = lane & 15, kq = lane >> 4;
-    const float *xb = p.x + (long long)b * p.x_bstride;
+    // rows are addressed relative to the block's first staged row: 32-bit byte offsets never leave the block's window,
+    // however long the item is
+    const int xrow0 = max(m0 - WW_HALO, 0);
+    const float *xb = p.x + (long long)b * p.x_bstride + (long long)xrow0 * p.ldx;
     const int nk8 = (p.cin + WW_BK - 1) / WW_BK;
 
     // ---- per-lane DMA sources of the activation rows (see wn_gate_winograd4w_kernel)
@@ -468,7 +474,7 @@ __global__ __launch_bounds__(256, 3) void wn_gate_winograd4p_kernel(ConvArgs p, 
         const int hi = (pos & 1) ^ ((cell >> 3) & 1);
         if (row < SH::AROWS && src >= 0 && src < rows) a_bits |= 1u << i;
         a_bits |= (unsigned)hi << (4 + i);
-        a_voff[i] = 4u * (unsigned)(min(max(src, 0), rows - 1) * p.ldx + 4 * hi);
+        a_voff[i] = 4u * (unsigned)((min(max(src, 0), rows - 1) - xrow0) * p.ldx + 4 * hi);
     }
     const bool fast_rows = p.fast_dma && m0 >= WW_HALO && m0 + ROWS + WW_HALO <= rows;
     const int whole_fills = p.cin / WW_BK;
@@ -686,7 +692,7 @@ bool launch_wn_gate_winograd4w(const ConvArgs &a, bool split, hipStream_t stream
                     a.cond_up <= 64 && (rows_blk + a.cond_up - 2) / a.cond_up + 2 <= (split ? 16 : 28) && a.lerp_w0 && a.lerp_w1 && a.max_rows < (1 << 24);
     if (!ok) return false;
     ConvArgs r = a;
-    r.fast_dma = (long long)a.max_rows * a.ldx * 4 < (1LL << 32);
+    r.fast_dma = 1;                 // byte offsets are relative to the block's window (< 2^32 for any item length)
     r.n_tiles = (a.channels + 31) / 32;
     r.m_tiles_per_item = (a.max_rows + rows_blk - 1) / rows_blk;
     r.m_tiles_total = r.m_tiles_per_item * a.batch;

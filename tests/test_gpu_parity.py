@@ -392,6 +392,36 @@ def test_several_wavenet_blocks(torch, overrides):
             syn.tick()
 
 
+def test_item_longer_than_4_gib_of_activation_rows(torch, monkeypatch):
+    """One utterance of 41 minutes: its (rows, C) activation tensors are 5.1 GiB, so byte offsets from the item's first
+    row do not fit 32 bits.  The LDS-DMA kernels address rows relative to their own block; the result must agree with the
+    direct-form path (which addresses with 64-bit pointers) over the whole length, the last seconds included, and its
+    first second with the oracle."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    cfg, raw, wt = build_case(*CANON)
+    T = 200_000
+    rng = np.random.default_rng(8)
+    base_mel, base_noise = synthetic_inputs(8, 1, 500)
+    mel = torch.as_tensor(np.tile(base_mel, (1, T // 500, 1))).cuda()
+    noise = torch.as_tensor(rng.normal(size=(1, T * 20)).astype(np.float32)).cuda()
+    assert T * 20 * 320 * 4 > 2 ** 32
+    outs = {}
+    for form in ("4", "0"):
+        monkeypatch.setenv("MBX_WINOGRAD", form)
+        eng = MBExWNEngine(cfg, raw, wt)
+        outs[form] = eng.forward(mel, noise=noise)
+        torch.cuda.synchronize()
+        del eng
+    amp = float(outs["0"].abs().max())
+    diff = (outs["4"] - outs["0"]).abs()
+    assert float(diff.max()) <= 5e-5 * max(1.0, amp), float(diff.max())
+    assert float(diff[:, -24000 * 30:].max()) <= 5e-5 * max(1.0, amp)          # the last 30 s live above the 4 GiB mark
+    assert float(outs["4"][:, -24000:].abs().max()) > 0.05
+    ref = orc.OracleModel(cfg, raw, wt).forward(mel[:, :80].cpu().numpy(), noise[:, :1600].cpu().numpy())
+    head = outs["4"][:, :68 * 300].cpu().numpy()
+    assert _maxdiff(head, ref[:, :68 * 300]) <= _tol(ref, E2E_TOL)
+
+
 def test_engine_without_weight_images_runs_the_generic_kernels(torch):
     """A handle created from the folded weights and tables alone (no operand-order images) must give the same audio
     through the generic convolution kernels (direct gate, C->2C res/skip with the skip tensor, separate end/post)."""
