@@ -996,6 +996,10 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         if (ex.fe_new_frames > 0) fe_frames = ex.fe_new_frames + ex.fe_margin_frames;
     }
     if (batch <= 0 || max_frames <= 0) return fail(MBX_ERR_INVALID_ARGUMENT, "batch and max_frames must be positive");
+    // row and sample indices inside the kernels are 32-bit ints (offsets are 64-bit or block relative): 2^24 sub-band
+    // rows per item = 2.9 h of audio at the canonical 1.6 kHz is the tested side of that
+    if ((long long)max_frames * hd->cfg.steps_per_frame >= (1LL << 24))
+        return fail(MBX_ERR_UNSUPPORTED, "an item may have at most 2^24 - 1 sub-band rows (split longer recordings)");
     if ((!hd->blocks.empty() || hd->cfg.wn_causal) && (active_frames || st_in || st_out || sub_carry || ex.lay || fe_on))
         return fail(MBX_ERR_UNSUPPORTED, "a model with several WaveNet blocks or causal padding runs whole items only (no stream windows / state)");
     DeviceGuard guard(hd->device);

@@ -645,6 +645,10 @@ class MBExWNEngine:
         B, T = int(mel.shape[0]), int(mel.shape[1])
         if B == 0 or T == 0:
             return torch.zeros((B, T * self.dims.hop_size), dtype=torch.float32, device=self.device)
+        if T * self.dims.steps_per_frame >= 1 << 24:
+            # mbx_forward's own limit (32-bit row / sample indices inside the kernels), checked before any allocation
+            raise NotImplementedError(f"an item may have at most 2^24 - 1 sub-band rows ({(1 << 24) // self.dims.steps_per_frame} "
+                                      f"frames); split longer recordings")
         steps = T * self.dims.wn_in_rows_per_frame            # one noise value per row of the (first) WaveNet block
         if self.dims.noise_sigma:
             if noise is None:

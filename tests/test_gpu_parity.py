@@ -420,6 +420,10 @@ def test_item_longer_than_4_gib_of_activation_rows(torch, monkeypatch):
     ref = orc.OracleModel(cfg, raw, wt).forward(mel[:, :80].cpu().numpy(), noise[:, :1600].cpu().numpy())
     head = outs["4"][:, :68 * 300].cpu().numpy()
     assert _maxdiff(head, ref[:, :68 * 300]) <= _tol(ref, E2E_TOL)
+    # the documented limit: 2^24 sub-band rows per item (2.9 h), refused before anything is allocated
+    eng = MBExWNEngine(cfg, raw, wt)
+    with pytest.raises(NotImplementedError, match="2\\^24"):
+        eng.forward(torch.zeros((1, (1 << 24) // 20 + 1, 80), device="cuda"), noise=torch.zeros((1, 8), device="cuda"))
 
 
 def test_engine_without_weight_images_runs_the_generic_kernels(torch):
