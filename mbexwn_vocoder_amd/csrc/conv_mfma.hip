@@ -111,7 +111,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x16 (&acc)[T
                         const float *c1 = cb + t3 * (2 * C);
                         const float zt = (acc[i][0][r] + bt) + (c0[0] * w0 + c1[0] * w1);
                         const float zs = (acc[i][1][r] + bsg) + (c0[C] * w0 + c1[C] * w1);
-                        ob[row * p.ldo] = gate_act(p.gate_act, zt, zs);
+                        ob[(long long)row * p.ldo] = gate_act(p.gate_act, zt, zs);
                     }
                 }
             }
