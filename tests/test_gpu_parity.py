@@ -426,6 +426,23 @@ def test_item_longer_than_4_gib_of_activation_rows(torch, monkeypatch):
         eng.forward(torch.zeros((1, (1 << 24) // 20 + 1, 80), device="cuda"), noise=torch.zeros((1, 8), device="cuda"))
 
 
+@pytest.mark.parametrize("form", ["4", "2"])
+def test_empty_items_inside_a_batch(torch, monkeypatch, form):
+    """Items of zero frames (and of one frame) between ordinary ones: they produce zeros and leave their neighbours alone."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    monkeypatch.setenv("MBX_WINOGRAD", form)
+    cfg, raw, wt = build_case(*CANON)
+    eng = MBExWNEngine(cfg, raw, wt)
+    mel, noise = synthetic_inputs(3, 4, 30)
+    nf = torch.tensor([30, 0, 11, 1], dtype=torch.int32, device="cuda")
+    got = eng.forward(dev(torch, mel), n_frames=nf, noise=dev(torch, noise)).cpu().numpy()
+    assert np.all(np.isfinite(got)) and np.all(got[1] == 0.0)
+    for ii, ll in ((0, 30), (2, 11), (3, 1)):
+        one = eng.forward(dev(torch, mel[ii:ii + 1, :ll]), noise=dev(torch, noise[ii:ii + 1, :ll * 20])).cpu().numpy()[0]
+        assert _maxdiff(got[ii, :ll * 300], one) <= 2e-5 * max(1.0, np.abs(one).max())
+        assert np.all(got[ii, ll * 300:] == 0.0)
+
+
 def test_engine_without_weight_images_runs_the_generic_kernels(torch):
     """A handle created from the folded weights and tables alone (no operand-order images) must give the same audio
     through the generic convolution kernels (direct gate, C->2C res/skip with the skip tensor, separate end/post)."""
