@@ -444,3 +444,51 @@ def test_gate_variants_at_full_width(torch, monkeypatch, act):
         got = eng.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
         assert _maxdiff(got, ref) <= _tol(ref), f"{act} {env}"
         del eng
+
+# ------------------------------------------------------------------------------------------------
+# geometries far from the canonical one: every size is configuration driven
+# ------------------------------------------------------------------------------------------------
+_P, _M = "preprocess_config:", "mbexwn_config:"
+_W = _M + "pp_mod_subnet:"
+_GEOMETRIES = {
+    "bands12_fold4": {_M + "multi_band_config": {"subbands": 12, "taps": 96, "cutoff_ratio": 0.05, "beta": 9.0},
+                      _M + "pulse_channels": 4, _W + "cond_lin_upsampling": 5, _W + "n_channels": 48, _W + "n_layers": 3},
+    "bands6_fold2": {_M + "multi_band_config": {"subbands": 6, "taps": 48, "cutoff_ratio": 0.1, "beta": 9.0},
+                     _M + "pulse_channels": 2, _W + "cond_lin_upsampling": 10, _W + "n_channels": 32, _W + "n_layers": 3},
+    # more than 16 bands / 32 output channels: the generic PQMF kernel and the un-fused end + post-net convolutions
+    "bands30_out60": {_M + "multi_band_config": {"subbands": 30, "taps": 240, "cutoff_ratio": 0.02, "beta": 9.0},
+                      _M + "pulse_channels": 10, _W + "cond_lin_upsampling": 5, _W + "n_channels": 32, _W + "n_layers": 2,
+                      _W + "n_out_channels": 60},
+    "sr16k_hop200": {_P + "sample_rate": 16000, _P + "hop_size": 200, _P + "win_size": 800, _P + "fft_size": 1024,
+                     _M + "pulse_rate_factor": 2, _M + "pulse_channels": 5,
+                     _M + "multi_band_config": {"subbands": 10, "taps": 80, "cutoff_ratio": 0.06, "beta": 9.0},
+                     _W + "cond_lin_upsampling": 10, _W + "n_channels": 64, _W + "n_layers": 3, _M + "ps_max_ceps_coefs": 120},
+    "mel40_out44": {_P + "mel_channels": 40, _W + "n_out_channels": 44, _W + "n_channels": 40, _W + "n_layers": 3},
+    "kernel5": {_W + "kernel_size": 5, _W + "n_channels": 32, _W + "n_layers": 3},
+}
+
+
+@pytest.mark.parametrize("name", sorted(_GEOMETRIES))
+def test_other_model_geometries(torch, name):
+    """Band counts, folded samples per row, sample rate / hop / FFT size, mel and output channel counts, kernel size: a
+    ragged batch through the engine against the float64 oracle."""
+    from mbexwn_vocoder_amd.config import ModelDims, canonical_config
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    from mbexwn_vocoder_amd.tables import WaveTables
+    from mbexwn_vocoder_amd.weights import synthetic_weights
+    cfg = canonical_config("SPEECH", **_GEOMETRIES[name])
+    dims = ModelDims(cfg)
+    raw = synthetic_weights(cfg, seed=77, bias_std=0.05, alpha_jitter=0.05)
+    wt = WaveTables(sample_rate=dims.pulse_rate, **cfg["mbexwn_config"]["wavetable_config"])
+    eng, om = MBExWNEngine(cfg, raw, wt), orc.OracleModel(cfg, raw, wt)
+    rng = np.random.default_rng(5)
+    frames, rpf, hop = 21, dims.wn_in_rows_per_frame, dims.hop_size
+    mel = np.clip(np.log(np.exp(rng.normal(-5.0, 2.0, size=(2, frames, dims.mel_channels))) + 1e-5), -11.5, 2.0).astype(np.float32)
+    noise = rng.normal(size=(2, frames * rpf)).astype(np.float32)
+    lengths = (frames, 8)
+    got = eng.forward(dev(torch, mel), n_frames=torch.tensor(lengths, dtype=torch.int32, device="cuda"),
+                      noise=dev(torch, noise)).cpu().numpy()
+    for ii, ll in enumerate(lengths):
+        ref = om.forward(mel[ii:ii + 1, :ll], noise[ii:ii + 1, :ll * rpf])[0]
+        assert _maxdiff(got[ii, :ll * hop], ref) <= _tol(ref)
+        assert np.all(got[ii, ll * hop:] == 0.0)
