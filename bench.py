@@ -278,6 +278,20 @@ def roofline(ctx, workload):
         "overlap_add": B * T * (win * 4 + hop * 4),                                # frames -> audio
         "wavetable": B * T * (ppf * 4 * 2),                                        # f0 -> pulse (phase + lookup)
     }
+    # what the measurements say limits each of these stages (profiles/README.md); the GB/s figure is
+    # their algorithmic traffic over the launch time whatever the limiter is
+    limiter = {
+        "gate0": "vector + transcendental issue of the gate activation, which shares the SIMD with its K = 24 fp32 MFMAs "
+                 "(ablation: arithmetic 81 us, block prologue 49, stores 29 of 158 us at 16 x 10 s)",
+        "tail": "32-byte row pieces per lane and a dependent chain of 32x32x2 MFMAs per wave; a row-owning variant reached "
+                "113 us but changes the summation order between launch sizes",
+        "stft_filter": "vector instructions of three FFT-1024 per frame (PMC: 77 % of VALU issue cycles; a radix-16 "
+                       "register-pass version took the same 196 us at two waves per SIMD)",
+        "wavetable": "the float32 phase chain: 1 000 dependent adds per chunk, kept in the reference's order",
+        "pqmf": "latency of a rows x 135 x 15 product per launch",
+        "overlap_add": "HBM",
+        "start": "HBM",
+    }
     stage_list = []
     for name, nbytes in stage_bytes.items():
         ms, cnt = stages[name]
@@ -287,7 +301,7 @@ def roofline(ctx, workload):
         gbs = nbytes / avg_s / 1e9 if avg_s > 0 else None
         stage_list.append({"stage": name, "bound": "hbm", "avg_launch_ms": avg_s * 1e3, "bytes": nbytes,
                            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": gbs / HBM_PEAK_GBS if gbs else None})
+                           "frac": gbs / HBM_PEAK_GBS if gbs else None, "limited_by": limiter.get(name, "HBM")})
     fe_ms, fe_n = stages["frontend"]
     return {"bound": "mfma", "kernel": kernel,
             "achieved": flop_exec / gate_s / 1e12, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
