@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""One-off fuzz (GPU box): random model configurations x random ragged batches through the engine against the oracle."""
+import os, sys, traceback
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from mbexwn_vocoder_amd.config import ModelDims, canonical_config
+from mbexwn_vocoder_amd.engine import MBExWNEngine
+from mbexwn_vocoder_amd.tables import WaveTables
+from mbexwn_vocoder_amd.weights import synthetic_weights
+from oracle.mbexwn_oracle import OracleModel
+M, W = "mbexwn_config:", "mbexwn_config:pp_mod_subnet:"
+n_cases, seed0 = int(sys.argv[1]), int(sys.argv[2])
+fails = 0
+for case in range(n_cases):
+    rng = np.random.default_rng(seed0 + case)
+    over = {W + "n_channels": int(rng.choice([24, 32, 36, 48, 64, 68, 96])), W + "n_layers": int(rng.integers(1, 7)),
+            W + "activation": str(rng.choice(["gtu", "gfu", "gsu", "glu"])),
+            W + "cond_lin_upsampling": int(rng.choice([2, 4, 5, 10, 20])), W + "cond_kernel_size": int(rng.choice([1, 3, 5])),
+            W + "dilation_rate_step": int(rng.choice([1, 2]))}
+    if rng.random() < 0.4:
+        over[W + "max_log2_dilation_rate"] = int(rng.integers(1, 5))
+    if rng.random() < 0.3:
+        over[W + "use_weight_norm"] = bool(rng.random() < 0.5)
+        over[W + "use_equalized_lr"] = bool(rng.random() < 0.5)
+    if rng.random() < 0.25:
+        over[W + "pre_cond_layer_channels"] = [int(rng.choice([16, 24, 40]))]
+    if rng.random() < 0.15:
+        over[W + "disable_conditioning"] = True
+    if rng.random() < 0.2:
+        over[M + "pp_mod_subnet_noise_channel_sigma"] = 0
+    if rng.random() < 0.2:
+        over[M + "spect_filters_preserve_energy"] = True
+    if rng.random() < 0.2:
+        over[M + "filter_max_db_range"] = None
+    if rng.random() < 0.2:
+        over[M + "ps_env_order_scale"] = None
+    if rng.random() < 0.15:
+        over[M + "wavetable_config:add_subharm_chans"] = int(rng.integers(1, 3))
+    if rng.random() < 0.15:
+        over[W + "n_ch_groups"] = 2
+    if rng.random() < 0.15:
+        over[M + "use_prelu"] = False
+    if rng.random() < 0.2:
+        over[M + "pp_subnet"] = [[int(rng.choice([3, 5])), int(rng.choice([32, 48]))], [3, 32, "L2"]] if rng.random() < 0.5 else [[3, 40], [5, 24]]
+    try:
+        cfg = canonical_config(str(rng.choice(["SPEECH", "VOICE"])), **over)
+        dims = ModelDims(cfg)
+    except Exception as ee:                                  # an invalid combination: the reference's own config errors
+        print(case, "config refused:", type(ee).__name__, str(ee)[:80], flush=True)
+        continue
+    try:
+        raw = synthetic_weights(cfg, seed=int(rng.integers(1, 10 ** 6)), bias_std=0.05, alpha_jitter=0.05)
+        wt = WaveTables(sample_rate=dims.pulse_rate, **cfg["mbexwn_config"]["wavetable_config"])
+        form = str(rng.choice(["4", "2", "0", "44"]))
+        os.environ["MBX_WINOGRAD"] = form
+        eng, om, om32 = MBExWNEngine(cfg, raw, wt), OracleModel(cfg, raw, wt), OracleModel(cfg, raw, wt, dtype=np.float32)
+        B, T = int(rng.integers(1, 5)), int(rng.integers(1, 45))
+        lengths = [T] + [int(rng.integers(1, T + 1)) for _ in range(B - 1)]
+        mel = np.clip(np.log(np.exp(rng.normal(-5.0, 2.0, size=(B, T, 80))) + 1e-5), -11.5, 2.0).astype(np.float32)
+        noise = rng.normal(size=(B, T * 20)).astype(np.float32)
+        got = eng.forward(torch.as_tensor(mel).cuda(), n_frames=torch.tensor(lengths, dtype=torch.int32, device="cuda"),
+                          noise=torch.as_tensor(noise).cuda() if dims.noise_sigma else None).cpu().numpy()
+        # yardstick: what float32 arithmetic itself does to this random model (the numpy float32 port of the same graph
+        # against the float64 one): glu gates are unbounded and sub-harmonic sinusoids jump where the phase wraps, so some
+        # draws are ill-conditioned; a kernel bug would show as a difference well above that
+        worst, yard = 0.0, 0.0
+        for ii, ll in enumerate(lengths):
+            nz = noise[ii:ii + 1, :ll * 20] if dims.noise_sigma else None
+            ref = om.forward(mel[ii:ii + 1, :ll], nz)[0]
+            amp = max(1.0, float(np.abs(ref).max()))
+            worst = max(worst, float(np.abs(got[ii, :ll * 300] - ref).max()) / amp)
+            yard = max(yard, float(np.abs(om32.forward(mel[ii:ii + 1, :ll], nz)[0] - ref).max()) / amp)
+            assert np.all(got[ii, ll * 300:] == 0.0), "tail not zero"
+        # (the few draws between 4 and 12 yardsticks seen in 800 cases all had an F0 contour 1.2-1.4e-3 Hz off -- twice the
+        # float32 port's own error -- which moves every pulse by that much: scripts/experiments/fuzz_case.py)
+        ok = worst <= max(1e-4, 16 * yard)
+        fails += not ok
+        print(case, "OK  " if ok else "FAIL", f"{worst:.1e}", f"(f32 port {yard:.1e})", "form", form, "B", B, "T", T, {kk.split(':')[-1]: vv for kk, vv in over.items()}, flush=True)
+        del eng
+    except Exception:                                        # noqa: BLE001
+        fails += 1
+        print(case, "EXC", over, flush=True)
+        traceback.print_exc()
+print("failures:", fails)
+sys.exit(1 if fails else 0)

@@ -492,3 +492,15 @@ def test_other_model_geometries(torch, name):
         ref = om.forward(mel[ii:ii + 1, :ll], noise[ii:ii + 1, :ll * rpf])[0]
         assert _maxdiff(got[ii, :ll * hop], ref) <= _tol(ref)
         assert np.all(got[ii, ll * hop:] == 0.0)
+
+def test_random_configurations_against_the_oracle(torch):
+    """Thirty random model configurations x random ragged batches x a random convolution form (the first cases of
+    scripts/experiments/config_fuzz.py, which ran 800 of them) against the float64 oracle; the numpy float32 port of the
+    graph is the yardstick for draws that float32 itself conditions badly."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "scripts", "experiments", "config_fuzz.py"), "30", "1000"],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "failures: 0" in res.stdout, res.stdout[-3000:] + res.stderr[-2000:]
+    assert res.stdout.count(" OK ") >= 25
