@@ -40,6 +40,33 @@ for case in range(n_cases):
         over[W + "n_ch_groups"] = 2
     if rng.random() < 0.15:
         over[M + "use_prelu"] = False
+    if len(sys.argv) > 3 and sys.argv[3] == "structure":     # structural variants: blocks, padding, excitation / filter paths
+        pick = rng.random()
+        if pick < 0.3:
+            ups, chf = [([2, 1], [1, 0.5]), ([1, 1], [1, 1]), ([2], [1]), ([2, 1], [0.5, 1])][int(rng.integers(0, 4))]
+            over[M + "pp_mod_subnet_upsampling_factors"], over[M + "pp_mod_subnet_channel_factors"] = ups, chf
+            if int(np.prod(ups)) == 2:
+                over[M + "pulse_channels"] = 10
+                over[W + "cond_lin_upsampling"] = int(rng.choice([2, 5, 10]))
+            over[W + "n_channels"] = int(rng.choice([32, 48, 64]))
+            over.pop(W + "n_ch_groups", None)
+            over.pop(M + "wavetable_config:add_subharm_chans", None)
+        if rng.random() < 0.25:
+            over[W + "padding"] = "CAUSAL"
+        pick = rng.random()
+        if pick < 0.15:
+            over[M + "ps_off"] = True
+        elif pick < 0.3:
+            over[M + "ps_use_stft"] = False
+        if rng.random() < 0.2:
+            over[M + "pp_mod_subnet_use_pqmf"] = False
+        if rng.random() < 0.2 and M + "wavetable_config:add_subharm_chans" not in over:
+            pc = over.get(M + "pulse_channels", 5)
+            over[M + "pulse_channels_use_pqmf"] = True
+            over[M + "pulse_channels_multi_band_config"] = {"subbands": pc, "taps": int(rng.choice([8, 6]) * pc),
+                                                            "cutoff_ratio": 0.6 / pc, "beta": 9.0}
+        if rng.random() < 0.2:
+            over[M + "wavetable_config:use_sinusoid_as_fun"] = True
     if rng.random() < 0.2:
         over[M + "pp_subnet"] = [[int(rng.choice([3, 5])), int(rng.choice([32, 48]))], [3, 32, "L2"]] if rng.random() < 0.5 else [[3, 40], [5, 24]]
     try:
@@ -57,7 +84,8 @@ for case in range(n_cases):
         B, T = int(rng.integers(1, 5)), int(rng.integers(1, 45))
         lengths = [T] + [int(rng.integers(1, T + 1)) for _ in range(B - 1)]
         mel = np.clip(np.log(np.exp(rng.normal(-5.0, 2.0, size=(B, T, 80))) + 1e-5), -11.5, 2.0).astype(np.float32)
-        noise = rng.normal(size=(B, T * 20)).astype(np.float32)
+        rpf = dims.wn_in_rows_per_frame
+        noise = rng.normal(size=(B, T * rpf)).astype(np.float32)
         got = eng.forward(torch.as_tensor(mel).cuda(), n_frames=torch.tensor(lengths, dtype=torch.int32, device="cuda"),
                           noise=torch.as_tensor(noise).cuda() if dims.noise_sigma else None).cpu().numpy()
         # yardstick: what float32 arithmetic itself does to this random model (the numpy float32 port of the same graph
@@ -65,7 +93,7 @@ for case in range(n_cases):
         # draws are ill-conditioned; a kernel bug would show as a difference well above that
         worst, yard = 0.0, 0.0
         for ii, ll in enumerate(lengths):
-            nz = noise[ii:ii + 1, :ll * 20] if dims.noise_sigma else None
+            nz = noise[ii:ii + 1, :ll * rpf] if dims.noise_sigma else None
             ref = om.forward(mel[ii:ii + 1, :ll], nz)[0]
             amp = max(1.0, float(np.abs(ref).max()))
             worst = max(worst, float(np.abs(got[ii, :ll * 300] - ref).max()) / amp)

@@ -504,3 +504,9 @@ def test_random_configurations_against_the_oracle(torch):
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "failures: 0" in res.stdout, res.stdout[-3000:] + res.stderr[-2000:]
     assert res.stdout.count(" OK ") >= 25
+    # and twenty draws with the structural options on top: WaveNet blocks, causal padding, ps_off, sub-band gains, no PQMF
+    # bank, PQMF analysis of the pulse signal, sinusoid-as-function (400 of them ran in the script)
+    res = subprocess.run([sys.executable, os.path.join(root, "scripts", "experiments", "config_fuzz.py"), "20", "9000", "structure"],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "failures: 0" in res.stdout, res.stdout[-3000:] + res.stderr[-2000:]
+    assert res.stdout.count(" OK ") >= 18
