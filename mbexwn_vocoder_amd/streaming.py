@@ -64,11 +64,21 @@ def stream_margins(dims, config):
     wn_steps += dims.cond_lin_upsampling - 1
     wn_frames = -(-wn_steps // spf)
     pqmf_frames = -(-(int(mb["multi_band_config"]["taps"]) // 2) // dims.hop_size)
-    cond_r = (dims.cond_kernel_size - 1) // 2 + 1
+    # conditioning chain: the conditioning layer and the pre-conditioning convolutions in front of it (same kernel size,
+    # zero SAME padding: (k - 1) // 2 frames to the left, k // 2 to the right, per convolution); + 1: the interpolation
+    # towards the next conditioning row
+    n_cond = 0 if dims.wn_disable_conditioning else 1 + len(dims.wn_pre_cond_channels)
+    cond_l = n_cond * ((dims.cond_kernel_size - 1) // 2)
+    cond_r = n_cond * (dims.cond_kernel_size // 2) + 1
+    vt_l, vt_r = (0, 0) if dims.no_envelope else subnet_reach(mb["ps_subnet"])     # cepstrum of a frame <- mel frames around it
     stft_l, stft_r = 3, 4                                  # frame t reaches excitation frames t-3 .. t+4
-    pulse_lead = nr + f0_l + 1                             # first window frame with reproducible F0 / phase
+    # first window frame whose mel-rate inputs of the WaveNet -- F0 / phase and the conditioning rows -- are reproducible
+    pulse_lead = nr + max(f0_l + 1, cond_l)
     left = pulse_lead + wn_frames + pqmf_frames + stft_l
     right = nr + max(f0_r, cond_r) + wn_frames + pqmf_frames + stft_r
+    # the envelope filter of the frames around the emitted ones needs their cepstra
+    left = max(left, nr + vt_l + stft_l)
+    right = max(right, nr + vt_r + stft_r)
     smooth = 3                                             # F0 smoother of the lifter selection: +-3 frames of valid F0
     left = max(left, pulse_lead + smooth + 1)
     right = max(right, nr + f0_r + smooth + 2)
