@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs p) {
 
     int b, mt_, nt_;
     if (!decode_tile(p, b, mt_, nt_)) return;
-    const int rows = p.n_frames ? p.n_frames[b] * p.rows_per_frame : p.max_rows;
+    const int rows = item_rows(p.n_frames, b, p.rows_per_frame, p.max_rows);
     const int m0 = mt_ * BM;
     if (m0 >= rows) return;
     const int C = p.channels;
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_dma_kernel(ConvArgs p) {
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float *)lds);
     int b, mt_, nt_;
     if (!decode_tile(p, b, mt_, nt_)) return;
-    const int rows = p.n_frames ? p.n_frames[b] * p.rows_per_frame : p.max_rows;
+    const int rows = item_rows(p.n_frames, b, p.rows_per_frame, p.max_rows);
     const int m0 = mt_ * BM;
     if (m0 >= rows) return;
     const int C = p.channels;
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_dma_kernel(ConvArgs p) {
 // phase accumulator: rounding there is audible in the last bits everywhere downstream).
 template <int RT, int CT>
 __device__ __forceinline__ void conv1d_small_tile(const ConvArgs &p, int bx, int by, int b, float *red) {
-    const int rows = p.n_frames ? p.n_frames[b] * p.rows_per_frame : p.max_rows;
+    const int rows = item_rows(p.n_frames, b, p.rows_per_frame, p.max_rows);
     const int m0 = bx * 32 * RT;
     if (m0 >= rows) return;
     const int n0 = by * 32 * CT;
@@ -749,7 +749,7 @@ constexpr int MT_B_FLOATS = MT_SLICE * MT_COLS * 8;
 template <int RT>
 __device__ __forceinline__ void conv1d_mel_tile(const ConvArgs &p, int bx, int by, int b, float *lds) {
     constexpr int MT_ROWS = 32 * RT, MT_A_FLOATS = MT_SLICE * MT_ROWS * 8;
-    const int rows = p.n_frames ? p.n_frames[b] * p.rows_per_frame : p.max_rows;
+    const int rows = item_rows(p.n_frames, b, p.rows_per_frame, p.max_rows);
     const int m0 = bx * MT_ROWS;
     if (m0 >= rows) return;
     const int n0 = by * MT_COLS;

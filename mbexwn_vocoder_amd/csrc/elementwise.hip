@@ -26,7 +26,7 @@ __global__ void lin_interp_kernel(const float *x, long long x_bstride, const int
                                   int max_rows, int channels, int up, const float *w0, const float *w1, int act,
                                   float scale, float offset, float *y, long long y_bstride) {
     const int b = blockIdx.y;
-    const int rows = n_frames ? n_frames[b] * rows_per_frame : max_rows;
+    const int rows = item_rows(n_frames, b, rows_per_frame, max_rows);
     const long long total = (long long)rows * up * channels;
     const float *xb = x + (long long)b * x_bstride;
     float *yb = y + (long long)b * y_bstride;
@@ -56,7 +56,7 @@ __global__ void activation_kernel(const float *x, long long x_bstride, const int
                                   int max_rows, int channels, int act, float scale, float offset, float *y,
                                   long long y_bstride) {
     const int b = blockIdx.y;
-    const int rows = n_frames ? n_frames[b] * rows_per_frame : max_rows;
+    const int rows = item_rows(n_frames, b, rows_per_frame, max_rows);
     const long long total = (long long)rows * channels;
     const float *xb = x + (long long)b * x_bstride;
     float *yb = y + (long long)b * y_bstride;
@@ -79,7 +79,7 @@ void launch_activation(const float *x, long long x_bstride, const int *n_frames,
 __global__ void prelu_kernel(float *x, long long x_bstride, const int *n_frames, int rows_per_frame, int max_rows,
                              int channels, const float *alpha, float leaky) {
     const int b = blockIdx.y;
-    const int rows = n_frames ? n_frames[b] * rows_per_frame : max_rows;
+    const int rows = item_rows(n_frames, b, rows_per_frame, max_rows);
     const long long total = (long long)rows * channels;
     float *xb = x + (long long)b * x_bstride;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -106,7 +106,7 @@ __global__ void subband_gain_kernel(float *sub, long long sub_bstride, const flo
                                     const int *n_frames, int max_frames, int rows_per_frame, int M, int hop,
                                     const float *w0, const float *w1, int remove_mean) {
     const int b = blockIdx.y;
-    const int T = n_frames ? n_frames[b] : max_frames;
+    const int T = item_rows(n_frames, b, 1, max_frames);
     const long long total = (long long)T * rows_per_frame * M;
     const float *gb = log_gain + (long long)b * gain_bstride;
     float *sb = sub + (long long)b * sub_bstride;
@@ -144,7 +144,7 @@ void launch_subband_gain(float *sub, long long sub_bstride, const float *log_gai
 __global__ void pulse_analysis_kernel(const float *pulse, long long bstride, const int *n_frames, int samples_per_frame,
                                       int n_max, const float *ana, int taps, int K, float *out) {
     const int b = blockIdx.y;
-    const int n = n_frames ? n_frames[b] * samples_per_frame : n_max;
+    const int n = item_rows(n_frames, b, samples_per_frame, n_max);
     const float *pb = pulse + (long long)b * bstride;
     float *ob = out + (long long)b * bstride;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -177,7 +177,7 @@ __global__ void wn_start_kernel(const float *pulse, long long pulse_bstride, con
                                 int max_steps, int pc, const float *w, const float *bias, int channels, float *h,
                                 long long h_bstride) {
     const int b = blockIdx.y;
-    const int steps = n_frames ? n_frames[b] * steps_per_frame : max_steps;
+    const int steps = item_rows(n_frames, b, steps_per_frame, max_steps);
     const int cq = channels >> 2;   // channels % 4 == 0 (checked on the host)
     const long long total = (long long)steps * cq;
     const float *pb = pulse + (long long)b * pulse_bstride;

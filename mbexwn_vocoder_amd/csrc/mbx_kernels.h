@@ -12,6 +12,15 @@ namespace mbx {
 //   float32, so t stays finite; s = inf gives 0, as it should);   zt / ((1 + |zt|)(1 + s)) etc. for the others.
 // `kind` is a kernel argument: the branch is wave-uniform.
 #if defined(__HIPCC__)
+// Rows (frames, samples) of batch item b: its own count from the device array -- clamped into [0, bound], so that an item
+// that claims more frames than the window holds is cut to the window instead of addressing past its buffers -- or the
+// bound itself when the batch has no per-item lengths.
+__device__ __forceinline__ int item_rows(const int *n_frames, int b, int per_frame, int bound) {
+    if (!n_frames) return bound;
+    const long long n = (long long)max(n_frames[b], 0) * per_frame;
+    return n < bound ? (int)n : bound;
+}
+
 __device__ __forceinline__ float wn_gate_act(int kind, float zt, float zs) {
     const float sg = __builtin_amdgcn_exp2f(zs * -1.4426950408889634f);
     if (kind == 0) {

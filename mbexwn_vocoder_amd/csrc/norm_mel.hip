@@ -25,7 +25,7 @@ constexpr float NM_EPS = 1e-7f;   // tf.keras.backend.epsilon()
 __global__ __launch_bounds__(64) void nm_rms_kernel(NormMelConsts c, const float *mell, long long mel_bstride,
                                                     const int *n_frames, int max_frames, float *rms) {
     const int b = blockIdx.y, t = blockIdx.x;
-    const int T = n_frames ? n_frames[b] : max_frames;
+    const int T = item_rows(n_frames, b, 1, max_frames);
     if (t >= T) return;
     const float *row = mell + (long long)b * mel_bstride + (long long)t * c.mel_channels;
     float s = 0.f;
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void nm_smooth_kernel(NormMelConsts c, const f
                                                         int max_frames, float *r_out) {
     __shared__ float red[4];
     const int b = blockIdx.y, t = blockIdx.x;
-    const int T = n_frames ? n_frames[b] : max_frames;
+    const int T = item_rows(n_frames, b, 1, max_frames);
     if (t >= T) return;
     const float *r = r_in + (long long)b * max_frames;
     float acc = 0.f;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void nm_smooth_kernel(NormMelConsts c, const f
 __global__ void nm_scale_kernel(NormMelConsts c, const float *mell, long long mel_bstride, const float *rms,
                                 const int *n_frames, int max_frames, float *out) {
     const int b = blockIdx.y;
-    const int T = n_frames ? n_frames[b] : max_frames;
+    const int T = item_rows(n_frames, b, 1, max_frames);
     const long long total = (long long)T * c.mel_channels;
     const float *mb = mell + (long long)b * mel_bstride;
     float *ob = out + (long long)b * mel_bstride;
@@ -93,7 +93,7 @@ __global__ void nm_scale_kernel(NormMelConsts c, const float *mell, long long me
 __global__ void nm_apply_gain_kernel(NormMelConsts c, const float *r_last, const int *n_frames, int max_frames,
                                      float *audio, long long audio_bstride, int overwrite) {
     const int b = blockIdx.y;
-    const int T = n_frames ? n_frames[b] : max_frames;
+    const int T = item_rows(n_frames, b, 1, max_frames);
     const long long total = (long long)T * c.hop;
     const float *r = r_last + (long long)b * max_frames;
     float *ab = audio + (long long)b * audio_bstride;

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void pqmf_kernel(const float *x, long long x_b
                                                    int n_dm, int dm_min, float *y, long long y_bstride) {
     extern __shared__ float smem[];
     const int b = blockIdx.y;
-    const int steps = n_frames ? n_frames[b] * steps_per_frame : max_steps;
+    const int steps = item_rows(n_frames, b, steps_per_frame, max_steps);
     const int q0 = blockIdx.x * PQMF_QB;
     if (q0 >= steps) return;
     const int n_rows = PQMF_QB + n_dm - 1;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void pqmf_generic_kernel(const float *x, long 
                                                            int n_dm, int dm_min, float *y, long long y_bstride) {
     extern __shared__ float smem[];
     const int b = blockIdx.y;
-    const int steps = n_frames ? n_frames[b] * steps_per_frame : max_steps;
+    const int steps = item_rows(n_frames, b, steps_per_frame, max_steps);
     const int q0 = blockIdx.x * PQMF_QB;
     if (q0 >= steps) return;
     const int n_rows = PQMF_QB + n_dm - 1;

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_filter_kernel(StftConsts c, 
     float2 *bufb = smem2 + nc;
     float2 *tw = smem2 + 2 * nc;           // nc twiddles exp(-2 pi i m / n)
     const int b = blockIdx.y, t = blockIdx.x;
-    const int T = n_frames ? n_frames[b] : max_frames;
+    const int T = item_rows(n_frames, b, 1, max_frames);
     if (t >= T) return;
     const int tid = threadIdx.x;
     for (int i = tid; i < nc; i += FFT_THREADS) tw[i] = reinterpret_cast<const float2 *>(c.twiddle)[i];
@@ -200,7 +200,7 @@ void launch_stft_filter(const StftConsts &c, const float *exc, long long exc_bst
 __global__ void overlap_add_kernel(StftConsts c, const float *frames, const int *n_frames, int max_frames,
                                    int out_frames, float *audio, long long audio_bstride) {
     const int b = blockIdx.y;
-    const int T = n_frames ? n_frames[b] : max_frames;
+    const int T = item_rows(n_frames, b, 1, max_frames);
     const int n_valid = T * c.hop, n_all = out_frames * c.hop;
     const float *fb = frames + (long long)b * max_frames * c.win;
     float *ab = audio + (long long)b * audio_bstride;

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64) void phase_chunk_kernel(const float *__restrict
     __shared__ __attribute__((aligned(16))) float vout[PHASE_MAX_CHUNK];
     const int b = blockIdx.y;
     const int c = blockIdx.x;
-    const int n = n_frames ? n_frames[b] * samples_per_frame : n_max;
+    const int n = item_rows(n_frames, b, samples_per_frame, n_max);
     int begin, end;
     float acc0;
     chunk_range(st, b, chunk, c, n, begin, end, acc0);
@@ -102,7 +102,7 @@ __global__ void wavetable_kernel(WaveTableConsts k, const float *f0, long long b
                                  int chunks_max, float *pulse, float *phase_out, const StreamState *st) {
     __shared__ float offs[WT_MAX_CHUNKS];
     const int b = blockIdx.y;
-    const int n = n_frames ? n_frames[b] * samples_per_frame : n_max;
+    const int n = item_rows(n_frames, b, samples_per_frame, n_max);
     const float *fb = f0 + (long long)b * bstride;
     const float *cb = cum + (long long)b * bstride;
     const float *lb = chunk_last + (long long)b * chunks_max;

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void wn_gate0_kernel(Gate0Args p) {
     const int g = id / p.n_tiles;
     const int b = g / p.m_tiles_per_item;
     const int mt = g - b * p.m_tiles_per_item;
-    const int rows = p.n_frames ? p.n_frames[b] * p.rows_per_frame : p.max_rows;
+    const int rows = item_rows(p.n_frames, b, p.rows_per_frame, p.max_rows);
     const int m0 = mt * G0_ROWS;
     if (m0 >= rows) return;
     const int C = p.channels;

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 4) void wn_resskip_kernel(ConvAr
     if (g >= p.m_tiles_total) return;
     const int b = g / p.m_tiles_per_item;
     const int mt = g - b * p.m_tiles_per_item;
-    const int rows = p.n_frames ? p.n_frames[b] * p.rows_per_frame : p.max_rows;
+    const int rows = item_rows(p.n_frames, b, p.rows_per_frame, p.max_rows);
     const int m0 = mt * ROWS;
     if (m0 >= rows) return;
     const int C = p.channels;

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, (RvShape<NPW, NSTAGE>::WAVES_PER_SIMD)) void w
         const int wt = 4 * g + w;
         if (wt >= p.m_tiles_total) break;
         const int bb = wt / tpi;
-        const int rr = p.n_frames ? p.n_frames[bb] * p.rows_per_frame : p.max_rows;
+        const int rr = item_rows(p.n_frames, bb, p.rows_per_frame, p.max_rows);
         const int mm = 16 * (wt - bb * tpi);
         any = any || mm < rr;
         if (w == wave) {

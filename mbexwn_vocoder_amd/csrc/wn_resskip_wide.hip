@@ -59,7 +59,7 @@ __global__ __launch_bounds__(512, 4) void wn_resskip_wide_kernel(ConvArgs p) {
     const int pair0 = SPLIT == 1 ? 0 : (blockIdx.x - g * SPLIT) * NP;
     const int b = g / p.m_tiles_per_item;
     const int mt = g - b * p.m_tiles_per_item;
-    const int rows = p.n_frames ? p.n_frames[b] * p.rows_per_frame : p.max_rows;
+    const int rows = item_rows(p.n_frames, b, p.rows_per_frame, p.max_rows);
     const int m0 = mt * RW_ROWS;
     if (m0 >= rows) return;
     const int C = p.channels;

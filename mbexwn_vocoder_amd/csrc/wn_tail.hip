@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void wn_tail_kernel(const float *skip, long lo
     __shared__ float tile[4 * 32 * 33];
     __shared__ float wp[32 * 16 + 16];            // n_out * M post weights, then M post biases
     const int b = blockIdx.y;
-    const int rows = n_frames ? n_frames[b] * rows_per_frame : max_rows;
+    const int rows = item_rows(n_frames, b, rows_per_frame, max_rows);
     const int m0 = blockIdx.x * 32;
     if (m0 >= rows) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

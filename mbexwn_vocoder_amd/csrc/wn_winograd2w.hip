@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, 4) void wn_gate_winograd2w_kernel(ConvArgs p, 
         const int wt = 4 * g_ + w;
         if (wt >= p.m_tiles_total) break;
         const int bb = wt / tpi;
-        const int rr = p.n_frames ? p.n_frames[bb] * p.rows_per_frame : p.max_rows;
+        const int rr = item_rows(p.n_frames, bb, p.rows_per_frame, p.max_rows);
         const int hi = p.out_rows > 0 ? min(rr, p.out_row0 + p.out_rows) : rr;
         const int mm = p.out_row0 + W2_TROWS * (wt - bb * tpi);
         any = any || mm < hi;

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, 3) void wn_gate_winograd4w_kernel(ConvArgs p, 
     if (g_ >= p.m_tiles_total) return;
     const int b = g_ / p.m_tiles_per_item;
     const int mt = g_ - b * p.m_tiles_per_item;
-    const int rows = p.n_frames ? p.n_frames[b] * p.rows_per_frame : p.max_rows;
+    const int rows = item_rows(p.n_frames, b, p.rows_per_frame, p.max_rows);
     const int m0 = mt * ROWS;
     if (m0 >= rows) return;
     const int C = p.channels;
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256, 3) void wn_gate_winograd4p_kernel(ConvArgs p, 
     if (g_ >= p.m_tiles_total) return;
     const int b = g_ / p.m_tiles_per_item;
     const int mt = g_ - b * p.m_tiles_per_item;
-    const int rows = p.n_frames ? p.n_frames[b] * p.rows_per_frame : p.max_rows;
+    const int rows = item_rows(p.n_frames, b, p.rows_per_frame, p.max_rows);
     const int m0 = mt * ROWS;
     if (m0 >= rows) return;
     const int C = p.channels;
