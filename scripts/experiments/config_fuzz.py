@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
-"""One-off fuzz (GPU box): random model configurations x random ragged batches through the engine against the oracle."""
+"""One-off fuzz (GPU box): random model configurations x random ragged batches through the engine against the oracle.
+
+Known non-bug outliers (fuzz_case.py shows them stage by stage): with add_subharm_chans the channels sin(2 pi phase / ii) of
+the WRAPPED phase jump wherever the phase wraps (the reference's own design); an F0 contour that differs by 3e-4 Hz can wrap
+one sample earlier, which moves that jump by a sample and shows as ~1e-2 in the audio around it (seed 30000 + 363)."""
 import os, sys, traceback
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))

@@ -16,7 +16,7 @@ from mbexwn_vocoder_amd.weights import synthetic_weights
 from oracle.mbexwn_oracle import OracleModel
 M, W = "mbexwn_config:", "mbexwn_config:pp_mod_subnet:"
 body = src[src.index("    rng = np.random.default_rng(seed0 + case)"):src.index("    try:\n        cfg = canonical_config")]
-ns = {"np": np, "seed0": seed0, "case": case, "M": M, "W": W}
+ns = {"np": np, "seed0": seed0, "case": case, "M": M, "W": W, "sys": sys}      # (a third argument "structure" is read by the body)
 exec("if True:\n" + body, ns)
 rng, over = ns["rng"], ns["over"]
 cfg = canonical_config(str(rng.choice(["SPEECH", "VOICE"])), **over)
@@ -30,13 +30,14 @@ om64, om32 = OracleModel(cfg, raw, wt), OracleModel(cfg, raw, wt, dtype=np.float
 B, T = int(rng.integers(1, 5)), int(rng.integers(1, 45))
 lengths = [T] + [int(rng.integers(1, T + 1)) for _ in range(B - 1)]
 mel = np.clip(np.log(np.exp(rng.normal(-5.0, 2.0, size=(B, T, 80))) + 1e-5), -11.5, 2.0).astype(np.float32)
-noise = rng.normal(size=(B, T * 20)).astype(np.float32)
+rpf = dims.wn_in_rows_per_frame
+noise = rng.normal(size=(B, T * rpf)).astype(np.float32)
 print("form", form, "B", B, "T", T, "lengths", lengths, over)
 got = eng.forward(torch.as_tensor(mel).cuda(), n_frames=torch.tensor(lengths, dtype=torch.int32, device="cuda"),
                   noise=torch.as_tensor(noise).cuda() if dims.noise_sigma else None).cpu().numpy()
 exc = eng.stage("excitation").cpu().numpy(); f0 = eng.stage("f0").cpu().numpy()
 for ii, ll in enumerate(lengths):
-    nz = noise[ii:ii + 1, :ll * 20] if dims.noise_sigma else None
+    nz = noise[ii:ii + 1, :ll * rpf] if dims.noise_sigma else None
     a64, s64 = om64.forward(mel[ii:ii + 1, :ll], nz, return_stages=True)
     a32, s32 = om32.forward(mel[ii:ii + 1, :ll], nz, return_stages=True)
     amp = max(1.0, float(np.abs(a64).max()))
@@ -44,3 +45,10 @@ for ii, ll in enumerate(lengths):
           "| hip-f64 audio", f"{np.abs(got[ii, :ll*300]-a64[0]).max()/amp:.1e}", "f32-f64 audio", f"{np.abs(a32[0]-a64[0]).max()/amp:.1e}",
           "| hip-f64 exc", f"{np.abs(exc[ii, :ll*300]-s64['excitation'][0]).max():.1e}", "f32-f64 exc", f"{np.abs(s32['excitation'][0]-s64['excitation'][0]).max():.1e}",
           "| f0 hip-f64", f"{np.abs(f0[ii, :ll*dims.pulse_per_frame]-s64['f0'][0]).max():.1e}", "f0 f32-f64", f"{np.abs(s32['f0'][0]-s64['f0'][0]).max():.1e}")
+    dex = np.abs(exc[ii, :ll*300]-s64['excitation'][0])
+    worst = int(dex.argmax())
+    ph_hip = eng.wavetable(eng.stage("f0")[ii:ii+1])[1].cpu().numpy()[0]
+    ph_ref = om64.phase_from_f0(np.asarray(s64['f0'], dtype=np.float32))[0]
+    flips = np.nonzero(np.abs(ph_hip[:ll*dims.pulse_per_frame] - ph_ref[:ll*dims.pulse_per_frame]) > 0.5)[0]
+    print("   largest excitation difference at sample", worst, "= pulse sample", worst * dims.pulse_per_frame // 300,
+          "| pulse samples where the wrapped phases differ by a whole turn:", flips[:10])
