@@ -53,6 +53,16 @@ def test_conv1d_same_dilated(T, cin, cout, K, dil):
     ref = F.conv1d(torch.as_tensor(x).permute(0, 2, 1), torch.as_tensor(w).permute(2, 1, 0), stride=3,
                    dilation=dil).permute(0, 2, 1).numpy()
     assert got.shape == ref.shape and _maxdiff(got, ref) <= TOL
+    # Keras padding="causal" (the golden cases "causal" / "causal1"): (K - 1) d zeros in front, none behind -- the function
+    # and the Keras-like layer the reference's TF2C_Conv1DWeightNorm wraps
+    xt = F.pad(torch.as_tensor(x).permute(0, 2, 1), (total, 0))
+    ref = F.conv1d(xt, torch.as_tensor(w).permute(2, 1, 0), dilation=dil).permute(0, 2, 1).numpy()
+    got = shim.conv1d_nwc(x, w, padding="CAUSAL", dilation=dil)
+    assert got.shape == ref.shape == (2, T, cout) and _maxdiff(got, ref) <= TOL
+    layer = shim.Conv1D(cout, K, padding="causal", dilation_rate=dil, use_bias=False)
+    layer.build(shim.Shape((2, T, cin)))
+    layer.kernel.assign(w)
+    assert _maxdiff(np.asarray(layer(shim.Tensor(x))), ref) <= TOL
 
 
 @pytest.mark.parametrize("W,C,kw,mult", [(12, 3, 2, 10), (7, 5, 2, 4), (20, 1, 3, 2)])
