@@ -251,3 +251,47 @@ print("RCCL_OK")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     res = subprocess.run([sys.executable, "-c", code, ROOT, model_dir], env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "RCCL_OK" in res.stdout, res.stderr[-2000:]
+
+@pytest.mark.parametrize("case", ["plain", "rmsnorm"])
+def test_infer_and_infer_components_against_the_reference_methods(case):
+    """engine.infer / infer_components against the reference's own PaNWaveNet.infer / infer_components bodies
+    (tests/golden/make_reference_infer.py): synth_length shorter than, equal to (0 = segment_length) and longer than the
+    mel (the last frame is repeated once), the parameter list of return_F0 with the reference's slices, a transposition
+    factor, an external F0 contour, with and without the RMS normalisation."""
+    import torch
+    from helpers import build_case
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "reference_infer.npz"))
+    over = dict(SMALL)
+    if case == "rmsnorm":
+        over.update({"mbexwn_config:normalize_rms_from_mell": True, "mbexwn_config:normalize_rms_num_smooth_iters": 1})
+    cfg, raw, wt = build_case("SPEECH", over)
+    cfg["preprocess_config"]["segment_length"] = 14 * 300          # what synth_length = 0 falls back to
+    eng = MBExWNEngine(cfg, raw, wt)
+    mell = gold[f"{case}/mell"]
+
+    def close(a, b, tol=1e-4):
+        a, b = np.asarray(a), np.asarray(b)
+        assert a.shape == b.shape, (a.shape, b.shape)
+        assert float(np.max(np.abs(a - b))) <= tol * max(1.0, float(np.abs(b).max())), float(np.max(np.abs(a - b)))
+
+    for tag, synth_length in (("short", 14 * 300 - 123), ("exact", 0), ("long", 14 * 300 + 150)):
+        audio, params = eng.infer(mell, synth_length=synth_length, return_F0=True, noise=gold[f"{case}/{tag}/noise"])
+        close(audio.numpy(), gold[f"{case}/{tag}/audio"])
+        assert [pp[0] for pp in params] == ["F0", "PSig", "PS"]
+        got = {pp[0]: pp[1].numpy() for pp in params}
+        close(got["F0"], gold[f"{case}/{tag}/F0"], tol=1e-5)       # Hz up to 600: 6e-3 Hz
+        close(got["PSig"], gold[f"{case}/{tag}/PSig"])
+        assert tuple(got["PS"].shape) == tuple(gold[f"{case}/{tag}/PS_shape"])
+        close(got["PS"][:, :, ::8], gold[f"{case}/{tag}/PS"], tol=1e-4)
+    f0, exc, env, gain = eng.infer_components(mell, synth_length=14 * 300, transposition_factor=1.25, noise=gold[f"{case}/comp/noise"])
+    close(f0, gold[f"{case}/comp/f0"], tol=1e-5)
+    close(exc, gold[f"{case}/comp/excitation"])
+    close(np.abs(env)[:, :, ::8], gold[f"{case}/comp/env_abs"])
+    if case == "rmsnorm":
+        close(gain, gold[f"{case}/comp/gain"])
+    else:
+        assert gain is None
+    _, exc, env, _ = eng.infer_components(mell, F0=gold[f"{case}/ext/f0_in"], noise=gold[f"{case}/comp/noise"])
+    close(exc, gold[f"{case}/ext/excitation"])
+    close(np.abs(env)[:, :, ::8], gold[f"{case}/ext/env_abs"])
