@@ -205,7 +205,8 @@ size_t mbx_workspace_size(const mbx_handle *handle, int32_t batch, int32_t max_f
  *   mel       device (batch, max_frames, mel_channels)
  *   n_frames  device int32 (batch) valid frames per item, or NULL (= max_frames for all); every boundary
  *             op honours the item's own length, so a padded batch equals one-at-a-time runs
- *   noise     device (batch, max_frames*steps_per_frame) N(0,1) draw of the noise channel
+ *   noise     device (batch, max_frames*steps_per_frame) N(0,1) draw of the noise channel (with n_wn_blocks >= 1: one value
+ *             per row of the FIRST block, i.e. max_frames * steps_per_frame / prod(wn_block_ups))
  *             (reference custom_pulsed_generator.py:905-906); NULL is only legal if noise_sigma == 0
  *   audio     device (batch, max_frames*hop_size); samples behind an item's own length are zeroed */
 mbx_status mbx_forward(mbx_handle *handle, const float *mel, const int32_t *n_frames, int32_t batch,
