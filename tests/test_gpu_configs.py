@@ -495,18 +495,18 @@ def test_other_model_geometries(torch, name):
 
 def test_random_configurations_against_the_oracle(torch):
     """Thirty random model configurations x random ragged batches x a random convolution form (the first cases of
-    scripts/experiments/config_fuzz.py, which ran 800 of them) against the float64 oracle; the numpy float32 port of the
+    tests/tools/config_fuzz.py, which ran 800 of them) against the float64 oracle; the numpy float32 port of the
     graph is the yardstick for draws that float32 itself conditions badly."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = subprocess.run([sys.executable, os.path.join(root, "scripts", "experiments", "config_fuzz.py"), "30", "1000"],
+    res = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "config_fuzz.py"), "30", "1000"],
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "failures: 0" in res.stdout, res.stdout[-3000:] + res.stderr[-2000:]
     assert res.stdout.count(" OK ") >= 25
     # and twenty draws with the structural options on top: WaveNet blocks, causal padding, ps_off, sub-band gains, no PQMF
     # bank, PQMF analysis of the pulse signal, sinusoid-as-function (400 of them ran in the script)
-    res = subprocess.run([sys.executable, os.path.join(root, "scripts", "experiments", "config_fuzz.py"), "20", "9000", "structure"],
+    res = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "config_fuzz.py"), "20", "9000", "structure"],
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "failures: 0" in res.stdout, res.stdout[-3000:] + res.stderr[-2000:]
     assert res.stdout.count(" OK ") >= 18

@@ -365,7 +365,7 @@ def test_frontend_ring_equals_whole_window_and_checks_its_arguments(engine):
         engine.forward(mel_d, noise=noise_d, stream_state=st, active=(8, act, T - 12), frontend=(ring, pos8, 13, 3))
 
 def test_random_models_and_stream_sets_stay_bit_equal():
-    """Forty draws of scripts/experiments/stream_fuzz.py (which ran 800: random single-block models incl. deep conditioning
+    """Forty draws of tests/tools/stream_fuzz.py (which ran 800: random single-block models incl. deep conditioning
     and VTF chains, RMS normalisation, ps_off, no PQMF bank; 1-5 streams joining at different ticks; chunks of 2-12 frames;
     irregular packets): every stream bit equal to the offline synthesis of its utterance.  Seed 20292 + is the region where
     the first run found the margins of a two-convolution conditioning chain one frame short."""
@@ -373,7 +373,7 @@ def test_random_models_and_stream_sets_stay_bit_equal():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = subprocess.run([sys.executable, os.path.join(root, "scripts", "experiments", "stream_fuzz.py"), "40", "20280"],
+    res = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "stream_fuzz.py"), "40", "20280"],
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "failures: 0" in res.stdout, res.stdout[-3000:] + res.stderr[-2000:]
     assert res.stdout.count(" OK ") == 40

@@ -104,7 +104,7 @@ for case in range(n_cases):
             yard = max(yard, float(np.abs(om32.forward(mel[ii:ii + 1, :ll], nz)[0] - ref).max()) / amp)
             assert np.all(got[ii, ll * 300:] == 0.0), "tail not zero"
         # (the few draws between 4 and 12 yardsticks seen in 800 cases all had an F0 contour 1.2-1.4e-3 Hz off -- twice the
-        # float32 port's own error -- which moves every pulse by that much: scripts/experiments/fuzz_case.py)
+        # float32 port's own error -- which moves every pulse by that much: tests/tools/fuzz_case.py)
         ok = worst <= max(1e-4, 16 * yard)
         if not ok and dims.wt_subharm:
             # the known class (see the docstring): the wrapped phases of the two F0 contours differ by a whole turn somewhere

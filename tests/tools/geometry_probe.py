@@ -4,7 +4,7 @@ counts) through the engine against the float64 oracle."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from mbexwn_vocoder_amd.config import ModelDims, canonical_config
 from mbexwn_vocoder_amd.engine import MBExWNEngine
 from mbexwn_vocoder_amd.tables import WaveTables
