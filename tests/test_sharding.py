@@ -93,6 +93,32 @@ def _worker(rank, world, port, tmpdir):
 
 
 @pytest.mark.timeout(300)
+def test_random_shardings_cover_every_utterance_exactly_once():
+    """Random utterance sets x world sizes x micro-batch limits: the ranks' local shards (no collective: every rank is
+    simulated in this process) together hold every utterance once, each equal to its one-at-a-time result, and no
+    micro-batch exceeds its limits."""
+    for seed in range(40):
+        rng = np.random.default_rng(seed)
+        n, world = int(rng.integers(1, 60)), int(rng.integers(1, 9))
+        max_batch, max_padded = int(rng.integers(1, 20)), int(rng.integers(60, 1500))
+        mels, noises = make_utterances(n, seed=100 + seed)
+        use_noise = bool(rng.integers(0, 2))
+        seen = {}
+        for rank in range(world):
+            def checked(mel, n_frames, noise, max_batch=max_batch, max_padded=max_padded):
+                assert mel.shape[0] <= max_batch and (mel.shape[0] == 1 or mel.shape[0] * mel.shape[1] <= max_padded)
+                return fake_forward(mel, n_frames, noise)
+            syn = ShardedSynthesizer(checked, HOP, SPF, rank=rank, world_size=world, max_batch=max_batch,
+                                     max_padded_frames=max_padded)
+            local = syn.run(mels, noises if use_noise else None, gather=None)
+            assert not set(local) & set(seen)
+            seen.update(local)
+        assert sorted(seen) == list(range(n))
+        for ii in range(n):
+            one = fake_forward(mels[ii][None], np.asarray([mels[ii].shape[0]]), noises[ii][None] if use_noise else None)[0]
+            assert np.array_equal(np.asarray(seen[ii]), one), (seed, ii)
+
+
 def test_world_size_2_gloo(tmp_path):
     import torch.multiprocessing as mp
     with socket.socket() as ss:
