@@ -165,6 +165,12 @@ PATCHES = {
     'g0n_onetile': [
         ('#pragma unroll\n    for (int i = 0; i < 4; ++i) {\n        cond_load(i, cr);', '#pragma unroll\n    for (int i = 0; i < 1; ++i) {\n        cond_load(i, cr);'),
     ],
+    # wn_tail.hip: every wave walks a contiguous quarter of the channels (consecutive 32-byte pieces of its rows) instead of
+    # every fourth 8-channel group
+    'tail_contig': [
+        ('#pragma unroll 4\n    for (int c = wave; c < nc8; c += 4) {',
+         '    const int per_ = (nc8 + 3) / 4;\n#pragma unroll 4\n    for (int c = wave * per_; c < min(nc8, (wave + 1) * per_); ++c) {'),
+    ],
     'base': [],
     # wn_winograd4w.hip
     'nodma': [
