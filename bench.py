@@ -38,6 +38,14 @@ WORKLOADS = {
     # BASELINE.json configs[4]: 64 concurrent streams, one tick = 8 mel frames (100 ms; "80 ms" = 6.4 frames is not
     # frame aligned) per stream
     "config5_sp_stream64": ("SPEECH", 64, -8),
+    # builder-run secondary (not a BASELINE config): the generic path -- two WaveNet blocks with in-block upsampling (the
+    # geometry of the golden case "blocks": C = 320 at 800 Hz, then C = 160 at 1600 Hz), the block runner's kernels
+    "variant_blocks2": ("SING", 16, 800),
+}
+WORKLOAD_OVERRIDES = {
+    "variant_blocks2": {"mbexwn_config:pp_mod_subnet_upsampling_factors": [2, 1],
+                        "mbexwn_config:pp_mod_subnet_channel_factors": [1, 0.5],
+                        "mbexwn_config:pulse_channels": 10, "mbexwn_config:pp_mod_subnet:cond_lin_upsampling": 5},
 }
 DEFAULT_WORKLOAD = "config3_si_b16_10s"
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
@@ -57,14 +65,14 @@ def mbx_env():
 _ENGINES = {}
 
 
-def build_engine(voice):
+def build_engine(voice, overrides=None):
     """(cfg, raw weights, wavetables, dims, engine) of the canonical model of a voice type; engines are shared
     between voice types whose configuration is identical (SING == SPEECH: C = 320)."""
     from mbexwn_vocoder_amd.config import ModelDims, canonical_config
     from mbexwn_vocoder_amd.engine import MBExWNEngine
     from mbexwn_vocoder_amd.tables import WaveTables
     from mbexwn_vocoder_amd.weights import synthetic_weights
-    cfg = canonical_config(voice)
+    cfg = canonical_config(voice, **(overrides or {}))
     key = json.dumps(cfg, sort_keys=True, default=str)
     if key not in _ENGINES:
         dims = ModelDims(cfg)
@@ -175,6 +183,7 @@ def max_abs_delta_small(eng, cfg, raw, wt, mel_h, noise_h, torch):
     got = eng.forward(torch.as_tensor(mel).cuda(), noise=torch.as_tensor(noise).cuda()).cpu().numpy()
     dd, pk = _delta_vs_oracle(got, cfg, raw, wt, mel, noise, nf)
     return {"max_abs_delta_small": dd, "max_abs_delta_small_tolerance": DELTA_TOL * max(1.0, pk),
+            "max_abs_delta_small_ok": bool(dd <= DELTA_TOL * max(1.0, pk)),
             "max_abs_delta_small_sample": f"separate forward of the first {nf} frames of item 0 (small-launch kernels: "
                                           f"{eng.gate_form(1, nf)})"}
 
@@ -212,9 +221,9 @@ def time_steps(step, steps, warmup, fence):
 def run_batch(args, name, rank, world, fence, torch, profile, steps=None, warmup=None):
     """configs[0..2]: one padded batch per GPU.  Returns (result dict, context for the roofline / delta legs)."""
     voice, batch, frames = WORKLOADS[name]
-    cfg, raw, wt, dims, eng = build_engine(voice)
+    cfg, raw, wt, dims, eng = build_engine(voice, WORKLOAD_OVERRIDES.get(name))
     rng = np.random.default_rng(42 + rank)
-    mel_h, noise_h = synthetic_batch(rng, batch, frames, dims.steps_per_frame)
+    mel_h, noise_h = synthetic_batch(rng, batch, frames, dims.wn_in_rows_per_frame)
     mel, noise = torch.as_tensor(mel_h).cuda(), torch.as_tensor(noise_h).cuda()
     out = torch.empty((batch, frames * dims.hop_size), dtype=torch.float32, device=mel.device)
     steps = args.steps if steps is None else steps
@@ -229,7 +238,7 @@ def run_batch(args, name, rank, world, fence, torch, profile, steps=None, warmup
                        f"{frames / 80:g} s per GPU, 80x{frames} synthetic mel, seeded synthetic weights",
            "batch_per_gpu": batch, "frames": frames, "value": samples / elapsed, "x_realtime": samples / elapsed / 24000.0,
            "ms_per_step": elapsed / steps * 1e3, "steps": steps, "scaling": "weak",
-           "gate_form": eng.gate_form(batch, frames)}
+           "gate_form": eng.gate_form(batch, frames), "conv_form": eng.conv_form_info()}
     ctx = {"cfg": cfg, "raw": raw, "wt": wt, "dims": dims, "eng": eng, "mel_h": mel_h, "noise_h": noise_h, "batch": batch,
            "frames": frames, "timed_out": timed_out, "delta_items": delta_items, "stages": None}
     if profile:
@@ -244,6 +253,38 @@ def run_batch(args, name, rank, world, fence, torch, profile, steps=None, warmup
         eng.profile_enable(False)
         ctx["stages"] = stages
     return res, ctx
+
+
+def roofline_blocks(ctx):
+    """The generic path (several WaveNet blocks, block runner of csrc/mbx_api.hip): all gate launches of a step against the
+    fp32 MFMA peak -- block b runs L full gate layers on T * spf_b rows with C_b channels (no folded first layer) -- and
+    the per-stage device times of a step."""
+    dims, eng, batch, frames, stages = ctx["dims"], ctx["eng"], ctx["batch"], ctx["frames"], ctx["stages"]
+    info = eng.conv_form_info()
+    executed = {"direct": 1.0, "f23": 2.0 / 3.0, "f43": 0.5}[info["form"]]
+    L, ks = dims.wn_layers, dims.wn_kernel_size
+    rpf = dims.wn_in_rows_per_frame
+    flop_alg, rs_flop, geometry = 0.0, 0.0, []
+    for C, ups in zip(dims.wn_block_channels, dims.wn_block_ups):
+        rows = batch * frames * rpf
+        flop_alg += L * 2.0 * rows * (ks * C) * (2 * C)
+        rs_flop += 2.0 * rows * C * ((L - 1) * 2 * C + C)            # un-folded res/skip layers: C -> 2C, last one C -> C
+        geometry.append({"channels": C, "rows_per_frame": rpf, "upsampling_behind": ups})
+        rpf *= ups
+    gate_ms, gate_n = stages["gate"]
+    rs_ms, rs_n = stages["res_skip"]
+    n_fwd = max(1, gate_n // (L * len(dims.wn_block_channels)))
+    gate_s, rs_s = gate_ms / n_fwd * 1e-3, rs_ms / n_fwd * 1e-3
+    per_step = {kk: stages[kk][0] / n_fwd for kk in stages if stages[kk][1]}
+    return {"bound": "mfma", "kernel": "block runner: wn_gate_winograd4w_kernel per block and layer where its image fits "
+                                       "(conv1d_mfma_dma_kernel<EPI_GATE> otherwise), wn_resskip_kernel<un-folded>",
+            "blocks": geometry, "gate_launches_per_step": L * len(dims.wn_block_channels),
+            "achieved": flop_alg * executed / gate_s / 1e12, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": flop_alg * executed / gate_s / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
+            "frac_algorithmic": flop_alg / gate_s / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
+            "gate_ms_per_step": gate_s * 1e3, "res_skip_ms_per_step": rs_s * 1e3,
+            "res_skip_frac": rs_flop / rs_s / 1e12 / FP32_MATRIX_PEAK_TFLOPS if rs_s else None,
+            "stage_ms_per_step": per_step, "traffic": None}
 
 
 def roofline(ctx, workload):
@@ -328,8 +369,10 @@ def roofline(ctx, workload):
 
 def run_sharded(args, name, rank, world, dist, fence, torch, steps=None, warmup=None, check_delta=False):
     """configs[3]: every rank sees the same seeded list of utterance lengths, ShardedSynthesizer takes its LPT shard,
-    stages the padded micro-batches in HBM once, and every step runs them and all-gathers the audio (RCCL, device
-    tensors: no host copy between the forward pass and the collective)."""
+    stages the padded micro-batches in HBM once, and every step runs them and gathers the audio on rank 0 (RCCL, device
+    tensors: no host copy between the forward pass and the collective; chunks of the shard are handed to the collective
+    as soon as their micro-batches are packed, so the transfer runs under the next forward pass).  The line carries the
+    step's compute and exposed-gather time of every rank."""
     from mbexwn_vocoder_amd.sharding import ShardedSynthesizer
     voice, n_utt, _ = WORKLOADS[name]
     cfg, raw, wt, dims, eng = build_engine(voice)
@@ -356,9 +399,18 @@ def run_sharded(args, name, rank, world, dist, fence, torch, steps=None, warmup=
     last = {}
 
     def step():
-        last["res"] = syn.run_staged(plan, gather="all")
+        last["res"] = syn.run_staged(plan, gather=args.gather)
 
     elapsed = time_steps(step, steps, warmup, fence)
+    # compute / exposed gather time of the last timed step, per rank (events on the launch stream, sharding.py)
+    timing = last["res"].timing
+    mine_ms = [float(timing.get("compute_ms", 0.0)), float(timing.get("gather_ms", 0.0))]
+    per_rank = [mine_ms]
+    if dist is not None and world > 1:
+        tt = torch.tensor(mine_ms, dtype=torch.float64, device="cuda")
+        every = [torch.empty_like(tt) for _ in range(world)]
+        dist.all_gather(every, tt)
+        per_rank = [[float(vv) for vv in ee.cpu()] for ee in every]
     samples = sum(lengths) * dims.hop_size * steps
     padded = sum(int(bb[1].shape[0]) * int(bb[1].shape[1]) for bb in plan["batches"])
     delta = {}
@@ -367,10 +419,13 @@ def run_sharded(args, name, rank, world, dist, fence, torch, steps=None, warmup=
         pick = max(mine, key=lambda ii: (lengths[ii], -ii))                 # the longest one: first micro-batch, large launch
         got = last["res"].item(pick)[:DELTA_FRAMES * dims.hop_size].cpu().numpy()
         delta = max_abs_delta_timed([(f"utterance {pick} ({lengths[pick]} frames)", got, mels[pick], noises[pick])],
-                                    cfg, raw, wt, "forward + all_gather of the sharded run")
+                                    cfg, raw, wt, f"forward + gather ({args.gather}) of the sharded run")
     return {**delta, "workload": f"{name}: MW-{voice[:2]}-FD canonical (C={dims.wn_channels}), {n_utt} utterances U[2 s,15 s] = "
                         f"{sum(lengths) / 80:.0f} s of audio, LPT-sharded over {world} ranks (ShardedSynthesizer), padded "
-                        f"micro-batches <= 16 items, device-resident all_gather of the audio each step",
+                        f"micro-batches <= 16 items, device-resident chunked asynchronous gather ({args.gather}) of the audio each step",
+            "gather": args.gather, "gather_chunks": int(timing.get("chunks", 0)),
+            "compute_ms_per_rank": [round(vv[0], 3) for vv in per_rank],
+            "gather_exposed_ms_per_rank": [round(vv[1], 3) for vv in per_rank],
             "value": samples / elapsed, "x_realtime": samples / elapsed / 24000.0, "ms_per_step": elapsed / steps * 1e3,
             "steps": steps, "scaling": "strong", "parallelism": f"utterance-sharded x{world}",
             "padding_overhead": padded / max(1, sum(lengths[ii] for ii in mine))}
@@ -499,9 +554,12 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary workloads (the other four configs) and the max|delta| legs: profiling runs")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-spawned ranks (default: probe a free one)")
+    ap.add_argument("--gather", default="rank0", choices=["rank0", "all", "none"],
+                    help="result gather of the sharded workload: on rank 0 (default), on every rank, or none (local shards)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even for one rank: exercises the N>1 code path on a 1-GPU box")
     args = ap.parse_args()
+    args.gather = None if args.gather == "none" else args.gather
     if args.gpus < 1 or args.steps < 1:
         raise SystemExit("--gpus and --steps must be >= 1")
     for kk in REJECTED_ENV:
@@ -557,8 +615,18 @@ def main():
             res2.update(max_abs_delta_timed([("item 0", ctx2["timed_out"][0], ctx2["mel_h"][0], ctx2["noise_h"][0])],
                                             ctx2["cfg"], ctx2["raw"], ctx2["wt"], "config 2 batch"))
         secondary["config2_sp_b1_10s"] = res2
-        res1, _ = run_batch(args, "config1_sp_b1_3s", rank, world, fence, torch, profile=False)
+        res1, ctx1 = run_batch(args, "config1_sp_b1_3s", rank, world, fence, torch, profile=False)
+        if rank == 0:
+            res1.update(max_abs_delta_timed([("item 0", ctx1["timed_out"][0], ctx1["mel_h"][0], ctx1["noise_h"][0])],
+                                            ctx1["cfg"], ctx1["raw"], ctx1["wt"], "config 1 batch"))
         secondary["config1_sp_b1_3s"] = res1
+        # the generic path (two WaveNet blocks, in-block upsampling): builder-run secondary, not a BASELINE config
+        resb, ctxb = run_batch(args, "variant_blocks2", rank, world, fence, torch, profile=True, steps=min(args.steps, 5), warmup=1)
+        if rank == 0:
+            resb.update(max_abs_delta_timed([("item 0", ctxb["timed_out"][0], ctxb["mel_h"][0], ctxb["noise_h"][0])],
+                                            ctxb["cfg"], ctxb["raw"], ctxb["wt"], "two-block variant batch"))
+            resb["roofline"] = roofline_blocks(ctxb)
+        secondary["variant_blocks2"] = resb
         secondary["config4_vo_256utt"] = run_sharded(args, "config4_vo_256utt", rank, world, dist, fence, torch,
                                                      steps=min(args.steps, 3), warmup=1, check_delta=True)
         secondary["config5_sp_stream64"] = run_streaming(args, "config5_sp_stream64", rank, world, fence, torch,
@@ -574,7 +642,7 @@ def main():
             "env": mbx_env()})
         line["config"]["parallelism"] = main_res.get("parallelism", f"utterance-sharded x{world}")
         if ctx is not None:
-            line["roofline"] = roofline(ctx, args.workload)
+            line["roofline"] = roofline_blocks(ctx) if args.workload in WORKLOAD_OVERRIDES else roofline(ctx, args.workload)
             if not args.no_secondary:
                 line.update(max_abs_delta_timed(
                     [(f"item {ii}", ctx["timed_out"][ii], ctx["mel_h"][ii], ctx["noise_h"][ii]) for ii in ctx["delta_items"]],
@@ -589,6 +657,24 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # a parity miss anywhere in the line fails the run: every max_abs_delta*_ok, main and secondary
+        bad = [path for path, ok in _delta_flags(line) if ok is False]
+        if bad:
+            print(f"bench.py: max|delta| out of tolerance: {', '.join(bad)}", file=sys.stderr)
+            raise SystemExit(3)
+
+
+def _delta_flags(node, path="line"):
+    """(path, value) of every key that starts with max_abs_delta and ends with _ok, anywhere in the line."""
+    found = []
+    if isinstance(node, dict):
+        for kk, vv in node.items():
+            if kk.startswith("max_abs_delta") and kk.endswith("_ok"):
+                found.append((f"{path}.{kk}", vv))
+            else:
+                found.extend(_delta_flags(vv, f"{path}.{kk}"))
+    return found
 
 
 if __name__ == "__main__":

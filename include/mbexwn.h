@@ -16,19 +16,10 @@
  *     not re-entrant; calls only enqueue work on the given stream and never synchronise
  *   - all tensors are float32, channels-last, row-major
  *
- * Environment switches read by mbx_create (the defaults are the measured best):
- *   MBX_WINOGRAD=0|2|4|44  form of the dilated convolution: direct / Winograd F(2,3) only / F(4,3) with the block shape
- *                        (and the res/skip kernel) picked by launch size (default 4; streams always run F(2,3)) /
- *                        F(4,3) with the large-launch kernel shapes at every size (tests).  A pinned form pins the
- *                        kernels: results then do not depend on the batch an item ran in.
- *   MBX_FOLD_SKIP=0      keep the un-folded skip path (C -> 2C res/skip layers, stage "wn_skip")
- *   MBX_FOLD_START=0     keep the start convolution and the full first layer (default: start convolution folded into
- *                        layer 0, a K = 24 contraction of the excitation; needs the folded skip path)
- *   MBX_WG_SMALL=0|1     measurements / tests: pins the F(4,3) block shape of launches below 4 x 768 full blocks
- *                        (0: 256-row blocks, 1: 128-row product-split blocks; both give the same bits)
- *   MBX_RV_TILES=n       measurements: under the default policy, res/skip launches of at most n 16-row tiles run the
- *                        wave-tiled kernel (default 2048; 0 = never)
- *   MBX_RV_SPLIT=1|2|3   measurements: pins the column split of the wave-tiled res/skip kernel (default: by launch size)
+ * The library reads NO environment variable: everything that changes numerics or the kernel choice is a field of
+ * mbx_config (wn_conv_form, batch_invariant, wn_keep_skip, wn_keep_start, tune_*), so two handles of one process may
+ * differ and a stray variable cannot change results.  (The Python host maps the MBX_* variables of its experiment
+ * scripts onto these fields and says so on stderr: mbexwn_vocoder_amd/engine.py::experiment_overrides.)
  * The optional operand-order images of the weights ("*.wino2w", "*.wino4w", "*.packed", "*.fold",
  * "*.fold_wide", "*.fold_wave", "*.start_fold", "*.fold_start", "*.fold_start_wide", "*.fold_start_wave",
  * "wn.tail.fold", "wn.end.packed";
@@ -45,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MBX_ABI_VERSION 6
+#define MBX_ABI_VERSION 7
 #define MBX_MAX_SUBNET_OPS 32
 #define MBX_MAX_WN_LAYERS 64
 #define MBX_MAX_PRECOND 8
@@ -86,6 +77,23 @@ typedef struct {
 #define MBX_GATE_GFU 1
 #define MBX_GATE_GSU 2
 #define MBX_GATE_GLU 3
+
+/* Form of the dilated convolution of the WaveNet layers (mbx_config.wn_conv_form).  All forms are float32 arithmetic of
+ * the same function (reference custom_AE_layers.py:305-321); they differ in rounding: the Winograd forms trade
+ * multiplications for additions of inputs / outputs, which multiplies the pre-activation rounding error by about 2
+ * (F(2,3)) and 5 (F(4,3)) -- an error that grows with the amplitude of the residual stream.
+ *   MBX_CONV_AUTO    F(4,3) when the handle's own weights allow it: mbx_create runs a short calibration forward through
+ *                    F(4,3), F(2,3) and the direct form and keeps the fastest form whose audio stays within
+ *                    calib_fraction of the 1e-4 * max(1, |audio|) parity budget of the direct form's (mbx_conv_form
+ *                    reports the decision and the measured differences; mbx_calibrate repeats it on the caller's data)
+ *   MBX_CONV_DIRECT  dilated convolution as written (K = 3C contraction)
+ *   MBX_CONV_F23     Winograd F(2,3): 4 contractions per 2 outputs
+ *   MBX_CONV_F43     Winograd F(4,3): 6 contractions per 4 outputs
+ * Streaming calls (state_in / state_out) run F(2,3) unless the handle's form is the direct one. */
+#define MBX_CONV_AUTO 0
+#define MBX_CONV_DIRECT 1
+#define MBX_CONV_F23 2
+#define MBX_CONV_F43 3
 
 typedef struct {
     int32_t struct_size;     /* sizeof(mbx_config), checked by mbx_create */
@@ -175,6 +183,23 @@ typedef struct {
      * convolutions of the WaveNet blocks pad dilation * (kernel size - 1) zeros in front and none behind.  Generic
      * kernels, whole items only. */
     int32_t wn_causal;
+    /* ---- ABI 7: numerics / kernel policy (all zero = the defaults) ------------------------------------------------ */
+    int32_t wn_conv_form;        /* MBX_CONV_* */
+    /* 1: the kernels of a forward do not follow its launch size, so an item's result does not depend on the batch it ran
+     * in (the reference runs one utterance at a time).  0: large and small launches may take different res/skip kernels,
+     * whose results differ by float32 rounding (<= 4e-5 on canonical audio).  The direct form and F(2,3) are batch
+     * invariant either way. */
+    int32_t batch_invariant;
+    int32_t wn_keep_skip;        /* 1: keep the un-folded skip path (C -> 2C res/skip layers, stage "wn_skip") */
+    int32_t wn_keep_start;       /* 1: keep the start convolution and the full first layer (default: folded into layer 0) */
+    float calib_fraction;        /* MBX_CONV_AUTO: share of the parity budget the form's own rounding may take; 0 = 0.25 */
+    /* measurement knobs, none changes what a kernel computes for a given kernel choice (scripts/experiments):
+     *   tune_gate_shape        0: by launch size, 1: 256-row F(4,3) blocks, 2: 128-row product-split blocks (same bits)
+     *   tune_resskip_wave_tiles 0: default (2048); n > 0: res/skip launches of at most n 16-row tiles run the wave-tiled
+     *                          kernel; -1: never
+     *   tune_resskip_split     0: by launch size, 1..3: column split of the wave-tiled res/skip kernel (same bits) */
+    int32_t tune_gate_shape, tune_resskip_wave_tiles, tune_resskip_split;
+    int32_t reserved7[4];
 } mbx_config;
 
 /* A named HOST tensor handed over at creation (weights already weight-norm folded, tables).
@@ -196,6 +221,30 @@ const char *mbx_last_error(void);
 mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32_t n_tensors, int32_t device,
                       mbx_handle **out);
 mbx_status mbx_destroy(mbx_handle *handle);
+
+/* What the handle decided about the dilated convolution (mbx_config.wn_conv_form). */
+typedef struct {
+    int32_t struct_size;      /* sizeof(mbx_conv_form_info), set by the caller */
+    int32_t requested;        /* mbx_config.wn_conv_form */
+    int32_t form;             /* MBX_CONV_DIRECT | _F23 | _F43: what whole-utterance forwards run */
+    int32_t stream_form;      /* what streaming calls run (F(2,3), or the direct form) */
+    int32_t calibrated;       /* 0: no calibration ran (form pinned by the config, or no Winograd images); 1: on the
+                               * built-in synthetic mel at mbx_create; 2: on the caller's data (mbx_calibrate) */
+    int32_t batch_invariant;
+    int32_t fold_skip, fold_start;   /* the folds in effect */
+    float err_f43, err_f23;   /* max |audio(form) - audio(direct)| of the calibration run; < 0: form not available */
+    float ref_max;            /* max |audio(direct)| of the calibration run */
+    float threshold;          /* calib_fraction * 1e-4 * max(1, ref_max): a form is accepted at or below it */
+} mbx_conv_form_info;
+mbx_status mbx_conv_form(const mbx_handle *handle, mbx_conv_form_info *info);
+
+/* Re-runs the calibration of MBX_CONV_AUTO on the caller's own input (same argument meaning as mbx_forward) and adopts
+ * its decision for the forwards that follow -- for a handle created with any wn_conv_form (a pinned form becomes the
+ * calibrated one).  Synchronises the stream, allocates and frees scratch memory: a set-up call, not part of the
+ * enqueue-only path.  Do not call it between the ticks of running streams (their form may change). */
+mbx_status mbx_calibrate(mbx_handle *handle, const float *mel, const int32_t *n_frames, int32_t batch,
+                         int32_t max_frames, const float *noise, void *workspace, size_t workspace_bytes,
+                         void *hip_stream);
 
 /* Bytes of device workspace mbx_forward needs for `batch` items of at most `max_frames` mel frames. */
 size_t mbx_workspace_size(const mbx_handle *handle, int32_t batch, int32_t max_frames);
@@ -331,7 +380,7 @@ mbx_status mbx_window_advance(mbx_handle *handle, float *mel_window, const float
  * tests.  Names: "f0" "pulse" "cond" "wn_hidden" "wn_skip" "wn_out" "subbands" "excitation" "cepstrum"
  * "ceps_index" "frames".  `count` = floats (int32 for ceps_index) per batch item, `stride` = item stride.
  * "wn_skip" (the C-wide skip sum) only exists when the skip path is not folded into the end convolution
- * (environment MBX_FOLD_SKIP=0 at mbx_create, or a handle created without the *.fold tensors). */
+ * (mbx_config.wn_keep_skip, or a handle created without the *.fold tensors). */
 mbx_status mbx_stage(const mbx_handle *handle, const char *name, const void **device_ptr, int64_t *count,
                      int64_t *stride);
 

@@ -101,10 +101,14 @@ struct mbx_handle {
     long long mb_hc_per_frame = 0;                 // max over the blocks of rows per frame x channels
     bool fold_skip = false;      // skip path folded into the end convolution (needs the *.fold tensors)
     bool fold_start = false;     // start convolution folded into layer 0 (needs fold_skip and the *.start_fold / *.fold_start tensors)
-    bool winograd4_always = false;   // MBX_WINOGRAD=44: F(4,3) at every size (tests)
-    int gate_small_shape = -1;       // MBX_WG_SMALL=0|1: pins the F(4,3) block shape of small launches (256-row | product-split; measurements, tests)
+    bool winograd4_always = false;   // mbx_config.batch_invariant with F(4,3): the large-launch kernel shapes at every size
+    int gate_small_shape = -1;       // mbx_config.tune_gate_shape: pins the F(4,3) block shape of small launches (0: 256-row | 1: product-split; same bits)
     long long resskip_wave_tiles = 2048;   // default policy: res/skip launches of at most this many 16-row tiles run the wave-tiled kernel
-    int winograd = 0;            // gate layer form: 0 direct, 2 Winograd F(2,3), 4 Winograd F(4,3) (needs the packed weights)
+    int resskip_split = 0;           // mbx_config.tune_resskip_split
+    int winograd = 0;            // gate layer form in effect: 0 direct, 2 Winograd F(2,3), 4 Winograd F(4,3) (needs the packed weights)
+    // what mbx_conv_form reports
+    int calibrated = 0;
+    float calib_err43 = -1.f, calib_err23 = -1.f, calib_ref = 0.f, calib_threshold = 0.f;
     // bench-only kernel timing (mbx_profile_*): one event pool per stage of the launch sequence
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool[PROF_KINDS];
@@ -437,6 +441,11 @@ mbx::StftConsts stft_consts(const mbx_handle *hd) {
 
 extern "C" {
 
+// the form of the dilated convolution (mbx_config.wn_conv_form) and its calibration: defined behind forward_impl
+static bool form_available(const mbx_handle *hd, int form);
+static void set_form(mbx_handle *hd, int form);
+static mbx_status calibrate_on_synthetic_mel(mbx_handle *hd);
+
 const char *mbx_last_error(void) { return g_last_error.c_str(); }
 
 mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32_t n_tensors, int32_t device,
@@ -724,11 +733,15 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
     if (!c.ps_off && (hd->vtf_time_factor != 1 || vtf_out != c.n_ceps))
         return bail(fail(MBX_ERR_INVALID_ARGUMENT, "VTF sub-net must end with n_ceps channels at the mel frame rate"));
     hd->subnet_buf_per_frame = std::max(pf0, pvtf);
+    if (c.wn_conv_form < MBX_CONV_AUTO || c.wn_conv_form > MBX_CONV_F43)
+        return bail(fail(MBX_ERR_INVALID_ARGUMENT, "wn_conv_form must be MBX_CONV_AUTO, _DIRECT, _F23 or _F43"));
+    if (c.tune_gate_shape < 0 || c.tune_gate_shape > 2 || c.tune_resskip_split < 0 || c.tune_resskip_split > 3 ||
+        c.tune_resskip_wave_tiles < -1 || c.calib_fraction < 0.f || c.calib_fraction > 1.f)
+        return bail(fail(MBX_ERR_INVALID_ARGUMENT, "tune_* / calib_fraction out of range"));
     {
-        // skip path folded into the end convolution when the host supplied the folded tensors (MBX_FOLD_SKIP=0: keep
+        // skip path folded into the end convolution when the host supplied the folded tensors (wn_keep_skip: keep
         // the skip tensor, e.g. to look at the "wn_skip" stage)
-        const char *fv = getenv("MBX_FOLD_SKIP");
-        bool have = (!fv || atoi(fv) != 0) && c.wn_out_channels <= 32 && M <= 16;
+        bool have = !c.wn_keep_skip && c.wn_out_channels <= 32 && M <= 16;
         const long long nct = (C + c.wn_out_channels + 127) / 128, nk = (C + 15) / 16;
         for (int l = 0; l + 1 < c.wn_layers && have; ++l)
             have = expect("wn.res_skip_" + std::to_string(l) + ".fold", nct * nk * 2048) &&
@@ -737,9 +750,8 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
         if (c.n_wn_blocks >= 1) have = false;      // several blocks: generic kernels (run_wavenet_blocks)
         const bool sym = !c.wn_causal;              // the folded first layer and the Winograd forms assume SAME padding
         hd->fold_skip = have;
-        // start convolution folded into layer 0 (wn_gate0.hip); MBX_FOLD_START=0 keeps the h0 tensor and the full layer
-        const char *sv = getenv("MBX_FOLD_START");
-        bool have0 = have && sym && (!sv || atoi(sv) != 0) && c.wn_kernel_size == 3 &&
+        // start convolution folded into layer 0 (wn_gate0.hip); wn_keep_start keeps the h0 tensor and the full layer
+        bool have0 = have && sym && !c.wn_keep_start && c.wn_kernel_size == 3 &&
                      mbx::wn_gate0_fits(C, c.pulse_channels * (1 + c.wt_subharm_channels), c.wn_dilations[0], c.cond_lin_upsampling) &&
                      expect("wn.conv1D_0.start_fold", (long long)((C + 31) / 32) * 1536);
         if (have0 && c.wn_layers > 1)
@@ -747,17 +759,23 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
         hd->fold_start = have0;
     }
     {
-        const char *wv = getenv("MBX_WINOGRAD");
-        hd->winograd = wv ? atoi(wv) : 4;   // default F(4,3) / F(2,3) by size; MBX_WINOGRAD=2: F(2,3) only, 0: direct form
-        if (c.wn_causal) hd->winograd = 0;  // causal padding: the direct form (generic kernel)
-        if (hd->winograd == 44) {
-            hd->winograd = 4;
-            hd->winograd4_always = true;
+        hd->gate_small_shape = c.tune_gate_shape - 1;
+        if (c.tune_resskip_wave_tiles) hd->resskip_wave_tiles = std::max(0, c.tune_resskip_wave_tiles);
+        hd->resskip_split = c.tune_resskip_split;
+        // form of the dilated convolution: a Winograd form needs its weight images (for every layer that runs the gate
+        // kernels), SAME padding and kernel size 3; a handle without them runs the direct form whatever was asked for
+        const bool can43 = form_available(hd, MBX_CONV_F43), can23 = form_available(hd, MBX_CONV_F23);
+        int form = c.wn_conv_form;
+        const bool autoform = form == MBX_CONV_AUTO;
+        if (autoform) form = can43 ? MBX_CONV_F43 : can23 ? MBX_CONV_F23 : MBX_CONV_DIRECT;
+        if (form == MBX_CONV_F43 && !can43) form = can23 ? MBX_CONV_F23 : MBX_CONV_DIRECT;
+        if (form == MBX_CONV_F23 && !can23) form = MBX_CONV_DIRECT;
+        set_form(hd, form);
+        if (autoform && form != MBX_CONV_DIRECT) {
+            // MBX_CONV_AUTO: the Winograd forms must earn their place on this handle's own weights
+            st = calibrate_on_synthetic_mel(hd);
+            if (st != MBX_OK) return bail(st);
         }
-        const char *gs = getenv("MBX_WG_SMALL");
-        if (gs) hd->gate_small_shape = atoi(gs);
-        const char *rv = getenv("MBX_RV_TILES");
-        if (rv) hd->resskip_wave_tiles = atoll(rv);
     }
     *out = hd;
     return MBX_OK;
@@ -1293,7 +1311,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
             // product-split blocks half a tile: the finer shape runs when its worst SIMD gets clearly less work (a 10 s
             // utterance: 630 blocks = 2.46 per CU -> 3 tiles, against 1250 = 4.88 -> 5 halves).  Both give the same bits.
             // Streams run F(2,3): a window is bit-identical to an offline result only if both use one form with one group
-            // alignment (streaming.py), and F(2,3) needs the shorter alignment; MBX_WINOGRAD=2 makes offline runs use it too.
+            // alignment (streaming.py), and F(2,3) needs the shorter alignment; MBX_CONV_F23 makes offline runs use it too.
             const long long full_blocks = ((nsteps + 255) / 256) * B * ((C + 31) / 32);
             const long long half_blocks = ((nsteps + 127) / 128) * B * ((C + 31) / 32);
             const double load_full = (double)((full_blocks + 255) / 256), load_half = 0.5 * (double)((half_blocks + 255) / 256);
@@ -1311,7 +1329,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                 gw.w = wino4->ptr;
                 done = mbx::launch_wn_gate_winograd4w(gw, split4, stream);
             }
-            // F(2,3): wave-tiled kernel on v_mfma_f32_16x16x4_f32 (wn_winograd2w.hip): streams, per-layer regions, MBX_WINOGRAD=2
+            // F(2,3): wave-tiled kernel on v_mfma_f32_16x16x4_f32 (wn_winograd2w.hip): streams, per-layer regions, MBX_CONV_F23
             const DevTensor *wino = (!done && hd->winograd) ? find(hd, "wn.conv1D_" + ls + ".wino2w") : nullptr;
             if (wino && wino->ndim == 3 && wino->shape[0] == (C + 31) / 32 && wino->shape[1] == (C + 7) / 8 &&
                 wino->shape[2] == 2048) {
@@ -1348,7 +1366,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                 ScopedEvents ev(hd, PROF_RES_SKIP, stream);
                 // large launches (>= two rounds of the 512 resident 128-row blocks): one block owns all columns of its rows.
                 // Like the gate kernels' block shape this follows the launch size only under the default policy: a pinned
-                // form (MBX_WINOGRAD=0|2|44, streams) pins the kernel, so results do not depend on the batch they ran in.
+                // form (MBX_CONV_DIRECT, MBX_CONV_F23, batch_invariant, streams) pins the kernel, so results do not depend on the batch they ran in.
                 bool done = false;
                 const DevTensor *fww = find(hd, "wn.res_skip_" + ls + (ext ? ".fold_start_wide" : ".fold_wide"));
                 const long long wide_blocks = ((nsteps + 127) / 128) * B;
@@ -1360,7 +1378,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                     done = mbx::launch_wn_resskip_wide(rw, stream);
                 }
                 // small launches: wave-granular tiles (wn_resskip_wave.hip).  The form pinned by the streams and by
-                // MBX_WINOGRAD=2 (F(2,3) gate) runs this kernel at every size: an output's arithmetic does not depend on
+                // MBX_CONV_F23 (F(2,3) gate) runs this kernel at every size: an output's arithmetic does not depend on
                 // its cut, so windows, per-layer regions and whole utterances agree bit for bit.
                 const DevTensor *fwv = done ? nullptr : find(hd, "wn.res_skip_" + ls + (ext ? ".fold_start_wave" : ".fold_wave"));
                 const long long wave_tiles = ((long long)rs.max_rows + 15) / 16 * B;
@@ -1369,6 +1387,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                     (pinned23 || (hd->winograd == 4 && !hd->winograd4_always && wave_tiles <= hd->resskip_wave_tiles))) {
                     mbx::ConvArgs rw = r;
                     rw.w = fwv->ptr;
+                    rw.tune_split = hd->resskip_split;
                     done = mbx::launch_wn_resskip_wave(rw, stream);
                 }
                 if (!done && !mbx::launch_wn_resskip(r, stream)) return fail(MBX_ERR_INVALID_ARGUMENT, "folded res/skip layer does not fit its kernel");
@@ -1511,6 +1530,175 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     sg["cepstrum"] = {w_base.ceps, (long long)T * c.n_ceps, (long long)T * c.n_ceps};
     sg["ceps_index"] = {w_base.ceps_index, (long long)T, (long long)T};
     sg["frames"] = {w_base.frames, (long long)T * c.stft_win, (long long)T * c.stft_win};
+    return MBX_OK;
+}
+
+// ---- form of the dilated convolution -----------------------------------------------------------------------------------
+// A Winograd form is available when the host supplied its weight images for every layer that runs a gate kernel, the
+// padding is SAME and the kernel size 3 (layers whose dilation does not fit the kernels fall back per layer).
+static bool form_available(const mbx_handle *hd, int form) {
+    const mbx_config &c = hd->cfg;
+    if (form == MBX_CONV_DIRECT) return true;
+    if (form != MBX_CONV_F23 && form != MBX_CONV_F43) return false;
+    if (c.wn_causal || c.wn_kernel_size != 3) return false;
+    const bool f43 = form == MBX_CONV_F43;
+    auto images = [&](const std::string &prefix, int C, int l0) {
+        if (l0 >= c.wn_layers) return false;
+        for (int l = l0; l < c.wn_layers; ++l) {
+            const DevTensor *t = find(hd, prefix + "conv1D_" + std::to_string(l) + (f43 ? ".wino4w" : ".wino2w"));
+            if (!t || t->ndim != 3 || t->shape[0] != (C + 31) / 32 || t->shape[1] != (C + 7) / 8 || t->shape[2] != (f43 ? 3072 : 2048))
+                return false;
+        }
+        return true;
+    };
+    if (!hd->blocks.empty()) {
+        if (!f43) return false;             // the block runner knows the F(4,3) and the direct form
+        for (const auto &blk : hd->blocks)
+            if (!images(blk.prefix, blk.C, 0)) return false;
+        return true;
+    }
+    return images("wn.", c.wn_channels, hd->fold_start ? 1 : 0);
+}
+
+static void set_form(mbx_handle *hd, int form) {
+    hd->winograd = form == MBX_CONV_F43 ? 4 : form == MBX_CONV_F23 ? 2 : 0;
+    if (hd->cfg.wn_causal) hd->winograd = 0;  // causal padding: the direct form (generic kernel)
+    hd->winograd4_always = hd->winograd == 4 && hd->cfg.batch_invariant != 0;
+}
+
+static int current_form(const mbx_handle *hd) {
+    return hd->winograd == 4 ? MBX_CONV_F43 : hd->winograd == 2 ? MBX_CONV_F23 : MBX_CONV_DIRECT;
+}
+
+// One calibration: the same input through the direct form, F(4,3) and F(2,3); the fastest form whose audio differs from
+// the direct form's by at most calib_fraction of the parity budget 1e-4 * max(1, |audio|) is adopted.  The difference
+// between two float32 forms measures the rounding of the less exact one (F(4,3): ~5x the direct form's, growing with the
+// amplitude of the residual stream).  Synchronises.
+static mbx_status calibrate_run(mbx_handle *hd, const float *mel, const int32_t *n_frames, int B, int T, const float *noise,
+                                void *workspace, size_t workspace_bytes, hipStream_t stream, int kind) {
+    const size_t n = (size_t)B * T * hd->cfg.hop_size;
+    float *audio_dev = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&audio_dev), n * sizeof(float)));
+    std::vector<float> ref(n), got(n);
+    const bool was_profiling = hd->profiling;
+    hd->profiling = false;
+    const int form_before = current_form(hd);
+    auto run = [&](int form, std::vector<float> &host) -> mbx_status {
+        set_form(hd, form);
+        mbx_status st = forward_impl(hd, mel, n_frames, B, T, noise, audio_dev, workspace, workspace_bytes, stream);
+        if (st != MBX_OK) return st;
+        if (hipMemcpyAsync(host.data(), audio_dev, n * sizeof(float), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess)
+            return fail(MBX_ERR_HIP, "calibration: reading the audio back failed");
+        return MBX_OK;
+    };
+    auto done = [&](mbx_status st) {
+        (void)hipFree(audio_dev);
+        hd->profiling = was_profiling;
+        if (st != MBX_OK) set_form(hd, form_before);
+        return st;
+    };
+    mbx_status st = run(MBX_CONV_DIRECT, ref);
+    if (st != MBX_OK) return done(st);
+    float ref_max = 0.f;
+    bool finite = true;
+    for (float v : ref) {
+        if (!std::isfinite(v)) finite = false;
+        ref_max = std::max(ref_max, std::fabs(v));
+    }
+    const float frac = hd->cfg.calib_fraction > 0.f ? hd->cfg.calib_fraction : 0.25f;
+    const float threshold = frac * 1e-4f * std::max(1.f, ref_max);
+    float err[2] = {-1.f, -1.f};
+    const int forms[2] = {MBX_CONV_F43, MBX_CONV_F23};
+    for (int k = 0; k < 2; ++k) {
+        if (!form_available(hd, forms[k])) continue;
+        st = run(forms[k], got);
+        if (st != MBX_OK) return done(st);
+        float e = 0.f;
+        for (size_t i = 0; i < n; ++i) {
+            const float d = std::fabs(got[i] - ref[i]);
+            e = std::isfinite(d) ? std::max(e, d) : INFINITY;
+        }
+        err[k] = e;
+    }
+    int form = MBX_CONV_DIRECT;
+    if (finite && err[0] >= 0.f && err[0] <= threshold) form = MBX_CONV_F43;
+    else if (finite && err[1] >= 0.f && err[1] <= threshold) form = MBX_CONV_F23;
+    set_form(hd, form);
+    hd->calibrated = kind;
+    hd->calib_err43 = err[0];
+    hd->calib_err23 = err[1];
+    hd->calib_ref = ref_max;
+    hd->calib_threshold = threshold;
+    return done(MBX_OK);
+}
+
+// MBX_CONV_AUTO at mbx_create: two items of 40 frames of seeded synthetic log-mel input -- one with independent values
+// of the level statistics the models are fed with (N(-5, 2^2) log amplitudes, clipped like scale_mel's output), one a
+// smooth loud sweep that drives the conditioning towards the saturated side of the gates -- and a seeded noise draw.
+// What is measured is this handle's own weights on plausible input, not the user's data: mbx_calibrate does that.
+static mbx_status calibrate_on_synthetic_mel(mbx_handle *hd) {
+    const mbx_config &c = hd->cfg;
+    const int B = 2, T = 40;
+    uint64_t rs = 0x9E3779B97F4A7C15ull;
+    auto uni = [&]() {                       // xorshift64*: (0, 1]
+        rs ^= rs >> 12;
+        rs ^= rs << 25;
+        rs ^= rs >> 27;
+        return (double)(((rs * 0x2545F4914F6CDD1Dull) >> 11) + 1) / 9007199254740992.0;
+    };
+    auto gauss = [&]() { return std::sqrt(-2.0 * std::log(uni())) * std::cos(2.0 * M_PI * uni()); };
+    std::vector<float> mel((size_t)B * T * c.mel_channels), noise((size_t)B * T * c.steps_per_frame);
+    for (int t = 0; t < T; ++t)
+        for (int m = 0; m < c.mel_channels; ++m) {
+            const double v0 = std::log(std::exp(-5.0 + 2.0 * gauss()) + 1e-5);
+            const double v1 = -3.0 + 4.0 * std::sin(0.21 * t + 0.08 * m) + 1.5 * std::cos(0.045 * m * (1 + t % 7)) + 0.3 * gauss();
+            mel[((size_t)0 * T + t) * c.mel_channels + m] = (float)std::min(2.0, std::max(-11.5, v0));
+            mel[((size_t)1 * T + t) * c.mel_channels + m] = (float)std::min(2.0, std::max(-11.5, v1));
+        }
+    for (float &v : noise) v = (float)gauss();
+    const size_t ws_bytes = mbx_workspace_size(hd, B, T);
+    float *mel_dev = nullptr, *noise_dev = nullptr;
+    void *ws = nullptr;
+    auto release = [&](mbx_status st) {
+        if (mel_dev) (void)hipFree(mel_dev);
+        if (noise_dev) (void)hipFree(noise_dev);
+        if (ws) (void)hipFree(ws);
+        return st;
+    };
+    if (hipMalloc(reinterpret_cast<void **>(&mel_dev), mel.size() * sizeof(float)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&noise_dev), noise.size() * sizeof(float)) != hipSuccess ||
+        hipMalloc(&ws, ws_bytes) != hipSuccess ||
+        hipMemcpy(mel_dev, mel.data(), mel.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(noise_dev, noise.data(), noise.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        return release(fail(MBX_ERR_HIP, "calibration: device allocation / upload failed"));
+    return release(calibrate_run(hd, mel_dev, nullptr, B, T, c.noise_sigma != 0.f ? noise_dev : nullptr, ws, ws_bytes, nullptr, 1));
+}
+
+mbx_status mbx_calibrate(mbx_handle *hd, const float *mel, const int32_t *n_frames, int32_t batch, int32_t max_frames,
+                         const float *noise, void *workspace, size_t workspace_bytes, void *hip_stream) {
+    if (!hd || !mel || !workspace) return fail(MBX_ERR_INVALID_ARGUMENT, "null argument");
+    if (batch <= 0 || max_frames <= 0) return fail(MBX_ERR_INVALID_ARGUMENT, "batch and max_frames must be positive");
+    DeviceGuard guard(hd->device);
+    if (!guard.ok) return fail(MBX_ERR_HIP, "cannot select the handle's device");
+    return calibrate_run(hd, mel, n_frames, batch, max_frames, noise, workspace, workspace_bytes,
+                         static_cast<hipStream_t>(hip_stream), 2);
+}
+
+mbx_status mbx_conv_form(const mbx_handle *hd, mbx_conv_form_info *info) {
+    if (!hd || !info || info->struct_size != (int32_t)sizeof(mbx_conv_form_info))
+        return fail(MBX_ERR_INVALID_ARGUMENT, "mbx_conv_form_info ABI mismatch (struct_size)");
+    info->requested = hd->cfg.wn_conv_form;
+    info->form = current_form(hd);
+    info->stream_form = hd->winograd != 0 && form_available(hd, MBX_CONV_F23) ? MBX_CONV_F23 : MBX_CONV_DIRECT;
+    info->calibrated = hd->calibrated;
+    info->batch_invariant = (hd->winograd != 4 || hd->winograd4_always) ? 1 : 0;
+    info->fold_skip = hd->fold_skip;
+    info->fold_start = hd->fold_start;
+    info->err_f43 = hd->calib_err43;
+    info->err_f23 = hd->calib_err23;
+    info->ref_max = hd->calib_ref;
+    info->threshold = hd->calib_threshold;
     return MBX_OK;
 }
 

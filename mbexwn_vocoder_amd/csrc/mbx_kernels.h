@@ -89,6 +89,7 @@ struct ConvArgs {
                               // computed (out_rows == 0: all rows; out_row0 a multiple of 2 * dil)
     const float *zeros;       // >= 16 bytes of zeros in global memory (LDS-DMA source of padding lanes)
     int fast_dma;             // set by the launcher: 32-bit source offsets are safe (LDS-DMA with a uniform base)
+    int tune_split;           // wave-tiled res/skip kernel: 1..3 pins its column split (mbx_config.tune_resskip_split; same bits), 0: by launch size
 };
 
 void launch_conv1d(const ConvArgs &a, int epilogue, hipStream_t stream);
@@ -99,7 +100,7 @@ void launch_conv1d_group(const ConvArgs *convs, int n, hipStream_t stream);
 // (same bits as the 256-row blocks)
 bool launch_wn_gate_winograd4w(const ConvArgs &a, bool split, hipStream_t stream);
 // Winograd F(2,3) form on v_mfma_f32_16x16x4_f32 with wave-granular tiles (wn_winograd2w.hip: streams, per-layer regions,
-// MBX_WINOGRAD=2); a.w = image of engine.pack_winograd2w_weights (ceil(C/32), ceil(C/8), 2048)
+// MBX_CONV_F23); a.w = image of engine.pack_winograd2w_weights (ceil(C/32), ceil(C/8), 2048)
 bool launch_wn_gate_winograd2w(const ConvArgs &a, hipStream_t stream);
 // First WaveNet layer with the start convolution folded into it (wn_gate0.hip)
 struct Gate0Args {

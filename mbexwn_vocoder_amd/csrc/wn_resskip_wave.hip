@@ -311,12 +311,8 @@ bool launch_wn_resskip_wave(const ConvArgs &a, hipStream_t stream) {
     r.m_tiles_per_item = (a.max_rows + 15) / 16;
     r.m_tiles_total = r.m_tiles_per_item * a.batch;
     const unsigned groups = (unsigned)((r.m_tiles_total + 3) / 4);
-    static const int forced = []() {
-        const char *sv = getenv("MBX_RV_SPLIT");
-        return sv ? atoi(sv) : 0;
-    }();
     // waves per SIMD with s column splits = tiles * s / 1024: take the cut whose last round is fullest
-    int split = forced;
+    int split = a.tune_split;
     if (split != 1 && split != 2 && split != 3) {
         double best = -1.0;
         for (int s = 1; s <= 3; ++s) {

@@ -19,7 +19,7 @@ from .config import ModelDims
 from .subnet import build_subnet
 from .weights import fold_weights, merge_channel_groups
 
-MBX_ABI_VERSION = 6
+MBX_ABI_VERSION = 7
 MBX_MAX_SUBNET_OPS = 32
 MBX_MAX_WN_LAYERS = 64
 MBX_MAX_PRECOND = 8
@@ -69,7 +69,22 @@ class mbx_config(ctypes.Structure):
                 ("ps_off", ctypes.c_int32), ("no_pqmf", ctypes.c_int32), ("n_wn_blocks", ctypes.c_int32),
                 ("wn_block_channels", ctypes.c_int32 * MBX_MAX_WN_BLOCKS), ("wn_block_ups", ctypes.c_int32 * MBX_MAX_WN_BLOCKS),
                 ("pulse_pqmf_taps", ctypes.c_int32), ("ps_subband_gain", ctypes.c_int32),
-                ("wn_causal", ctypes.c_int32)]
+                ("wn_causal", ctypes.c_int32),
+                ("wn_conv_form", ctypes.c_int32), ("batch_invariant", ctypes.c_int32), ("wn_keep_skip", ctypes.c_int32),
+                ("wn_keep_start", ctypes.c_int32), ("calib_fraction", ctypes.c_float), ("tune_gate_shape", ctypes.c_int32),
+                ("tune_resskip_wave_tiles", ctypes.c_int32), ("tune_resskip_split", ctypes.c_int32),
+                ("reserved7", ctypes.c_int32 * 4)]
+
+
+class mbx_conv_form_info(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_int32), ("requested", ctypes.c_int32), ("form", ctypes.c_int32),
+                ("stream_form", ctypes.c_int32), ("calibrated", ctypes.c_int32), ("batch_invariant", ctypes.c_int32),
+                ("fold_skip", ctypes.c_int32), ("fold_start", ctypes.c_int32), ("err_f43", ctypes.c_float),
+                ("err_f23", ctypes.c_float), ("ref_max", ctypes.c_float), ("threshold", ctypes.c_float)]
+
+
+CONV_FORMS = {"auto": 0, "direct": 1, "f23": 2, "f43": 3}
+_CONV_FORM_NAMES = {vv: kk for kk, vv in CONV_FORMS.items()}
 
 
 class mbx_forward_options(ctypes.Structure):
@@ -101,9 +116,12 @@ def load_library():
     # live in ONE HIP runtime instance (torch bundles libamdhip64.so.7; loading ours first would give the
     # process a second, separate runtime).
     import torch  # noqa: F401
-    # MBX_LIB_PATH: another build of the same library (kernel experiments, scripts/experiments/) -- never a fallback; it is
-    # an MBX_* variable, so bench.py records it in its line
+    # MBX_LIB_PATH: another build of the same library (kernel experiments, scripts/experiments/, whose ablated kernels
+    # produce wrong audio on purpose) -- never a fallback; said on stderr so that a stale variable cannot go unnoticed
     path = os.environ.get("MBX_LIB_PATH") or LIB_PATH
+    if path != LIB_PATH:
+        import sys
+        print(f"mbexwn_vocoder_amd: MBX_LIB_PATH overrides the product library: loading {path}", file=sys.stderr)
     if not os.path.exists(path):
         raise RuntimeError(f"HIP extension {path} is missing: run `python -m mbexwn_vocoder_amd.build` "
                            "(there is no CPU fallback for the mel-inversion path)")
@@ -116,6 +134,10 @@ def load_library():
                                ctypes.POINTER(ctypes.c_void_p)]
     lib.mbx_destroy.restype = i32
     lib.mbx_destroy.argtypes = [vp]
+    lib.mbx_conv_form.restype = i32
+    lib.mbx_conv_form.argtypes = [vp, ctypes.POINTER(mbx_conv_form_info)]
+    lib.mbx_calibrate.restype = i32
+    lib.mbx_calibrate.argtypes = [vp, fp, vp, i32, i32, fp, vp, ctypes.c_size_t, vp]
     lib.mbx_workspace_size.restype = ctypes.c_size_t
     lib.mbx_workspace_size.argtypes = [vp, i32, i32]
     lib.mbx_forward.restype = i32
@@ -153,7 +175,7 @@ def load_library():
     return lib
 
 
-EXPORTED_SYMBOLS = ["mbx_last_error", "mbx_create", "mbx_destroy", "mbx_workspace_size", "mbx_forward",
+EXPORTED_SYMBOLS = ["mbx_last_error", "mbx_create", "mbx_destroy", "mbx_conv_form", "mbx_calibrate", "mbx_workspace_size", "mbx_forward",
                     "mbx_forward_stream", "mbx_forward_ex", "mbx_layer_state_info", "mbx_window_advance", "mbx_stage",
                     "mbx_profile_enable", "mbx_profile_read", "mbx_pqmf_synthesis", "mbx_conv1d", "mbx_lin_interp", "mbx_wavetable", "mbx_stft_filter", "mbx_norm_mel", "mbx_mel_analysis"]
 
@@ -208,7 +230,45 @@ def _fill_ops(dst, ops):
     return len(ops)
 
 
-def make_config(config, wavetables):
+def experiment_overrides():
+    """The MBX_* environment variables of the experiment scripts and fuzzers, mapped onto the mbx_config policy fields
+    (the library itself reads no environment variable): MBX_WINOGRAD=0|2|4|44 -> conv_form direct / f23 / f43 / f43 +
+    batch_invariant, MBX_FOLD_SKIP=0 / MBX_FOLD_START=0 -> keep_skip / keep_start, MBX_WG_SMALL=0|1 -> tune_gate_shape 1|2,
+    MBX_RV_TILES=n -> tune_resskip_wave_tiles (0 = never), MBX_RV_SPLIT=1|2|3 -> tune_resskip_split.  Only consulted for
+    policy arguments the caller left unset; every variable in effect is named on stderr."""
+    env, out = os.environ, {}
+    if "MBX_WINOGRAD" in env:
+        mode = int(env["MBX_WINOGRAD"])
+        out["conv_form"] = {0: "direct", 2: "f23", 4: "f43", 44: "f43"}[mode]
+        if mode == 44:
+            out["batch_invariant"] = True
+    if env.get("MBX_FOLD_SKIP", "1") == "0":
+        out["keep_skip"] = True
+    if env.get("MBX_FOLD_START", "1") == "0":
+        out["keep_start"] = True
+    tune = {}
+    if "MBX_WG_SMALL" in env:
+        tune["gate_shape"] = 1 if int(env["MBX_WG_SMALL"]) == 0 else 2
+    if "MBX_RV_TILES" in env:
+        tune["resskip_wave_tiles"] = int(env["MBX_RV_TILES"]) or -1
+    if "MBX_RV_SPLIT" in env:
+        tune["resskip_split"] = int(env["MBX_RV_SPLIT"])
+    if tune:
+        out["tune"] = tune
+    if out:
+        import sys
+        names = [kk for kk in ("MBX_WINOGRAD", "MBX_FOLD_SKIP", "MBX_FOLD_START", "MBX_WG_SMALL", "MBX_RV_TILES", "MBX_RV_SPLIT")
+                 if kk in env]
+        print(f"mbexwn_vocoder_amd: experiment variables in effect: {' '.join(f'{kk}={env[kk]}' for kk in names)}",
+              file=sys.stderr)
+    return out
+
+
+def make_config(config, wavetables, conv_form=None, batch_invariant=None, keep_skip=None, keep_start=None,
+                calib_fraction=None, tune=None):
+    """mbx_config of a model.  Policy arguments (None = default, or the experiment variable if one is set):
+    conv_form "auto" | "direct" | "f23" | "f43" (mbx_config.wn_conv_form), batch_invariant, keep_skip, keep_start,
+    calib_fraction, tune = {"gate_shape": 0|1|2, "resskip_wave_tiles": n, "resskip_split": 0..3}."""
     dims = ModelDims(config)
     mb = config["mbexwn_config"]
     cc = mbx_config()
@@ -277,6 +337,19 @@ def make_config(config, wavetables):
         cc.nm_compressor_exp = float(nm.compressor_exp) if nm.compressor_exp is not None else 1.0
         cc.nm_lin_amp_scale, cc.nm_lin_amp_off = float(nm.lin_amp_scale), float(nm.lin_amp_off)
         cc.nm_mel_amp_scale = float(nm.mel_amp_scale)
+    over = experiment_overrides() if None in (conv_form, batch_invariant, keep_skip, keep_start, tune) else {}
+    conv_form = over.get("conv_form", "auto") if conv_form is None else conv_form
+    if conv_form not in CONV_FORMS:
+        raise ValueError(f"conv_form must be one of {sorted(CONV_FORMS)}")
+    cc.wn_conv_form = CONV_FORMS[conv_form]
+    cc.batch_invariant = int(over.get("batch_invariant", False) if batch_invariant is None else batch_invariant)
+    cc.wn_keep_skip = int(over.get("keep_skip", False) if keep_skip is None else keep_skip)
+    cc.wn_keep_start = int(over.get("keep_start", False) if keep_start is None else keep_start)
+    cc.calib_fraction = float(calib_fraction or 0.0)
+    tune = over.get("tune", {}) if tune is None else tune
+    cc.tune_gate_shape = int(tune.get("gate_shape", 0))
+    cc.tune_resskip_wave_tiles = int(tune.get("resskip_wave_tiles", 0))
+    cc.tune_resskip_split = int(tune.get("resskip_split", 0))
     return cc, dims
 
 
@@ -545,9 +618,16 @@ def tensor_table(config, raw_weights, wavetables):
 class MBExWNEngine:
     """Device-resident MBExWN generator. One instance per GPU (one process per GPU)."""
 
-    def __init__(self, config, raw_weights, wavetables=None, device=None, weight_images=True):
+    def __init__(self, config, raw_weights, wavetables=None, device=None, weight_images=True, conv_form=None,
+                 batch_invariant=None, keep_skip=None, keep_start=None, calib_fraction=None, tune=None):
         """``weight_images=False`` hands mbx_create only the folded weights and the tables (what a minimal binding of the
-        C ABI would do): the engine then runs its generic kernels instead of the specialised ones."""
+        C ABI would do): the engine then runs its generic kernels instead of the specialised ones.
+
+        ``conv_form`` = "auto" (default: Winograd F(4,3) when a calibration forward on this model's own weights stays
+        within a quarter of the parity budget of the direct form, else F(2,3), else the direct form -- see
+        :meth:`conv_form_info`, :meth:`calibrate`), "direct", "f23" or "f43"; ``batch_invariant=True`` pins the kernels so
+        that an utterance's bits do not depend on the batch it ran in; ``keep_skip`` / ``keep_start`` keep the un-folded
+        graph; ``tune`` holds measurement knobs (make_config)."""
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("MBExWNEngine needs an AMD GPU (no CPU fallback for the mel-inversion path)")
@@ -559,7 +639,9 @@ class MBExWNEngine:
             wavetables = tb.WaveTables(sample_rate=dims.pulse_rate, **config["mbexwn_config"]["wavetable_config"])
         self.wavetables = wavetables
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
-        cconf, self.dims = make_config(config, wavetables)
+        cconf, self.dims = make_config(config, wavetables, conv_form=conv_form, batch_invariant=batch_invariant,
+                                       keep_skip=keep_skip, keep_start=keep_start, calib_fraction=calib_fraction, tune=tune)
+        self._tune_gate_shape = cconf.tune_gate_shape
         self.normalizes_rms = cconf.nm_iters > 0            # row A14: done on the device inside mbx_forward
         self._tensors = tensor_table(config, raw_weights, wavetables)   # keep the host arrays alive
         if not weight_images:
@@ -796,38 +878,64 @@ class MBExWNEngine:
         _check(self._lib.mbx_profile_read(self._handle, kernel.encode(), ctypes.byref(ms), ctypes.byref(cnt)))
         return ms.value, cnt.value
 
+    def conv_form_info(self):
+        """What the handle decided about the dilated convolution (mbx_conv_form): dict with ``requested`` / ``form`` /
+        ``stream_form`` ("auto" | "direct" | "f23" | "f43"), ``calibrated`` (0 no, 1 on the built-in synthetic mel at
+        creation, 2 on caller data), ``batch_invariant``, ``fold_skip``, ``fold_start``, and the calibration's numbers
+        ``err_f43`` / ``err_f23`` (max |audio(form) - audio(direct)|, None: form not available), ``ref_max``,
+        ``threshold``."""
+        info = mbx_conv_form_info()
+        info.struct_size = ctypes.sizeof(mbx_conv_form_info)
+        _check(self._lib.mbx_conv_form(self._handle, ctypes.byref(info)))
+        return {"requested": _CONV_FORM_NAMES[info.requested], "form": _CONV_FORM_NAMES[info.form],
+                "stream_form": _CONV_FORM_NAMES[info.stream_form], "calibrated": info.calibrated,
+                "batch_invariant": bool(info.batch_invariant), "fold_skip": bool(info.fold_skip),
+                "fold_start": bool(info.fold_start),
+                "err_f43": None if info.err_f43 < 0 else float(info.err_f43),
+                "err_f23": None if info.err_f23 < 0 else float(info.err_f23),
+                "ref_max": float(info.ref_max), "threshold": float(info.threshold)}
+
+    def calibrate(self, mel, n_frames=None, noise=None):
+        """mbx_calibrate: repeat the form calibration on the caller's own mel batch (device tensors as for
+        :meth:`forward`) and adopt its decision; returns :meth:`conv_form_info`.  Synchronises."""
+        torch = self._torch
+        mel = mel.to(self.device, torch.float32).contiguous()
+        B, T = int(mel.shape[0]), int(mel.shape[1])
+        if self.dims.noise_sigma and noise is None:
+            noise = torch.randn((B, T * self.dims.wn_in_rows_per_frame), device=self.device, dtype=torch.float32)
+        if noise is not None:
+            noise = noise.to(self.device, torch.float32).contiguous()
+        ws, need = self._get_workspace(B, T)
+        _check(self._lib.mbx_calibrate(self._handle, mel.data_ptr(), n_frames.data_ptr() if n_frames is not None else None,
+                                       B, T, noise.data_ptr() if noise is not None else None, ws.data_ptr(), need,
+                                       self._stream()))
+        return self.conv_form_info()
+
     def gate_form(self, batch, max_frames):
-        """Which implementation of the dilated convolution a forward of this size runs (mirror of the policy in
-        csrc/mbx_api.hip: MBX_WINOGRAD, read by mbx_create, default 4 = F(4,3), with 256-row blocks, or 128-row blocks
-        whose waves split the six products where those spread the work clearly more evenly over the SIMDs; streams always
-        run F(2,3)): "direct", "winograd_f23", "winograd_f43" or "winograd_f43_psplit"."""
-        mode = int(os.environ.get("MBX_WINOGRAD", "4"))
-        if mode == 0 or self.dims.wn_kernel_size != 3:
+        """Which implementation of the dilated convolution a forward of this size runs: the handle's form
+        (mbx_conv_form) and, for F(4,3), the block shape the library's launch-size rule picks (csrc/mbx_api.hip: 256-row
+        blocks, or 128-row blocks whose waves split the six products where those spread the work clearly more evenly over
+        the SIMDs; both give the same bits): "direct", "winograd_f23", "winograd_f43" or "winograd_f43_psplit"."""
+        info = self.conv_form_info()
+        if info["form"] == "direct":
             return "direct"
-        if mode not in (4, 44):
+        if info["form"] == "f23":
             return "winograd_f23"
         rows = max_frames * self.dims.steps_per_frame
         tiles = (self.dims.wn_channels + 31) // 32
         full_blocks = ((rows + 255) // 256) * batch * tiles
         half_blocks = ((rows + 127) // 128) * batch * tiles
-        if mode == 44:
+        if info["batch_invariant"]:
             return "winograd_f43"
-        small = os.environ.get("MBX_WG_SMALL")
-        if small is not None and full_blocks < 4 * 768:
-            return "winograd_f43" if small == "0" else "winograd_f43_psplit"
+        if self._tune_gate_shape and full_blocks < 4 * 768:
+            return "winograd_f43" if self._tune_gate_shape == 1 else "winograd_f43_psplit"
         load_full, load_half = (full_blocks + 255) // 256, 0.5 * ((half_blocks + 255) // 256)
         return "winograd_f43_psplit" if full_blocks <= 1024 and load_half <= load_full else "winograd_f43"
 
     @property
     def folds_start(self):
-        """True when layer 0 runs with the start convolution folded in (csrc/wn_gate0.hip): mirror of mbx_create's
-        policy (MBX_FOLD_SKIP / MBX_FOLD_START not 0, the folded tensors exist and the layer fits the kernel)."""
-        cu = self.dims.cond_lin_upsampling
-        fits = ((256 + cu - 2) // cu + 2 <= 32 and self.dims.wn_dilation(0) <= 16 and self.dims.pulse_channels_eff + 2 <= 8 and
-                self.dims.wn_kernel_size == 3 and self.dims.wn_padding == "SAME" and not self.dims.wn_multi)   # wn_gate0_fits (csrc/wn_gate0.hip)
-        return (int(os.environ.get("MBX_FOLD_SKIP", "1")) != 0 and int(os.environ.get("MBX_FOLD_START", "1")) != 0 and fits and
-                "wn.conv1D_0.start_fold" in self._tensors and
-                (self.dims.wn_layers == 1 or "wn.res_skip_0.fold_start" in self._tensors))
+        """True when layer 0 runs with the start convolution folded in (csrc/wn_gate0.hip): what mbx_create decided."""
+        return self.conv_form_info()["fold_start"]
 
     def stage(self, name):
         """Intermediate tensor of the last forward (copy), shaped (B, count); see mbx_stage."""

@@ -235,7 +235,7 @@ def create_synthetic_model_dir(path, voice_type="SPEECH", seed=1234, weights_for
     raw = synthetic_weights(cfg, seed=seed)
     if weights_format == "tf":
         from .tf_checkpoint import to_reference_variables, write_checkpoint
-        write_checkpoint(os.path.join(path, "weights.tf"), to_reference_variables(raw))
+        write_checkpoint(os.path.join(path, "weights.tf"), to_reference_variables(raw, config=cfg))
     else:
         save_weights(os.path.join(path, "weights.npz"), raw)
     return path

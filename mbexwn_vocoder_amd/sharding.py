@@ -47,8 +47,11 @@ class ShardResult:
     ``parts[r]`` is rank r's shard: its utterances (LPT order) packed back to back in one flat float32 tensor
     (``None`` for ranks whose shard this process does not hold)."""
 
-    def __init__(self, parts, shards, lengths, hop):
+    def __init__(self, parts, shards, lengths, hop, timing=None):
         self.parts, self.shards, self.lengths, self.hop = parts, shards, lengths, hop
+        # {"compute_ms", "gather_ms", "chunks"} of the run that produced it (this rank): forward passes + packing, and the
+        # part of the gather that was NOT hidden behind them (time between the last forward and the last chunk's arrival)
+        self.timing = timing or {}
 
     def item(self, index):
         """Audio of utterance ``index`` as a view of the flat shard (tensor), or None if its shard is not held here."""
@@ -88,7 +91,7 @@ class ShardedSynthesizer:
     """
 
     def __init__(self, forward_fn, hop_size, steps_per_frame, rank=0, world_size=1, max_batch=16,
-                 max_padded_frames=16 * 1200, device=None, force_collective=False):
+                 max_padded_frames=16 * 1200, device=None, force_collective=False, gather_chunk_floats=1 << 22):
         self.forward_fn = forward_fn
         self.hop = int(hop_size)
         self.spf = int(steps_per_frame)
@@ -98,6 +101,9 @@ class ShardedSynthesizer:
         # run the gather collective even with one rank (an initialised process group is then required): lets a 1-GPU
         # box execute the RCCL path that N > 1 takes
         self.force_collective = bool(force_collective)
+        # the shard buffer is gathered in chunks of this many floats (16 MB), each as soon as the micro-batches that fill it
+        # have been packed, asynchronously: the transfer of micro-batch i runs under the forward pass of micro-batch i + 1
+        self.gather_chunk_floats = max(1, int(gather_chunk_floats))
 
     def stage(self, mels, noises=None):
         """Partition, pad and (with a device) upload this rank's micro-batches.  Returns the plan for run_staged."""
@@ -121,46 +127,96 @@ class ShardedSynthesizer:
         totals = [sum(lengths[ii] for ii in ss) * self.hop for ss in shards]
         dev = self.device if self.device is not None else torch.device("cpu")
         # one padded flat buffer per rank (all_gather needs equal sizes); reused by every run_staged of this plan
-        flat = torch.zeros(max(totals) if totals else 0, dtype=torch.float32, device=dev)
+        flat = torch.zeros(max(totals) if totals else 0, dtype=torch.float32, device=dev)   # (equal sizes: collectives)
         return {"lengths": lengths, "shards": shards, "batches": batches, "totals": totals, "flat": flat, "parts": None}
 
-    def run_staged(self, plan, gather="all"):
+    def _now(self):
+        """Time stamp of this point of the launch sequence: an event on the device's current stream, wall clock on the CPU."""
+        import time
+        import torch
+        if self.device is not None and torch.device(self.device).type == "cuda":
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(self.device))
+            return ev
+        return time.perf_counter()
+
+    @staticmethod
+    def _elapsed_ms(t0, t1):
+        if isinstance(t0, float):
+            return (t1 - t0) * 1e3
+        t1.synchronize()
+        return float(t0.elapsed_time(t1))
+
+    def run_staged(self, plan, gather="rank0"):
         """Forward passes of this rank's micro-batches + the result gather; everything stays on the plan's device.
-        gather: "all" (every rank gets every shard), "rank0" (rank 0 only) or None (local shard only)."""
+        gather: "rank0" (default: rank 0 gets every shard -- the shape of the CLI job, whose audio one process writes out),
+        "all" (every rank gets every shard) or None (local shard only: zero collectives, e.g. every rank writes its own
+        files).  The gather is chunked and asynchronous: the shard buffer (micro-batches packed back to back, the same
+        size on every rank) is cut into ``gather_chunk_floats`` pieces, and a piece is handed to the collective as soon as
+        the micro-batches that fill it have been packed -- on NCCL/RCCL the transfer then runs on the communicator's own
+        stream under the next micro-batch's forward pass.  Every rank issues the pieces in the same order."""
         import torch
         lengths, shards, flat = plan["lengths"], plan["shards"], plan["flat"]
+        collective = gather is not None and (self.world > 1 or self.force_collective)
+        chunk = self.gather_chunk_floats
+        n_chunks = (int(flat.numel()) + chunk - 1) // chunk if collective else 0
+        if collective:
+            import torch.distributed as dist
+            if plan["parts"] is None and (gather == "all" or self.rank == 0):
+                plan["parts"] = [torch.empty_like(flat) for _ in range(self.world)]
+        works, issued = [], 0
+
+        def issue_upto(filled):
+            """Hand every piece that lies completely in front of position ``filled`` to the collective."""
+            nonlocal issued
+            while issued < n_chunks and min((issued + 1) * chunk, int(flat.numel())) <= filled:
+                lo, hi = issued * chunk, min((issued + 1) * chunk, int(flat.numel()))
+                src = flat[lo:hi]
+                if gather == "rank0":
+                    dst = [pp[lo:hi] for pp in plan["parts"]] if self.rank == 0 else None
+                    works.append(dist.gather(src, dst, dst=0, async_op=True))
+                else:
+                    works.append(dist.all_gather([pp[lo:hi] for pp in plan["parts"]], src, async_op=True))
+                issued += 1
+
+        t_start = self._now()
+        pos, order = 0, list(shards[self.rank])
+        done = 0                                           # utterances of the shard packed so far (shard order)
         where = {}
         for group, mel, nfr, noise in plan["batches"]:
             audio = self.forward_fn(mel, nfr, noise)
             audio = audio if torch.is_tensor(audio) else torch.as_tensor(np.asarray(audio))
             for jj, ii in enumerate(group):
                 where[ii] = (audio, jj)
-        pos = 0
-        for ii in shards[self.rank]:                       # pack in shard order (device-side copies, no sync)
-            audio, jj = where[ii]
-            nn = lengths[ii] * self.hop
-            flat[pos:pos + nn] = audio[jj, :nn]
-            pos += nn
-        assert pos == plan["totals"][self.rank]
+            # pack what is complete, in shard order (device-side copies, no sync): micro-batches and shards are both sorted
+            # by falling length, so a micro-batch fills the next contiguous stretch of the shard buffer
+            while done < len(order) and order[done] in where:
+                audio_i, jj = where.pop(order[done])
+                nn = lengths[order[done]] * self.hop
+                flat[pos:pos + nn] = audio_i[jj, :nn]
+                pos += nn
+                done += 1
+            if collective:
+                issue_upto(pos)
+        assert pos == plan["totals"][self.rank] and done == len(order) and not where
+        t_compute = self._now()
         parts = [None] * self.world
-        if (self.world == 1 and not self.force_collective) or gather is None:
+        if not collective:
             parts[self.rank] = flat[:pos]
         else:
-            import torch.distributed as dist
-            if plan["parts"] is None:
-                plan["parts"] = [torch.empty_like(flat) for _ in range(self.world)]
-            if gather == "rank0":
-                dist.gather(flat, plan["parts"] if self.rank == 0 else None, dst=0)
-                if self.rank == 0:
-                    parts = [pp[:tt] for pp, tt in zip(plan["parts"], plan["totals"])]
-            else:
-                dist.all_gather(plan["parts"], flat)
+            issue_upto(int(flat.numel()))                  # the pieces behind this rank's own audio (zeros) and the last one
+            for ww in works:
+                ww.wait()
+            if gather == "all" or self.rank == 0:
                 parts = [pp[:tt] for pp, tt in zip(plan["parts"], plan["totals"])]
-        return ShardResult(parts, shards, lengths, self.hop)
+        t_end = self._now()
+        timing = {"compute_ms": self._elapsed_ms(t_start, t_compute), "gather_ms": self._elapsed_ms(t_compute, t_end),
+                  "chunks": n_chunks}
+        return ShardResult(parts, shards, lengths, self.hop, timing)
 
-    def run(self, mels, noises=None, gather="all"):
-        """Returns the list of audio arrays in input order on every rank (gather="all"), on rank 0 only
-        (gather="rank0", other ranks get None) or the local dict {index: audio} (gather=None)."""
+    def run(self, mels, noises=None, gather="rank0"):
+        """Returns the list of audio arrays in input order on rank 0 only (gather="rank0", the default; other ranks get
+        None), on every rank (gather="all") or the local dict {index: audio} (gather=None)."""
         plan = self.stage(mels, noises)
         res = self.run_staged(plan, gather)
         if gather is None:

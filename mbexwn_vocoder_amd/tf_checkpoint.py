@@ -465,21 +465,39 @@ def map_reference_variables(named_arrays):
     return weights, unmatched
 
 
-def to_reference_variables(raw, model_scope="mb_ex_wn"):
+def to_reference_variables(raw, model_scope="mb_ex_wn", config=None):
     """Inverse of :func:`map_reference_variables`: the engine's raw weights under the variable names the reference's
-    Keras model gives them (enclosing scopes are a guess and irrelevant to the reader)."""
+    Keras model gives them (enclosing scopes are a guess and irrelevant to the reader).  WaveNet block ``i`` is named
+    ``PP_waveNetBlock_ups{ups_i}_{i}`` (reference custom_pulsed_generator.py:487), its WaveNet ``<block>_WNBlock_WN``
+    (custom_AE_layers.py:516) and its up-sampling convolution -- which only exists when ``ups_i > 1`` --
+    ``<block>_WNBlock_UP_{ups_i}`` (custom_AE_layers.py:519-526): ``config`` supplies the factors
+    (``pp_mod_subnet_upsampling_factors``; without it a single block without upsampling is assumed)."""
+    ups = [1]
+    if config is not None:
+        from .config import ModelDims
+        ups = list(ModelDims(config).wn_block_ups)
     out = {}
     inverse = {vv: kk for kk, vv in _WAVENET_LAYERS.items()}
+
+    def block_name(idx):
+        if idx >= len(ups):
+            raise ValueError(f"weights of WaveNet block {idx}, but the configuration has {len(ups)} block(s): pass config")
+        return f"PP_waveNetBlock_ups{ups[idx]}_{idx}"
+
     for name, arr in raw.items():
         layer, kind = name.rsplit(".", 1)
         blk = re.match(r"wn(\d*)\.(.*)", layer)
         up = re.fullmatch(r"up(\d+)", layer)
         if blk:
             idx, inner = int(blk.group(1) or 0), "wn." + blk.group(2)
-            ref, scope = inverse.get(inner, blk.group(2)), f"{model_scope}/PP_waveNetBlock_ups1_{idx}/wave_net_ae/"
+            ref = inverse.get(inner, blk.group(2))
+            scope = f"{model_scope}/{block_name(idx)}/{block_name(idx)}_WNBlock_WN/"
         elif up:
-            ref = f"PP_waveNetBlock_ups1_{up.group(1)}_WNBlock_UP_2"
-            scope = f"{model_scope}/PP_waveNetBlock_ups1_{up.group(1)}/"
+            idx = int(up.group(1))
+            if idx >= len(ups) or ups[idx] <= 1:
+                raise ValueError(f"{name}: block {idx} has no up-sampling convolution in this configuration (pass config)")
+            ref = f"{block_name(idx)}_WNBlock_UP_{ups[idx]}"
+            scope = f"{model_scope}/{block_name(idx)}/"
         elif layer == "post":
             ref, scope = f"{model_scope}_PaNMPulseWaveNet_Post", f"{model_scope}/"
         else:

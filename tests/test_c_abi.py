@@ -34,10 +34,12 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_c(tmp_path):
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mbexwn.h"\n'
-                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mbx_config), sizeof(mbx_subnet_op),'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mbx_config), sizeof(mbx_subnet_op),'
                    ' sizeof(mbx_tensor), offsetof(mbx_config, n_f0_ops), offsetof(mbx_config, vtf_ops),'
                    ' offsetof(mbx_config, wt_nominal_f0), sizeof(mbx_forward_options), offsetof(mbx_forward_options, wn_frames),'
-                   ' offsetof(mbx_forward_options, sub_carry), offsetof(mbx_forward_options, layer_rows)); return 0;}\n')
+                   ' offsetof(mbx_forward_options, sub_carry), offsetof(mbx_forward_options, layer_rows),'
+                   ' offsetof(mbx_config, wn_conv_form), offsetof(mbx_config, tune_resskip_split), sizeof(mbx_conv_form_info),'
+                   ' offsetof(mbx_conv_form_info, err_f23)); return 0;}\n')
     exe = tmp_path / "sizes"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
@@ -46,7 +48,35 @@ def test_struct_layout_matches_c(tmp_path):
     assert got == [ctypes.sizeof(cc), ctypes.sizeof(engine.mbx_subnet_op), ctypes.sizeof(engine.mbx_tensor),
                    cc.n_f0_ops.offset, cc.vtf_ops.offset, cc.wt_nominal_f0.offset,
                    ctypes.sizeof(engine.mbx_forward_options), engine.mbx_forward_options.wn_frames.offset,
-                   engine.mbx_forward_options.sub_carry.offset, engine.mbx_forward_options.layer_rows.offset]
+                   engine.mbx_forward_options.sub_carry.offset, engine.mbx_forward_options.layer_rows.offset,
+                   cc.wn_conv_form.offset, cc.tune_resskip_split.offset, ctypes.sizeof(engine.mbx_conv_form_info),
+                   engine.mbx_conv_form_info.err_f23.offset]
+
+
+def test_policy_fields_and_experiment_variables(monkeypatch, capsys):
+    """The library reads no environment variable: the policy is mbx_config fields, which the Python host fills from its
+    arguments -- or, for the experiment scripts, from the MBX_* variables, naming them on stderr."""
+    from helpers import build_case
+    cfg, raw, wt = build_case("SPEECH", {})
+    for kk in ("MBX_WINOGRAD", "MBX_FOLD_SKIP", "MBX_FOLD_START", "MBX_WG_SMALL", "MBX_RV_TILES", "MBX_RV_SPLIT"):
+        monkeypatch.delenv(kk, raising=False)
+    cc, _ = engine.make_config(cfg, wt)
+    assert (cc.wn_conv_form, cc.batch_invariant, cc.wn_keep_skip, cc.wn_keep_start, cc.tune_gate_shape) == (0, 0, 0, 0, 0)
+    assert capsys.readouterr().err == ""
+    cc, _ = engine.make_config(cfg, wt, conv_form="f23", batch_invariant=True, keep_start=True, tune={"resskip_split": 2})
+    assert (cc.wn_conv_form, cc.batch_invariant, cc.wn_keep_start, cc.tune_resskip_split) == (2, 1, 1, 2)
+    monkeypatch.setenv("MBX_WINOGRAD", "44")
+    monkeypatch.setenv("MBX_FOLD_START", "0")
+    monkeypatch.setenv("MBX_WG_SMALL", "1")
+    cc, _ = engine.make_config(cfg, wt)
+    assert (cc.wn_conv_form, cc.batch_invariant, cc.wn_keep_start, cc.tune_gate_shape) == (3, 1, 1, 2)
+    assert "MBX_WINOGRAD=44" in capsys.readouterr().err
+    cc, _ = engine.make_config(cfg, wt, conv_form="direct")           # an explicit argument wins over the variable
+    assert cc.wn_conv_form == 1
+    with pytest.raises(ValueError):
+        engine.make_config(cfg, wt, conv_form="f63")
+    src = open(os.path.join(ROOT, "mbexwn_vocoder_amd", "csrc", "mbx_api.hip")).read()
+    assert "getenv" not in src
 
 
 def test_make_config_and_tensor_table():

@@ -92,6 +92,63 @@ def _worker(rank, world, port, tmpdir):
         dist.destroy_process_group()
 
 
+def _worker4(rank, world, port, tmpdir):
+    """world_size 4: uneven shards (one long utterance dominates a rank), one rank without any utterance, the shard buffer
+    cut into many chunks that are gathered asynchronously while later micro-batches still run."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = True
+        for case, n_utt in (("uneven", 11), ("empty_rank", 3)):
+            mels, noises = make_utterances(n_utt, seed=17 + n_utt)
+            if case == "uneven":
+                rng = np.random.default_rng(5)
+                mels[4] = rng.normal(size=(400, 80)).astype(np.float32)            # one utterance as long as all others together
+                noises[4] = rng.normal(size=(400 * SPF,)).astype(np.float32)
+            lengths = [mm.shape[0] for mm in mels]
+            shards = lpt_partition(lengths, world)
+            if case == "empty_rank":
+                ok = ok and shards[3] == []
+            calls = []
+
+            def counted(mel, n_frames, noise, calls=calls):
+                calls.append(mel.shape[0])
+                return fake_forward(mel, n_frames, noise)
+            syn = ShardedSynthesizer(counted, HOP, SPF, rank=rank, world_size=world, max_batch=2, gather_chunk_floats=7001)
+            plan = syn.stage(mels, noises)
+            for mode in ("rank0", "all"):
+                res = syn.run_staged(plan, gather=mode)
+                ok = ok and res.timing["chunks"] == -(-int(plan["flat"].numel()) // 7001) and res.timing["chunks"] >= 2
+                ok = ok and res.timing["compute_ms"] >= 0.0 and res.timing["gather_ms"] >= 0.0
+                if mode == "all" or rank == 0:
+                    got = res.to_list()
+                    for ii, mm in enumerate(mels):
+                        ref = fake_forward(mm[None], np.asarray([mm.shape[0]], np.int32), noises[ii][None])[0]
+                        ok = ok and np.array_equal(got[ii], ref)
+                else:
+                    ok = ok and all(pp is None for pp in res.parts)
+            ok = ok and len(calls) == 2 * len(plan["batches"])
+            default = syn.run(mels, noises)                               # the default: gathered on rank 0 only
+            ok = ok and ((default is None) if rank else len(default) == n_utt)
+        with open(os.path.join(tmpdir, f"ok{rank}"), "w") as fo:
+            fo.write("1" if ok else "0")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world_size_4_gloo_uneven_shards_and_an_empty_rank(tmp_path):
+    import torch.multiprocessing as mp
+    with socket.socket() as ss:
+        ss.bind(("127.0.0.1", 0))
+        port = ss.getsockname()[1]
+    mp.spawn(_worker4, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    for rank in range(4):
+        assert (tmp_path / f"ok{rank}").read_text() == "1", f"rank {rank}"
+
+
 @pytest.mark.timeout(300)
 def test_random_shardings_cover_every_utterance_exactly_once():
     """Random utterance sets x world sizes x micro-batch limits: the ranks' local shards (no collective: every rank is

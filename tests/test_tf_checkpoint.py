@@ -143,7 +143,7 @@ def test_pre_conditioning_layers_and_missing_conditioning_round_trip(tmp_path):
         prefix = str(tmp_path / ("w" + str(len(raw))))
         named = _reference_names(raw)
         if "wn.precond_1.v" in raw:
-            assert any(kk.endswith("wave_net_ae/precond_1/kernel") for kk in named)
+            assert any(kk.endswith("PP_waveNetBlock_ups1_0_WNBlock_WN/precond_1/kernel") for kk in named)
         tfc.write_checkpoint(prefix, named)
         got = tfc.load_reference_checkpoint(prefix, cfg)
         assert sorted(got) == sorted(raw)
@@ -161,9 +161,19 @@ def test_several_wavenet_blocks_round_trip(tmp_path):
                                         "mbexwn_config:pulse_channels": 10, "mbexwn_config:pp_mod_subnet:cond_lin_upsampling": 5})
     raw = synthetic_weights(cfg, seed=13)
     assert raw["wn1.start.v"].shape == (1, 30, 16) and raw["up0.v"].shape == (3, 30, 60) and raw["wn1.cond.v"].shape == (3, 80, 2 * 16 * 4)
-    named = _reference_names(raw)
-    assert any("PP_waveNetBlock_ups1_1/wave_net_ae/conv1D_0/kernel" in kk for kk in named)
-    assert any(kk.endswith("PP_waveNetBlock_ups1_0_WNBlock_UP_2/kernel") for kk in named)
+    named = _reference_names(raw, config=cfg)
+    # names built the way the reference builds them: block "PP_waveNetBlock_ups{ups}_{iwn}" (custom_pulsed_generator.py:487),
+    # its WaveNet self.name + "_WNBlock_WN" (custom_AE_layers.py:516), its up layer self.name + f"_WNBlock_UP_{factor}" --
+    # which exists only for ups > 1 (custom_AE_layers.py:518-526)
+    ups = cfg["mbexwn_config"]["pp_mod_subnet_upsampling_factors"]
+    blocks = ["PP_waveNetBlock_ups{}_{}".format(uu, ii) for ii, uu in enumerate(ups)]
+    for ii, (blk, uu) in enumerate(zip(blocks, ups)):
+        assert any(f"/{blk}/{blk}_WNBlock_WN/conv1D_0/kernel" in kk for kk in named), blk
+        has_up = any(f"/{blk}/{blk}_WNBlock_UP_{uu}/kernel" in kk for kk in named)
+        assert has_up == (uu > 1), blk
+    assert not any("_WNBlock_UP_1" in kk or "ups1_0" in kk for kk in named)
+    with pytest.raises(ValueError, match="pass config"):
+        _reference_names(raw)                                          # two blocks need the configuration's factors
     prefix = str(tmp_path / "blocks")
     tfc.write_checkpoint(prefix, named)
     got = tfc.load_reference_checkpoint(prefix, cfg)

@@ -82,9 +82,11 @@ for case in range(n_cases):
     try:
         raw = synthetic_weights(cfg, seed=int(rng.integers(1, 10 ** 6)), bias_std=0.05, alpha_jitter=0.05)
         wt = WaveTables(sample_rate=dims.pulse_rate, **cfg["mbexwn_config"]["wavetable_config"])
-        form = str(rng.choice(["4", "2", "0", "44"]))
-        os.environ["MBX_WINOGRAD"] = form
-        eng, om, om32 = MBExWNEngine(cfg, raw, wt), OracleModel(cfg, raw, wt), OracleModel(cfg, raw, wt, dtype=np.float32)
+        # the default handle (auto: the form is calibrated on the model's own weights) in half of the draws, a pinned form
+        # (direct, F(2,3), F(4,3), F(4,3) with batch-invariant kernels) in the others
+        form = str(rng.choice(["auto", "auto", "auto", "auto", "f43", "f23", "direct", "f43i"]))
+        eng = MBExWNEngine(cfg, raw, wt, conv_form=form.rstrip("i"), batch_invariant=form.endswith("i"))
+        om, om32 = OracleModel(cfg, raw, wt), OracleModel(cfg, raw, wt, dtype=np.float32)
         B, T = int(rng.integers(1, 5)), int(rng.integers(1, 45))
         lengths = [T] + [int(rng.integers(1, T + 1)) for _ in range(B - 1)]
         mel = np.clip(np.log(np.exp(rng.normal(-5.0, 2.0, size=(B, T, 80))) + 1e-5), -11.5, 2.0).astype(np.float32)
@@ -105,7 +107,13 @@ for case in range(n_cases):
             assert np.all(got[ii, ll * 300:] == 0.0), "tail not zero"
         # (the few draws between 4 and 12 yardsticks seen in 800 cases all had an F0 contour 1.2-1.4e-3 Hz off -- twice the
         # float32 port's own error -- which moves every pulse by that much: tests/tools/fuzz_case.py)
-        ok = worst <= max(1e-4, 16 * yard)
+        # The bar: the plain tolerance 1e-4 * max(1, |ref|) for the default handle on the bounded gates (gtu / gfu / gsu).  The
+        # 16-yardstick escape is left to the draws that are ill-conditioned by construction -- glu (unbounded linear half),
+        # sub-harmonic sinusoids (jumps at phase wraps) -- and to the pinned Winograd forms, whose rounding nothing checks
+        # against the weights (that is what auto is for).
+        ill = dims.wn_activation == "glu" or bool(dims.wt_subharm)
+        plain = form == "auto" and not ill
+        ok = worst <= (1e-4 if plain else max(1e-4, 16 * yard))
         if not ok and dims.wt_subharm:
             # the known class (see the docstring): the wrapped phases of the two F0 contours differ by a whole turn somewhere
             ph_hip = eng.wavetable(eng.stage("f0"))[1].cpu().numpy()
@@ -115,7 +123,7 @@ for case in range(n_cases):
                 if np.any(np.abs(ph_hip[ii, :ph_ref.shape[0]] - ph_ref) > 0.5):
                     ok = "wrap"
         fails += not ok
-        print(case, "OK  " if ok is True else ("WRAP" if ok else "FAIL"), f"{worst:.1e}", f"(f32 port {yard:.1e})", "form", form, "B", B, "T", T, {kk.split(':')[-1]: vv for kk, vv in over.items()}, flush=True)
+        print(case, "OK  " if ok is True else ("WRAP" if ok else "FAIL"), f"{worst:.1e}", f"(f32 port {yard:.1e})", "form", form + "->" + eng.conv_form_info()["form"], "B", B, "T", T, {kk.split(':')[-1]: vv for kk, vv in over.items()}, flush=True)
         del eng
     except Exception:                                        # noqa: BLE001
         fails += 1

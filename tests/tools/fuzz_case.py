@@ -23,9 +23,9 @@ cfg = canonical_config(str(rng.choice(["SPEECH", "VOICE"])), **over)
 dims = ModelDims(cfg)
 raw = synthetic_weights(cfg, seed=int(rng.integers(1, 10 ** 6)), bias_std=0.05, alpha_jitter=0.05)
 wt = WaveTables(sample_rate=dims.pulse_rate, **cfg["mbexwn_config"]["wavetable_config"])
-form = str(rng.choice(["4", "2", "0", "44"]))
-os.environ["MBX_WINOGRAD"] = form
-eng = MBExWNEngine(cfg, raw, wt)
+form = str(rng.choice(["auto", "auto", "auto", "auto", "f43", "f23", "direct", "f43i"]))      # as config_fuzz.py draws it
+eng = MBExWNEngine(cfg, raw, wt, conv_form=form.rstrip("i"), batch_invariant=form.endswith("i"))
+print("conv form:", eng.conv_form_info())
 om64, om32 = OracleModel(cfg, raw, wt), OracleModel(cfg, raw, wt, dtype=np.float32)
 B, T = int(rng.integers(1, 5)), int(rng.integers(1, 45))
 lengths = [T] + [int(rng.integers(1, T + 1)) for _ in range(B - 1)]
