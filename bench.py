@@ -38,6 +38,8 @@ WORKLOADS = {
     # BASELINE.json configs[4]: 64 concurrent streams, one tick = 8 mel frames (100 ms; "80 ms" = 6.4 frames is not
     # frame aligned) per stream
     "config5_sp_stream64": ("SPEECH", 64, -8),
+    # the same at the stated 80 ms: 6.4 frames per tick = the cyclic schedule 6 / 6 / 7 / 6 / 7 frames (400 ms per period)
+    "config5_sp_stream64_80ms": ("SPEECH", 64, (6, 6, 7, 6, 7)),
     # builder-run secondary (not a BASELINE config): the generic path -- two WaveNet blocks with in-block upsampling (the
     # geometry of the golden case "blocks": C = 320 at 800 Hz, then C = 160 at 1600 Hz), the block runner's kernels
     "variant_blocks2": ("SING", 16, 800),
@@ -437,15 +439,19 @@ def run_streaming(args, name, rank, world, fence, torch, steps=None, warmup=None
     the launch stream around each tick) and, separately, host-inclusive through the Python driver."""
     from mbexwn_vocoder_amd.streaming import StreamingSynthesizer
     voice, n_streams, chunk = WORKLOADS[name]
-    chunk = -chunk
+    schedule = list(chunk) if isinstance(chunk, tuple) else [-chunk]
     cfg, raw, wt, dims, eng = build_engine(voice)
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
-    syn = StreamingSynthesizer(eng, chunk_frames=chunk)
+    if len(schedule) > 1:                            # whole periods of the schedule, so that the mean tick is the stated one
+        steps = max(len(schedule), steps // len(schedule) * len(schedule))
+    syn = StreamingSynthesizer(eng, chunk_frames=schedule if len(schedule) > 1 else schedule[0])
     syn.time_device = True
-    lead_ticks = 4                                   # ticks before the steady state (growing left context)
+    lead_ticks = 4 if len(schedule) == 1 else len(schedule)   # ticks before the steady state (growing left context)
     n_ticks = lead_ticks + warmup + steps
-    total = (n_ticks + 1) * chunk + syn.right + 8
+    emitted = [schedule[ii % len(schedule)] for ii in range(n_ticks + 1)]
+    chunk = float(np.mean(emitted[lead_ticks + warmup:lead_ticks + warmup + steps]))     # frames per timed tick (mean)
+    total = int(sum(emitted)) + syn.right + 8
     for sid in range(n_streams):
         syn.open(sid)
         mm, nn = synthetic_batch(np.random.default_rng(1000 * rank + sid), 1, total, dims.steps_per_frame)
@@ -465,11 +471,14 @@ def run_streaming(args, name, rank, world, fence, torch, steps=None, warmup=None
     fence()
     elapsed = fence.max_over_ranks(float(np.sum(dev_ms)) * 1e-3)       # device time of the timed ticks
     samples = world * n_streams * chunk * dims.hop_size * steps
-    return {"workload": f"{name}: MW-SP-FD canonical, {n_streams} streams per GPU, tick = {chunk} frames "
+    how = ("steady ticks are one replayed hipGraph (upload of the new frames + window advance + forward + read-back of the "
+           "chunk)") if len(schedule) == 1 else (f"cyclic tick schedule {schedule} frames (mean {chunk:g}): the window geometry "
+           "changes from tick to tick, so ticks run launch by launch (per-layer state, sub-bands and phase carried)")
+    return {"workload": f"{name}: MW-SP-FD canonical, {n_streams} streams per GPU, tick = {chunk:g} frames "
                         f"({chunk * 12.5:g} ms) per stream, look-ahead {syn.right * 12.5:g} ms, carried phase state, "
-                        f"bit-equal to offline synthesis; steady ticks are one replayed hipGraph (upload of the new frames + "
-                        f"window advance + forward + read-back of the chunk); value = emitted audio / device time of the ticks "
-                        f"(HIP events around the graph launch of each tick, copies included), host-inclusive latency beside it",
+                        f"bit-equal to offline synthesis; {how}; value = emitted audio / device time of the ticks "
+                        f"(HIP events around each tick's launches, copies included), host-inclusive latency beside it",
+            "tick_ms": chunk * 12.5, "conv_form": eng.conv_form_info()["stream_form"],
             "value": samples / elapsed, "x_realtime": samples / elapsed / 24000.0, "ms_per_step": elapsed / steps * 1e3,
             "steps": steps, "scaling": "weak",
             "ticks_replayed_as_graph": int(syn.graph_ticks), "ticks_total": int(n_ticks),
@@ -600,7 +609,7 @@ def main():
     ctx = None
     if frames is None:
         main_res = run_sharded(args, args.workload, rank, world, dist, fence, torch, check_delta=not args.no_secondary)
-    elif frames < 0:
+    elif isinstance(frames, tuple) or frames < 0:
         main_res = run_streaming(args, args.workload, rank, world, fence, torch)
     else:
         main_res, ctx = run_batch(args, args.workload, rank, world, fence, torch, profile=True)
@@ -631,6 +640,8 @@ def main():
                                                      steps=min(args.steps, 3), warmup=1, check_delta=True)
         secondary["config5_sp_stream64"] = run_streaming(args, "config5_sp_stream64", rank, world, fence, torch,
                                                          steps=max(20, min(args.steps, 50)), warmup=3)
+        secondary["config5_sp_stream64_80ms"] = run_streaming(args, "config5_sp_stream64_80ms", rank, world, fence, torch,
+                                                              steps=max(20, min(args.steps, 50)), warmup=5)
 
     if rank == 0:
         line.update({

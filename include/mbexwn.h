@@ -199,7 +199,12 @@ typedef struct {
      *                          kernel; -1: never
      *   tune_resskip_split     0: by launch size, 1..3: column split of the wave-tiled res/skip kernel (same bits) */
     int32_t tune_gate_shape, tune_resskip_wave_tiles, tune_resskip_split;
-    int32_t reserved7[4];
+    /* normalize_use_pinv (reference wavegen_1d.py:603-608, 683-685): the frame RMS of the normalisation is the energy of
+     * mel . pinv(mel filters)^T / nm_win_norm over the fft_size / 2 + 1 bins; table "table.nm_pinv" (mel_channels,
+     * fft_size / 2 + 1), nm_win_norm = L2 norm of the analysis window */
+    int32_t nm_use_pinv;
+    float nm_win_norm;
+    int32_t reserved7[2];
 } mbx_config;
 
 /* A named HOST tensor handed over at creation (weights already weight-norm folded, tables).

@@ -412,6 +412,9 @@ mbx::NormMelConsts norm_mel_consts(const mbx_handle *hd) {
     k.use_compressor = c.nm_use_compressor;
     k.use_max_limit = c.nm_use_max_limit;
     k.inv_enorm = find(hd, "table.nm_inv_enorm")->ptr;
+    k.pinv = c.nm_use_pinv ? find(hd, "table.nm_pinv")->ptr : nullptr;
+    k.n_bins = c.fft_size / 2 + 1;
+    k.win_norm = c.nm_win_norm;
     k.gwin = find(hd, "table.nm_gwin")->ptr;
     k.smooth_win_table = find(hd, "table.nm_smooth_win")->ptr;
     return k;
@@ -667,6 +670,11 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
         need.push_back("table.nm_inv_enorm");
         need.push_back("table.nm_gwin");
         need.push_back("table.nm_smooth_win");
+        if (c.nm_use_pinv) {
+            if (c.mel_channels > 256 || !(c.nm_win_norm > 0.f))
+                return bail(fail(MBX_ERR_INVALID_ARGUMENT, "normalize_use_pinv: at most 256 mel channels, nm_win_norm > 0"));
+            need.push_back("table.nm_pinv");
+        }
     }
     if (c.pulse_pqmf_taps > 0) need.push_back("table.pulse_ana");
     if (c.n_ceps_windows) {
@@ -717,7 +725,8 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
              expect("table.f0_smooth", 2 * c.hop_size + 1);
     if (c.nm_iters > 0)
         ok = ok && expect("table.nm_inv_enorm", c.mel_channels) && expect("table.nm_gwin", c.stft_win) &&
-             expect("table.nm_smooth_win", c.nm_smooth_win);
+             expect("table.nm_smooth_win", c.nm_smooth_win) &&
+             (!c.nm_use_pinv || expect("table.nm_pinv", (long long)c.mel_channels * (c.fft_size / 2 + 1)));
     if (!ok) return bail(fail(MBX_ERR_INVALID_ARGUMENT, "a tensor has the wrong number of elements"));
 
     long long pf0 = 0, pvtf = 0;

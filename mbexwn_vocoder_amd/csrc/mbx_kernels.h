@@ -291,6 +291,9 @@ struct NormMelConsts {
     float rms_norm_fact, rms_floor, compressor_exp, lin_amp_scale, lin_amp_off, mel_amp_scale;
     int use_compressor, use_max_limit;
     const float *inv_enorm;          // (mel_channels)
+    const float *pinv;               // normalize_use_pinv: (mel_channels, n_bins) pseudo inverse of the mel filters, else null
+    int n_bins;                      // fft_size / 2 + 1
+    float win_norm;                  // L2 norm of the analysis window
     const float *gwin;               // (win) unit-sum analysis window
     const float *smooth_win_table;   // (smooth_win)
 };

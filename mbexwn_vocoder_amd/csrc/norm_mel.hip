@@ -2,8 +2,9 @@
 //
 // restates NormMelComponents.normalize_inputs_by_rms   reference MBExWN_NVoc/vocoder/model/wavegen_1d.py:638-769
 // as PaNWaveNet.infer applies it (wavegen_1d.py:493-495, 506-507), smoothing variant
-// (normalize_rms_num_smooth_iters > 0, normalize_use_pinv = False):
+// (normalize_rms_num_smooth_iters > 0):
 //   rms[t]   = sqrt(sum_c (exp(mell[t,c]) * inv_enorm[c])^2 / rms_norm_fact)            (:689)
+//              or, normalize_use_pinv: sqrt(sum_k (sum_c exp(mell[t,c]) pinv[c,k] / win_norm)^2 / rms_norm_fact)  (:684-685)
 //              floored at 1/max_norm_fact (:690-691), compressed by pow(., exp) (:692-693)
 //   per smoothing iteration (:697-726):
 //     ext    = [rms[0], rms[0], rms[0..T-1], rms[T-1], rms[T-1]]                         (T + 4 frames)
@@ -29,9 +30,24 @@ __global__ __launch_bounds__(64) void nm_rms_kernel(NormMelConsts c, const float
     if (t >= T) return;
     const float *row = mell + (long long)b * mel_bstride + (long long)t * c.mel_channels;
     float s = 0.f;
-    for (int ch = threadIdx.x; ch < c.mel_channels; ch += 64) {
-        const float v = expf(row[ch]) * c.inv_enorm[ch];
-        s += v * v;
+    if (c.pinv) {
+        // normalize_use_pinv (:684-685): spectrum = exp(mell) . pinv(mel filters)^T / win_norm, energy over all bins; a lane
+        // walks the bins k = lane, lane + 64, ... (rows of the table are read coalesced)
+        __shared__ float lin[256];
+        for (int ch = threadIdx.x; ch < c.mel_channels; ch += 64) lin[ch] = expf(row[ch]);
+        __syncthreads();
+        const float inv_norm = 1.0f / c.win_norm;
+        for (int k = threadIdx.x; k < c.n_bins; k += 64) {
+            float v = 0.f;
+            for (int ch = 0; ch < c.mel_channels; ++ch) v = fmaf(lin[ch], c.pinv[(long long)ch * c.n_bins + k], v);
+            v *= inv_norm;
+            s += v * v;
+        }
+    } else {
+        for (int ch = threadIdx.x; ch < c.mel_channels; ch += 64) {
+            const float v = expf(row[ch]) * c.inv_enorm[ch];
+            s += v * v;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);

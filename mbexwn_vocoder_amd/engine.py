@@ -73,7 +73,7 @@ class mbx_config(ctypes.Structure):
                 ("wn_conv_form", ctypes.c_int32), ("batch_invariant", ctypes.c_int32), ("wn_keep_skip", ctypes.c_int32),
                 ("wn_keep_start", ctypes.c_int32), ("calib_fraction", ctypes.c_float), ("tune_gate_shape", ctypes.c_int32),
                 ("tune_resskip_wave_tiles", ctypes.c_int32), ("tune_resskip_split", ctypes.c_int32),
-                ("reserved7", ctypes.c_int32 * 4)]
+                ("nm_use_pinv", ctypes.c_int32), ("nm_win_norm", ctypes.c_float), ("reserved7", ctypes.c_int32 * 2)]
 
 
 class mbx_conv_form_info(ctypes.Structure):
@@ -337,6 +337,7 @@ def make_config(config, wavetables, conv_form=None, batch_invariant=None, keep_s
         cc.nm_compressor_exp = float(nm.compressor_exp) if nm.compressor_exp is not None else 1.0
         cc.nm_lin_amp_scale, cc.nm_lin_amp_off = float(nm.lin_amp_scale), float(nm.lin_amp_off)
         cc.nm_mel_amp_scale = float(nm.mel_amp_scale)
+        cc.nm_use_pinv, cc.nm_win_norm = int(nm.use_pinv), float(nm.win_norm)
     over = experiment_overrides() if None in (conv_form, batch_invariant, keep_skip, keep_start, tune) else {}
     conv_form = over.get("conv_form", "auto") if conv_form is None else conv_form
     if conv_form not in CONV_FORMS:
@@ -609,6 +610,8 @@ def tensor_table(config, raw_weights, wavetables):
         out["table.nm_inv_enorm"] = nm.inv_enorm
         out["table.nm_gwin"] = nm.gwin
         out["table.nm_smooth_win"] = nm.smooth_syn_win
+        if nm.use_pinv:
+            out["table.nm_pinv"] = nm.pinv
     return {kk: np.ascontiguousarray(vv, dtype=np.float32) for kk, vv in out.items()}
 
 

@@ -63,11 +63,15 @@ def _utf8_number(value):
 
 
 def to_pcm16(data):
-    """float audio in [-1, 1) -> int16 (rounded, clipped); int16 passes through.  (frames,) or (frames, channels)."""
+    """float audio in [-1, 1] -> int16, scaled by 0x7FFF as libsndfile scales normalised floats for a 16-bit file (the
+    reference's sndio path, bin/resynth_mel.py:104-105), rounded and clipped; int16 passes through; any other integer type
+    is refused (its scale is ambiguous: convert it yourself).  (frames,) or (frames, channels)."""
     data = np.asarray(data)
     if data.dtype == np.int16:
         return data
-    return np.clip(np.rint(data.astype(np.float64) * 32768.0), -32768, 32767).astype(np.int16)
+    if not np.issubdtype(data.dtype, np.floating):
+        raise TypeError(f"FLAC writer: float or int16 samples expected, got {data.dtype}")
+    return np.clip(np.rint(data.astype(np.float64) * 32767.0), -32768, 32767).astype(np.int16)
 
 
 def encode(data, rate):

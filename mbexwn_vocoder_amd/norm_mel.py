@@ -6,13 +6,15 @@ mel spectrogram is divided by an RMS contour estimated from the mel bands, and t
 the up-sampled contour.  Both steps are cheap pre/post-processing around the HIP forward pass (mel rate / one multiply
 per output sample) and run on the host in float32 numpy next to ``scale_mel``.
 
-``librosa.mel_frequencies`` (third party, absent here) is restated by ``analysis.mel_frequencies`` (Slaney scale).
-Only the smoothing variant (``normalize_rms_num_smooth_iters > 0``) and ``normalize_use_pinv = False`` are supported:
-the other branches of the reference reduce over the wrong axis / need the librosa mel basis inverse.
+``librosa.mel_frequencies`` / ``librosa.filters.mel`` (third party, absent here) are restated by
+``analysis.mel_frequencies`` / ``analysis.mel_basis_slaney`` (Slaney scale, area-normalised triangles).
+Both RMS estimates are built: the band-width weighted one and ``normalize_use_pinv`` (the energy of the minimum-energy
+spectrum that explains the mel frame: pseudo inverse of the mel filters, reference :603-608, 683-685).  Only the smoothing
+variant (``normalize_rms_num_smooth_iters > 0``) is supported: the reference's other branch reduces over the wrong axis.
 """
 import numpy as np
 
-from .analysis import hann_symmetric, mel_frequencies
+from .analysis import hann_symmetric, mel_basis_slaney, mel_frequencies
 
 EPS = np.float32(1e-7)   # tf.keras.backend.epsilon()
 
@@ -34,8 +36,7 @@ class NormMel:
         if 4 * self.hop != self.win:
             raise RuntimeError("NormMelComponents:error: this module currently supports only the case where "
                                f"win_size {self.win} = 4 * hop_size {self.hop}")          # reference :592-594
-        if mb.get("normalize_use_pinv", False):
-            raise NotImplementedError("normalize_use_pinv needs the librosa mel basis (not part of this build)")
+        self.use_pinv = bool(mb.get("normalize_use_pinv", False))
         self.iters = int(mb.get("normalize_rms_num_smooth_iters", 0))
         if self.iters <= 0:
             raise NotImplementedError("normalize_rms_from_mell is supported with normalize_rms_num_smooth_iters > 0 only")
@@ -43,6 +44,11 @@ class NormMel:
         self.rms_norm_fact = np.float32(pp["fft_size"] * self.win * 0.5)
         mel_f = mel_frequencies(self.n_mels + 2, pp["fmin"], pp["fmax"])
         self.inv_enorm = ((mel_f[2:self.n_mels + 2] - mel_f[:self.n_mels]) / 2.0).astype(np.float32)
+        self.win_norm, self.pinv = np.float32(1.0), None
+        if self.use_pinv:                                     # reference :603-608
+            self.win_norm = np.sqrt(np.sum(hann_symmetric(self.win).astype(np.float32) ** 2)).astype(np.float32)
+            basis = mel_basis_slaney(pp["sample_rate"], pp["fft_size"], self.n_mels, pp["fmin"], pp["fmax"], dtype=np.float32)
+            self.pinv = np.ascontiguousarray(np.linalg.pinv(basis).T, dtype=np.float32)      # (n_mels, fft_size / 2 + 1)
         self.max_norm_fact = mb.get("max_norm_fact", None)
         self.compressor_exp = mb.get("normalize_compressor_exp", None)
         self.lin_amp_scale = np.float32(mb.get("lin_amp_scale", 1.0))
@@ -62,7 +68,11 @@ class NormMel:
         mell = np.asarray(mell, dtype=np.float32)
         T = mell.shape[1]
         mel = np.exp(mell)
-        rms = np.sqrt(np.sum(np.square(mel * self.inv_enorm), axis=-1) / self.rms_norm_fact).astype(np.float32)
+        if self.use_pinv:                                     # reference :684-685
+            spec = (np.tensordot(mel, self.pinv, axes=1) / self.win_norm).astype(np.float32)
+            rms = np.sqrt(np.sum(np.square(spec), axis=-1, dtype=np.float32) / self.rms_norm_fact).astype(np.float32)
+        else:
+            rms = np.sqrt(np.sum(np.square(mel * self.inv_enorm), axis=-1) / self.rms_norm_fact).astype(np.float32)
         if self.max_norm_fact:
             rms = np.maximum(rms, np.float32(1.0 / self.max_norm_fact))
         if self.compressor_exp is not None:

@@ -39,6 +39,15 @@ def norm_reach(dims, config):
     return nm.iters * ((nm.smooth_win_size + nm.win) // (2 * nm.hop))
 
 
+def cond_chain_reach(dims):
+    """(left, right) reach in mel frames of the conditioning chain -- the conditioning layer and the pre-conditioning
+    convolutions in front of it, all with kernel size cond_kernel_size and zero SAME padding, which the library pads
+    (k - 1) // 2 frames in front and k // 2 behind (csrc/mbx_api.hip, cond_chain): an even kernel size reaches one frame
+    further to the right than to the left, per convolution."""
+    n_cond = 0 if dims.wn_disable_conditioning else 1 + len(dims.wn_pre_cond_channels)
+    return n_cond * ((dims.cond_kernel_size - 1) // 2), n_cond * (dims.cond_kernel_size // 2)
+
+
 def stream_margins(dims, config):
     """(left, right, pulse_lead, act_left, act_right, wn_reach) in mel frames, from the layer geometry of the model."""
     mb = config["mbexwn_config"]
@@ -67,9 +76,8 @@ def stream_margins(dims, config):
     # conditioning chain: the conditioning layer and the pre-conditioning convolutions in front of it (same kernel size,
     # zero SAME padding: (k - 1) // 2 frames to the left, k // 2 to the right, per convolution); + 1: the interpolation
     # towards the next conditioning row
-    n_cond = 0 if dims.wn_disable_conditioning else 1 + len(dims.wn_pre_cond_channels)
-    cond_l = n_cond * ((dims.cond_kernel_size - 1) // 2)
-    cond_r = n_cond * (dims.cond_kernel_size // 2) + 1
+    cond_l, cond_r = cond_chain_reach(dims)
+    cond_r += 1
     vt_l, vt_r = (0, 0) if dims.no_envelope else subnet_reach(mb["ps_subnet"])     # cepstrum of a frame <- mel frames around it
     stft_l, stft_r = 3, 4                                  # frame t reaches excitation frames t-3 .. t+4
     # first window frame whose mel-rate inputs of the WaveNet -- F0 / phase and the conditioning rows -- are reproducible
@@ -106,9 +114,9 @@ def frontend_reach(dims, config):
     f0_l, f0_r = reach(mb["pp_subnet"])
     vt_l, vt_r = reach(mb["ps_subnet"])
     # the conditioning layer and the pre-conditioning convolutions in front of it (same kernel size, zero SAME padding)
-    ck = ((dims.cond_kernel_size - 1) // 2) * (1 + len(dims.wn_pre_cond_channels))
+    ck_l, ck_r = cond_chain_reach(dims)
     # + 1: the interpolators (F0 contour, conditioning rows) reach the next frame
-    return max(f0_l, vt_l, ck), max(f0_r, vt_r, ck) + 1
+    return max(f0_l, vt_l, ck_l), max(f0_r, vt_r, ck_r) + 1
 
 
 class _Stream:
@@ -126,15 +134,26 @@ class _Stream:
         # phase state valid just in front of absolute pulse sample `state_frame * pulse_per_frame`
         self.state = (0.0, 0.0, 0)
         self.state_frame = 0
+        self.ticks = 0            # chunks emitted so far: position in the synthesizer's tick schedule
 
 
 class StreamingSynthesizer:
     """Serves any number of concurrent streams with one batched engine call per tick."""
 
     def __init__(self, engine, chunk_frames=8):
+        """``chunk_frames``: frames a stream emits per tick -- an int, or a cyclic schedule of ints for tick lengths that
+        are not a whole number of frames: BASELINE config 5's 80 ms are 6.4 frames of 12.5 ms, which the schedule
+        (6, 6, 7, 6, 7) delivers exactly on average (32 frames = 400 ms per period).  Every stream walks the schedule from
+        its own first tick.  Only a uniform schedule whose tick is a multiple of the window alignment (8 frames for the
+        canonical model) has ticks of constant geometry, which is what the replayed hipGraph needs; other schedules run
+        launch by launch (still with the carried sub-bands, per-layer state and phase)."""
         self.engine = engine
         self.dims = engine.dims
-        self.chunk = int(chunk_frames)
+        self.schedule = [int(chunk_frames)] if np.isscalar(chunk_frames) else [int(cc) for cc in chunk_frames]
+        if not self.schedule or min(self.schedule) < 1:
+            raise ValueError("chunk_frames must be a positive int or a non-empty schedule of positive ints")
+        self.uniform = len(set(self.schedule)) == 1
+        self.chunk = self.schedule[0] if self.uniform else min(self.schedule)
         (self.left, self.right, self.lead, self.act_left, self.act_right,
          self.wn_reach) = stream_margins(engine.dims, engine.config)
         # sub-band rows carried from tick to tick: the stages behind the WaveNet reach sr_left frames in front of the
@@ -275,9 +294,10 @@ class StreamingSynthesizer:
         have = st.have
         if st.emitted >= have:
             return 0
+        chunk = self.schedule[st.ticks % len(self.schedule)]
         if st.closed:
-            return min(self.chunk, have - st.emitted)
-        return self.chunk if have >= st.emitted + self.chunk + self.right else 0
+            return min(chunk, have - st.emitted)
+        return chunk if have >= st.emitted + chunk + self.right else 0
 
     def tick(self):
         """One batched engine call over every stream that can emit. Returns {stream_id: audio ndarray}."""
@@ -443,7 +463,10 @@ class StreamingSynthesizer:
         audio = audio[:, lo:hi].cpu().numpy()
         state_out = state_out.cpu().numpy()
         steady_ctx = None
-        if layer_rows and self.use_graph and self.chunk % self.align == 0:
+        # (mbx_window_advance keeps the part of a window that stays in LDS: at most 64 KB per item -- wide windows, e.g. the
+        # RMS normalisation with several smoothing iterations or deep pre-conditioning chains, run launch by launch)
+        window_fits = (tmax - self.chunk) * max(self.dims.mel_channels, spf) * 4 <= 64 * 1024
+        if layer_rows and self.use_graph and self.uniform and self.chunk % self.align == 0 and window_fits:
             # a steady tick: if the next one continues every stream the same way, it is this launch sequence on windows
             # that moved by `chunk` frames -- every window-relative argument is the same (_steady_continues checks it)
             (sid0, st0, _), (ws0, _) = todo[0], windows[0]
@@ -460,6 +483,7 @@ class StreamingSynthesizer:
             a0 = (st.emitted - ws) * hop - lo
             result[sid] = audio[bb, a0:a0 + nn * hop].copy()
             st.emitted += nn
+            st.ticks += 1
             st.carry_pos, st.carry_frames = next_carry[bb]
             st.layer_end = next_layer_end[bb]
             if next_state_frame[bb] < we:
@@ -483,6 +507,7 @@ class StreamingSynthesizer:
         adv = ctx["pending"] * self.chunk
         sf = ctx["state_v"][:, :2].copy().view(np.float32)
         for bb, st in enumerate(ctx["streams"]):
+            st.ticks += ctx["pending"]
             st.emitted += adv
             st.carry_pos = st.emitted
             st.layer_end += adv
@@ -572,7 +597,18 @@ class StreamingSynthesizer:
         import torch
         ctx = self._steady
         if self._graph is None or self._graph["ctx"] is not ctx:
-            self._graph = self._capture(ctx)
+            try:
+                self._graph = self._capture(ctx)
+            except Exception as exc:                          # noqa: BLE001 -- whatever made the capture fail
+                # the streams must not get stuck retrying a capture that cannot succeed: from here on every tick runs
+                # launch by launch (bit-identical results, more host time)
+                import sys
+                print(f"mbexwn_vocoder_amd.streaming: hipGraph capture of the steady tick failed ({type(exc).__name__}: "
+                      f"{exc}); ticks run launch by launch from here on", file=sys.stderr)
+                self._graph = None
+                self.use_graph = False
+                self._leave_steady()
+                return self.tick()
         gg = self._graph
         dims, chunk = self.dims, self.chunk
         hop, B = dims.hop_size, ctx["B"]

@@ -602,9 +602,24 @@ def slaney_mel_frequencies(n_mels, fmin, fmax):
     return np.where(mels >= min_log_mel, min_log_hz * np.exp(logstep * (mels - min_log_mel)), f_sp * mels)
 
 
+def slaney_mel_basis(sr, n_fft, n_mels, fmin, fmax):
+    """librosa.filters.mel(htk=False, norm="slaney") restated from the published construction (third party, absent
+    here; reference preprocess.py:52-74 calls it): triangles between neighbouring Slaney mel frequencies over the
+    n_fft // 2 + 1 bin frequencies, each divided by half its band width.  Returns (n_mels, n_fft // 2 + 1) float32."""
+    freqs = np.linspace(0.0, sr / 2.0, n_fft // 2 + 1)
+    mel_f = slaney_mel_frequencies(n_mels + 2, fmin, fmax)
+    basis = np.zeros((n_mels, freqs.shape[0]))
+    for ii in range(n_mels):
+        up = (freqs - mel_f[ii]) / (mel_f[ii + 1] - mel_f[ii])
+        down = (mel_f[ii + 2] - freqs) / (mel_f[ii + 2] - mel_f[ii + 1])
+        basis[ii] = np.maximum(0.0, np.minimum(up, down)) * (2.0 / (mel_f[ii + 2] - mel_f[ii]))
+    return basis.astype(np.float32)
+
+
 def normalize_inputs_by_rms(mell, config, synth_length, dtype=np.float64):
-    """wavegen_1d.py:638-769 (NormMelComponents.normalize_inputs_by_rms, audio=None, smoothing variant,
-    use_pinv=False) with the constructor constants of :580-636.  Returns (mell', gain (B, synth_length))."""
+    """wavegen_1d.py:638-769 (NormMelComponents.normalize_inputs_by_rms, audio=None, smoothing variant; both RMS
+    estimates: the band-width weighted one and normalize_use_pinv, :603-611, 683-689) with the constructor constants of
+    :580-636.  Returns (mell', gain (B, synth_length))."""
     pp, mb = config["preprocess_config"], config["mbexwn_config"]
     hop, win, n_mels = pp["hop_size"], pp.get("win_size", pp["fft_size"]), pp["mel_channels"]
     iters = mb.get("normalize_rms_num_smooth_iters", 0)
@@ -639,7 +654,16 @@ def normalize_inputs_by_rms(mell, config, synth_length, dtype=np.float64):
     mell = np.asarray(mell).astype(dtype)
     T = mell.shape[1]
     mel = np.exp(mell)
-    rms = np.sqrt(np.sum(np.square(mel * inv_enorm), axis=-1) / rms_norm_fact)                   # :689
+    if mb.get("normalize_use_pinv", False):
+        # :603-608: the mel filters inverted (pseudo inverse, float32 like the basis), the window's L2 norm; :684-685: the
+        # minimum-energy spectrum that explains the mel frame, its energy over all bins
+        win_norm = np.sqrt(np.sum(hann(win).astype(np.float32) ** 2))
+        basis = slaney_mel_basis(pp["sample_rate"], pp["fft_size"], n_mels, pp["fmin"], pp["fmax"])
+        inverted = np.linalg.pinv(basis).T.astype(dtype)                                         # (n_mels, bins)
+        spec = np.tensordot(mel, inverted, axes=1) / win_norm
+        rms = np.sqrt(np.sum(np.square(spec), axis=-1) / rms_norm_fact)
+    else:
+        rms = np.sqrt(np.sum(np.square(mel * inv_enorm), axis=-1) / rms_norm_fact)               # :689
     if mb.get("max_norm_fact", None):
         rms = np.maximum(rms, 1.0 / mb["max_norm_fact"])                                         # :690-691
     if mb.get("normalize_compressor_exp", None) is not None:

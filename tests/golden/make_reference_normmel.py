@@ -2,8 +2,9 @@
 """Golden vectors of the optional RMS normalisation (row A14) from the reference's own NormMelComponents
 (reference MBExWN_NVoc/vocoder/model/wavegen_1d.py:578-769) executed on the numpy TensorFlow stand-in.
 
-librosa is absent: ``librosa.core.convert.mel_frequencies`` is provided by this repo's restatement of the published
-Slaney formulas (mbexwn_vocoder_amd/analysis.py) -- the golden pins the reference's arithmetic around it, not librosa.
+librosa is absent: ``librosa.core.convert.mel_frequencies`` and (case "pinv": normalize_use_pinv) ``librosa.filters.mel``
+are provided by this repo's restatement of the published Slaney formulas (mbexwn_vocoder_amd/analysis.py) -- the golden
+pins the reference's arithmetic around them (the pseudo inverse, the window norm, the reductions), not librosa.
 Writes tests/golden/reference_normmel.npz.   (build container only; needs /root/reference)
 """
 import os
@@ -23,6 +24,7 @@ CASES = {
     "iters2_comp": {"normalize_rms_num_smooth_iters": 2, "normalize_compressor_exp": 0.8, "max_norm_fact": 200.0},
     "scaled_win": {"normalize_rms_num_smooth_iters": 1, "normalize_smooth_win_scale": 2,
                    "normalize_smooth_with_squared_win": False, "lin_amp_scale": 1.5, "mel_amp_scale": 0.5},
+    "pinv": {"normalize_rms_num_smooth_iters": 1, "normalize_use_pinv": True},
 }
 
 
@@ -32,6 +34,11 @@ def main():
     from mbexwn_vocoder_amd.config import canonical_config
     sys.modules["librosa.core.convert"].mel_frequencies = \
         lambda n_mels=128, fmin=0.0, fmax=11025.0, htk=False: analysis.mel_frequencies(n_mels, fmin, fmax)
+    # reference preprocess.py:69-72 (get_mel_filter): librosa.filters.mel(sr=, n_fft=, n_mels=, fmin=, fmax=, htk=False,
+    # norm="slaney", dtype=)
+    sys.modules["librosa.filters"].mel = \
+        lambda sr, n_fft, n_mels, fmin, fmax, htk=False, norm="slaney", dtype=np.float32: \
+        analysis.mel_basis_slaney(sr, n_fft, n_mels, fmin, fmax, dtype=dtype)
     out = {}
     for tag, ftype in (("f32", np.float32), ("f64", np.float64)):
         shim.set_float(ftype)

@@ -148,6 +148,9 @@ tf.zeros = lambda shape, dtype=None, name=None: _t(np.zeros(tuple(shape) if not 
 tf.range = lambda *a, dtype=None, **kw: _t(np.arange(*a, dtype=_dt(dtype)))
 tf.shape = lambda x: Shape(np.asarray(x).shape)
 tf.concat = lambda values, axis, name=None: _t(np.concatenate([np.asarray(v) for v in values], axis=axis))
+# tf.tensordot(a, b, axes): contraction of the last `axes` axes of a with the first `axes` of b (numpy's definition is the
+# published one); a float constant b takes the float type of a, like TensorFlow's implicit conversion of numpy arguments
+tf.tensordot = lambda a, b, axes: _t(np.tensordot(np.asarray(a), np.asarray(b).astype(np.asarray(a).dtype), axes=axes))
 tf.stack = lambda values, axis=0, name=None: _t(np.stack([np.asarray(v) for v in values], axis=axis))
 tf.tile = lambda x, multiples, name=None: _t(np.tile(np.asarray(x), tuple(multiples)))
 tf.reshape = lambda x, shape, name=None: _t(np.reshape(np.asarray(x), tuple(shape)))

@@ -5,6 +5,7 @@ import hashlib
 import struct
 
 import numpy as np
+import pytest
 
 from mbexwn_vocoder_amd import flac
 
@@ -69,7 +70,7 @@ def test_mono_stream_round_trip(tmp_path):
     path = flac.write(str(tmp_path / "a.flac"), audio, 24000)
     rate, pcm, rate_code = _parse(open(path, "rb").read())
     assert rate == 24000 and rate_code == 7 and pcm.shape == (audio.size, 1)
-    want = np.clip(np.rint(audio.astype(np.float64) * 32768), -32768, 32767).astype(np.int16)
+    want = np.clip(np.rint(audio.astype(np.float64) * 32767), -32768, 32767).astype(np.int16)   # libsndfile's scale
     assert np.array_equal(pcm[:, 0], want)
 
 
@@ -78,3 +79,17 @@ def test_stereo_unlisted_rate_and_many_frames():
     pcm_in = rng.integers(-32768, 32768, size=(4096 * 130 + 1, 2)).astype(np.int16)          # frame numbers above 127
     rate, pcm, rate_code = _parse(flac.encode(pcm_in, 12345))
     assert rate == 12345 and rate_code == 0 and np.array_equal(pcm, pcm_in)
+
+
+def test_other_integer_types_are_refused_and_soundfile_decodes_when_installed(tmp_path):
+    """int32 (or any integer but int16) has no agreed scale: refused instead of being clipped to full scale.  Where a real
+    decoder is installed (soundfile = libsndfile), it must read back what was written."""
+    from mbexwn_vocoder_amd import flac
+    with pytest.raises(TypeError):
+        flac.to_pcm16(np.arange(10, dtype=np.int32))
+    sf = pytest.importorskip("soundfile")
+    rng = np.random.default_rng(3)
+    audio = rng.uniform(-0.9, 0.9, size=5000).astype(np.float32)
+    path = flac.write(str(tmp_path / "x.flac"), audio, 24000)
+    data, rate = sf.read(path, dtype="int16")
+    assert rate == 24000 and np.array_equal(data, flac.to_pcm16(audio))

@@ -152,15 +152,60 @@ def test_voice_reference_golden(torch, golden_dir):
 # ------------------------------------------------------------------------------------------------
 # config 5: canonical model, 64 streams
 # ------------------------------------------------------------------------------------------------
-def test_canonical_streaming_64_streams_bit_equal(torch, monkeypatch):
-    """What `bench.py --workload config5_sp_stream64` times: 64 concurrent streams of the canonical C = 320 model,
-    8-frame ticks.  The concatenated stream output must be bit-equal to the offline synthesis of the same utterance
-    with the same convolution form (streams run Winograd F(2,3); MBX_WINOGRAD=2 pins the offline engine to it)."""
+def test_canonical_streaming_64_streams_80ms_schedule_bit_equal(torch):
+    """BASELINE config 5 as written: 80 ms ticks.  80 ms are 6.4 mel frames, so the streams walk the cyclic schedule
+    6 / 6 / 7 / 6 / 7 frames (32 frames = 400 ms per period: exactly 80 ms per tick on average).  64 concurrent streams of
+    the canonical C = 320 model, packets arriving in the same rhythm; the concatenated output of every stream must be
+    bit-equal to the offline synthesis with the same convolution form (F(2,3)), and the per-layer state must have been
+    carried (ticks that run every WaveNet layer on the tick's new rows only)."""
     from mbexwn_vocoder_amd.engine import MBExWNEngine
     from mbexwn_vocoder_amd.streaming import StreamingSynthesizer
-    monkeypatch.setenv("MBX_WINOGRAD", "2")
     cfg, raw, wt = build_case("SPEECH", {})
-    eng = MBExWNEngine(cfg, raw, wt)
+    eng = MBExWNEngine(cfg, raw, wt, conv_form="f23")
+    n_streams, schedule = 64, (6, 6, 7, 6, 7)
+    rng = np.random.default_rng(6)
+    lengths = [int(vv) for vv in rng.integers(60, 90, size=n_streams)]
+    syn = StreamingSynthesizer(eng, chunk_frames=schedule)
+    assert not syn.uniform and syn.schedule == list(schedule)
+    utts = []
+    for sid, ll in enumerate(lengths):
+        mm, nn = synthetic_inputs(1900 + sid, 1, ll)
+        utts.append((mm[0], nn[0]))
+        syn.open(sid)
+    got = {sid: [] for sid in range(n_streams)}
+    pos = [0] * n_streams
+    ticks, layered, sizes = 0, 0, set()
+    while not all(syn.finished(sid) for sid in range(n_streams)):
+        for sid, ll in enumerate(lengths):
+            if pos[sid] < ll:
+                nn = min(schedule[ticks % len(schedule)], ll - pos[sid])
+                syn.push(sid, utts[sid][0][pos[sid]:pos[sid] + nn], utts[sid][1][pos[sid] * 20:(pos[sid] + nn) * 20],
+                         last=pos[sid] + nn >= ll)
+                pos[sid] += nn
+        out = syn.tick()
+        for sid, audio in out.items():
+            got[sid].append(audio)
+            sizes.add(audio.shape[0] // 300)
+        ticks += 1
+        layered += syn.last_tick_layer_rows > 0
+        assert ticks < 300
+    assert {6, 7} <= sizes and layered >= 3 and syn.graph_ticks == 0
+    for sid in range(n_streams):
+        ll = lengths[sid]
+        offline = eng.forward(dev(torch, utts[sid][0][None]), noise=dev(torch, utts[sid][1][None])).cpu().numpy()[0]
+        stream = np.concatenate(got[sid])
+        assert stream.shape == (ll * 300,)
+        assert np.array_equal(stream, offline), f"stream {sid} is not bit-equal to the offline synthesis"
+
+
+def test_canonical_streaming_64_streams_bit_equal(torch):
+    """What `bench.py --workload config5_sp_stream64` times: 64 concurrent streams of the canonical C = 320 model,
+    8-frame ticks.  The concatenated stream output must be bit-equal to the offline synthesis of the same utterance
+    with the same convolution form (streams run Winograd F(2,3); conv_form="f23" pins the offline engine to it)."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    from mbexwn_vocoder_amd.streaming import StreamingSynthesizer
+    cfg, raw, wt = build_case("SPEECH", {})
+    eng = MBExWNEngine(cfg, raw, wt, conv_form="f23")
     n_streams, chunk = 64, 8
     rng = np.random.default_rng(5)
     lengths = [int(vv) for vv in rng.integers(50, 75, size=n_streams)]      # >= 5 ticks each, ragged ends
@@ -250,6 +295,7 @@ NORM_CASES = {
     "iters2_comp": {"normalize_rms_num_smooth_iters": 2, "normalize_compressor_exp": 0.8, "max_norm_fact": 200.0},
     "scaled_win": {"normalize_rms_num_smooth_iters": 1, "normalize_smooth_win_scale": 2,
                    "normalize_smooth_with_squared_win": False, "lin_amp_scale": 1.5, "mel_amp_scale": 0.5},
+    "pinv": {"normalize_rms_num_smooth_iters": 1, "normalize_use_pinv": True},      # reference wavegen_1d.py:603-608, 683-685
 }
 
 
@@ -274,8 +320,9 @@ def test_norm_mel_device_vs_reference_goldens(torch, golden_dir, case):
     cfg, raw, wt, eng = _norm_engine(NORM_CASES[case])
     mell = gold[f"f32/{case}/mell"]
     out, gain = eng.norm_mel_stage(dev(torch, mell))
-    np.testing.assert_allclose(out.cpu().numpy(), gold[f"f32/{case}/mell_norm"], rtol=0, atol=2e-5)
-    np.testing.assert_allclose(gain.cpu().numpy(), gold[f"f32/{case}/gain"], rtol=2e-5, atol=0)
+    tol = 2e-4 if case == "pinv" else 2e-5          # pinv: a float32 contraction over 1025 bins of +-1e3 entries
+    np.testing.assert_allclose(out.cpu().numpy(), gold[f"f32/{case}/mell_norm"], rtol=0, atol=tol)
+    np.testing.assert_allclose(gain.cpu().numpy(), gold[f"f32/{case}/gain"], rtol=tol, atol=0)
     # ragged: the smoothing uses the item's own edges
     nf = torch.as_tensor([17, 9], dtype=torch.int32).cuda()
     out_r, gain_r = eng.norm_mel_stage(dev(torch, mell), n_frames=nf)

@@ -92,6 +92,43 @@ def test_cli_round_trip(model_dir, tmp_path):
     assert " - SPEECH/MBExWN_SIIConv_V71g_SPEECH" in listing.stdout
 
 
+def test_cli_config1_canonical_3s_against_the_oracle(tmp_path):
+    """BASELINE config 1 as written: the MW-SP-FD model (canonical C = 320, L = 5), one 3 s utterance (80 x 240 mel) through
+    resynth_mel.py (reference protocol bin/resynth_mel.py:74-104: load the .mell pickle, scale_mel, synth_from_mel, write
+    the audio).  The file the CLI wrote is held to the float64 oracle run on the same scaled mel and the same noise draw
+    (the CLI seeds torch with 42 and draws the noise channel on the device, reference :65-67)."""
+    import torch
+    from scipy.io import wavfile
+    from mbexwn_vocoder_amd.config import read_config
+    from mbexwn_vocoder_amd.fileio import save_var
+    from mbexwn_vocoder_amd.mel_inverter import MELInverter, create_synthetic_model_dir
+    from mbexwn_vocoder_amd.tables import WaveTables
+    from mbexwn_vocoder_amd.weights import load_weights
+    from oracle.mbexwn_oracle import OracleModel
+    canon_dir = create_synthetic_model_dir(str(tmp_path / "MW-SP-FD_canonical"), "SPEECH")
+    frames = 240
+    dd = mell_dict(frames, seed=21)
+    path = str(tmp_path / "utt3s.mell")
+    save_var(path, dd)
+    cli = os.path.join(ROOT, "mbexwn_vocoder_amd", "bin", "resynth_mel.py")
+    out_dir = str(tmp_path / "out")
+    res = subprocess.run([sys.executable, cli, canon_dir, "-i", path, "-o", out_dir, "--format", "wav", "-g"],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    rate, data = wavfile.read(os.path.join(out_dir, "syn_utt3s.wav"))
+    assert rate == 24000 and data.dtype == np.float32 and data.shape == (frames * 300,)
+    inv = MELInverter(canon_dir)
+    assert inv.model.dims.wn_channels == 320 and inv.model.dims.wn_layers == 5
+    mell = inv.scale_mel(dd)
+    torch.manual_seed(42)                                   # the CLI's seed; its first draw is the noise channel
+    noise = torch.randn((1, frames * 20), device="cuda", dtype=torch.float32).cpu().numpy()
+    cfg = read_config(os.path.join(canon_dir, "config.yaml"))
+    wt = WaveTables(sample_rate=8000.0, **cfg["mbexwn_config"]["wavetable_config"])
+    ref = OracleModel(cfg, load_weights(os.path.join(canon_dir, "weights.npz")), wt).forward(mell, noise)[0]
+    err = float(np.max(np.abs(data.astype(np.float64) - ref)))
+    assert err <= 1e-4 * max(1.0, float(np.abs(ref).max())), err
+
+
 def test_sharded_synthesis_matches_single_runs(model_dir):
     """config 4 in miniature: ragged utterances, LPT shards, padded micro-batches, per-item parity."""
     import torch

@@ -79,23 +79,14 @@ def test_layer_state_geometry_and_argument_checks(engine):
 
 @pytest.fixture(scope="module")
 def offline_f23_engine():
-    """Offline engine pinned to the convolution form the streams use (Winograd F(2,3); MBX_WINOGRAD is read by
-    mbx_create): bit-equality needs the same arithmetic on both sides, the default offline form is picked by size."""
-    import os
+    """Offline engine pinned to the convolution form the streams use (Winograd F(2,3): mbx_config.wn_conv_form): bit-equality
+    needs the same arithmetic on both sides, the default offline form is calibrated and picked by size."""
     from mbexwn_vocoder_amd.engine import MBExWNEngine
     cfg, raw, wt = build_case("SPEECH", SMALL)
-    old = os.environ.get("MBX_WINOGRAD")
-    os.environ["MBX_WINOGRAD"] = "2"
-    try:
-        return MBExWNEngine(cfg, raw, wt)
-    finally:
-        if old is None:
-            del os.environ["MBX_WINOGRAD"]
-        else:
-            os.environ["MBX_WINOGRAD"] = old
+    return MBExWNEngine(cfg, raw, wt, conv_form="f23")
 
 
-@pytest.mark.parametrize("chunk", [8, 5, 2])
+@pytest.mark.parametrize("chunk", [8, 5, 2, (6, 6, 7, 6, 7)], ids=["8", "5", "2", "80ms_schedule"])
 def test_streaming_equals_offline(engine, offline_f23_engine, chunk):
     import torch
     from mbexwn_vocoder_amd.streaming import StreamingSynthesizer

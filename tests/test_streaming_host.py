@@ -35,6 +35,21 @@ def test_margins_follow_the_kernel_sizes():
     assert right5 >= 3 + 2 + 1 + 4                                             # conditioning conv reaches 2 (+1) frames ahead
 
 
+def test_even_conditioning_kernels_reach_further_right():
+    """The library pads a conditioning convolution (k - 1) // 2 frames in front and k // 2 behind: an even kernel size
+    reaches one frame more to the right, per convolution of the chain -- in the window margins and in the reach of the
+    carried front end alike (one shared helper)."""
+    from mbexwn_vocoder_amd.config import ModelDims, canonical_config
+    from mbexwn_vocoder_amd.streaming import cond_chain_reach, frontend_reach
+    for ks, pre, want in ((3, [], (1, 1)), (4, [], (1, 2)), (4, [48, 40], (3, 6)), (2, [16], (0, 2)), (5, [16], (4, 4))):
+        cfg = canonical_config("SPEECH", **{P + "cond_kernel_size": ks, P + "pre_cond_layer_channels": pre,
+                                            P + "n_channels": 32})
+        dims = ModelDims(cfg)
+        assert cond_chain_reach(dims) == want, (ks, pre)
+        fe_l, fe_r = frontend_reach(dims, cfg)
+        assert fe_l >= want[0] and fe_r >= want[1] + 1
+
+
 def test_pack_state_layout():
     st = pack_state(0.25, 3.5, 17, 400, 1200)
     assert st.dtype.name == "int32" and st.shape == (6,)

@@ -16,7 +16,7 @@ for case in range(n_cases):
     rng = np.random.default_rng(seed0 + case)
     over = {W + "n_channels": int(rng.choice([32, 48, 64])), W + "n_layers": int(rng.integers(1, 6)),
             W + "activation": str(rng.choice(["gtu", "gfu", "gsu", "glu"])),
-            W + "cond_lin_upsampling": int(rng.choice([10, 20, 5])), W + "cond_kernel_size": int(rng.choice([1, 3, 5]))}
+            W + "cond_lin_upsampling": int(rng.choice([10, 20, 5])), W + "cond_kernel_size": int(rng.choice([1, 3, 5, 2, 4]))}   # (even sizes: one frame more reach to the right)
     if rng.random() < 0.3:
         over[W + "max_log2_dilation_rate"] = int(rng.integers(1, 4))
     if rng.random() < 0.2:
