@@ -264,6 +264,8 @@ def roofline_blocks(ctx):
     dims, eng, batch, frames, stages = ctx["dims"], ctx["eng"], ctx["batch"], ctx["frames"], ctx["stages"]
     info = eng.conv_form_info()
     executed = {"direct": 1.0, "f23": 2.0 / 3.0, "f43": 0.5}[info["form"]]
+    if info["form"] == "f43" and (256 + dims.cond_lin_upsampling - 2) // dims.cond_lin_upsampling + 2 > 56:
+        executed = 1.0          # the F(4,3) kernel's conditioning tile holds 56 rows: finer conditioning runs the direct form
     L, ks = dims.wn_layers, dims.wn_kernel_size
     rpf = dims.wn_in_rows_per_frame
     flop_alg, rs_flop, geometry = 0.0, 0.0, []

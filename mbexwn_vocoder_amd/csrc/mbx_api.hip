@@ -1336,7 +1336,8 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                 wino4->shape[2] == 3072 && gs.cphase == 0) {
                 mbx::ConvArgs gw = g;
                 gw.w = wino4->ptr;
-                done = mbx::launch_wn_gate_winograd4w(gw, split4, stream);
+                // (the product-split shape holds 16 conditioning rows: cond_up >= 10; the 256-row shape takes cond_up >= 5)
+                done = mbx::launch_wn_gate_winograd4w(gw, split4, stream) || (split4 && mbx::launch_wn_gate_winograd4w(gw, false, stream));
             }
             // F(2,3): wave-tiled kernel on v_mfma_f32_16x16x4_f32 (wn_winograd2w.hip): streams, per-layer regions, MBX_CONV_F23
             const DevTensor *wino = (!done && hd->winograd) ? find(hd, "wn.conv1D_" + ls + ".wino2w") : nullptr;

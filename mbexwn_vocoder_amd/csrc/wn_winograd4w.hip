@@ -58,6 +58,9 @@ constexpr int WW_HALO = 16;
 constexpr int WW_BK = 8;
 constexpr int WW_B_FLOATS = 6 * WW_BK * 64;            // 3072: packed weights of one 8-channel slice
 
+// CR = conditioning rows the block's tile holds: 28 for cond_up >= 10 (the canonical models: 3 blocks per CU), 56 for
+// cond_up >= 5 (block-runner geometries whose first block runs at half the sub-band rate: 60.9 KB, 2 blocks per CU)
+template <int CR>
 struct WwShape {
     static constexpr int ROWS = 256;
     static constexpr int AROWS = ROWS + 2 * WW_HALO;            // rows that can be needed
@@ -68,8 +71,8 @@ struct WwShape {
     static constexpr int STAGE = A_FLOATS + WW_B_FLOATS;        // one 8-channel slice: A, B behind it: 5632 floats
     static constexpr int NSTAGE = 2;
     static constexpr int DMA_PER_STAGE = 6;                     // 3 (A) + 3 (B) requests per wave
-    static constexpr int COND_ROWS = 28;                        // conditioning rows of 64 floats (cond_up >= 10)
-    static constexpr int COND_CHUNKS = COND_ROWS / 4;           // 1 KB LDS-DMA requests: 7, dealt round-robin
+    static constexpr int COND_ROWS = CR;                        // conditioning rows of 64 floats
+    static constexpr int COND_CHUNKS = COND_ROWS / 4;           // 1 KB LDS-DMA requests: 7 | 14, dealt round-robin
     // behind the stages: conditioning tile; per block row lr: (float offset of its conditioning row) << 8 | phase u of
     // the interpolation; the interpolation weights w0[64], w1[64]
     static constexpr int COND = NSTAGE * STAGE;
@@ -99,8 +102,9 @@ __device__ __forceinline__ float2 ww_sub(float2 a, float2 b) { return make_float
 template <int N>
 using ww_int = std::integral_constant<int, N>;
 
-__global__ __launch_bounds__(256, 3) void wn_gate_winograd4w_kernel(ConvArgs p, int log2d) {
-    using SH = WwShape;
+template <int CR>
+__global__ __launch_bounds__(256, CR <= 28 ? 3 : 2) void wn_gate_winograd4w_kernel(ConvArgs p, int log2d) {
+    using SH = WwShape<CR>;
     constexpr int ROWS = SH::ROWS, NSTAGE = SH::NSTAGE, STAGE = SH::STAGE, A_FLOATS = SH::A_FLOATS, PHASE = SH::PHASE;
     typedef __attribute__((address_space(3))) float lds_float;
     __shared__ __attribute__((aligned(16))) float lds[SH::LDS_FLOATS];
@@ -685,11 +689,12 @@ bool launch_wn_gate_winograd4w(const ConvArgs &a, bool split, hipStream_t stream
     while ((1 << log2d) < a.dil) ++log2d;
     const int rows_blk = split ? 128 : 256;
     const int nk8 = (a.cin + WW_BK - 1) / WW_BK;
+    const int cond_rows = a.cond_up >= 1 ? (rows_blk + a.cond_up - 2) / a.cond_up + 2 : 1 << 30;   // conditioning rows a block touches
     const bool ok = a.ks == 3 && (1 << log2d) == a.dil && a.dil <= WW_HALO && nk8 >= 4 && a.pad_l == a.dil && a.pad_mode == 0 &&
                     a.cin % 4 == 0 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 && a.channels % 4 == 0 &&
                     a.cout == 2 * a.channels && (uintptr_t)a.x % 16 == 0 && (uintptr_t)a.w % 16 == 0 && a.zeros &&
                     a.cond && (uintptr_t)a.cond % 16 == 0 && a.cond_bstride % 4 == 0 && a.cond_up >= 1 &&
-                    a.cond_up <= 64 && (rows_blk + a.cond_up - 2) / a.cond_up + 2 <= (split ? 16 : 28) && a.lerp_w0 && a.lerp_w1 && a.max_rows < (1 << 24);
+                    a.cond_up <= 64 && cond_rows <= (split ? 16 : 56) && a.lerp_w0 && a.lerp_w1 && a.max_rows < (1 << 24);
     if (!ok) return false;
     ConvArgs r = a;
     r.fast_dma = 1;                 // byte offsets are relative to the block's window (< 2^32 for any item length)
@@ -698,7 +703,8 @@ bool launch_wn_gate_winograd4w(const ConvArgs &a, bool split, hipStream_t stream
     r.m_tiles_total = r.m_tiles_per_item * a.batch;
     const long long blocks = 8LL * ((r.m_tiles_total + 7) / 8) * r.n_tiles;
     if (split) hipLaunchKernelGGL(wn_gate_winograd4p_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, r, log2d);
-    else hipLaunchKernelGGL(wn_gate_winograd4w_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, r, log2d);
+    else if (cond_rows <= 28) hipLaunchKernelGGL(wn_gate_winograd4w_kernel<28>, dim3((unsigned)blocks), dim3(256), 0, stream, r, log2d);
+    else hipLaunchKernelGGL(wn_gate_winograd4w_kernel<56>, dim3((unsigned)blocks), dim3(256), 0, stream, r, log2d);
     return true;
 }
 
