@@ -144,15 +144,19 @@ class StreamingSynthesizer:
         """``chunk_frames``: frames a stream emits per tick -- an int, or a cyclic schedule of ints for tick lengths that
         are not a whole number of frames: BASELINE config 5's 80 ms are 6.4 frames of 12.5 ms, which the schedule
         (6, 6, 7, 6, 7) delivers exactly on average (32 frames = 400 ms per period).  Every stream walks the schedule from
-        its own first tick.  Only a uniform schedule whose tick is a multiple of the window alignment (8 frames for the
-        canonical model) has ticks of constant geometry, which is what the replayed hipGraph needs; other schedules run
-        launch by launch (still with the carried sub-bands, per-layer state and phase)."""
+        its own first tick.  The geometry of a steady tick (position of the aligned window start relative to the emitted
+        frames, window length) repeats with the period of the schedule when that period is a multiple of the window
+        alignment (8 frames for the canonical model: 8-frame ticks, or the 32-frame period of the 80 ms schedule): each
+        phase of the period then has its own captured hipGraph, all of them working on one device-resident window; any
+        other schedule runs launch by launch (still with the carried sub-bands, per-layer state and phase)."""
         self.engine = engine
         self.dims = engine.dims
         self.schedule = [int(chunk_frames)] if np.isscalar(chunk_frames) else [int(cc) for cc in chunk_frames]
         if not self.schedule or min(self.schedule) < 1:
             raise ValueError("chunk_frames must be a positive int or a non-empty schedule of positive ints")
         self.uniform = len(set(self.schedule)) == 1
+        if self.uniform:
+            self.schedule = self.schedule[:1]
         self.chunk = self.schedule[0] if self.uniform else min(self.schedule)
         (self.left, self.right, self.lead, self.act_left, self.act_right,
          self.wn_reach) = stream_margins(engine.dims, engine.config)
@@ -191,14 +195,17 @@ class StreamingSynthesizer:
         d_max = max(engine.dims.wn_dilation(ll) for ll in range(engine.dims.wn_layers))
         self.align = (2 * d_max) // math.gcd(2 * d_max, engine.dims.steps_per_frame)
         self.streams = {}
+        # ticks of a schedule whose period is a whole number of alignment steps have a geometry that repeats per phase
+        self.periodic = sum(self.schedule) % self.align == 0
+        # frames of the device windows of such a schedule: every phase's window fits (uniform: the window length itself)
+        self._tcap = 0 if self.uniform else self.left + max(self.schedule) + self.right + self.align
         # Steady ticks (every stream continues with the geometry of the tick before) are replayed as a captured hipGraph:
         # the windows stay on the device (mbx_window_advance appends the new frames), every integer argument of the call is
         # a constant of the capture, and one graph launch stands for the ~30 kernel launches of a tick.  This is the
         # practical form of BASELINE config 5's "persistent-kernel path": the launch sequence persists, not a kernel.
         self.use_graph = True
         self._inputs_changed = True
-        self._steady = None               # what the last steady tick of the launch-by-launch path left behind
-        self._graph = None                # the captured tick and its fixed buffers
+        self._steady = None               # the steady run in progress: its streams, the recorded phases and their graphs
         self.graph_ticks = 0              # ticks served by a graph replay
         self.last_tick_replayed = False
         self.time_device = False          # bench: bracket the engine call of a tick with events on its stream
@@ -248,7 +255,7 @@ class StreamingSynthesizer:
                 if old_f is not None:
                     self._fe_store[:n_old] = old_f
             self._free_slots = list(range(n_new - 1, n_old - 1, -1))
-            self._graph = None            # the stores moved: a captured tick points at the old ones
+            # (the stores moved: captured ticks point at the old ones -- open() has left the steady run above)
             self._grow_inputs(n_new, self._in_cap)
         st.slot = self._free_slots.pop()
         self.streams[stream_id] = st
@@ -304,9 +311,13 @@ class StreamingSynthesizer:
         import torch
         self.last_tick_replayed = False
         if self._steady is not None:
-            if self.use_graph and self._steady_continues():
+            status = self._steady_status()
+            if status == "replay" and self.use_graph:
                 return self._graph_tick()
-            self._leave_steady()
+            if status == "broken":
+                self._leave_steady()
+            else:                                     # a phase of the schedule that has no recorded tick yet
+                self._sync_streams()
         todo = [(sid, st, self._ready(st)) for sid, st in self.streams.items()]
         todo = [(sid, st, nn) for sid, st, nn in todo if nn > 0]
         if not todo:
@@ -407,8 +418,9 @@ class StreamingSynthesizer:
                 for bb, ((sid, st, nn), (ws, we)) in enumerate(zip(todo, windows)):
                     ldesc[bb, 1] = (st.layer_end - ws) * spf
                     wn[bb] = ends[bb] - ws - wa
-        mel = np.zeros((B, tmax, self.dims.mel_channels), dtype=np.float32)
-        noise = np.zeros((B, tmax * spf), dtype=np.float32)
+        tpad = max(tmax, self._tcap)              # periodic schedules keep one window size for all phases (n_frames masks)
+        mel = np.zeros((B, tpad, self.dims.mel_channels), dtype=np.float32)
+        noise = np.zeros((B, tpad * spf), dtype=np.float32)
         nfr = np.zeros((B,), dtype=np.int32)
         states = np.zeros((B, 6), dtype=np.int32)
         st_f = np.zeros((B, 2), dtype=np.float32)
@@ -430,7 +442,7 @@ class StreamingSynthesizer:
         mel_d = torch.as_tensor(mel, device=dev)
         noise_d = torch.as_tensor(noise, device=dev) if self.dims.noise_sigma else None
         # every int32 argument of the call in one upload
-        use_fe = self.fe_carry and self.carry and tmax <= self._fe_ring
+        use_fe = self.fe_carry and self.carry and tpad <= self._fe_ring
         fpos = np.asarray([ws % self._fe_ring for ws, _ in windows], dtype=np.int32)
         parts = [states.ravel(), desc.ravel(), ldesc.ravel(), nfr, act, wn if wn is not None else act, fpos]
         ints_d = torch.as_tensor(np.concatenate(parts), device=dev)
@@ -465,19 +477,21 @@ class StreamingSynthesizer:
         steady_ctx = None
         # (mbx_window_advance keeps the part of a window that stays in LDS: at most 64 KB per item -- wide windows, e.g. the
         # RMS normalisation with several smoothing iterations or deep pre-conditioning chains, run launch by launch)
-        window_fits = (tmax - self.chunk) * max(self.dims.mel_channels, spf) * 4 <= 64 * 1024
-        if layer_rows and self.use_graph and self.uniform and self.chunk % self.align == 0 and window_fits:
-            # a steady tick: if the next one continues every stream the same way, it is this launch sequence on windows
-            # that moved by `chunk` frames -- every window-relative argument is the same (_steady_continues checks it)
-            (sid0, st0, _), (ws0, _) = todo[0], windows[0]
+        window_fits = tpad * max(self.dims.mel_channels, spf) * 4 <= 64 * 1024
+        phases = {st.ticks % len(self.schedule) for _, st, _ in todo}
+        if (layer_rows and self.use_graph and self.periodic and window_fits and len(phases) == 1 and
+                len({nn for _, _, nn in todo}) == 1 and len(set(windows)) >= 1 and
+                len({(st.emitted - ws, we - ws) for (_, st, _), (ws, we) in zip(todo, windows)}) == 1):
+            # a steady tick: when this phase of the schedule comes round again with every stream continuing the same way,
+            # it is this launch sequence on windows that moved on by one period -- every window-relative argument is the
+            # same (_steady_status checks it)
+            (sid0, st0, nn0), (ws0, we0) = todo[0], windows[0]
             steady_ctx = {
-                "sids": [sid for sid, _, _ in todo], "streams": [st for _, st, _ in todo], "B": B, "T": tmax, "a0": a0,
-                "wa": wa, "lo": lo, "hi": hi, "layer_rows": layer_rows, "act": act.copy(), "wn": wn.copy(),
-                "nfr": nfr.copy(), "desc": desc.copy(), "ldesc": ldesc.copy(), "state_consts": states[:, 3:5].copy(),
-                "mel_d": mel_d, "noise_d": noise_d, "rel0": st0.emitted - ws0, "state_v": state_out.copy(),
-                "slots": np.asarray([st.slot for _, st, _ in todo], dtype=np.int64), "pending": 0, "use_fe": use_fe,
+                "phase": phases.pop(), "chunk": nn0, "T": we0 - ws0, "tpad": tpad, "a0": a0, "wa": wa, "lo": lo, "hi": hi,
+                "layer_rows": layer_rows, "act": act.copy(), "wn": wn.copy(), "nfr": nfr.copy(), "desc": desc.copy(),
+                "ldesc": ldesc.copy(), "state_consts": states[:, 3:5].copy(), "rel0": st0.emitted - ws0, "use_fe": use_fe,
                 "frames": self.last_tick_frames, "active_frames": self.last_tick_active_frames,
-                "wavenet_frames": self.last_tick_wavenet_frames}
+                "wavenet_frames": self.last_tick_wavenet_frames, "ws0": ws0}
         result = {}
         for bb, ((sid, st, nn), (ws, we)) in enumerate(zip(todo, windows)):
             a0 = (st.emitted - ws) * hop - lo
@@ -490,66 +504,117 @@ class StreamingSynthesizer:
                 ff = state_out[bb, :2].copy().view(np.float32)
                 st.state = (float(ff[0]), float(ff[1]), int(state_out[bb, 2]))
                 st.state_frame = next_state_frame[bb]
-        if steady_ctx is not None:
-            steady_ctx["emitted_v"] = np.asarray([st.emitted for _, st, _ in todo], dtype=np.int64)
-            self._steady = steady_ctx
+        sids = [sid for sid, _, _ in todo]
+        if steady_ctx is None:
+            self._steady = None                   # not a steady tick: whatever run was being recorded is over
+        else:
+            run = self._steady
+            if run is None or run["sids"] != sids or run["tpad"] != tpad:
+                run = {"sids": sids, "streams": [st for _, st, _ in todo], "B": B, "tpad": tpad, "phases": {}, "graphs": {},
+                       "slots": np.asarray([st.slot for _, st, _ in todo], dtype=np.int64), "win": None, "shared": None}
+                self._steady = run
+            old = run["phases"].get(steady_ctx["phase"])
+            if old is not None and any(not np.array_equal(old[kk], steady_ctx[kk]) if isinstance(old[kk], np.ndarray)
+                                       else old[kk] != steady_ctx[kk] for kk in steady_ctx if kk != "ws0"):
+                run["graphs"].pop(steady_ctx["phase"], None)          # the geometry of this phase changed: capture it anew
+            run["phases"][steady_ctx["phase"]] = steady_ctx
+            # where the run stands: the windows this tick worked on (device tensors) and their first frame, the streams'
+            # progress and phase states as vectors (replayed ticks keep them there, _sync_streams writes them back)
+            run["win_src"] = (mel_d, noise_d)
+            run["win_ws0"] = steady_ctx["ws0"]
+            run["win_T"] = steady_ctx["T"]
+            run["state_v"] = state_out.copy()
+            run["emitted_v"] = np.asarray([st.emitted for _, st, _ in todo], dtype=np.int64)
+            run["next_phase"] = todo[0][1].ticks % len(self.schedule)
+            run["pending"], run["pending_frames"] = 0, 0
+            run.pop("need_v", None)
         return result
 
     # ------------------------------------------------------------------------------------------------------------------
-    # steady ticks as a replayed hipGraph
+    # steady ticks as replayed hipGraphs (one per phase of the tick schedule)
     # ------------------------------------------------------------------------------------------------------------------
     def _sync_streams(self):
         """Write the progress of the replayed ticks back to the stream objects (inside a run of replayed ticks it is kept
         in vectors: emitted frames, carried phase states)."""
-        ctx = self._steady
-        if ctx is None or not ctx["pending"]:
+        run = self._steady
+        if run is None or not run["pending"]:
             return
-        adv = ctx["pending"] * self.chunk
-        sf = ctx["state_v"][:, :2].copy().view(np.float32)
-        for bb, st in enumerate(ctx["streams"]):
-            st.ticks += ctx["pending"]
+        adv = run["pending_frames"]
+        sf = run["state_v"][:, :2].copy().view(np.float32)
+        for bb, st in enumerate(run["streams"]):
+            st.ticks += run["pending"]
             st.emitted += adv
             st.carry_pos = st.emitted
             st.layer_end += adv
             st.state_frame += adv
-            st.state = (float(sf[bb, 0]), float(sf[bb, 1]), int(ctx["state_v"][bb, 2]))
-        ctx["pending"] = 0
+            st.state = (float(sf[bb, 0]), float(sf[bb, 1]), int(run["state_v"][bb, 2]))
+        run["pending"], run["pending_frames"] = 0, 0
 
     def _leave_steady(self):
         self._sync_streams()
         self._steady = None
 
-    def _steady_continues(self):
-        """True when this tick is the steady tick recorded in self._steady moved on by `chunk` frames: the same streams
-        (and no other one ready), each with a whole chunk and its look-ahead available and no utterance end inside the
-        window, the same position of the window relative to the emitted frames -- then every window-relative argument of
-        the engine call is unchanged."""
-        ctx = self._steady
-        streams, B = ctx["streams"], ctx["B"]
-        if self._inputs_changed or "need_v" not in ctx:
+    def _steady_status(self):
+        """What the tick about to run is for the steady run in self._steady: "replay" -- its phase of the schedule has been
+        recorded and this tick is that recorded tick moved on (the same streams and no other one ready, each with a whole
+        chunk and its look-ahead available and no utterance end inside the window, the same position of the window
+        relative to the emitted frames: then every window-relative argument of the engine call is unchanged); "record" --
+        the streams continue but this phase has no recorded tick yet (it runs launch by launch and is recorded);
+        "broken" -- anything else."""
+        run = self._steady
+        streams, B = run["streams"], run["B"]
+        if self._inputs_changed or "need_v" not in run:
             # frames received (+ whether the stream is closed: its last frame must then lie behind the window) and the
             # column of absolute frame 0 in the shared input rows; only push() changes them
-            ctx["need_v"] = np.fromiter((st.have - st.closed for st in streams), np.int64, B)
-            ctx["base_v"] = np.fromiter((st.base for st in streams), np.int64, B)
+            run["need_v"] = np.fromiter((st.have - st.closed for st in streams), np.int64, B)
+            run["base_v"] = np.fromiter((st.base for st in streams), np.int64, B)
             self._inputs_changed = False
-        emitted = ctx["emitted_v"]
-        if int((ctx["need_v"] - emitted).min()) < self.chunk + self.right:
-            return False
-        ws = np.maximum(0, ((emitted - self.left) // self.align) * self.align)
-        if np.any(emitted - ws != ctx["rel0"]):
-            return False
+        phase = run["next_phase"]
+        chunk = self.schedule[phase]
+        emitted = run["emitted_v"]
+        if int((run["need_v"] - emitted).min()) < chunk + self.right:
+            return "broken"
         if len(self.streams) != B:                        # a stream outside the recorded set must not be ready
-            inside = set(ctx["sids"])
+            inside = set(run["sids"])
             if any(self._ready(st) > 0 for sid, st in self.streams.items() if sid not in inside):
-                return False
-        return True
+                return "broken"
+        ctx = run["phases"].get(phase)
+        if ctx is None:
+            return "record"
+        ws = np.maximum(0, ((emitted - self.left) // self.align) * self.align)
+        if np.any(emitted - ws != ctx["rel0"]) or ctx["chunk"] != chunk:
+            return "broken"
+        return "replay"
 
-    def _capture(self, ctx):
-        """Fixed buffers + the captured launch sequence of the steady tick described by ctx."""
+    def _capture(self, run, phase):
+        """Fixed buffers + the captured launch sequence of the steady tick of one phase of the schedule.  All phases of a
+        run work on ONE pair of device-resident windows (run["win"]: mel (B, tpad, channels), noise (B, tpad * spf)); a
+        tick moves them on -- shift by the frames the aligned window start advanced since the tick before, append the
+        tick's new frames -- and runs the forward pass with the phase's constant arguments."""
         import torch
+        ctx = run["phases"][phase]
+        n_ph = len(self.schedule)
+        prev = run["phases"][(phase - 1) % n_ph]
         eng, dims, dev = self.engine, self.dims, self.engine.device
-        B, T, chunk, spf, hop = ctx["B"], ctx["T"], self.chunk, dims.steps_per_frame, dims.hop_size
+        B, tpad, chunk, spf, hop = run["B"], run["tpad"], ctx["chunk"], dims.steps_per_frame, dims.hop_size
+        # the window of the tick before held T_prev frames from ws_prev on; this one T frames from ws on: the start moved
+        # by `shift` = (emitted - rel0) - (emitted_prev - rel0_prev) frames, `chunk` frames are new at the end
+        shift = prev["chunk"] - (ctx["rel0"] - prev["rel0"])
+        keep = prev["T"] - shift
+        if shift < 0 or keep < 0 or keep + chunk != ctx["T"] or ctx["T"] > tpad:
+            raise RuntimeError(f"steady ticks of phases {(phase - 1) % n_ph} and {phase} do not chain: shift {shift}, "
+                               f"windows {prev['T']} -> {ctx['T']} frames, chunk {chunk}")
         use_noise = bool(dims.noise_sigma)
+        if run["win"] is None:
+            mel_win = torch.zeros((B, tpad, dims.mel_channels), dtype=torch.float32, device=dev)
+            noise_win = torch.zeros((B, tpad * spf), dtype=torch.float32, device=dev) if use_noise else None
+            run["win"] = (mel_win, noise_win)
+            run["shared"] = {
+                "audio_buf": torch.empty((B, tpad * hop), dtype=torch.float32, device=dev),
+                "state_out": torch.empty((B, 6), dtype=torch.int32, device=dev),
+                "state_host": torch.empty((B, 6), dtype=torch.int32).pin_memory()}
+        mel_win, noise_win = run["win"]
+        shared = run["shared"]
         n_mel, n_noise = B * chunk * dims.mel_channels, (B * chunk * spf if use_noise else 0)
         # one pinned host buffer / one device buffer for everything a tick uploads: new mel frames, new noise, phase states
         stage_host = torch.empty(n_mel + n_noise + B * 7, dtype=torch.float32).pin_memory()
@@ -558,63 +623,85 @@ class StreamingSynthesizer:
         noise_new = stage_dev[n_mel:n_mel + n_noise].view(B, chunk * spf) if use_noise else None
         states_d = stage_dev[n_mel + n_noise:n_mel + n_noise + B * 6].view(torch.int32).view(B, 6)
         fpos_d = stage_dev[n_mel + n_noise + B * 6:].view(torch.int32)
-        # front end: the window moved by `chunk` frames and the last fe_right frames of the window before were inexact
+        # front end: the window gained `chunk` frames and the last fe_right frames of the window before were inexact; the
+        # carried front end computes the LAST frames of the buffer, so it needs a window that fills it (uniform schedules)
         fe_new, fe_margin = chunk + self.fe_right, self.fe_left
-        use_fe = ctx["use_fe"] and fe_new + fe_margin <= T
+        use_fe = ctx["use_fe"] and ctx["T"] == tpad and shift == chunk and fe_new + fe_margin <= tpad
         ints = {kk: torch.as_tensor(ctx[kk], device=dev) for kk in ("act", "wn", "nfr", "desc", "ldesc")}
-        audio_buf = torch.empty((B, T * hop), dtype=torch.float32, device=dev)
-        state_out = torch.empty((B, 6), dtype=torch.int32, device=dev)
+        audio_buf, state_out, state_host = shared["audio_buf"], shared["state_out"], shared["state_host"]
         emit_buf = torch.empty((B, ctx["hi"] - ctx["lo"]), dtype=torch.float32, device=dev)
         audio_host = torch.empty((B, ctx["hi"] - ctx["lo"]), dtype=torch.float32).pin_memory()
-        state_host = torch.empty((B, 6), dtype=torch.int32).pin_memory()
-        mel_win, noise_win = ctx["mel_d"], ctx["noise_d"] if use_noise else None
+        one_launch = shift == chunk and ctx["T"] == tpad
+        # source of the frames a pure shift "appends" (they land behind the kept part, where the new frames are written next)
+        pad_mel = torch.zeros((B, shift, dims.mel_channels), dtype=torch.float32, device=dev) if shift and not one_launch else None
+        pad_noise = torch.zeros((B, shift * spf), dtype=torch.float32, device=dev) if pad_mel is not None and use_noise else None
         graph = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(dev)
         # thread_local: another thread of the process (the RCCL watchdog of a multi-rank job) may touch the runtime while
         # this one captures
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             stage_dev.copy_(stage_host, non_blocking=True)
-            eng.window_advance(mel_win, mel_new, noise_win, noise_new)
+            if one_launch:
+                eng.window_advance(mel_win, mel_new, noise_win, noise_new)         # shift and append in one launch
+            else:
+                if shift > 0:
+                    eng.window_advance(mel_win, pad_mel, noise_win, pad_noise)
+                mel_win[:, keep:keep + chunk].copy_(mel_new)
+                if use_noise:
+                    noise_win[:, keep * spf:(keep + chunk) * spf].copy_(noise_new)
             eng.forward(mel_win, n_frames=ints["nfr"], noise=noise_win, stream_state=states_d,
                         active=(ctx["a0"], ints["act"], int(ctx["act"].max())),
                         wavenet=(ctx["wa"], ints["wn"], int(ctx["wn"].max())),
                         carry=(self._store, ints["desc"].view(B, 5)) if self.carry else None,
                         layers=(self._layer_store, ints["ldesc"].view(B, 3), ctx["layer_rows"]),
-                        frontend=(self._fe_store, fpos_d, fe_new, fe_margin) if use_fe else None,
+                        frontend=(self._fe_store, fpos_d, fe_new if use_fe else 0, fe_margin if use_fe else 0)
+                        if ctx["use_fe"] else None,
                         out=audio_buf, state_out=state_out)
             emit_buf.copy_(audio_buf[:, ctx["lo"]:ctx["hi"]])
             audio_host.copy_(emit_buf, non_blocking=True)
             state_host.copy_(state_out, non_blocking=True)
         n_state = n_mel + n_noise
-        return {"ctx": ctx, "graph": graph, "stage_host": stage_host, "stage_np": stage_host.numpy(), "n_mel": n_mel,
-                "arange": np.arange(chunk, dtype=np.int64),
-                "n_noise": n_noise, "n_state": n_state, "audio_host": audio_host, "state_host": state_host,
-                "keep": (stage_dev, ints, audio_buf, state_out, emit_buf, mel_win, noise_win)}
+        return {"graph": graph, "stage_host": stage_host, "stage_np": stage_host.numpy(), "n_mel": n_mel,
+                "arange": np.arange(chunk, dtype=np.int64), "n_noise": n_noise, "n_state": n_state,
+                "audio_host": audio_host, "state_host": state_host, "shift": shift, "keep": keep,
+                "keep_alive": (stage_dev, ints, emit_buf, pad_mel, pad_noise)}
 
     def _graph_tick(self):
         """A steady tick as one graph launch: gather and upload the new frames and the phase states, replay, read the
         chunk back.  Nothing here loops over the streams."""
         import torch
-        ctx = self._steady
-        if self._graph is None or self._graph["ctx"] is not ctx:
+        run = self._steady
+        phase = run["next_phase"]
+        ctx = run["phases"][phase]
+        n_ph = len(self.schedule)
+        gg = run["graphs"].get(phase)
+        if gg is None:
             try:
-                self._graph = self._capture(ctx)
+                if (phase - 1) % n_ph not in run["phases"]:
+                    raise RuntimeError("the phase in front of this one has no recorded tick")
+                gg = run["graphs"][phase] = self._capture(run, phase)
             except Exception as exc:                          # noqa: BLE001 -- whatever made the capture fail
                 # the streams must not get stuck retrying a capture that cannot succeed: from here on every tick runs
                 # launch by launch (bit-identical results, more host time)
                 import sys
                 print(f"mbexwn_vocoder_amd.streaming: hipGraph capture of the steady tick failed ({type(exc).__name__}: "
                       f"{exc}); ticks run launch by launch from here on", file=sys.stderr)
-                self._graph = None
                 self.use_graph = False
                 self._leave_steady()
                 return self.tick()
-        gg = self._graph
-        dims, chunk = self.dims, self.chunk
-        hop, B = dims.hop_size, ctx["B"]
+        dims, chunk = self.dims, ctx["chunk"]
+        hop, B = dims.hop_size, run["B"]
+        # the device windows hold the window of the tick before: written there by a replayed tick, or still in the tensors a
+        # launch-by-launch tick uploaded
+        if run["win_src"] is not run["win"]:
+            src_mel, src_noise = run["win_src"]
+            run["win"][0].copy_(src_mel)
+            if run["win"][1] is not None:
+                run["win"][1].copy_(src_noise)
+            run["win_src"] = run["win"]
         stage = gg["stage_np"]
-        emitted, slots = ctx["emitted_v"], ctx["slots"]
-        base = ctx["base_v"]
+        emitted, slots = run["emitted_v"], run["slots"]
+        base = run["base_v"]
         # the frames the windows gain: [emitted + right, emitted + right + chunk) of every stream
         cols = (emitted + self.right - base)[:, None] + gg["arange"]
         np.copyto(stage[:gg["n_mel"]].reshape(B, chunk, dims.mel_channels), self._in_mel[slots[:, None], cols])
@@ -624,7 +711,7 @@ class StreamingSynthesizer:
         ints = stage[gg["n_state"]:].view(np.int32)
         states = ints[:B * 6].reshape(B, 6)
         ints[B * 6:] = (emitted - ctx["rel0"]) % self._fe_ring              # ring frame of each window's first frame
-        states[:, :3] = ctx["state_v"][:, :3]
+        states[:, :3] = run["state_v"][:, :3]
         states[:, 3:5] = ctx["state_consts"]
         states[:, 5] = 0
         if self.time_device:
@@ -637,11 +724,13 @@ class StreamingSynthesizer:
         if self.time_device:
             self.last_tick_device_ms = ev0.elapsed_time(ev1)
         audio = gg["audio_host"].numpy().copy()
-        ctx["state_v"] = gg["state_host"].numpy().copy()
+        run["state_v"] = gg["state_host"].numpy().copy()
         a0 = ctx["rel0"] * hop - ctx["lo"]
-        result = dict(zip(ctx["sids"], audio[:, a0:a0 + chunk * hop]))
+        result = dict(zip(run["sids"], audio[:, a0:a0 + chunk * hop]))
         emitted += chunk
-        ctx["pending"] += 1
+        run["pending"] += 1
+        run["pending_frames"] += chunk
+        run["next_phase"] = (phase + 1) % n_ph
         self.last_tick_frames, self.last_tick_active_frames = ctx["frames"], ctx["active_frames"]
         self.last_tick_wavenet_frames, self.last_tick_layer_rows = ctx["wavenet_frames"], ctx["layer_rows"]
         self.last_tick_replayed = True

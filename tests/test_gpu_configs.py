@@ -164,7 +164,7 @@ def test_canonical_streaming_64_streams_80ms_schedule_bit_equal(torch):
     eng = MBExWNEngine(cfg, raw, wt, conv_form="f23")
     n_streams, schedule = 64, (6, 6, 7, 6, 7)
     rng = np.random.default_rng(6)
-    lengths = [int(vv) for vv in rng.integers(60, 90, size=n_streams)]
+    lengths = [int(vv) for vv in rng.integers(110, 140, size=n_streams)]
     syn = StreamingSynthesizer(eng, chunk_frames=schedule)
     assert not syn.uniform and syn.schedule == list(schedule)
     utts = []
@@ -189,7 +189,8 @@ def test_canonical_streaming_64_streams_80ms_schedule_bit_equal(torch):
         ticks += 1
         layered += syn.last_tick_layer_rows > 0
         assert ticks < 300
-    assert {6, 7} <= sizes and layered >= 3 and syn.graph_ticks == 0
+    assert {6, 7} <= sizes and layered >= 3
+    assert syn.graph_ticks >= 3                            # phases recorded in the first period are replayed as graphs afterwards
     for sid in range(n_streams):
         ll = lengths[sid]
         offline = eng.forward(dev(torch, utts[sid][0][None]), noise=dev(torch, utts[sid][1][None])).cpu().numpy()[0]

@@ -43,12 +43,16 @@ for case in range(n_cases):
         dims = ModelDims(cfg)
         raw = synthetic_weights(cfg, seed=int(rng.integers(1, 10 ** 6)), bias_std=0.05, alpha_jitter=0.05)
         wt = WaveTables(sample_rate=dims.pulse_rate, **cfg["mbexwn_config"]["wavetable_config"])
-        os.environ["MBX_WINOGRAD"] = "2"
-        off = MBExWNEngine(cfg, raw, wt)
-        del os.environ["MBX_WINOGRAD"]
+        off = MBExWNEngine(cfg, raw, wt, conv_form="f23")        # the form the streams run
         eng = MBExWNEngine(cfg, raw, wt)
         chunk = int(rng.integers(2, 13))
-        syn = StreamingSynthesizer(eng, chunk_frames=chunk)
+        sched = chunk
+        if rng.random() < 0.35:
+            # a cyclic tick schedule (BASELINE config 5's 80 ms are 6 / 6 / 7 / 6 / 7 frames); some of them periodic in the
+            # window alignment, so that their phases are captured as graphs
+            sched = [(6, 6, 7, 6, 7), (3, 5), (4, 4, 8), (2, 3, 3), (7, 9), (5, 6, 5)][int(rng.integers(0, 6))]
+            chunk = max(sched)
+        syn = StreamingSynthesizer(eng, chunk_frames=sched)
         n_streams = int(rng.integers(1, 6))
         data, offline, got, pos = {}, {}, {}, {}
         for sid in range(n_streams):
@@ -78,7 +82,7 @@ for case in range(n_cases):
                 raise RuntimeError("streams do not finish")
         bad = [sid for sid in data if not np.array_equal(np.concatenate(got[sid]) if got[sid] else np.zeros(0, np.float32), offline[sid])]
         fails += bool(bad)
-        print(case, "FAIL" if bad else "OK  ", "streams", n_streams, "chunk", chunk, "ticks", ticks, "steady", steady, "graph", syn.graph_ticks,
+        print(case, "FAIL" if bad else "OK  ", "streams", n_streams, "chunk", sched, "ticks", ticks, "steady", steady, "graph", syn.graph_ticks,
               {kk.split(':')[-1]: vv for kk, vv in over.items()}, "bad", bad, flush=True)
         del eng, off, syn
     except Exception:                                        # noqa: BLE001
