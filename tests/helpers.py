@@ -100,3 +100,11 @@ def synthetic_inputs(seed, batch, frames, steps_per_frame=20):
     mell = np.clip(mell, -11.5, 2.0).astype(np.float32)
     noise = rng.normal(size=(batch, frames * steps_per_frame)).astype(np.float32)
     return mell, noise
+
+
+def form_kwargs(form):
+    """Engine arguments of the convolution forms the parity tests pin: "default" (auto), "0" direct, "2" Winograd F(2,3),
+    "4" F(4,3), "44" F(4,3) with batch-invariant kernels (the names are those of the experiment variable MBX_WINOGRAD, which
+    the library no longer reads: mbx_config.wn_conv_form / batch_invariant)."""
+    return {"default": {}, "0": {"conv_form": "direct"}, "2": {"conv_form": "f23"}, "4": {"conv_form": "f43"},
+            "44": {"conv_form": "f43", "batch_invariant": True}}[str(form)]

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from oracle import mbexwn_oracle as orc
-from helpers import GOLDEN_CASES, build_case, synthetic_inputs
+from helpers import form_kwargs, GOLDEN_CASES, build_case, synthetic_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -57,17 +57,13 @@ def voice_case():
 @pytest.mark.parametrize("form", ["default", "0", "2", "44"])
 def test_voice_ragged_batch_of_16(torch, monkeypatch, voice_case, form):
     """Every item of the ragged batch equals its one-at-a-time run: bit for bit when the convolution form is pinned
-    (MBX_WINOGRAD = 0 direct, 2 Winograd F(2,3), 44 Winograd F(4,3) at every size); with the default policy the batch
+    (conv_form direct / f23, or f43 with batch_invariant: "0", "2", "44"); with the default policy the batch
     runs the large-launch F(4,3) kernel and a single item the channel-split one (two K halves summed), which agree to
     float32 rounding: 4e-5 relative to the peak (measured 2.1e-5; each is within 1e-4 of the float64 oracle).
     The two shortest items are held to the float64 oracle, the longest to the prefix property."""
     from mbexwn_vocoder_amd.engine import MBExWNEngine
     cfg, raw, wt, lengths, mel, noise = voice_case
-    if form != "default":
-        monkeypatch.setenv("MBX_WINOGRAD", form)
-    else:
-        monkeypatch.delenv("MBX_WINOGRAD", raising=False)
-    eng = MBExWNEngine(cfg, raw, wt)
+    eng = MBExWNEngine(cfg, raw, wt, **form_kwargs(form))
     assert eng.dims.wn_channels == 340
     nf = torch.as_tensor(lengths, dtype=torch.int32).cuda()
     batch = eng.forward(dev(torch, mel), n_frames=nf, noise=dev(torch, noise)).cpu().numpy()
@@ -111,8 +107,9 @@ def test_canon_ragged_batch_of_16(torch, monkeypatch, canon_case):
     one-at-a-time run (which takes the small-launch kernels: equal to float32 rounding)."""
     from mbexwn_vocoder_amd.engine import MBExWNEngine
     cfg, raw, wt, lengths, mel, noise = canon_case
-    monkeypatch.delenv("MBX_WINOGRAD", raising=False)
     eng = MBExWNEngine(cfg, raw, wt)
+    info = eng.conv_form_info()
+    assert info["requested"] == "auto" and info["calibrated"] == 1 and info["form"] == "f43"      # the default earned F(4,3)
     assert eng.dims.wn_channels == 320 and eng.gate_form(16, 800) == "winograd_f43" and eng.folds_start
     nf = torch.as_tensor(lengths, dtype=torch.int32).cuda()
     out = torch.full((16, 800 * 300), float("nan"), dtype=torch.float32).cuda()
@@ -355,9 +352,8 @@ def test_streaming_with_rms_normalisation(torch, monkeypatch):
     although every window normalises its own frames; steady ticks replay the captured graph."""
     from mbexwn_vocoder_amd.engine import MBExWNEngine
     from mbexwn_vocoder_amd.streaming import StreamingSynthesizer, norm_reach, stream_margins
-    monkeypatch.setenv("MBX_WINOGRAD", "2")
     cfg, raw, wt, _ = _norm_engine(NORM_CASES["iters2_comp"])
-    eng = MBExWNEngine(cfg, raw, wt)
+    eng = MBExWNEngine(cfg, raw, wt, conv_form="f23")
     assert eng.normalizes_rms and norm_reach(eng.dims, cfg) == 8
     import copy
     plain = copy.deepcopy(cfg)
@@ -478,17 +474,13 @@ def test_ps_off_model_returns_only_the_f0_parameter(torch):
 @pytest.mark.parametrize("act", ["gfu", "gsu", "glu"])
 def test_gate_variants_at_full_width(torch, monkeypatch, act):
     """The other two gates through every gate kernel of the canonical geometry (C = 320): the folded first layer, F(4,3) in
-    both block shapes, F(2,3) (MBX_WINOGRAD=2) and the direct form (MBX_WINOGRAD=0), each against the float64 oracle."""
+    both block shapes, F(2,3) and the direct form (mbx_config.wn_conv_form / tune_gate_shape), each against the float64 oracle."""
     from mbexwn_vocoder_amd.engine import MBExWNEngine
     cfg, raw, wt = build_case("SPEECH", {"mbexwn_config:pp_mod_subnet:activation": act})
     mel, noise = synthetic_inputs(55, 2, 60)
     ref = orc.OracleModel(cfg, raw, wt).forward(mel, noise)
-    for env in ({}, {"MBX_WG_SMALL": "0"}, {"MBX_WINOGRAD": "2"}, {"MBX_WINOGRAD": "0"}):
-        for kk in ("MBX_WG_SMALL", "MBX_WINOGRAD"):
-            monkeypatch.delenv(kk, raising=False)
-        for kk, vv in env.items():
-            monkeypatch.setenv(kk, vv)
-        eng = MBExWNEngine(cfg, raw, wt)
+    for env in ({"conv_form": "f43"}, {"conv_form": "f43", "tune": {"gate_shape": 1}}, {"conv_form": "f23"}, {"conv_form": "direct"}):
+        eng = MBExWNEngine(cfg, raw, wt, **env)
         got = eng.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
         assert _maxdiff(got, ref) <= _tol(ref), f"{act} {env}"
         del eng

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from oracle import mbexwn_oracle as orc
-from helpers import GOLDEN_CASES, build_case, synthetic_inputs
+from helpers import form_kwargs, GOLDEN_CASES, build_case, synthetic_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -244,12 +244,11 @@ def test_forward_matches_reference_goldens(torch, golden_dir, case):
 @pytest.mark.parametrize("key,spec,batch,frames", [("canon", CANON, 2, 40), ("voice", VOICE, 1, 17)])
 def test_gate_layer_forms_match_oracle(torch, monkeypatch, form, key, spec, batch, frames):
     """The dilated convolution has three float32 implementations (direct, Winograd F(2,3), Winograd F(4,3); the engine
-    picks by launch size): each one is forced here (MBX_WINOGRAD is read by mbx_create) and held to the same tolerance,
+    calibrates and picks by launch size): each one is pinned here (mbx_config.wn_conv_form) and held to the same tolerance,
     including a ragged batch."""
     from mbexwn_vocoder_amd.engine import MBExWNEngine
-    monkeypatch.setenv("MBX_WINOGRAD", form)
     cfg, raw, wt = build_case(*spec)
-    eng = MBExWNEngine(cfg, raw, wt)
+    eng = MBExWNEngine(cfg, raw, wt, **form_kwargs(form))
     om = get_engine(key, *spec)[1]
     mel, noise = synthetic_inputs(5, batch, frames)
     got = eng.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
@@ -268,7 +267,7 @@ def test_gate_layer_forms_match_oracle(torch, monkeypatch, form, key, spec, batc
 @pytest.mark.parametrize("key,spec", [("canon", CANON), ("voice", VOICE)])
 def test_start_convolution_folded_into_layer_0_matches_the_unfolded_graph(torch, monkeypatch, key, spec):
     """Layer 0 with the start convolution folded in (csrc/wn_gate0.hip, the default) against the un-folded graph
-    (MBX_FOLD_START=0: start kernel writes h0, layer 0 runs the full dilated convolution): same audio to float32
+    (mbx_config.wn_keep_start: start kernel writes h0, layer 0 runs the full dilated convolution): same audio to float32
     rounding, both inside the tolerance against the oracle; ragged batch, item shorter than one block."""
     from mbexwn_vocoder_amd.engine import MBExWNEngine
     cfg, raw, wt = build_case(*spec)
@@ -278,8 +277,7 @@ def test_start_convolution_folded_into_layer_0_matches_the_unfolded_graph(torch,
     nf = torch.as_tensor(lengths, dtype=torch.int32).cuda()
     outs = {}
     for flag in ("1", "0"):
-        monkeypatch.setenv("MBX_FOLD_START", flag)
-        eng = MBExWNEngine(cfg, raw, wt)
+        eng = MBExWNEngine(cfg, raw, wt, keep_start=flag == "0")
         assert eng.folds_start == (flag == "1")
         outs[flag] = eng.forward(dev(torch, mel), n_frames=nf, noise=dev(torch, noise)).cpu().numpy()
     for ii, ll in enumerate(lengths):
@@ -407,8 +405,7 @@ def test_item_longer_than_4_gib_of_activation_rows(torch, monkeypatch):
     assert T * 20 * 320 * 4 > 2 ** 32
     outs = {}
     for form in ("4", "0"):
-        monkeypatch.setenv("MBX_WINOGRAD", form)
-        eng = MBExWNEngine(cfg, raw, wt)
+        eng = MBExWNEngine(cfg, raw, wt, **form_kwargs(form))
         outs[form] = eng.forward(mel, noise=noise)
         torch.cuda.synchronize()
         del eng
@@ -430,9 +427,8 @@ def test_item_longer_than_4_gib_of_activation_rows(torch, monkeypatch):
 def test_empty_items_inside_a_batch(torch, monkeypatch, form):
     """Items of zero frames (and of one frame) between ordinary ones: they produce zeros and leave their neighbours alone."""
     from mbexwn_vocoder_amd.engine import MBExWNEngine
-    monkeypatch.setenv("MBX_WINOGRAD", form)
     cfg, raw, wt = build_case(*CANON)
-    eng = MBExWNEngine(cfg, raw, wt)
+    eng = MBExWNEngine(cfg, raw, wt, **form_kwargs(form))
     mel, noise = synthetic_inputs(3, 4, 30)
     nf = torch.tensor([30, 0, 11, 1], dtype=torch.int32, device="cuda")
     got = eng.forward(dev(torch, mel), n_frames=nf, noise=dev(torch, noise)).cpu().numpy()
@@ -468,8 +464,7 @@ def test_full_size_gate_forms_agree(torch, monkeypatch, batch):
     mel, noise = synthetic_inputs(21, batch, 800)
     outs = {}
     for form in ("4", "2"):
-        monkeypatch.setenv("MBX_WINOGRAD", form)
-        eng = MBExWNEngine(cfg, raw, wt)
+        eng = MBExWNEngine(cfg, raw, wt, **form_kwargs(form))
         outs[form] = eng.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
         del eng
     assert np.all(np.isfinite(outs["4"]))
@@ -479,7 +474,7 @@ def test_full_size_gate_forms_agree(torch, monkeypatch, batch):
 
 @pytest.mark.parametrize("voice", ["SPEECH", "VOICE"])
 def test_f43_block_shapes_give_the_same_bits(torch, monkeypatch, voice):
-    """The two block shapes of the F(4,3) gate kernel (MBX_WG_SMALL pins the one small launches take): 256-row blocks and
+    """The two block shapes of the F(4,3) gate kernel (mbx_config.tune_gate_shape pins the one small launches take): 256-row blocks and
     128-row blocks whose waves split the six PRODUCTS form every sum in the same order -> identical audio.  C = 320 and
     C = 340 (partial column tile, partial last slice), ragged batch of two with an item that ends inside a block; the
     short item is held to the oracle."""
@@ -490,8 +485,7 @@ def test_f43_block_shapes_give_the_same_bits(torch, monkeypatch, voice):
     nf = torch.as_tensor(lengths, dtype=torch.int32).cuda()
     outs = {}
     for shape in ("0", "1"):
-        monkeypatch.setenv("MBX_WG_SMALL", shape)
-        eng = MBExWNEngine(cfg, raw, wt)
+        eng = MBExWNEngine(cfg, raw, wt, conv_form="f43", tune={"gate_shape": 1 if shape == "0" else 2})
         assert eng.gate_form(2, 240) == {"0": "winograd_f43", "1": "winograd_f43_psplit"}[shape]
         outs[shape] = eng.forward(dev(torch, mel), n_frames=nf, noise=dev(torch, noise)).cpu().numpy()
         del eng
@@ -499,8 +493,7 @@ def test_f43_block_shapes_give_the_same_bits(torch, monkeypatch, voice):
     ref = orc.OracleModel(cfg, raw, wt).forward(mel[1:2, :133], noise[1:2, :133 * 20])[0]
     assert _maxdiff(outs["1"][1, :133 * 300], ref) <= _tol(ref, E2E_TOL)
     # the default policy picks one of the two equivalent shapes by how the work divides over the SIMDs
-    monkeypatch.delenv("MBX_WG_SMALL")
-    eng = MBExWNEngine(cfg, raw, wt)
+    eng = MBExWNEngine(cfg, raw, wt, conv_form="f43")
     assert eng.gate_form(2, 240) in ("winograd_f43", "winograd_f43_psplit")
     assert np.array_equal(eng.forward(dev(torch, mel), n_frames=nf, noise=dev(torch, noise)).cpu().numpy(), outs["1"])
 

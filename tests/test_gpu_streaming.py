@@ -128,14 +128,13 @@ def test_streaming_equals_offline(engine, offline_f23_engine, chunk):
 
 
 def test_streaming_without_layer_state(monkeypatch):
-    """A handle that cannot carry the per-layer state (direct form of the dilated convolution: MBX_WINOGRAD=0) still
+    """A handle that cannot carry the per-layer state (direct form of the dilated convolution: conv_form="direct") still
     streams -- every tick runs the WaveNet on its whole region -- and is bit-equal to its own offline synthesis."""
     import torch
     from mbexwn_vocoder_amd.engine import MBExWNEngine
     from mbexwn_vocoder_amd.streaming import StreamingSynthesizer
-    monkeypatch.setenv("MBX_WINOGRAD", "0")
     cfg, raw, wt = build_case("SPEECH", SMALL)
-    eng = MBExWNEngine(cfg, raw, wt)
+    eng = MBExWNEngine(cfg, raw, wt, conv_form="direct")
     assert eng.layer_state_info()[0] == 0
     syn = StreamingSynthesizer(eng, chunk_frames=8)
     assert not syn.layer_carry
@@ -169,9 +168,8 @@ def test_streaming_with_the_second_batch_of_options(monkeypatch, extra):
     import torch
     from mbexwn_vocoder_amd.engine import MBExWNEngine
     from mbexwn_vocoder_amd.streaming import StreamingSynthesizer, frontend_reach
-    monkeypatch.setenv("MBX_WINOGRAD", "2")
     cfg, raw, wt = build_case("SPEECH", dict(SMALL, **extra))
-    eng = MBExWNEngine(cfg, raw, wt)
+    eng = MBExWNEngine(cfg, raw, wt, conv_form="f23")
     if "mbexwn_config:pp_mod_subnet:pre_cond_layer_channels" in extra:
         base_cfg, _, _ = build_case("SPEECH", SMALL)
         from mbexwn_vocoder_amd.config import ModelDims
@@ -209,9 +207,8 @@ def test_streaming_dilation_cycle_model(monkeypatch):
     from mbexwn_vocoder_amd.streaming import StreamingSynthesizer
     over = {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 7,
             "mbexwn_config:pp_mod_subnet:max_log2_dilation_rate": 3}
-    monkeypatch.setenv("MBX_WINOGRAD", "2")
     cfg, raw, wt = build_case("SPEECH", over)
-    eng = MBExWNEngine(cfg, raw, wt)
+    eng = MBExWNEngine(cfg, raw, wt, conv_form="f23")
     floats, reach, min_rows = eng.layer_state_info()
     dil = [2, 4, 1, 2, 4, 1]                                   # layers 1..6
     assert floats == sum((d + d + d % 2) * 32 + (d + d % 2) * 30 for d in dil) and reach == 40 and min_rows == 8
