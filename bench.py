@@ -43,7 +43,12 @@ WORKLOADS = {
     # builder-run secondary (not a BASELINE config): the generic path -- two WaveNet blocks with in-block upsampling (the
     # geometry of the golden case "blocks": C = 320 at 800 Hz, then C = 160 at 1600 Hz), the block runner's kernels
     "variant_blocks2": ("SING", 16, 800),
+    # builder-run secondary, NOT float32 end to end and never the headline: the config-3 workload with the opt-in split half
+    # precision of the res/skip layers (mbx_config.wn_precision: fp16-split operands, three products, float32 accumulation)
+    "config3_split_f16": ("SING", 16, 800),
 }
+ENGINE_KW = {"config3_split_f16": {"precision": "split_f16"}}
+FP16_MATRIX_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16 / FP16 MFMA dense peak (spec)
 WORKLOAD_OVERRIDES = {
     "variant_blocks2": {"mbexwn_config:pp_mod_subnet_upsampling_factors": [2, 1],
                         "mbexwn_config:pp_mod_subnet_channel_factors": [1, 0.5],
@@ -67,7 +72,7 @@ def mbx_env():
 _ENGINES = {}
 
 
-def build_engine(voice, overrides=None):
+def build_engine(voice, overrides=None, **engine_kw):
     """(cfg, raw weights, wavetables, dims, engine) of the canonical model of a voice type; engines are shared
     between voice types whose configuration is identical (SING == SPEECH: C = 320)."""
     from mbexwn_vocoder_amd.config import ModelDims, canonical_config
@@ -75,12 +80,12 @@ def build_engine(voice, overrides=None):
     from mbexwn_vocoder_amd.tables import WaveTables
     from mbexwn_vocoder_amd.weights import synthetic_weights
     cfg = canonical_config(voice, **(overrides or {}))
-    key = json.dumps(cfg, sort_keys=True, default=str)
+    key = json.dumps([cfg, engine_kw], sort_keys=True, default=str)
     if key not in _ENGINES:
         dims = ModelDims(cfg)
         raw = synthetic_weights(cfg, seed=1234)          # bias 0, PReLU alpha 0.2
         wt = WaveTables(sample_rate=dims.pulse_rate, **cfg["mbexwn_config"]["wavetable_config"])
-        _ENGINES[key] = (cfg, raw, wt, dims, MBExWNEngine(cfg, raw, wt))
+        _ENGINES[key] = (cfg, raw, wt, dims, MBExWNEngine(cfg, raw, wt, **engine_kw))
     return _ENGINES[key]
 
 
@@ -223,7 +228,7 @@ def time_steps(step, steps, warmup, fence):
 def run_batch(args, name, rank, world, fence, torch, profile, steps=None, warmup=None):
     """configs[0..2]: one padded batch per GPU.  Returns (result dict, context for the roofline / delta legs)."""
     voice, batch, frames = WORKLOADS[name]
-    cfg, raw, wt, dims, eng = build_engine(voice, WORKLOAD_OVERRIDES.get(name))
+    cfg, raw, wt, dims, eng = build_engine(voice, WORKLOAD_OVERRIDES.get(name), **ENGINE_KW.get(name, {}))
     rng = np.random.default_rng(42 + rank)
     mel_h, noise_h = synthetic_batch(rng, batch, frames, dims.wn_in_rows_per_frame)
     mel, noise = torch.as_tensor(mel_h).cuda(), torch.as_tensor(noise_h).cuda()
@@ -250,10 +255,11 @@ def run_batch(args, name, rank, world, fence, torch, profile, steps=None, warmup
         for _ in range(max(3, min(steps, 10))):
             eng.forward(mel, noise=noise, out=out)
         torch.cuda.synchronize()
-        stages = {kk: eng.profile_read(kk) for kk in ("gate", "gate0", "res_skip", "frontend", "wavetable", "start", "tail",
-                                                       "pqmf", "stft_filter", "overlap_add")}
+        stages = {kk: eng.profile_read(kk) for kk in ("gate", "gate0", "res_skip", "res_skip_f16", "frontend", "wavetable",
+                                                       "start", "tail", "pqmf", "stft_filter", "overlap_add")}
         eng.profile_enable(False)
         ctx["stages"] = stages
+
     return res, ctx
 
 
@@ -641,6 +647,32 @@ def main():
                                             ctxb["cfg"], ctxb["raw"], ctxb["wt"], "two-block variant batch"))
             resb["roofline"] = roofline_blocks(ctxb)
         secondary["variant_blocks2"] = resb
+        # opt-in split half precision of the res/skip layers: NOT the float32 path, reported beside it with its own max|delta|
+        ress, ctxs = run_batch(args, "config3_split_f16", rank, world, fence, torch, profile=True, steps=min(args.steps, 5), warmup=1)
+        if rank == 0:
+            ress.update(max_abs_delta_timed(
+                [(f"item {ii}", ctxs["timed_out"][ii], ctxs["mel_h"][ii], ctxs["noise_h"][ii]) for ii in ctxs["delta_items"]],
+                ctxs["cfg"], ctxs["raw"], ctxs["wt"], "config-3 batch, res/skip layers in split half precision"))
+            rs_ms, rs_n = ctxs["stages"]["res_skip"]              # layer 0 (float32: its rows carry the excitation too)
+            sp_ms, sp_n = ctxs["stages"]["res_skip_f16"]          # layers 1 .. L-2: three fp16 products each
+            dd = ctxs["dims"]
+            rows = ctxs["batch"] * ctxs["frames"] * dd.steps_per_frame
+            L, C, n_out = dd.wn_layers, dd.wn_channels, dd.wn_out_channels
+            n_fwd = max(1, rs_n)
+            split_ms = sp_ms / sp_n if sp_n else None
+            flop = 3 * 2.0 * rows * C * (C + n_out)
+            hbm = rows * (3 * C + 2 * n_out) * 4.0
+            ress["precision"] = "res/skip layers 1..L-2: fp16 x 3 (hi hi + 2^-11 (hi lo' + lo' hi)), float32 accumulation; everything else float32"
+            ress["res_skip_ms_per_forward"] = rs_ms / n_fwd + (sp_ms / sp_n * (L - 2) if sp_n else 0.0)
+            ress["res_skip_split_launch_ms"] = split_ms
+            if split_ms:
+                ress["roofline"] = {"kernel": "wn_resskip_f16_kernel", "bound": "hbm", "avg_launch_ms": split_ms,
+                                    "achieved": hbm / (split_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": hbm / (split_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "mfma_frac_of_fp16_peak": flop / (split_ms * 1e-3) / 1e12 / FP16_MATRIX_PEAK_TFLOPS,
+                                    "bytes": hbm, "flop_executed": flop,
+                                    "note": "algorithmic bytes: a read, h read + written, output accumulator read + written"}
+        secondary["config3_split_f16"] = ress
         secondary["config4_vo_256utt"] = run_sharded(args, "config4_vo_256utt", rank, world, dist, fence, torch,
                                                      steps=min(args.steps, 3), warmup=1, check_delta=True)
         secondary["config5_sp_stream64"] = run_streaming(args, "config5_sp_stream64", rank, world, fence, torch,
@@ -654,7 +686,8 @@ def main():
             "x_realtime_per_gpu": main_res["x_realtime"] / world, "n_gpus": world, "steps": main_res["steps"],
             "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True,
             "scaling": main_res["scaling"], "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {kk: vv for kk, vv in main_res.items() if kk not in ("value", "x_realtime", "ms_per_step", "steps", "scaling")},
+            "config": {kk: vv for kk, vv in main_res.items()
+                       if kk not in ("value", "x_realtime", "ms_per_step", "steps", "scaling") and not kk.startswith("_")},
             "env": mbx_env()})
         line["config"]["parallelism"] = main_res.get("parallelism", f"utterance-sharded x{world}")
         if ctx is not None:

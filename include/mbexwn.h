@@ -21,7 +21,7 @@
  * differ and a stray variable cannot change results.  (The Python host maps the MBX_* variables of its experiment
  * scripts onto these fields and says so on stderr: mbexwn_vocoder_amd/engine.py::experiment_overrides.)
  * The optional operand-order images of the weights ("*.wino2w", "*.wino4w", "*.packed", "*.fold",
- * "*.fold_wide", "*.fold_wave", "*.start_fold", "*.fold_start", "*.fold_start_wide", "*.fold_start_wave",
+ * "*.fold_wide", "*.fold_wave", "*.fold_f16", "*.start_fold", "*.fold_start", "*.fold_start_wide", "*.fold_start_wave",
  * "wn.tail.fold", "wn.end.packed";
  * engine.tensor_table builds them) select the specialised kernels; a handle created from the plain folded weights
  * alone runs the generic ones.
@@ -90,6 +90,8 @@ typedef struct {
  *   MBX_CONV_F23     Winograd F(2,3): 4 contractions per 2 outputs
  *   MBX_CONV_F43     Winograd F(4,3): 6 contractions per 4 outputs
  * Streaming calls (state_in / state_out) run F(2,3) unless the handle's form is the direct one. */
+#define MBX_PRECISION_F32 0
+#define MBX_PRECISION_SPLIT_F16 1
 #define MBX_CONV_AUTO 0
 #define MBX_CONV_DIRECT 1
 #define MBX_CONV_F23 2
@@ -204,7 +206,12 @@ typedef struct {
      * fft_size / 2 + 1), nm_win_norm = L2 norm of the analysis window */
     int32_t nm_use_pinv;
     float nm_win_norm;
-    int32_t reserved7[2];
+    /* MBX_PRECISION_F32 (0, the default and the only arithmetic the parity claims and the headline benchmark are made in) or
+     * MBX_PRECISION_SPLIT_F16: an opt-in experiment -- the res/skip layers behind the first one run their contraction on the
+     * 16-bit matrix pipe with every float32 operand split into two fp16 parts (three products, float32 accumulation:
+     * float32-class error, csrc/wn_resskip_f16.hip; needs the "*.fold_f16" weight images; not with the glu gate) */
+    int32_t wn_precision;
+    int32_t reserved7[1];
 } mbx_config;
 
 /* A named HOST tensor handed over at creation (weights already weight-norm folded, tables).
@@ -237,6 +244,7 @@ typedef struct {
                                * built-in synthetic mel at mbx_create; 2: on the caller's data (mbx_calibrate) */
     int32_t batch_invariant;
     int32_t fold_skip, fold_start;   /* the folds in effect */
+    int32_t split_f16_layers; /* res/skip layers that run in split half precision (mbx_config.wn_precision; 0: none) */
     float err_f43, err_f23;   /* max |audio(form) - audio(direct)| of the calibration run; < 0: form not available */
     float ref_max;            /* max |audio(direct)| of the calibration run */
     float threshold;          /* calib_fraction * 1e-4 * max(1, ref_max): a form is accepted at or below it */
@@ -394,7 +402,8 @@ mbx_status mbx_stage(const mbx_handle *handle, const char *name, const void **de
  * recorded events, returns the summed device time and the number of bracketed launch groups of one stage since the
  * last read, and recycles the events.  Stages: "gate" (dilated conv + gate, one per layer), "res_skip" (one per layer),
  * "frontend" (F0-net, VTF-net, conditioning conv: the mel-rate launches), "wavetable" (phase + lookup), "start",
- * "tail" (end conv + post-net), "pqmf", "stft_filter", "overlap_add", "norm_mel". */
+ * "tail" (end conv + post-net), "pqmf", "stft_filter", "overlap_add", "norm_mel", "gate0" (first layer with the start
+ * convolution folded in), "res_skip_f16" (res/skip launches of the opt-in split half precision). */
 mbx_status mbx_profile_enable(mbx_handle *handle, int32_t enabled);
 mbx_status mbx_profile_read(mbx_handle *handle, const char *kernel, double *total_ms, int64_t *launches);
 

@@ -69,9 +69,9 @@ struct DeviceGuard {
 
 // stages of the launch sequence that mbx_profile_read can report (names in kProfNames)
 enum { PROF_GATE = 0, PROF_RES_SKIP, PROF_FRONTEND, PROF_WAVETABLE, PROF_START, PROF_TAIL, PROF_PQMF, PROF_STFT_FILTER,
-       PROF_OVERLAP_ADD, PROF_NORM_MEL, PROF_GATE0, PROF_KINDS };
+       PROF_OVERLAP_ADD, PROF_NORM_MEL, PROF_GATE0, PROF_RES_SKIP_F16, PROF_KINDS };
 static const char *const kProfNames[PROF_KINDS] = {"gate", "res_skip", "frontend", "wavetable", "start", "tail", "pqmf",
-                                                   "stft_filter", "overlap_add", "norm_mel", "gate0"};
+                                                   "stft_filter", "overlap_add", "norm_mel", "gate0", "res_skip_f16"};
 
 struct mbx_handle {
     mbx_config cfg;
@@ -105,6 +105,7 @@ struct mbx_handle {
     int gate_small_shape = -1;       // mbx_config.tune_gate_shape: pins the F(4,3) block shape of small launches (0: 256-row | 1: product-split; same bits)
     long long resskip_wave_tiles = 2048;   // default policy: res/skip launches of at most this many 16-row tiles run the wave-tiled kernel
     int resskip_split = 0;           // mbx_config.tune_resskip_split
+    bool split_f16 = false;          // mbx_config.wn_precision == MBX_PRECISION_SPLIT_F16 and the images are there
     int winograd = 0;            // gate layer form in effect: 0 direct, 2 Winograd F(2,3), 4 Winograd F(4,3) (needs the packed weights)
     // what mbx_conv_form reports
     int calibrated = 0;
@@ -767,6 +768,20 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
             have0 = expect("wn.res_skip_0.fold_start", nct * ((C + 16 + 15) / 16) * 2048);
         hd->fold_start = have0;
     }
+    if (c.wn_precision != MBX_PRECISION_F32 && c.wn_precision != MBX_PRECISION_SPLIT_F16)
+        return bail(fail(MBX_ERR_INVALID_ARGUMENT, "wn_precision must be MBX_PRECISION_F32 or MBX_PRECISION_SPLIT_F16"));
+    if (c.wn_precision == MBX_PRECISION_SPLIT_F16) {
+        // opt-in experiment: folded res/skip layers 1 .. L-2 on the 16-bit matrix pipe (wn_resskip_f16.hip)
+        if (c.wn_gate_activation == MBX_GATE_GLU)
+            return bail(fail(MBX_ERR_UNSUPPORTED, "wn_precision = split f16 needs a bounded gate (not glu)"));
+        bool have16 = hd->fold_skip && c.wn_layers >= 3 && C + c.wn_out_channels <= 384;
+        for (int l = 1; l + 1 < c.wn_layers && have16; ++l)
+            have16 = expect("wn.res_skip_" + std::to_string(l) + ".fold_f16", (long long)((C + 31) / 32) * 12 * 1024);
+        if (!have16)
+            return bail(fail(MBX_ERR_INVALID_ARGUMENT, "wn_precision = split f16 needs the folded skip path, >= 3 layers, C + n_out <= 384 "
+                                                        "and the wn.res_skip_<l>.fold_f16 images"));
+        hd->split_f16 = true;
+    }
     {
         hd->gate_small_shape = c.tune_gate_shape - 1;
         if (c.tune_resskip_wave_tiles) hd->resskip_wave_tiles = std::max(0, c.tune_resskip_wave_tiles);
@@ -1373,12 +1388,20 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                 r.skip_bstride = nsteps * n_out;
                 r.hs_bstride = nsteps * C;
                 r.skip_init = (l == 0);
-                ScopedEvents ev(hd, PROF_RES_SKIP, stream);
+                ScopedEvents ev(hd, (hd->split_f16 && !ext) ? PROF_RES_SKIP_F16 : PROF_RES_SKIP, stream);
                 // large launches (>= two rounds of the 512 resident 128-row blocks): one block owns all columns of its rows.
                 // Like the gate kernels' block shape this follows the launch size only under the default policy: a pinned
                 // form (MBX_CONV_DIRECT, MBX_CONV_F23, batch_invariant, streams) pins the kernel, so results do not depend on the batch they ran in.
                 bool done = false;
-                const DevTensor *fww = find(hd, "wn.res_skip_" + ls + (ext ? ".fold_start_wide" : ".fold_wide"));
+                // opt-in split half precision (mbx_config.wn_precision): every launch size, the layers whose input is a gate
+                // output alone (not layer 0 with the folded start convolution, whose rows carry the excitation as well)
+                if (hd->split_f16 && !ext) {
+                    mbx::ConvArgs rh = r;
+                    rh.w = find(hd, "wn.res_skip_" + ls + ".fold_f16")->ptr;
+                    rh.gate_act = c.wn_gate_activation;
+                    done = mbx::launch_wn_resskip_f16(rh, stream);
+                }
+                const DevTensor *fww = done ? nullptr : find(hd, "wn.res_skip_" + ls + (ext ? ".fold_start_wide" : ".fold_wide"));
                 const long long wide_blocks = ((nsteps + 127) / 128) * B;
                 const int npair = (C + n_out + 31) / 32;
                 if (fww && fww->ndim == 3 && fww->shape[0] == (cin_l + 7) / 8 && fww->shape[1] == npair && fww->shape[2] == 256 &&
@@ -1705,6 +1728,7 @@ mbx_status mbx_conv_form(const mbx_handle *hd, mbx_conv_form_info *info) {
     info->batch_invariant = (hd->winograd != 4 || hd->winograd4_always) ? 1 : 0;
     info->fold_skip = hd->fold_skip;
     info->fold_start = hd->fold_start;
+    info->split_f16_layers = hd->split_f16 ? std::max(0, hd->cfg.wn_layers - 2) : 0;
     info->err_f43 = hd->calib_err43;
     info->err_f23 = hd->calib_err23;
     info->ref_max = hd->calib_ref;

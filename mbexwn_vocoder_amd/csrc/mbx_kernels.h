@@ -135,6 +135,9 @@ bool launch_wn_resskip_wide(const ConvArgs &a, hipStream_t stream);
 // the same layer for small launches (one utterance, streaming ticks), tiled at wave granularity (wn_resskip_wave.hip);
 // a.w = image of engine.pack_resskip_wave_weights (ceil(cin/16), 12, 512)
 bool launch_wn_resskip_wave(const ConvArgs &a, hipStream_t stream);
+// the same layer in split half precision (wn_resskip_f16.hip; opt-in, mbx_config.wn_precision); a.w = image of
+// engine.pack_resskip_f16_weights (ceil(cin/32), 12, 1024); a.gate_act must be set (glu is refused)
+bool launch_wn_resskip_f16(const ConvArgs &a, hipStream_t stream);
 // WaveNet end convolution + post-net in one pass over the skip tensor (wn_tail.hip); w_end_packed = host-packed
 // weights (ceil(C/8), 2, 32, 4); false: shapes do not fit
 bool launch_wn_tail(const float *skip, long long skip_bstride, const int *n_frames, int rows_per_frame, int max_rows,

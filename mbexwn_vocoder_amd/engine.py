@@ -73,13 +73,15 @@ class mbx_config(ctypes.Structure):
                 ("wn_conv_form", ctypes.c_int32), ("batch_invariant", ctypes.c_int32), ("wn_keep_skip", ctypes.c_int32),
                 ("wn_keep_start", ctypes.c_int32), ("calib_fraction", ctypes.c_float), ("tune_gate_shape", ctypes.c_int32),
                 ("tune_resskip_wave_tiles", ctypes.c_int32), ("tune_resskip_split", ctypes.c_int32),
-                ("nm_use_pinv", ctypes.c_int32), ("nm_win_norm", ctypes.c_float), ("reserved7", ctypes.c_int32 * 2)]
+                ("nm_use_pinv", ctypes.c_int32), ("nm_win_norm", ctypes.c_float), ("wn_precision", ctypes.c_int32),
+                ("reserved7", ctypes.c_int32 * 1)]
 
 
 class mbx_conv_form_info(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_int32), ("requested", ctypes.c_int32), ("form", ctypes.c_int32),
                 ("stream_form", ctypes.c_int32), ("calibrated", ctypes.c_int32), ("batch_invariant", ctypes.c_int32),
-                ("fold_skip", ctypes.c_int32), ("fold_start", ctypes.c_int32), ("err_f43", ctypes.c_float),
+                ("fold_skip", ctypes.c_int32), ("fold_start", ctypes.c_int32), ("split_f16_layers", ctypes.c_int32),
+                ("err_f43", ctypes.c_float),
                 ("err_f23", ctypes.c_float), ("ref_max", ctypes.c_float), ("threshold", ctypes.c_float)]
 
 
@@ -264,8 +266,11 @@ def experiment_overrides():
     return out
 
 
+PRECISIONS = {"f32": 0, "split_f16": 1}
+
+
 def make_config(config, wavetables, conv_form=None, batch_invariant=None, keep_skip=None, keep_start=None,
-                calib_fraction=None, tune=None):
+                calib_fraction=None, tune=None, precision="f32"):
     """mbx_config of a model.  Policy arguments (None = default, or the experiment variable if one is set):
     conv_form "auto" | "direct" | "f23" | "f43" (mbx_config.wn_conv_form), batch_invariant, keep_skip, keep_start,
     calib_fraction, tune = {"gate_shape": 0|1|2, "resskip_wave_tiles": n, "resskip_split": 0..3}."""
@@ -351,6 +356,9 @@ def make_config(config, wavetables, conv_form=None, batch_invariant=None, keep_s
     cc.tune_gate_shape = int(tune.get("gate_shape", 0))
     cc.tune_resskip_wave_tiles = int(tune.get("resskip_wave_tiles", 0))
     cc.tune_resskip_split = int(tune.get("resskip_split", 0))
+    if precision not in PRECISIONS:
+        raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
+    cc.wn_precision = PRECISIONS[precision]
     return cc, dims
 
 
@@ -454,6 +462,33 @@ def pack_resskip_wave_weights(w):
     return np.ascontiguousarray(wp.transpose(0, 3, 5, 1, 4, 2).reshape(nk, 12, 512))
 
 
+def pack_resskip_f16_weights(w):
+    """Weights (1, K, cout <= 384) of a folded WaveNet res/skip layer for wn_resskip_f16_kernel (csrc/wn_resskip_f16.hip,
+    v_mfma_f32_16x16x32_f16; opt-in split half precision): every float32 weight is split into hi = fp16(w) and
+    lo' = fp16((w - hi) * 2^11).
+
+    Layout (ceil(K/32) steps, 12 column tile pairs, 1024 float32 words = 4 images x 64 lanes x 8 halves): images [even tile
+    hi | even tile lo' | odd tile hi | odd tile lo'], lane = 16 kq + n holds the input channels 32 step + 4 kq .. + 3 and
+    32 step + 16 + 4 kq .. + 3 of output column 32 p + 2 n + (0 even | 1 odd); out-of-range entries are zero.  Returned as
+    float32 words (two halves each) because the tensor table of the C ABI is float32; the bits are what counts.
+    """
+    w = np.asarray(w, dtype=np.float32)
+    assert w.ndim == 3 and w.shape[0] == 1 and w.shape[2] <= 384
+    K, cout = w.shape[1], w.shape[2]
+    nk = (K + 31) // 32
+    wp = np.zeros((nk * 32, 384), dtype=np.float32)
+    wp[:K, :cout] = w[0]
+    hi = wp.astype(np.float16)
+    lo = ((wp - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+    if not (np.all(np.isfinite(hi)) and np.all(np.isfinite(lo))):
+        raise ValueError("res/skip weights outside fp16's range: split half precision is not available for this model")
+    both = np.stack((hi, lo))                                      # (part, channel, column)
+    both = both.reshape(2, nk, 2, 4, 4, 12, 16, 2)                 # part, step, half (0 | +16), kq, v, pair, n, parity
+    img = both.transpose(1, 5, 7, 0, 3, 6, 2, 4)                   # step, pair, parity, part, kq, n, half, v
+    img = np.ascontiguousarray(img).reshape(nk, 12, 4, 64, 8)      # image = 2 parity + part ; lane = 16 kq + n ; 8 halves
+    return np.ascontiguousarray(img).view(np.float32).reshape(nk, 12, 1024)
+
+
 def pack_end_weights(w):
     """Weights (1, C, n_out <= 32) of the WaveNet end convolution packed for wn_tail_kernel (csrc/wn_tail.hip):
     (ceil(C/8), 2, 32, 4) = [channel group c][lane half lk][column n][k step st] with input channel 8c + 4lk + st,
@@ -467,7 +502,7 @@ def pack_end_weights(w):
     return np.ascontiguousarray(wp.reshape(nc8, 2, 4, 32).transpose(0, 1, 3, 2))
 
 
-def fold_skip_weights(folded, n_layers, channels):
+def fold_skip_weights(folded, n_layers, channels, split_f16=False):
     """Fold the skip path of the WaveNet into its end convolution (both are linear, reference
     MBExWN_NVoc/vocoder/model/custom_AE_layers.py:322-341: output += res_skip[:, C:]; ...; self.end(output)):
 
@@ -501,6 +536,8 @@ def fold_skip_weights(folded, n_layers, channels):
             out[f"wn.res_skip_{ll}.fold_wide"] = pack_resskip_wide_weights(np.concatenate((w[0][:, :C], proj), axis=1)[None])
             if C + n_out <= 384:
                 out[f"wn.res_skip_{ll}.fold_wave"] = pack_resskip_wave_weights(np.concatenate((w[0][:, :C], proj), axis=1)[None])
+                if ll >= 1 and split_f16:
+                    out[f"wn.res_skip_{ll}.fold_f16"] = pack_resskip_f16_weights(np.concatenate((w[0][:, :C], proj), axis=1)[None])
             if ll == 0:
                 out["__proj_0"] = proj                 # for fold_start_weights; not a device tensor
             biases.append(np.concatenate((b[:C], np.zeros(n_out))))
@@ -558,8 +595,9 @@ def fold_start_weights(folded, dims, fold_skip):
     return out
 
 
-def tensor_table(config, raw_weights, wavetables):
-    """name -> float32 array of everything mbx_create needs: folded weights + constant tables."""
+def tensor_table(config, raw_weights, wavetables, split_f16=False):
+    """name -> float32 array of everything mbx_create needs: folded weights + constant tables (+ with ``split_f16`` the
+    fp16-split images of the res/skip layers for the opt-in precision mode)."""
     dims = ModelDims(config)
     mb = config["mbexwn_config"]
     mbc = mb["multi_band_config"]
@@ -576,7 +614,7 @@ def tensor_table(config, raw_weights, wavetables):
     # (several WaveNet blocks / in-block upsampling run the library's generic kernels: no operand-order images)
     if not dims.wn_multi and out["wn.end.w"].shape[0] == 1 and out["wn.end.w"].shape[2] <= 32:
         out["wn.end.packed"] = pack_end_weights(out["wn.end.w"])
-        fs = fold_skip_weights(out, dims.wn_layers, dims.wn_channels)
+        fs = fold_skip_weights(out, dims.wn_layers, dims.wn_channels, split_f16=split_f16)
         if dims.wn_kernel_size == 3:
             out.update(fold_start_weights(out, dims, fs))
         fs.pop("__proj_0", None)
@@ -622,7 +660,7 @@ class MBExWNEngine:
     """Device-resident MBExWN generator. One instance per GPU (one process per GPU)."""
 
     def __init__(self, config, raw_weights, wavetables=None, device=None, weight_images=True, conv_form=None,
-                 batch_invariant=None, keep_skip=None, keep_start=None, calib_fraction=None, tune=None):
+                 batch_invariant=None, keep_skip=None, keep_start=None, calib_fraction=None, tune=None, precision="f32"):
         """``weight_images=False`` hands mbx_create only the folded weights and the tables (what a minimal binding of the
         C ABI would do): the engine then runs its generic kernels instead of the specialised ones.
 
@@ -630,7 +668,9 @@ class MBExWNEngine:
         within a quarter of the parity budget of the direct form, else F(2,3), else the direct form -- see
         :meth:`conv_form_info`, :meth:`calibrate`), "direct", "f23" or "f43"; ``batch_invariant=True`` pins the kernels so
         that an utterance's bits do not depend on the batch it ran in; ``keep_skip`` / ``keep_start`` keep the un-folded
-        graph; ``tune`` holds measurement knobs (make_config)."""
+        graph; ``tune`` holds measurement knobs (make_config).  ``precision="split_f16"`` is an opt-in experiment (never
+        the default): the res/skip layers behind the first one contract on the 16-bit matrix pipe with fp16-split operands
+        (three products, float32 accumulation; csrc/wn_resskip_f16.hip)."""
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("MBExWNEngine needs an AMD GPU (no CPU fallback for the mel-inversion path)")
@@ -643,10 +683,11 @@ class MBExWNEngine:
         self.wavetables = wavetables
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         cconf, self.dims = make_config(config, wavetables, conv_form=conv_form, batch_invariant=batch_invariant,
-                                       keep_skip=keep_skip, keep_start=keep_start, calib_fraction=calib_fraction, tune=tune)
+                                       keep_skip=keep_skip, keep_start=keep_start, calib_fraction=calib_fraction, tune=tune,
+                                       precision=precision)
         self._tune_gate_shape = cconf.tune_gate_shape
         self.normalizes_rms = cconf.nm_iters > 0            # row A14: done on the device inside mbx_forward
-        self._tensors = tensor_table(config, raw_weights, wavetables)   # keep the host arrays alive
+        self._tensors = tensor_table(config, raw_weights, wavetables, split_f16=precision == "split_f16")   # keep the host arrays alive
         if not weight_images:
             self._tensors = {kk: vv for kk, vv in self._tensors.items()
                              if kk.startswith("table.") or kk.rsplit(".", 1)[-1] in ("w", "b", "alpha")}
@@ -893,7 +934,7 @@ class MBExWNEngine:
         return {"requested": _CONV_FORM_NAMES[info.requested], "form": _CONV_FORM_NAMES[info.form],
                 "stream_form": _CONV_FORM_NAMES[info.stream_form], "calibrated": info.calibrated,
                 "batch_invariant": bool(info.batch_invariant), "fold_skip": bool(info.fold_skip),
-                "fold_start": bool(info.fold_start),
+                "fold_start": bool(info.fold_start), "split_f16_layers": int(info.split_f16_layers),
                 "err_f43": None if info.err_f43 < 0 else float(info.err_f43),
                 "err_f23": None if info.err_f23 < 0 else float(info.err_f23),
                 "ref_max": float(info.ref_max), "threshold": float(info.threshold)}

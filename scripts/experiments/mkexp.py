@@ -207,6 +207,30 @@ PATCHES = {
         ('        const float4 we = bw[P % 3][0], wo = bw[P % 3][1];\n',
          '        const float4 we = bw[P % 3][0], wo = bw[P % 3][1];\n        if (P % 2 == 1) return;\n'),
     ],
+    # wn_resskip_f16.hip: timing ablations of the opt-in split half precision kernel (outputs wrong on purpose)
+    'rh_nomfma': [
+        ('            acc[2 * pr] = RH_MFMA(ahs, beh, acc[2 * pr]);\n            acc[2 * pr + 1] = RH_MFMA(ahs, boh, acc[2 * pr + 1]);\n            acc[2 * pr] = RH_MFMA(ah, bel, acc[2 * pr]);\n            acc[2 * pr + 1] = RH_MFMA(ah, bol, acc[2 * pr + 1]);\n            acc[2 * pr] = RH_MFMA(al, beh, acc[2 * pr]);\n            acc[2 * pr + 1] = RH_MFMA(al, boh, acc[2 * pr + 1]);',
+         '            acc[2 * pr] = RH_MFMA(ahs, beh, acc[2 * pr]);\n            acc[2 * pr + 1] = RH_MFMA(al, bol, acc[2 * pr + 1]);'),
+    ],
+    'rh_nosplit': [
+        ('        rh_split(a_lo4[SLOT], a_hi4[SLOT], ah, ahs, al);',
+         '        ah = __builtin_bit_cast(f16x8, a_lo4[SLOT]); ahs = __builtin_bit_cast(f16x8, a_hi4[SLOT]); al = ah;'),
+    ],
+    'rh_noaload': [
+        ('            load_a(kt + 2, SLOT);\n', ''),
+    ],
+    'rh_nodma': [
+        ('            issue(kt + 2, (kt + 2) % RH_NSTAGE);\n', ''),
+        ('        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(5)"', '        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(2)"'),
+    ],
+    'rh_nopre': [
+        ('            const float2 old = *reinterpret_cast<const float2 *>(src + (long long)row * ld);',
+         '            const float2 old = make_float2(0.f, 0.f);'),
+    ],
+    'rh_nostore': [
+        ('            if (row < rows)\n                *reinterpret_cast<float2 *>(dst + (long long)row * ld) =',
+         '            if (row < rows && acc[0][0] == 123.456f)\n                *reinterpret_cast<float2 *>(dst + (long long)row * ld) ='),
+    ],
     # wn_winograd4w.hip
     'noepi': [
         ('    // ---- epilogue: combine the six products, add the conditioning',

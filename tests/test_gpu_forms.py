@@ -174,3 +174,39 @@ def test_handle_without_images_runs_the_direct_form(torch):
     eng = MBExWNEngine(cfg, raw, wt, weight_images=False, conv_form="f43")
     info = eng.conv_form_info()
     assert info["form"] == "direct" and info["requested"] == "f43" and not info["fold_skip"] and not info["fold_start"]
+
+
+@pytest.mark.parametrize("voice", ["SING", "VOICE"])
+def test_split_f16_res_skip_layers(torch, voice):
+    """mbx_config.wn_precision = MBX_PRECISION_SPLIT_F16 (opt-in experiment, never the default): the res/skip layers behind
+    the first one contract on the 16-bit matrix pipe with fp16-split operands (hi x hi + 2^-11 (hi x lo' + lo' x hi), float32
+    accumulation: csrc/wn_resskip_f16.hip).  Held to the float64 oracle at the SAME tolerance as the float32 path, ragged
+    batch, C = 320 (11 column tile pairs) and C = 340 (12 pairs, a partial last K step); next to it the float32 handle."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    cfg, raw, wt = build_case(voice, {})
+    lengths = [60, 37, 1]
+    mel, noise = synthetic_inputs(17, 3, 60)
+    nf = torch.as_tensor(lengths, dtype=torch.int32).cuda()
+    outs = {}
+    for prec in ("f32", "split_f16"):
+        eng = MBExWNEngine(cfg, raw, wt, conv_form="direct", precision=prec)
+        assert eng.conv_form_info()["split_f16_layers"] == (3 if prec == "split_f16" else 0)
+        outs[prec] = eng.forward(dev(torch, mel), n_frames=nf, noise=dev(torch, noise)).cpu().numpy()
+        outs[prec + "_h"] = eng.stage("wn_hidden").cpu().numpy()
+        eng.close()
+    om = orc.OracleModel(cfg, raw, wt)
+    for ii, ll in enumerate(lengths):
+        ref = om.forward(mel[ii:ii + 1, :ll], noise[ii:ii + 1, :ll * 20])[0]
+        tol = 1e-4 * max(1.0, float(np.abs(ref).max()))
+        e32 = float(np.abs(outs["f32"][ii, :ll * 300] - ref).max())
+        e16 = float(np.abs(outs["split_f16"][ii, :ll * 300] - ref).max())
+        print(f"\nsplit f16 {voice} item {ii} ({ll} frames): float32 {e32:.2e}  split f16 {e16:.2e}  tolerance {tol:.1e}")
+        assert e16 <= tol and e32 <= tol
+        assert np.all(outs["split_f16"][ii, ll * 300:] == 0.0)
+    # the hidden state after the last res/skip layer: the split form is a different rounding of the same numbers
+    hd = float(np.abs(outs["split_f16_h"] - outs["f32_h"]).max())
+    assert 0.0 < hd <= 2e-5 * max(1.0, float(np.abs(outs["f32_h"]).max())), hd
+    # not with the glu gate (its linear half is unbounded: the activation's high part times 2^11 must stay inside fp16)
+    cfg_g, raw_g, wt_g = build_case(voice, {"mbexwn_config:pp_mod_subnet:activation": "glu"})
+    with pytest.raises(NotImplementedError):
+        MBExWNEngine(cfg_g, raw_g, wt_g, precision="split_f16")
