@@ -457,7 +457,9 @@ def run_streaming(args, name, rank, world, fence, torch, steps=None, warmup=None
     syn.time_device = True
     # ticks before the timed ones: the growing left context, then (schedules) one period in which every phase's steady tick
     # is recorded and one in which its graph is captured
-    lead_ticks = 4 if len(schedule) == 1 else 3 * len(schedule) + 2
+    # (+ three periods more: a one-off stall of tens of ms has been seen within a few ticks behind the captures -- runtime
+    # housekeeping after graph instantiation, not a property of the steady state)
+    lead_ticks = 4 if len(schedule) == 1 else 6 * len(schedule)
     n_ticks = lead_ticks + warmup + steps
     emitted = [schedule[ii % len(schedule)] for ii in range(n_ticks + 1)]
     chunk = float(np.mean(emitted[lead_ticks + warmup:lead_ticks + warmup + steps]))     # frames per timed tick (mean)
@@ -484,7 +486,7 @@ def run_streaming(args, name, rank, world, fence, torch, steps=None, warmup=None
     how = ("steady ticks are one replayed hipGraph (upload of the new frames + window advance + forward + read-back of the "
            "chunk)") if len(schedule) == 1 else (f"cyclic tick schedule {schedule} frames (mean {chunk:g}): the window geometry "
            "repeats with the schedule's period, every phase has its own captured hipGraph, all working on one device-resident "
-           "window (the mel-rate front end is recomputed per window: its ring carry needs windows of one length)")
+           "window")
     return {"workload": f"{name}: MW-SP-FD canonical, {n_streams} streams per GPU, tick = {chunk:g} frames "
                         f"({chunk * 12.5:g} ms) per stream, look-ahead {syn.right * 12.5:g} ms, carried phase state, "
                         f"bit-equal to offline synthesis; {how}; value = emitted audio / device time of the ticks "

@@ -368,6 +368,10 @@ typedef struct {
     int32_t fe_ring_frames;
     const int32_t *fe_pos;
     int32_t fe_new_frames, fe_margin_frames;
+    /* with fe_new_frames > 0: frames of every item's window (0: max_frames).  A device window that is longer than what a
+     * tick uses (one buffer for the phases of a tick schedule, n_frames masks the rest) computes the last fe_new_frames +
+     * fe_margin_frames frames IN FRONT OF fe_end_frames */
+    int32_t fe_end_frames;
 } mbx_forward_options;
 
 /* Geometry of the per-layer state (mbx_forward_options.layer_store): floats per slot (0: the handle cannot carry layer

@@ -897,7 +897,7 @@ struct ForwardExtras {
     int active_max_frames = 0, wn_max_frames = 0;
     const LayerOpts *lay = nullptr;
     float *fe_store = nullptr;
-    int fe_ring_frames = 0, fe_new_frames = 0, fe_margin_frames = 0;
+    int fe_ring_frames = 0, fe_new_frames = 0, fe_margin_frames = 0, fe_end_frames = 0;
     const int32_t *fe_pos = nullptr;
 };
 
@@ -1025,11 +1025,12 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     // last fe_frames frames of the window are computed, the frames in front of them come from the ring
     const bool fe_on = ex.fe_store != nullptr;
     int fe_frames = 0;
+    const int fe_end = ex.fe_end_frames > 0 ? ex.fe_end_frames : max_frames;      // frames of the items of a steady tick
     if (fe_on) {
         if (!ex.fe_pos || !ex.sub_carry || ex.fe_ring_frames < max_frames || ex.fe_new_frames < 0 || ex.fe_margin_frames < 0 ||
-            ex.fe_new_frames + ex.fe_margin_frames > max_frames)
-            return fail(MBX_ERR_INVALID_ARGUMENT, "fe_store needs fe_pos, sub_carry (slots), fe_ring_frames >= max_frames and "
-                                                  "fe_new_frames + fe_margin_frames <= max_frames");
+            fe_end > max_frames || ex.fe_new_frames + ex.fe_margin_frames > fe_end)
+            return fail(MBX_ERR_INVALID_ARGUMENT, "fe_store needs fe_pos, sub_carry (slots), fe_ring_frames >= max_frames, "
+                                                  "fe_end_frames <= max_frames and fe_new_frames + fe_margin_frames <= fe_end_frames");
         if (hd->cfg.nm_iters > 0 || hd->f0_time_factor > hd->cfg.pulse_per_frame || ex.f0_in)
             return fail(MBX_ERR_UNSUPPORTED, "the front end cannot be carried for this model / call (RMS normalisation, an F0-net "
                                              "that runs above the pulse rate, an external F0 contour)");
@@ -1082,10 +1083,10 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     // mel-rate convolutions are latency-bound)
     {
         ScopedEvents ev(hd, PROF_FRONTEND, stream);
-        // a carried front end computes the frames [T - fe_frames, T) of every item only (all items then span the whole
-        // window: a steady tick); batch strides stay those of the window
+        // a carried front end computes the frames [fe_end - fe_frames, fe_end) of every item only (all items then have
+        // fe_end frames: a steady tick); batch strides stay those of the window
         const int Tf = fe_frames ? fe_frames : T;
-        const long long f_off = T - Tf;
+        const long long f_off = fe_frames ? fe_end - Tf : 0;
         const int32_t *nf_fe = fe_frames ? nullptr : n_frames;
         const float *mel_fe = mel + f_off * c.mel_channels;
         SubnetRun cond(hd, hd->cond_ops.data(), (int)hd->cond_ops.size(), mel_fe, c.mel_channels, nf_fe, B, Tf, w.sub4,
@@ -1161,7 +1162,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         fc.ring_frames = ex.fe_ring_frames;
         fc.pos = ex.fe_pos;
         fc.slot_desc = ex.sub_carry;
-        fc.first_new = fe_frames ? T - ex.fe_new_frames : 0;
+        fc.first_new = fe_frames ? fe_end - ex.fe_new_frames : 0;
         mbx::launch_frontend_carry(fc, B, stream);
     }
     // ---- wavetable excitation (reference :889)
@@ -1782,6 +1783,7 @@ mbx_status mbx_forward_ex(mbx_handle *hd, const float *mel, const int32_t *n_fra
     ex.fe_pos = options->fe_pos;
     ex.fe_new_frames = options->fe_new_frames;
     ex.fe_margin_frames = options->fe_margin_frames;
+    ex.fe_end_frames = options->fe_end_frames;
     return forward_impl(hd, mel, n_frames, batch, max_frames, noise, audio, workspace, workspace_bytes, hip_stream, ex);
 }
 

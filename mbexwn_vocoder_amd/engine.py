@@ -96,7 +96,8 @@ class mbx_forward_options(ctypes.Structure):
                 ("active_max_frames", ctypes.c_int32), ("wn_max_frames", ctypes.c_int32), ("sub_store", ctypes.c_void_p), ("sub_store_rows", ctypes.c_int32), ("sub_carry", ctypes.c_void_p),
                 ("layer_store", ctypes.c_void_p), ("layer_store_floats", ctypes.c_int32), ("layer_carry", ctypes.c_void_p),
                 ("layer_rows", ctypes.c_int32), ("fe_store", ctypes.c_void_p), ("fe_ring_frames", ctypes.c_int32),
-                ("fe_pos", ctypes.c_void_p), ("fe_new_frames", ctypes.c_int32), ("fe_margin_frames", ctypes.c_int32)]
+                ("fe_pos", ctypes.c_void_p), ("fe_new_frames", ctypes.c_int32), ("fe_margin_frames", ctypes.c_int32),
+                ("fe_end_frames", ctypes.c_int32)]
 
 
 class mbx_tensor(ctypes.Structure):
@@ -846,7 +847,8 @@ class MBExWNEngine:
                     opt.layer_store, opt.layer_store_floats = lstore.data_ptr(), int(lstore.shape[1])
                     opt.layer_carry, opt.layer_rows = ldesc.data_ptr(), int(lrows)
                 if frontend is not None:
-                    ring, fpos, fnew, fmargin = frontend
+                    ring, fpos, fnew, fmargin = frontend[:4]
+                    opt.fe_end_frames = int(frontend[4]) if len(frontend) > 4 else 0
                     if (ring.dtype != torch.float32 or ring.dim() != 3 or ring.device != self.device or not ring.is_contiguous() or
                             ring.shape[2] != self.frontend_frame_floats):
                         raise ValueError("front-end ring must be a contiguous float32 tensor (slots, ring frames, "

@@ -623,10 +623,11 @@ class StreamingSynthesizer:
         noise_new = stage_dev[n_mel:n_mel + n_noise].view(B, chunk * spf) if use_noise else None
         states_d = stage_dev[n_mel + n_noise:n_mel + n_noise + B * 6].view(torch.int32).view(B, 6)
         fpos_d = stage_dev[n_mel + n_noise + B * 6:].view(torch.int32)
-        # front end: the window gained `chunk` frames and the last fe_right frames of the window before were inexact; the
-        # carried front end computes the LAST frames of the buffer, so it needs a window that fills it (uniform schedules)
+        # front end: the window gained `chunk` frames and the last fe_right frames of the window before were inexact: the
+        # sub-nets run on the last chunk + fe_right (+ their reach) frames in front of the window's end (frame ctx["T"] of the
+        # buffer: fe_end_frames), everything in front of that comes from the ring
         fe_new, fe_margin = chunk + self.fe_right, self.fe_left
-        use_fe = ctx["use_fe"] and ctx["T"] == tpad and shift == chunk and fe_new + fe_margin <= tpad
+        use_fe = ctx["use_fe"] and fe_new + fe_margin <= ctx["T"]
         ints = {kk: torch.as_tensor(ctx[kk], device=dev) for kk in ("act", "wn", "nfr", "desc", "ldesc")}
         audio_buf, state_out, state_host = shared["audio_buf"], shared["state_out"], shared["state_host"]
         emit_buf = torch.empty((B, ctx["hi"] - ctx["lo"]), dtype=torch.float32, device=dev)
@@ -654,7 +655,7 @@ class StreamingSynthesizer:
                         wavenet=(ctx["wa"], ints["wn"], int(ctx["wn"].max())),
                         carry=(self._store, ints["desc"].view(B, 5)) if self.carry else None,
                         layers=(self._layer_store, ints["ldesc"].view(B, 3), ctx["layer_rows"]),
-                        frontend=(self._fe_store, fpos_d, fe_new if use_fe else 0, fe_margin if use_fe else 0)
+                        frontend=(self._fe_store, fpos_d, fe_new if use_fe else 0, fe_margin if use_fe else 0, ctx["T"])
                         if ctx["use_fe"] else None,
                         out=audio_buf, state_out=state_out)
             emit_buf.copy_(audio_buf[:, ctx["lo"]:ctx["hi"]])
