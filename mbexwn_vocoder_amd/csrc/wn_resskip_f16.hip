@@ -16,13 +16,18 @@
 // Block = 8 waves, 128 rows x 6 pairs of 16-column tiles (two blocks per row tile: 12 pairs = 384 columns cover C + n_out
 // <= 384); wave w owns rows 16 w .. 16 w + 15 x 12 column tiles (48 accumulator registers; 2 blocks per CU).
 // K steps of 32 channels = one v_mfma_f32_16x16x32_f16 per (tile, product):
-//   A: a lane (row r = lane & 15, kq = lane >> 4) loads the channels k0 + 4 kq .. + 3 and k0 + 16 + 4 kq .. + 3 of its row
-//      straight from global memory (two 16-byte loads, two steps ahead; 16 rows x 64 contiguous bytes per wave instruction)
-//      and splits them in registers: ~50 vector instructions per step, which hide in the issue slots the 36 16-bit MFMAs
-//      of a step leave free (an MFMA of this kind holds the vector issue for 8 of its 16 cycles; MI355X_MICROARCH.md);
+//   A: a lane (row r = lane & 15, kq = lane >> 4) holds the channels k0 + 4 kq .. + 3 and k0 + 16 + 4 kq .. + 3 of its row:
+//      two LDS-DMA requests per wave and step land them in a 2 KB zone of the wave's own (the lane that requested a
+//      16-byte piece reads it back: 16 rows x 64 contiguous bytes per request), and the lane splits them in registers:
+//      ~65 vector instructions per step, which hide in the issue slots the 36 16-bit MFMAs of a step leave free (an MFMA
+//      of this kind holds the vector issue for 8 of its 16 cycles; MI355X_MICROARCH.md).  (Register loads do not work
+//      here: a load the compiler sees makes it insert a wait that -- blind to the LDS-DMA requests queued behind -- drains
+//      the whole prefetch; a load hidden in inline asm lets the compiler copy the destination before the data is there.)
 //   B: 12 pairs x [even hi | even lo | odd hi | odd lo] x 64 lanes x 8 halves, packed on the host in MFMA operand order
 //      (lane n of pair p holds columns 32 p + 2 n, 32 p + 2 n + 1: float2 access to h and the accumulator as in
-//      wn_resskip_wide.hip), copied into LDS by LDS-DMA, three stages of 24 KB, 3 requests per wave and step, one barrier per step.
+//      wn_resskip_wide.hip), copied into LDS by LDS-DMA, 3 requests per wave and step.
+// Two stages of 24 KB (weights) + 16 KB (activations): 80 KB, two blocks per CU; a step's requests are issued behind the
+// barrier of the step before, one barrier per step.
 // Accumulators start from 2^11 (old value + bias); the epilogue stores 2^-11 times them.
 #include <cstdlib>
 #include <type_traits>
@@ -37,22 +42,18 @@ constexpr int RH_ROWS = 128;
 constexpr int RH_BK = 32;
 constexpr int RH_NP = 6;                               // pairs per block
 constexpr int RH_PAIR_FLOATS = 4 * 64 * 4;             // one pair of one step: 4 operand images x 64 lanes x 16 bytes = 4 KB
-constexpr int RH_STAGE = RH_NP * RH_PAIR_FLOATS;       // 24 KB
-constexpr int RH_NSTAGE = 3;
+constexpr int RH_B_FLOATS = RH_NP * RH_PAIR_FLOATS;    // weights of a step: 24 KB
+constexpr int RH_A_FLOATS = 8 * 512;                   // activations of a step: 8 waves x 2 KB
+constexpr int RH_STAGE = RH_B_FLOATS + RH_A_FLOATS;    // 40 KB
+constexpr int RH_NSTAGE = 2;
 
 __device__ __forceinline__ void rh_lds_dma16_s(const float *sbase, unsigned voff_bytes, unsigned lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte_addr), "v"(voff_bytes), "s"(sbase)
                  : "memory", "m0");
 }
 
-// 16-byte global load whose completion the kernel waits for itself (counted s_waitcnt vmcnt): a load the compiler knows
-// about would make it insert its own wait, and since it does not see the LDS-DMA requests that were issued behind that
-// load, its count is smaller than the queue really is -- which drains the whole prefetch pipeline at every step (first
-// version of this kernel: 3.9 us per 32-channel step).  `ok` false: the lane gets zeros (channels behind cin).
-__device__ __forceinline__ f32x4 rh_load16(const float *src, bool ok) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (ok) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(src) : "memory");
-    return v;
+__device__ __forceinline__ void rh_lds_dma16(const float *src, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(src) : "memory", "m0");
 }
 
 #define RH_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
@@ -95,8 +96,12 @@ __global__ __launch_bounds__(512, 4) void wn_resskip_f16_kernel(ConvArgs p) {
     const int r16 = lane & 15, kq = lane >> 4;
     const int nk = (p.cin + RH_BK - 1) / RH_BK;
 
-    // ---- weights: step kt = 12 pairs x 4 KB; this block's 6 pairs are 24 consecutive 1 KB pieces, three per wave
+    // ---- requests of a step: weights (step kt = 12 pairs x 4 KB; this block's 6 pairs are 24 consecutive 1 KB pieces, three
+    // per wave) and this wave's activation rows (row of this lane clamped: rows behind the item's end are computed and not
+    // stored; channels behind cin come from the zero buffer)
     const unsigned b_voff = 16u * (unsigned)lane;
+    const int arow = min(m0 + 16 * wave + r16, rows - 1);
+    const float *ap = p.x + (long long)b * p.x_bstride + (long long)arow * p.ldx + 4 * kq;
     auto issue = [&](int kt, int stage) {
         const unsigned dst = lds_base + 4u * (unsigned)(stage * RH_STAGE);
         const float *src = p.w + ((long long)kt * 12 + pair0) * RH_PAIR_FLOATS;
@@ -105,22 +110,12 @@ __global__ __launch_bounds__(512, 4) void wn_resskip_f16_kernel(ConvArgs p) {
             const int piece = wave + 8 * i;
             rh_lds_dma16_s(src + piece * 256, b_voff, dst + 1024u * (unsigned)piece);
         }
+        const unsigned adst = dst + 4u * (unsigned)(RH_B_FLOATS + wave * 512);
+        const int c0 = kt * RH_BK + 4 * kq;
+        rh_lds_dma16(c0 < p.cin ? ap + kt * RH_BK : p.zeros, adst);
+        rh_lds_dma16(c0 + 16 < p.cin ? ap + kt * RH_BK + 16 : p.zeros, adst + 1024u);
     };
     issue(0, 0);
-
-    // ---- activations: row of this lane (clamped: rows behind the item's end are computed and not stored)
-    const int arow = min(m0 + 16 * wave + r16, rows - 1);
-    const float *ap = p.x + (long long)b * p.x_bstride + (long long)arow * p.ldx + 4 * kq;
-    // channels k0 + 4 kq .. + 3 and k0 + 16 + 4 kq .. + 3 of the steps in flight: two steps ahead of the one being multiplied.
-    // Whether a lane's channels exist is the same for every row (wave-uniform per kq group): lanes behind cin keep zeros.
-    f32x4 a_lo4[2], a_hi4[2];
-    auto load_a = [&](int kt, int slot) {
-        const int c0 = kt * RH_BK + 4 * kq, c1 = c0 + 16;
-        a_lo4[slot] = rh_load16(ap + kt * RH_BK, c0 < p.cin);
-        a_hi4[slot] = rh_load16(ap + kt * RH_BK + 16, c1 < p.cin);
-    };
-
-    load_a(0, 0);
 
     // ---- accumulators: 2^11 x (old value + bias) (h columns accumulate, skip columns unless skip_init)
     f32x4 acc[2 * RH_NP];
@@ -149,27 +144,17 @@ __global__ __launch_bounds__(512, 4) void wn_resskip_f16_kernel(ConvArgs p) {
             acc[2 * pr + 1][v] = 2048.0f * ((accumulate ? old.y : 0.f) + (col_ok ? bias.y : 0.f));
         }
     }
-    if (nk > 1) {
-        issue(1, 1);
-        load_a(1, 1);
-    }
-
     const f16x8 *bptr = reinterpret_cast<const f16x8 *>(lds) + lane;      // + stage * (RH_STAGE / 4) + (4 pr + image) * 64
-    auto step = [&](int kt, auto slot_c) {
-        constexpr int SLOT = decltype(slot_c)::value;
-        const int stage = kt % RH_NSTAGE;
-        // Queue of this wave's vector-memory requests, oldest first: [activations of step kt: 2 (lanes behind cin: fewer --
-        // then the wait below only gets stricter)] [weights of step kt: 3] [activations kt + 1: 2] [weights kt + 1: 3].
-        // Step kt's operands have landed when at most the last five are outstanding.
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(5)" : "+v"(a_lo4[SLOT]), "+v"(a_hi4[SLOT]) : : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(a_lo4[SLOT]), "+v"(a_hi4[SLOT]) : : "memory");
+    const f32x4 *aptr = reinterpret_cast<const f32x4 *>(lds) + RH_B_FLOATS / 4 + wave * 128 + lane;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt & 1;
+        // every request this wave has in flight belongs to step kt (the next step's are issued behind the barrier)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                               // step kt's operands are there for every wave; and every wave is done
+        if (kt + 1 < nk) issue(kt + 1, stage ^ 1);     // with step kt - 1, whose stage takes step kt + 1
+        const f32x4 a_lo4 = aptr[stage * (RH_STAGE / 4)], a_hi4 = aptr[stage * (RH_STAGE / 4) + 64];
         f16x8 ah, ahs, al;
-        rh_split(a_lo4[SLOT], a_hi4[SLOT], ah, ahs, al);
-        __syncthreads();                               // step kt's weights are there for every wave; and every wave is done
-        if (kt + 2 < nk) {                             // with step kt - 1, whose stage takes step kt + 2
-            issue(kt + 2, (kt + 2) % RH_NSTAGE);
-            load_a(kt + 2, SLOT);
-        }
+        rh_split(a_lo4, a_hi4, ah, ahs, al);
         const f16x8 *bs = bptr + stage * (RH_STAGE / 4);
 #pragma unroll
         for (int pr = 0; pr < RH_NP; ++pr) {
@@ -182,14 +167,6 @@ __global__ __launch_bounds__(512, 4) void wn_resskip_f16_kernel(ConvArgs p) {
             acc[2 * pr] = RH_MFMA(al, beh, acc[2 * pr]);
             acc[2 * pr + 1] = RH_MFMA(al, boh, acc[2 * pr + 1]);
         }
-    };
-    {
-        int kt = 0;
-        for (; kt + 2 <= nk; kt += 2) {
-            step(kt, std::integral_constant<int, 0>());
-            step(kt + 1, std::integral_constant<int, 1>());
-        }
-        if (kt < nk) step(kt, std::integral_constant<int, 0>());
     }
 
     // ---- epilogue: new value = 2^-11 x accumulator
@@ -218,7 +195,7 @@ bool launch_wn_resskip_f16(const ConvArgs &a, hipStream_t stream) {
                     a.cin % 4 == 0 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 && a.channels % 2 == 0 && a.skip_ld % 2 == 0 &&
                     a.cout % 2 == 0 && a.cout <= a.channels + a.skip_ld && (uintptr_t)a.x % 16 == 0 &&
                     (uintptr_t)a.w % 16 == 0 && (uintptr_t)a.h % 8 == 0 && (uintptr_t)a.skip % 8 == 0 &&
-                    (!a.bias || (uintptr_t)a.bias % 8 == 0) && a.hs_bstride % 2 == 0 && a.h && a.skip;
+                    (!a.bias || (uintptr_t)a.bias % 8 == 0) && a.hs_bstride % 2 == 0 && a.h && a.skip && a.zeros;
     if (!ok) return false;
     ConvArgs r = a;
     r.m_tiles_per_item = (a.max_rows + RH_ROWS - 1) / RH_ROWS;

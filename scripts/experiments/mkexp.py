@@ -213,15 +213,16 @@ PATCHES = {
          '            acc[2 * pr] = RH_MFMA(ahs, beh, acc[2 * pr]);\n            acc[2 * pr + 1] = RH_MFMA(al, bol, acc[2 * pr + 1]);'),
     ],
     'rh_nosplit': [
-        ('        rh_split(a_lo4[SLOT], a_hi4[SLOT], ah, ahs, al);',
-         '        ah = __builtin_bit_cast(f16x8, a_lo4[SLOT]); ahs = __builtin_bit_cast(f16x8, a_hi4[SLOT]); al = ah;'),
+        ('        rh_split(a_lo4, a_hi4, ah, ahs, al);',
+         '        ah = __builtin_bit_cast(f16x8, a_lo4); ahs = __builtin_bit_cast(f16x8, a_hi4); al = ah;'),
     ],
     'rh_noaload': [
-        ('            load_a(kt + 2, SLOT);\n', ''),
+        ('        rh_lds_dma16(c0 < p.cin ? ap + kt * RH_BK : p.zeros, adst);\n        rh_lds_dma16(c0 + 16 < p.cin ? ap + kt * RH_BK + 16 : p.zeros, adst + 1024u);\n',
+         '        if (kt == 0) { rh_lds_dma16(p.zeros, adst); rh_lds_dma16(p.zeros, adst + 1024u); }\n'),
     ],
     'rh_nodma': [
-        ('            issue(kt + 2, (kt + 2) % RH_NSTAGE);\n', ''),
-        ('        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(5)"', '        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(2)"'),
+        ('        for (int i = 0; i < 3; ++i) {\n            const int piece = wave + 8 * i;\n            rh_lds_dma16_s(',
+         '        for (int i = 0; i < (kt == 0 ? 3 : 0); ++i) {\n            const int piece = wave + 8 * i;\n            rh_lds_dma16_s('),
     ],
     'rh_nopre': [
         ('            const float2 old = *reinterpret_cast<const float2 *>(src + (long long)row * ld);',

@@ -210,3 +210,23 @@ def test_split_f16_res_skip_layers(torch, voice):
     cfg_g, raw_g, wt_g = build_case(voice, {"mbexwn_config:pp_mod_subnet:activation": "glu"})
     with pytest.raises(NotImplementedError):
         MBExWNEngine(cfg_g, raw_g, wt_g, precision="split_f16")
+
+
+def test_split_f16_large_launch_against_the_float32_handle(torch):
+    """The same at a launch size where the latencies are those of a loaded chip (16 x 400 frames: 1 000 row tiles): a race in
+    the operand pipeline shows up here and not in a 60-frame test (the first version of the kernel loaded its activations
+    through inline-asm register loads, which the compiler was free to copy before the data had arrived: right at 60 frames,
+    wrong by 0.2 at 16 x 800).  Against the float32 handle, item by item; two runs must agree bit for bit."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    cfg, raw, wt = build_case("SING", {})
+    mel, noise = synthetic_inputs(23, 16, 400)
+    e32 = MBExWNEngine(cfg, raw, wt, conv_form="f43")
+    e16 = MBExWNEngine(cfg, raw, wt, conv_form="f43", precision="split_f16")
+    a32 = e32.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
+    a16 = e16.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
+    b16 = e16.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
+    assert np.array_equal(a16, b16)
+    amp = max(1.0, float(np.abs(a32).max()))
+    worst = float(np.abs(a16 - a32).max())
+    print(f"\nsplit f16 vs float32 at 16 x 400 frames: max difference {worst:.2e} (amplitude {amp:.2f})")
+    assert worst <= 2e-5 * amp
