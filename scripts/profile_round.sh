@@ -20,3 +20,9 @@ for WL in config2_sp_b1_10s config3_si_b16_10s config5_sp_stream64; do
       python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $R/gpurun_out/${TAG}_pmc_sq_$WL.log 2>&1
   tail -1 $R/gpurun_out/${TAG}_trace_$WL.log | cut -c1-200
 done
+# builder-run secondaries (kernel trace only): the opt-in split half precision of the res/skip layers and the two-block variant
+for WL in config3_split_f16 variant_blocks2 config5_sp_stream64_80ms; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_trace_$WL -- \
+      python3 $R/bench.py --workload $WL --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $R/gpurun_out/${TAG}_trace_$WL.log 2>&1
+  tail -1 $R/gpurun_out/${TAG}_trace_$WL.log | cut -c1-200
+done

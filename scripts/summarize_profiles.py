@@ -21,6 +21,8 @@ summary = {}
 def short(name):
     if "wn_gate_winograd" in name or ("conv1d_mfma_dma_kernel" in name and ", 1>" in name):
         return "gate"
+    if "wn_resskip_f16_kernel" in name:
+        return "res_skip_f16"
     if "wn_resskip_kernel" in name or "wn_resskip_wide_kernel" in name or "wn_resskip_wave_kernel" in name or ("conv1d_mfma_kernel" in name and ", 2, true" in name):
         return "res_skip"
     return None
@@ -63,6 +65,12 @@ for wl in ("config2_sp_b1_10s", "config3_si_b16_10s", "config5_sp_stream64"):
             # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs
             ee["mfma_util"] = ee["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (ee["GRBM_GUI_ACTIVE"] / 8.0)
     summary[wl] = entry
+# kernel stats of the builder-run secondaries (trace only)
+for wl in ("config3_split_f16", "variant_blocks2", "config5_sp_stream64_80ms"):
+    stats = sorted(glob.glob(os.path.join(src, f"{tag}_trace_{wl}", "*", "*kernel_stats.csv")), key=os.path.getmtime, reverse=True)
+    if stats:
+        with open(os.path.join(dst, f"{tag}_kernel_stats_{wl}.csv"), "w") as fo:
+            fo.write(open(stats[0]).read())
 with open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w") as fo:
     json.dump(summary, fo, indent=1, sort_keys=True)
 print(json.dumps(summary, indent=1, sort_keys=True))
