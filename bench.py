@@ -44,7 +44,8 @@ WORKLOADS = {
     # geometry of the golden case "blocks": C = 320 at 800 Hz, then C = 160 at 1600 Hz), the block runner's kernels
     "variant_blocks2": ("SING", 16, 800),
     # builder-run secondary, NOT float32 end to end and never the headline: the config-3 workload with the opt-in split half
-    # precision of the res/skip layers (mbx_config.wn_precision: fp16-split operands, three products, float32 accumulation)
+    # precision of the gate and res/skip layers behind the first one (mbx_config.wn_precision: fp16-split operands, three
+    # products on the 16-bit matrix pipe, float32 accumulation)
     "config3_split_f16": ("SING", 16, 800),
 }
 ENGINE_KW = {"config3_split_f16": {"precision": "split_f16"}}
@@ -664,7 +665,18 @@ def main():
             split_ms = sp_ms / sp_n if sp_n else None
             flop = 3 * 2.0 * rows * C * (C + n_out)
             hbm = rows * (3 * C + 2 * n_out) * 4.0
-            ress["precision"] = "res/skip layers 1..L-2: fp16 x 3 (hi hi + 2^-11 (hi lo' + lo' hi)), float32 accumulation; everything else float32"
+            g_ms, g_n = ctxs["stages"]["gate"]
+            ress["precision"] = ("gate layers 1..L-1 and res/skip layers 1..L-2: fp16 x 3 (hi hi + 2^-11 (hi lo' + lo' hi)) on "
+                                 "v_mfma_f32_16x16x32_f16, float32 accumulation; everything else float32")
+            ress["gate_split_launch_ms"] = g_ms / g_n if g_n else None
+            if g_n:
+                gflop = 3 * 2.0 * rows * (3 * C) * (2 * C)
+                ress["gate_roofline"] = {"kernel": "wn_gate_f16_kernel (direct form, three fp16 products)", "bound": "mfma",
+                                         "avg_launch_ms": g_ms / g_n, "flop_executed": gflop,
+                                         "achieved": gflop / (g_ms / g_n * 1e-3) / 1e12, "peak": FP16_MATRIX_PEAK_TFLOPS,
+                                         "unit": "TFLOP/s", "frac": gflop / (g_ms / g_n * 1e-3) / 1e12 / FP16_MATRIX_PEAK_TFLOPS,
+                                         "note": "against the fp16 matrix peak; the kernel is bound by its LDS operand reads and "
+                                                 "the float32 -> (hi, lo') conversion pass, not by the matrix pipe"}
             ress["res_skip_ms_per_forward"] = rs_ms / n_fwd + (sp_ms / sp_n * (L - 2) if sp_n else 0.0)
             ress["res_skip_split_launch_ms"] = split_ms
             if split_ms:

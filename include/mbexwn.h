@@ -207,9 +207,10 @@ typedef struct {
     int32_t nm_use_pinv;
     float nm_win_norm;
     /* MBX_PRECISION_F32 (0, the default and the only arithmetic the parity claims and the headline benchmark are made in) or
-     * MBX_PRECISION_SPLIT_F16: an opt-in experiment -- the res/skip layers behind the first one run their contraction on the
-     * 16-bit matrix pipe with every float32 operand split into two fp16 parts (three products, float32 accumulation:
-     * float32-class error, csrc/wn_resskip_f16.hip; needs the "*.fold_f16" weight images; not with the glu gate) */
+     * MBX_PRECISION_SPLIT_F16: an opt-in experiment -- the res/skip layers and (whole-item forwards) the gate layers behind
+     * the first one run their contractions on the 16-bit matrix pipe with every float32 operand split into two fp16 parts
+     * (three products, float32 accumulation: float32-class error; csrc/wn_resskip_f16.hip, csrc/wn_gate_f16.hip; needs the
+     * "*.fold_f16" / "*.gate_f16" weight images; not with the glu gate; |h| must stay inside fp16's range) */
     int32_t wn_precision;
     int32_t reserved7[1];
 } mbx_config;
@@ -245,6 +246,7 @@ typedef struct {
     int32_t batch_invariant;
     int32_t fold_skip, fold_start;   /* the folds in effect */
     int32_t split_f16_layers; /* res/skip layers that run in split half precision (mbx_config.wn_precision; 0: none) */
+    int32_t split_f16_gate_layers; /* gate layers that do (whole-item forwards; streams keep their float32 form) */
     float err_f43, err_f23;   /* max |audio(form) - audio(direct)| of the calibration run; < 0: form not available */
     float ref_max;            /* max |audio(direct)| of the calibration run */
     float threshold;          /* calib_fraction * 1e-4 * max(1, ref_max): a form is accepted at or below it */

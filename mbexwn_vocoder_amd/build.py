@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ_DIR = os.path.join(HERE, "build")
 LIB_PATH = os.path.join(HERE, "libmbexwn_hip.so")
-SOURCES = ["conv_mfma.hip", "wn_winograd2w.hip", "wn_winograd4w.hip", "wn_gate0.hip", "wn_resskip.hip", "wn_resskip_wide.hip", "wn_resskip_wave.hip", "wn_resskip_f16.hip", "wn_tail.hip",
+SOURCES = ["conv_mfma.hip", "wn_winograd2w.hip", "wn_winograd4w.hip", "wn_gate0.hip", "wn_resskip.hip", "wn_resskip_wide.hip", "wn_resskip_wave.hip", "wn_resskip_f16.hip", "wn_gate_f16.hip", "wn_tail.hip",
            "elementwise.hip", "wavetable.hip", "pqmf.hip", "stft_filter.hip", "mel_analysis.hip", "norm_mel.hip", "mbx_api.hip"]
 HEADERS = ["mbx_kernels.h", "fft_lds.h", os.path.join("..", "..", "include", "mbexwn.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]

@@ -106,6 +106,7 @@ struct mbx_handle {
     long long resskip_wave_tiles = 2048;   // default policy: res/skip launches of at most this many 16-row tiles run the wave-tiled kernel
     int resskip_split = 0;           // mbx_config.tune_resskip_split
     bool split_f16 = false;          // mbx_config.wn_precision == MBX_PRECISION_SPLIT_F16 and the images are there
+    bool split_f16_gate = false;     // ... for the gate layers too (wn_gate_f16.hip)
     int winograd = 0;            // gate layer form in effect: 0 direct, 2 Winograd F(2,3), 4 Winograd F(4,3) (needs the packed weights)
     // what mbx_conv_form reports
     int calibrated = 0;
@@ -781,6 +782,10 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
             return bail(fail(MBX_ERR_INVALID_ARGUMENT, "wn_precision = split f16 needs the folded skip path, >= 3 layers, C + n_out <= 384 "
                                                         "and the wn.res_skip_<l>.fold_f16 images"));
         hd->split_f16 = true;
+        // ... and the gate layers behind the folded first one (wn_gate_f16.hip), where the host supplied their images
+        hd->split_f16_gate = hd->fold_start && !c.wn_causal && c.wn_kernel_size == 3;
+        for (int l = 1; l < c.wn_layers && hd->split_f16_gate; ++l)
+            hd->split_f16_gate = expect("wn.conv1D_" + std::to_string(l) + ".gate_f16", (long long)((C + 31) / 32) * ((C + 31) / 32) * 6144);
     }
     {
         hd->gate_small_shape = c.tune_gate_shape - 1;
@@ -1346,7 +1351,13 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
             // per MFMA (the weight slice serves half the rows) and shorter slices tell
             bool split4 = !hd->winograd4_always && full_blocks <= 1024 && load_half <= load_full;
             if (hd->gate_small_shape >= 0 && !hd->winograd4_always && full_blocks < 4 * 768) split4 = hd->gate_small_shape != 0;
-            const bool use4 = hd->winograd == 4 && !st_in && !st_out;
+            // opt-in split half precision: whole-item forwards of the layers behind the folded first one
+            if (hd->split_f16_gate && !st_in && !st_out && gs.cphase == 0 && gs.out_rows == 0) {
+                mbx::ConvArgs gh = g;
+                gh.w = find(hd, "wn.conv1D_" + ls + ".gate_f16")->ptr;
+                done = mbx::launch_wn_gate_f16(gh, stream);
+            }
+            const bool use4 = !done && hd->winograd == 4 && !st_in && !st_out;
             const DevTensor *wino4 = use4 ? find(hd, "wn.conv1D_" + ls + ".wino4w") : nullptr;
             if (wino4 && wino4->ndim == 3 && wino4->shape[0] == (C + 31) / 32 && wino4->shape[1] == (C + 7) / 8 &&
                 wino4->shape[2] == 3072 && gs.cphase == 0) {
@@ -1730,6 +1741,7 @@ mbx_status mbx_conv_form(const mbx_handle *hd, mbx_conv_form_info *info) {
     info->fold_skip = hd->fold_skip;
     info->fold_start = hd->fold_start;
     info->split_f16_layers = hd->split_f16 ? std::max(0, hd->cfg.wn_layers - 2) : 0;
+    info->split_f16_gate_layers = hd->split_f16_gate ? std::max(0, hd->cfg.wn_layers - 1) : 0;
     info->err_f43 = hd->calib_err43;
     info->err_f23 = hd->calib_err23;
     info->ref_max = hd->calib_ref;

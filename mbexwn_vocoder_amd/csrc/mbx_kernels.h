@@ -102,6 +102,9 @@ bool launch_wn_gate_winograd4w(const ConvArgs &a, bool split, hipStream_t stream
 // Winograd F(2,3) form on v_mfma_f32_16x16x4_f32 with wave-granular tiles (wn_winograd2w.hip: streams, per-layer regions,
 // MBX_CONV_F23); a.w = image of engine.pack_winograd2w_weights (ceil(C/32), ceil(C/8), 2048)
 bool launch_wn_gate_winograd2w(const ConvArgs &a, hipStream_t stream);
+// the dilated convolution + gate in split half precision, direct form (wn_gate_f16.hip; opt-in, mbx_config.wn_precision);
+// a.w = image of engine.pack_gate_f16_weights (ceil(C/32), ceil(C/32), 6144)
+bool launch_wn_gate_f16(const ConvArgs &a, hipStream_t stream);
 // First WaveNet layer with the start convolution folded into it (wn_gate0.hip)
 struct Gate0Args {
     const float *pulse;       // (batch, rows * pulse_channels): the excitation, folded to pulse_channels per row

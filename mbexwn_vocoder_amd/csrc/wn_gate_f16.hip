@@ -1,0 +1,278 @@
+// WaveNet dilated convolution (k = 3) + conditioning + gate in SPLIT half precision, direct form (opt-in:
+// mbx_config.wn_precision = MBX_PRECISION_SPLIT_F16; never the default and never the headline measurement -- the float32
+// kernels are wn_winograd4w.hip / wn_winograd2w.hip / conv_mfma.hip).
+//
+// Same layer as wn_gate_winograd4w_kernel (reference MBExWN_NVoc/vocoder/model/custom_AE_layers.py:305-321), computed as
+// the plain K = 3C contraction on the 16-bit matrix pipe (16 x the float32 rate) with both operands split into
+// hi = fp16(x) and lo' = fp16((x - hi) 2^11):  x y ~ hi hi + 2^-11 (hi lo' + lo' hi)  -- float32-class error (DESIGN.md
+// section 9).  Unlike the res/skip layer's input the hidden state h is not bounded, so nothing is pre-scaled: the hi hi
+// products go to one accumulator set, the two cross products to a second one, and the epilogue forms main + 2^-11 cross.
+// fp16's range bounds |h| at 65 504 (the engine's calibration forward would show an overflow as non-finite audio).
+//
+// Block = 8 waves, 256 rows x 64 weight columns ([16 tanh | 16 sigmoid] of the even and of the odd gate channels of a
+// 32-channel column tile: the epilogue is the one of wn_gate_winograd4w_kernel); wave w owns rows 32 w .. 32 w + 31 (two
+// 16-row tiles) x the four column tiles x 2 accumulator sets = 64 registers.  K steps of 32 channels:
+//   A: the rows [m0 - 16, m0 + 272) x 32 channels of h land as float32 in a staging tile X (LDS-DMA, 36 KB); the block
+//      converts them ONCE into the operand tile Y: per row 64 bytes of hi and 64 bytes of lo' halves, 16-byte chunk c8
+//      (channels 8 (c8 & 3) .. + 7, hi: c8 < 4, lo': c8 >= 4) at chunk position c8 ^ ((row >> 1) & 7), so that the 16 lanes
+//      of an operand read (16 consecutive rows, one chunk) hit 64 different banks at every tap offset.  (The first version
+//      split in registers, once per tap and row tile -- 6 splits of 8 values per wave and step: 1.09 ms per launch, 0.83
+//      with the split removed.)  Lane (i = lane & 15, kq = lane >> 4) reads the channels 8 kq .. + 7 of its row;
+//   B: 3 taps x 4 column tiles x [hi | lo'] x 64 lanes x 8 halves, packed on the host in MFMA operand order
+//      (engine.pack_gate_f16_weights), 24 KB per step, copied verbatim by LDS-DMA into one of two stages.
+// Per step: wait for the step's requests, barrier, convert X -> Y, barrier, request the next step (X is free, the other
+// weight stage too), multiply.  X + Y + 2 weight stages + conditioning tile + tables: 128.5 KB, one block per CU.
+#include <cstdlib>
+#include <type_traits>
+#include "mbx_kernels.h"
+
+namespace mbx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int GH_ROWS = 256;
+constexpr int GH_HALO = 16;
+constexpr int GH_AROWS = GH_ROWS + 2 * GH_HALO;            // 288 staged rows
+constexpr int GH_BK = 32;
+constexpr int GH_A_FLOATS = GH_AROWS * GH_BK;              // 9216 floats = 36 KB
+constexpr int GH_B_FLOATS = 3 * 4 * 2 * 256;               // 3 taps x 4 tiles x 2 images x 1 KB = 24 KB
+constexpr int GH_X = 0;                                    // float32 landing tile
+constexpr int GH_Y = GH_A_FLOATS;                          // operand tile (hi / lo' halves), same size
+constexpr int GH_B = 2 * GH_A_FLOATS;                      // two weight stages
+constexpr int GH_COND_ROWS = 28;                           // conditioning rows of 64 floats (cond_up >= 10)
+constexpr int GH_COND = GH_B + 2 * GH_B_FLOATS;
+constexpr int GH_TAB = GH_COND + GH_COND_ROWS * 64;
+constexpr int GH_LERP = GH_TAB + GH_ROWS;
+constexpr int GH_LDS_FLOATS = GH_LERP + 128;               // 18432 + 12288 + 1792 + 256 + 128 floats = 128.5 KB
+
+__device__ __forceinline__ void gh_lds_dma16(const float *src, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(src) : "memory", "m0");
+}
+__device__ __forceinline__ void gh_lds_dma16_s(const float *sbase, unsigned voff_bytes, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte_addr), "v"(voff_bytes), "s"(sbase)
+                 : "memory", "m0");
+}
+
+#define GH_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// x -> (hi, lo'): hi = fp16(x) (round to nearest), lo' = fp16(2^11 x - 2^11 hi): exact in float32 before the final rounding
+__device__ __forceinline__ void gh_split4(const f32x4 &x, f16x4 &h, f16x4 &l) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const _Float16 hh = (_Float16)x[i];
+        h[i] = hh;
+        l[i] = (_Float16)__builtin_fmaf(x[i], 2048.0f, -2048.0f * (float)hh);
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void wn_gate_f16_kernel(ConvArgs p, int log2d) {
+    typedef __attribute__((address_space(3))) float lds_float;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float *)lds);
+
+    // XCD-aware decode (as in wn_gate_winograd4w_kernel): the column tiles of a row tile run back to back on one XCD
+    const int id = blockIdx.x;
+    const int l = id >> 3;
+    const int g_ = (l / p.n_tiles) * 8 + (id & 7);
+    const int nt = l % p.n_tiles;
+    if (g_ >= p.m_tiles_total) return;
+    const int b = g_ / p.m_tiles_per_item;
+    const int mt = g_ - b * p.m_tiles_per_item;
+    const int rows = item_rows(p.n_frames, b, p.rows_per_frame, p.max_rows);
+    const int m0 = mt * GH_ROWS;
+    if (m0 >= rows) return;
+    const int C = p.channels;
+    const int n0 = nt * 32;
+    const int d = 1 << log2d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;
+    const float *xb = p.x + (long long)b * p.x_bstride;
+    const int nk = (p.cin + GH_BK - 1) / GH_BK;
+
+    // ---- LDS-DMA requests of a step: 36 pieces of activations (piece j = staged rows 8 j .. 8 j + 7: lane -> row 8 j +
+    // (lane >> 3), chunk position lane & 7), dealt round-robin over the 8 waves, and 24 pieces of weights, 3 per wave
+    const float *wtile = p.w + (long long)nt * nk * GH_B_FLOATS;
+    const unsigned b_voff = 16u * (unsigned)lane;
+    auto issue_a = [&](int kt) {
+        const unsigned adst = lds_base + 4u * (unsigned)GH_X;
+        const int ci0 = kt * GH_BK;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int piece = wave + 8 * i;
+            if (piece >= GH_AROWS / 8) break;
+            const int r = 8 * piece + (lane >> 3);                 // staged row: source row m0 - 16 + r
+            const int src_row = m0 - GH_HALO + r;
+            const int ch = ci0 + 4 * (lane & 7);                   // 4-channel chunk lane & 7 of the step
+            const bool ok = src_row >= 0 && src_row < rows && ch < p.cin;
+            gh_lds_dma16(ok ? xb + (long long)src_row * p.ldx + ch : p.zeros, adst + 1024u * (unsigned)piece);
+        }
+    };
+    auto issue_b = [&](int kt, int stage) {
+        const unsigned bdst = lds_base + 4u * (unsigned)(GH_B + stage * GH_B_FLOATS);
+        const float *bsrc = wtile + (long long)kt * GH_B_FLOATS;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int piece = wave + 8 * i;
+            gh_lds_dma16_s(bsrc + piece * 256, b_voff, bdst + 1024u * (unsigned)piece);
+        }
+    };
+    // ---- conditioning rows of this block (28 x (32 tanh | 32 sigmoid) columns), requested first
+    const int cond_up = p.cond_up;
+    const int t2base = m0 / cond_up;
+    if (wave < GH_COND_ROWS / 4) {
+        const int n2 = rows / cond_up;
+        const float *cbase = p.cond + (long long)b * p.cond_bstride;
+        const int pos = wave * 64 + lane;
+        const int crow = pos >> 4, cq = pos & 15;
+        const int chn = n0 + 4 * (cq & 7);
+        const int t = min(t2base + crow, n2 - 1);
+        gh_lds_dma16(chn < C ? cbase + (long long)t * (2 * C) + (cq >> 3) * C + chn : p.zeros,
+                     lds_base + 4u * (unsigned)GH_COND + 1024u * (unsigned)wave);
+    }
+    issue_a(0);
+    issue_b(0, 0);
+
+    // lane n of column tile (e, tanh | sigmoid) holds gate channel n0 + 2 n + e
+    const bool ch_ok = n0 + 2 * r16 < C;
+    f32x4 accm[2][4], accx[2][4];          // [row tile][column tile: 2 e + (0 tanh | 1 sigmoid)]: hi hi | cross products
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float bv = (p.bias && ch_ok) ? p.bias[(c & 1) * C + n0 + 2 * r16 + (c >> 1)] : 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                accm[rt][c][v] = bv;
+                accx[rt][c][v] = 0.f;
+            }
+        }
+    if (tid < GH_ROWS) {
+        // block row lr = tid: conditioning row offset and interpolation phase (read in the epilogue)
+        const int row = m0 + tid;
+        const int t2 = row / cond_up;
+        const int u = row - t2 * cond_up;
+        reinterpret_cast<int *>(lds + GH_TAB)[tid] = (((t2 - t2base) * 64) << 8) | u;
+    }
+    if (tid < 64) {
+        lds[GH_LERP + tid] = tid < cond_up ? p.lerp_w0[tid] : 0.f;
+        lds[GH_LERP + 64 + tid] = tid < cond_up ? p.lerp_w1[tid] : 0.f;
+    }
+
+    const f16x8 *bbase = reinterpret_cast<const f16x8 *>(lds) + GH_B / 4 + lane;   // + stage * (GH_B_FLOATS / 4) + ((tap * 4 + tile) * 2 + image) * 64
+    const f32x4 *xs = reinterpret_cast<const f32x4 *>(lds + GH_X);
+    char *ys = reinterpret_cast<char *>(lds + GH_Y);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt & 1;
+        // every request this wave has in flight belongs to step kt (and, in step 0, to the conditioning tile)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                       // X and this step's weights are complete; nobody reads Y or the other stage
+        // the next step's weights can go to the other stage at once (its readers passed the barrier)
+        if (kt + 1 < nk) issue_b(kt + 1, stage ^ 1);
+        // ---- X -> Y: thread t converts the 16-byte chunks t, t + 512, ... (chunk q: staged row q >> 3, channels 4 (q & 7) ..);
+        // all reads first, so that their latencies overlap
+        f32x4 xv[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int q = tid + 512 * i;
+            xv[i] = xs[q < GH_AROWS * 8 ? q : tid];
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int q = tid + 512 * i;
+            if (q < GH_AROWS * 8) {
+                const int r = q >> 3, c4 = q & 7;
+                f16x4 hh, ll;
+                gh_split4(xv[i], hh, ll);
+                const int key = (r >> 1) & 7;
+                char *yr = ys + 128 * r + 8 * (c4 & 1);
+                *reinterpret_cast<f16x4 *>(yr + 16 * ((c4 >> 1) ^ key)) = hh;
+                *reinterpret_cast<f16x4 *>(yr + 16 * ((4 + (c4 >> 1)) ^ key)) = ll;
+            }
+        }
+        __syncthreads();                       // Y is complete, X is free
+        if (kt + 1 < nk) issue_a(kt + 1);
+        const f16x8 *bs = bbase + stage * (GH_B_FLOATS / 4);
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            f16x8 bh[4], bl[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                bh[c] = bs[((tap * 4 + c) * 2 + 0) * 64];
+                bl[c] = bs[((tap * 4 + c) * 2 + 1) * 64];
+            }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                // staged row of this lane's operand: output row 32 wave + 16 rt + r16, input row + (tap - 1) d, + halo
+                const int r = 32 * wave + 16 * rt + r16 + GH_HALO + (tap - 1) * d;
+                const int key = (r >> 1) & 7;
+                const f16x8 ah = *reinterpret_cast<const f16x8 *>(ys + 128 * r + 16 * (kq ^ key));
+                const f16x8 al = *reinterpret_cast<const f16x8 *>(ys + 128 * r + 16 * ((4 + kq) ^ key));
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    accm[rt][c] = GH_MFMA(ah, bh[c], accm[rt][c]);
+                    accx[rt][c] = GH_MFMA(ah, bl[c], accx[rt][c]);
+                    accx[rt][c] = GH_MFMA(al, bh[c], accx[rt][c]);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: main + 2^-11 cross, conditioning, gate, store (layout of wn_gate_winograd4w_kernel: register v of
+    // column tile c holds row 16 rt + 4 kq + v of the wave's rows, lane n = r16 the gate channels n0 + 2 n + e)
+    const float *cl = lds + GH_COND;
+    float *obase = p.out + (long long)b * p.out_bstride + n0 + 2 * r16;
+    const float *clane = cl + 2 * r16;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int lr = 32 * wave + 16 * rt + 4 * kq + v;
+            const int row = m0 + lr;
+            const int e = reinterpret_cast<const int *>(lds + GH_TAB)[lr];
+            const float2 w = make_float2(lds[GH_LERP + (e & 255)], lds[GH_LERP + 64 + (e & 255)]);
+            const float *c0 = clane + (e >> 8);
+            const float2 ct0 = *reinterpret_cast<const float2 *>(c0), ct1 = *reinterpret_cast<const float2 *>(c0 + 64);
+            const float2 cs0 = *reinterpret_cast<const float2 *>(c0 + 32), cs1 = *reinterpret_cast<const float2 *>(c0 + 96);
+            float y[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) y[c] = fmaf(accx[rt][c][v], 1.0f / 2048.0f, accm[rt][c][v]);
+            float2 res;
+            res.x = wn_gate_act(p.gate_act, y[0] + (ct0.x * w.x + ct1.x * w.y), y[1] + (cs0.x * w.x + cs1.x * w.y));
+            res.y = wn_gate_act(p.gate_act, y[2] + (ct0.y * w.x + ct1.y * w.y), y[3] + (cs0.y * w.x + cs1.y * w.y));
+            if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res;
+        }
+}
+
+// a.w must point at the image of engine.pack_gate_f16_weights (ceil(C/32) column tiles, ceil(C/32) steps, 6144 floats);
+// returns false if the layer does not fit (the caller then runs the float32 kernels)
+bool launch_wn_gate_f16(const ConvArgs &a, hipStream_t stream) {
+    int log2d = 0;
+    while ((1 << log2d) < a.dil) ++log2d;
+    const bool ok = a.ks == 3 && (1 << log2d) == a.dil && a.dil <= GH_HALO && a.pad_l == a.dil && a.pad_mode == 0 &&
+                    a.cin % 4 == 0 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 && a.channels % 4 == 0 && a.cin == a.channels &&
+                    a.cout == 2 * a.channels && (uintptr_t)a.x % 16 == 0 && (uintptr_t)a.w % 16 == 0 && a.zeros && a.cond &&
+                    (uintptr_t)a.cond % 16 == 0 && a.cond_bstride % 4 == 0 && a.cond_up >= 1 && a.cond_up <= 64 &&
+                    (GH_ROWS + a.cond_up - 2) / a.cond_up + 2 <= GH_COND_ROWS && a.lerp_w0 && a.lerp_w1 &&
+                    a.cond_phase == 0 && a.out_rows == 0 && a.max_rows < (1 << 24);
+    if (!ok) return false;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(wn_gate_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GH_LDS_FLOATS * (int)sizeof(float)) != hipSuccess)
+            return false;
+        attr_set = true;
+    }
+    ConvArgs r = a;
+    r.n_tiles = (a.channels + 31) / 32;
+    r.m_tiles_per_item = (a.max_rows + GH_ROWS - 1) / GH_ROWS;
+    r.m_tiles_total = r.m_tiles_per_item * a.batch;
+    const long long blocks = 8LL * ((r.m_tiles_total + 7) / 8) * r.n_tiles;
+    hipLaunchKernelGGL(wn_gate_f16_kernel, dim3((unsigned)blocks), dim3(512), GH_LDS_FLOATS * sizeof(float), stream, r, log2d);
+    return true;
+}
+
+}  // namespace mbx

@@ -81,7 +81,7 @@ class mbx_conv_form_info(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_int32), ("requested", ctypes.c_int32), ("form", ctypes.c_int32),
                 ("stream_form", ctypes.c_int32), ("calibrated", ctypes.c_int32), ("batch_invariant", ctypes.c_int32),
                 ("fold_skip", ctypes.c_int32), ("fold_start", ctypes.c_int32), ("split_f16_layers", ctypes.c_int32),
-                ("err_f43", ctypes.c_float),
+                ("split_f16_gate_layers", ctypes.c_int32), ("err_f43", ctypes.c_float),
                 ("err_f23", ctypes.c_float), ("ref_max", ctypes.c_float), ("threshold", ctypes.c_float)]
 
 
@@ -490,6 +490,31 @@ def pack_resskip_f16_weights(w):
     return np.ascontiguousarray(img).view(np.float32).reshape(nk, 12, 1024)
 
 
+def pack_gate_f16_weights(w):
+    """The three taps (3, C, 2C) of a dilated WaveNet convolution for wn_gate_f16_kernel (csrc/wn_gate_f16.hip,
+    v_mfma_f32_16x16x32_f16; opt-in split half precision): hi = fp16(w), lo' = fp16((w - hi) * 2^11).
+
+    Layout (ceil(C/32) column tiles, ceil(C/32) steps, 6144 float32 words): [tap][tile c = 2 e + (0 tanh | 1 sigmoid)]
+    [hi | lo'][lane = 16 kq + n][8 halves], input channels 32 step + 8 kq .. + 7, output column (0 | C) + 32 tile block + 2 n
+    + e; out-of-range entries are zero.  float32 words hold two halves each."""
+    w = np.asarray(w, dtype=np.float32)
+    C = w.shape[1]
+    assert w.shape == (3, C, 2 * C)
+    nt = nk = (C + 31) // 32
+    wp = np.zeros((3, nk * 32, 2, nt * 32), dtype=np.float32)          # tap, channel, tanh|sigmoid, gate channel
+    wp[:, :C, 0, :C] = w[:, :, :C]
+    wp[:, :C, 1, :C] = w[:, :, C:]
+    hi = wp.astype(np.float16)
+    lo = ((wp - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+    if not (np.all(np.isfinite(hi)) and np.all(np.isfinite(lo))):
+        raise ValueError("gate weights outside fp16's range: split half precision is not available for this model")
+    both = np.stack((hi, lo))                                          # part, tap, channel, s, gate channel
+    both = both.reshape(2, 3, nk, 4, 8, 2, nt, 16, 2)                  # part, tap, step, kq, v, s, block, n, e
+    img = both.transpose(6, 2, 1, 8, 5, 0, 3, 7, 4)                    # block, step, tap, e, s, part, kq, n, v
+    img = np.ascontiguousarray(img).reshape(nt, nk, 3 * 4 * 2 * 64 * 8)
+    return np.ascontiguousarray(img).view(np.float32).reshape(nt, nk, 6144)
+
+
 def pack_end_weights(w):
     """Weights (1, C, n_out <= 32) of the WaveNet end convolution packed for wn_tail_kernel (csrc/wn_tail.hip):
     (ceil(C/8), 2, 32, 4) = [channel group c][lane half lk][column n][k step st] with input channel 8c + 4lk + st,
@@ -626,6 +651,8 @@ def tensor_table(config, raw_weights, wavetables, split_f16=False):
         for ll in range(dims.wn_layers):
             out[f"wn.conv1D_{ll}.wino4w"] = pack_winograd4w_weights(out[f"wn.conv1D_{ll}.w"])
             out[f"wn.conv1D_{ll}.wino2w"] = pack_winograd2w_weights(out[f"wn.conv1D_{ll}.w"])
+            if split_f16 and ll >= 1:
+                out[f"wn.conv1D_{ll}.gate_f16"] = pack_gate_f16_weights(out[f"wn.conv1D_{ll}.w"])
     if dims.wn_multi:
         # several blocks: the library's block runner takes the packed res/skip weights and the F(4,3) images per block
         from .weights import block_prefix
@@ -937,6 +964,7 @@ class MBExWNEngine:
                 "stream_form": _CONV_FORM_NAMES[info.stream_form], "calibrated": info.calibrated,
                 "batch_invariant": bool(info.batch_invariant), "fold_skip": bool(info.fold_skip),
                 "fold_start": bool(info.fold_start), "split_f16_layers": int(info.split_f16_layers),
+                "split_f16_gate_layers": int(info.split_f16_gate_layers),
                 "err_f43": None if info.err_f43 < 0 else float(info.err_f43),
                 "err_f23": None if info.err_f23 < 0 else float(info.err_f23),
                 "ref_max": float(info.ref_max), "threshold": float(info.threshold)}

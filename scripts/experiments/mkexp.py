@@ -232,6 +232,25 @@ PATCHES = {
         ('            if (row < rows)\n                *reinterpret_cast<float2 *>(dst + (long long)row * ld) =',
          '            if (row < rows && acc[0][0] == 123.456f)\n                *reinterpret_cast<float2 *>(dst + (long long)row * ld) ='),
     ],
+    # wn_gate_f16.hip: timing ablations of the opt-in split half precision gate kernel (outputs wrong on purpose)
+    'gh_noA': [
+        ('            if (piece >= GH_AROWS / 8) break;\n', '            if (piece >= GH_AROWS / 8 || kt > 0) break;\n'),
+    ],
+    'gh_noB': [
+        ('        for (int i = 0; i < 3; ++i) {\n            const int piece = wave + 8 * i;\n            gh_lds_dma16_s(',
+         '        for (int i = 0; i < (kt == 0 ? 3 : 0); ++i) {\n            const int piece = wave + 8 * i;\n            gh_lds_dma16_s('),
+    ],
+    'gh_nomfma': [
+        ('                    accm[rt][c] = GH_MFMA(ah, bh[c], accm[rt][c]);\n                    accx[rt][c] = GH_MFMA(ah, bl[c], accx[rt][c]);\n                    accx[rt][c] = GH_MFMA(al, bh[c], accx[rt][c]);',
+         '                    if (c == 0) accm[rt][c] = GH_MFMA(ah, bh[c], accm[rt][c]);\n                    if (c == 1) accx[rt][c] = GH_MFMA(al, bl[c], accx[rt][c]);'),
+    ],
+    'gh_nosplit': [
+        ('                gh_split(a0, a1, ah, al);', '                ah = __builtin_bit_cast(f16x8, a0); al = __builtin_bit_cast(f16x8, a1);'),
+    ],
+    'gh_noepi': [
+        ('            if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res;',
+         '            if (ch_ok && row < rows && res.x == 123.456f) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res;'),
+    ],
     # wn_winograd4w.hip
     'noepi': [
         ('    // ---- epilogue: combine the six products, add the conditioning',

@@ -20,4 +20,5 @@ for batch, frames in ((16, 800), (1, 800)):
         torch.cuda.synchronize()
         out = {kk: eng.profile_read(kk) for kk in ("res_skip", "res_skip_f16", "gate")}
         eng.profile_enable(False)
+        print(eng.conv_form_info()["split_f16_gate_layers"], end=" ")
         print(batch, frames, prec, {kk: (round(vv[0] / vv[1] * 1e3, 1) if vv[1] else None, vv[1]) for kk, vv in out.items()}, flush=True)

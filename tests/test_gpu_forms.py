@@ -190,7 +190,9 @@ def test_split_f16_res_skip_layers(torch, voice):
     outs = {}
     for prec in ("f32", "split_f16"):
         eng = MBExWNEngine(cfg, raw, wt, conv_form="direct", precision=prec)
-        assert eng.conv_form_info()["split_f16_layers"] == (3 if prec == "split_f16" else 0)
+        info = eng.conv_form_info()
+        assert info["split_f16_layers"] == (3 if prec == "split_f16" else 0)
+        assert info["split_f16_gate_layers"] == (4 if prec == "split_f16" else 0)
         outs[prec] = eng.forward(dev(torch, mel), n_frames=nf, noise=dev(torch, noise)).cpu().numpy()
         outs[prec + "_h"] = eng.stage("wn_hidden").cpu().numpy()
         eng.close()
