@@ -264,6 +264,44 @@ def run_batch(args, name, rank, world, fence, torch, profile, steps=None, warmup
     return res, ctx
 
 
+def split_report(ress, ctxs):
+    """Fields of a run with the opt-in split half precision (mbx_config.wn_precision): max|delta| of the timed output, launch
+    times of the split kernels and their rooflines (res/skip: HBM; gate: executed fp16 FLOPs against the fp16 matrix peak)."""
+    ress.update(max_abs_delta_timed(
+        [(f"item {ii}", ctxs["timed_out"][ii], ctxs["mel_h"][ii], ctxs["noise_h"][ii]) for ii in ctxs["delta_items"]],
+        ctxs["cfg"], ctxs["raw"], ctxs["wt"], "config-3 batch, gate and res/skip layers in split half precision"))
+    rs_ms, rs_n = ctxs["stages"]["res_skip"]              # layer 0 (float32: its rows carry the excitation too)
+    sp_ms, sp_n = ctxs["stages"]["res_skip_f16"]          # layers 1 .. L-2: three fp16 products each
+    dd = ctxs["dims"]
+    rows = ctxs["batch"] * ctxs["frames"] * dd.steps_per_frame
+    L, C, n_out = dd.wn_layers, dd.wn_channels, dd.wn_out_channels
+    n_fwd = max(1, rs_n)
+    split_ms = sp_ms / sp_n if sp_n else None
+    flop = 3 * 2.0 * rows * C * (C + n_out)
+    hbm = rows * (3 * C + 2 * n_out) * 4.0
+    g_ms, g_n = ctxs["stages"]["gate"]
+    ress["precision"] = ("gate layers 1..L-1 and res/skip layers 1..L-2: fp16 x 3 (hi hi + 2^-11 (hi lo' + lo' hi)) on "
+                         "v_mfma_f32_16x16x32_f16, float32 accumulation; everything else float32")
+    ress["gate_split_launch_ms"] = g_ms / g_n if g_n else None
+    if g_n:
+        gflop = 3 * 2.0 * rows * (3 * C) * (2 * C)
+        ress["gate_roofline"] = {"kernel": "wn_gate_f16_kernel (direct form, three fp16 products)", "bound": "mfma",
+                                 "avg_launch_ms": g_ms / g_n, "flop_executed": gflop,
+                                 "achieved": gflop / (g_ms / g_n * 1e-3) / 1e12, "peak": FP16_MATRIX_PEAK_TFLOPS,
+                                 "unit": "TFLOP/s", "frac": gflop / (g_ms / g_n * 1e-3) / 1e12 / FP16_MATRIX_PEAK_TFLOPS,
+                                 "note": "against the fp16 matrix peak; the kernel is bound by its LDS operand reads and "
+                                         "the float32 -> (hi, lo') conversion pass, not by the matrix pipe"}
+    ress["res_skip_ms_per_forward"] = rs_ms / n_fwd + (sp_ms / sp_n * (L - 2) if sp_n else 0.0)
+    ress["res_skip_split_launch_ms"] = split_ms
+    if split_ms:
+        ress["roofline"] = {"kernel": "wn_resskip_f16_kernel", "bound": "hbm", "avg_launch_ms": split_ms,
+                            "achieved": hbm / (split_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": hbm / (split_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "mfma_frac_of_fp16_peak": flop / (split_ms * 1e-3) / 1e12 / FP16_MATRIX_PEAK_TFLOPS,
+                            "bytes": hbm, "flop_executed": flop,
+                            "note": "algorithmic bytes: a read, h read + written, output accumulator read + written"}
+
+
 def roofline_blocks(ctx):
     """The generic path (several WaveNet blocks, block runner of csrc/mbx_api.hip): all gate launches of a step against the
     fp32 MFMA peak -- block b runs L full gate layers on T * spf_b rows with C_b channels (no folded first layer) -- and
@@ -653,39 +691,7 @@ def main():
         # opt-in split half precision of the res/skip layers: NOT the float32 path, reported beside it with its own max|delta|
         ress, ctxs = run_batch(args, "config3_split_f16", rank, world, fence, torch, profile=True, steps=min(args.steps, 5), warmup=1)
         if rank == 0:
-            ress.update(max_abs_delta_timed(
-                [(f"item {ii}", ctxs["timed_out"][ii], ctxs["mel_h"][ii], ctxs["noise_h"][ii]) for ii in ctxs["delta_items"]],
-                ctxs["cfg"], ctxs["raw"], ctxs["wt"], "config-3 batch, res/skip layers in split half precision"))
-            rs_ms, rs_n = ctxs["stages"]["res_skip"]              # layer 0 (float32: its rows carry the excitation too)
-            sp_ms, sp_n = ctxs["stages"]["res_skip_f16"]          # layers 1 .. L-2: three fp16 products each
-            dd = ctxs["dims"]
-            rows = ctxs["batch"] * ctxs["frames"] * dd.steps_per_frame
-            L, C, n_out = dd.wn_layers, dd.wn_channels, dd.wn_out_channels
-            n_fwd = max(1, rs_n)
-            split_ms = sp_ms / sp_n if sp_n else None
-            flop = 3 * 2.0 * rows * C * (C + n_out)
-            hbm = rows * (3 * C + 2 * n_out) * 4.0
-            g_ms, g_n = ctxs["stages"]["gate"]
-            ress["precision"] = ("gate layers 1..L-1 and res/skip layers 1..L-2: fp16 x 3 (hi hi + 2^-11 (hi lo' + lo' hi)) on "
-                                 "v_mfma_f32_16x16x32_f16, float32 accumulation; everything else float32")
-            ress["gate_split_launch_ms"] = g_ms / g_n if g_n else None
-            if g_n:
-                gflop = 3 * 2.0 * rows * (3 * C) * (2 * C)
-                ress["gate_roofline"] = {"kernel": "wn_gate_f16_kernel (direct form, three fp16 products)", "bound": "mfma",
-                                         "avg_launch_ms": g_ms / g_n, "flop_executed": gflop,
-                                         "achieved": gflop / (g_ms / g_n * 1e-3) / 1e12, "peak": FP16_MATRIX_PEAK_TFLOPS,
-                                         "unit": "TFLOP/s", "frac": gflop / (g_ms / g_n * 1e-3) / 1e12 / FP16_MATRIX_PEAK_TFLOPS,
-                                         "note": "against the fp16 matrix peak; the kernel is bound by its LDS operand reads and "
-                                                 "the float32 -> (hi, lo') conversion pass, not by the matrix pipe"}
-            ress["res_skip_ms_per_forward"] = rs_ms / n_fwd + (sp_ms / sp_n * (L - 2) if sp_n else 0.0)
-            ress["res_skip_split_launch_ms"] = split_ms
-            if split_ms:
-                ress["roofline"] = {"kernel": "wn_resskip_f16_kernel", "bound": "hbm", "avg_launch_ms": split_ms,
-                                    "achieved": hbm / (split_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": hbm / (split_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                    "mfma_frac_of_fp16_peak": flop / (split_ms * 1e-3) / 1e12 / FP16_MATRIX_PEAK_TFLOPS,
-                                    "bytes": hbm, "flop_executed": flop,
-                                    "note": "algorithmic bytes: a read, h read + written, output accumulator read + written"}
+            split_report(ress, ctxs)
         secondary["config3_split_f16"] = ress
         secondary["config4_vo_256utt"] = run_sharded(args, "config4_vo_256utt", rank, world, dist, fence, torch,
                                                      steps=min(args.steps, 3), warmup=1, check_delta=True)
@@ -705,7 +711,13 @@ def main():
             "env": mbx_env()})
         line["config"]["parallelism"] = main_res.get("parallelism", f"utterance-sharded x{world}")
         if ctx is not None:
-            line["roofline"] = roofline_blocks(ctx) if args.workload in WORKLOAD_OVERRIDES else roofline(ctx, args.workload)
+            if args.workload in ENGINE_KW:                  # the opt-in split precision as the main workload (profiling runs)
+                main_res_extra = {}
+                split_report(main_res_extra, ctx)
+                line["config"].update({kk: vv for kk, vv in main_res_extra.items() if not kk.startswith("max_abs_delta")})
+                line["roofline"] = main_res_extra.get("gate_roofline")
+            else:
+                line["roofline"] = roofline_blocks(ctx) if args.workload in WORKLOAD_OVERRIDES else roofline(ctx, args.workload)
             if not args.no_secondary:
                 line.update(max_abs_delta_timed(
                     [(f"item {ii}", ctx["timed_out"][ii], ctx["mel_h"][ii], ctx["noise_h"][ii]) for ii in ctx["delta_items"]],

@@ -579,8 +579,8 @@ class StreamingSynthesizer:
             if any(self._ready(st) > 0 for sid, st in self.streams.items() if sid not in inside):
                 return "broken"
         ctx = run["phases"].get(phase)
-        if ctx is None:
-            return "record"
+        if ctx is None or (phase - 1) % len(self.schedule) not in run["phases"]:
+            return "record"                               # (a phase's graph shifts the window of the phase before it)
         ws = np.maximum(0, ((emitted - self.left) // self.align) * self.align)
         if np.any(emitted - ws != ctx["rel0"]) or ctx["chunk"] != chunk:
             return "broken"
