@@ -479,10 +479,10 @@ def pack_resskip_f16_weights(w):
     nk = (K + 31) // 32
     wp = np.zeros((nk * 32, 384), dtype=np.float32)
     wp[:K, :cout] = w[0]
+    if not np.all(np.abs(wp) < 65000.0):
+        raise ValueError("res/skip weights outside fp16's range: split half precision is not available for this model")
     hi = wp.astype(np.float16)
     lo = ((wp - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
-    if not (np.all(np.isfinite(hi)) and np.all(np.isfinite(lo))):
-        raise ValueError("res/skip weights outside fp16's range: split half precision is not available for this model")
     both = np.stack((hi, lo))                                      # (part, channel, column)
     both = both.reshape(2, nk, 2, 4, 4, 12, 16, 2)                 # part, step, half (0 | +16), kq, v, pair, n, parity
     img = both.transpose(1, 5, 7, 0, 3, 6, 2, 4)                   # step, pair, parity, part, kq, n, half, v
@@ -504,10 +504,10 @@ def pack_gate_f16_weights(w):
     wp = np.zeros((3, nk * 32, 2, nt * 32), dtype=np.float32)          # tap, channel, tanh|sigmoid, gate channel
     wp[:, :C, 0, :C] = w[:, :, :C]
     wp[:, :C, 1, :C] = w[:, :, C:]
+    if not np.all(np.abs(wp) < 65000.0):
+        raise ValueError("gate weights outside fp16's range: split half precision is not available for this model")
     hi = wp.astype(np.float16)
     lo = ((wp - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
-    if not (np.all(np.isfinite(hi)) and np.all(np.isfinite(lo))):
-        raise ValueError("gate weights outside fp16's range: split half precision is not available for this model")
     both = np.stack((hi, lo))                                          # part, tap, channel, s, gate channel
     both = both.reshape(2, 3, nk, 4, 8, 2, nt, 16, 2)                  # part, tap, step, kq, v, s, block, n, e
     img = both.transpose(6, 2, 1, 8, 5, 0, 3, 7, 4)                    # block, step, tap, e, s, part, kq, n, v

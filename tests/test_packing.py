@@ -344,3 +344,50 @@ def test_equalized_lr_folds():
     # the post-net is not a WaveNetAE layer: weight norm as always
     ref = fold_weights(raw)["post.w"]
     assert np.array_equal(normed["post.w"], ref) and np.array_equal(plain["post.w"], ref)
+
+
+def test_split_f16_weight_images():
+    """The fp16-split weight images of the opt-in precision mode (csrc/wn_resskip_f16.hip, csrc/wn_gate_f16.hip): every
+    image entry sits where the kernel's MFMA operand order expects it, hi + 2^-11 lo' reproduces the float32 weight to
+    2^-21 of its magnitude, and out-of-range entries are zero."""
+    from mbexwn_vocoder_amd.engine import pack_gate_f16_weights, pack_resskip_f16_weights
+    rng = np.random.default_rng(11)
+    # res/skip: (1, K, cout), K = 340 (partial last step), cout = 370 (12 pairs, the last one partial)
+    K, cout = 340, 370
+    w = (rng.normal(size=(1, K, cout)) * 0.07).astype(np.float32)
+    img = pack_resskip_f16_weights(w)
+    nk = (K + 31) // 32
+    assert img.shape == (nk, 12, 1024) and img.dtype == np.float32
+    halves = img.view(np.float16).reshape(nk, 12, 4, 64, 8)            # step, pair, [even hi, even lo, odd hi, odd lo], lane, v
+    rebuilt = np.zeros((nk * 32, 384))
+    for kq in range(4):
+        for vv in range(8):
+            chan = 4 * kq + (vv if vv < 4 else 12 + vv)               # 4 kq .. + 3 and 16 + 4 kq .. + 3
+            for par in range(2):
+                hi = halves[:, :, 2 * par, 16 * kq:16 * kq + 16, vv].astype(np.float64)       # (step, pair, n)
+                lo = halves[:, :, 2 * par + 1, 16 * kq:16 * kq + 16, vv].astype(np.float64)
+                val = hi + lo / 2048.0
+                for step in range(nk):
+                    rebuilt[32 * step + chan, par::2][:384 // 2] = val[step].reshape(-1)      # columns 32 p + 2 n + par
+    assert np.max(np.abs(rebuilt[:K, :cout] - w[0])) <= 2.0 ** -21 * np.max(np.abs(w))
+    assert np.all(rebuilt[K:] == 0) and np.all(rebuilt[:, cout:] == 0)
+    # gate: (3, C, 2C), C = 68 (three column tile blocks, the last one partial; three steps)
+    C = 68
+    wg = (rng.normal(size=(3, C, 2 * C)) * 0.05).astype(np.float32)
+    gi = pack_gate_f16_weights(wg)
+    nt = (C + 31) // 32
+    assert gi.shape == (nt, nt, 6144)
+    gh = gi.view(np.float16).reshape(nt, nt, 3, 2, 2, 2, 4, 16, 8)     # block, step, tap, e, s, part, kq, n, v
+    val = gh[:, :, :, :, :, 0].astype(np.float64) + gh[:, :, :, :, :, 1].astype(np.float64) / 2048.0
+    back = np.zeros((3, nt * 32, 2, nt * 32))                          # tap, channel, s, gate channel
+    for blk in range(nt):
+        for step in range(nt):
+            # val[blk, step]: (tap, e, s, kq, n, v) -> channel 32 step + 8 kq + v, gate channel 32 blk + 2 n + e
+            vv = val[blk, step].transpose(0, 2, 3, 5, 4, 1)            # tap, s, kq, v, n, e
+            back[:, 32 * step:32 * step + 32, :, 32 * blk:32 * blk + 32] = \
+                vv.reshape(3, 2, 32, 32).transpose(0, 2, 1, 3)
+    want = np.zeros_like(back)
+    want[:, :C, 0, :C], want[:, :C, 1, :C] = wg[:, :, :C], wg[:, :, C:]
+    assert np.max(np.abs(back - want)) <= 2.0 ** -21 * np.max(np.abs(wg))
+    with pytest.raises(ValueError, match="fp16"):
+        pack_gate_f16_weights(wg * 1e6)
