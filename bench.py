@@ -114,39 +114,55 @@ def pmc_traffic(workload):
 
 
 def cpu_baseline(cfg, raw, wt, seconds=3.0):
-    """The oracle (numpy float32 port of the reference graph; its matrix products go to the host BLAS) timed on the
-    host cores on a bounded sample: one 3 s utterance (the reference's own CPU-runnable case, configs[0]) at 2 threads --
-    the reference CLI's default `-nt 2`, bin/resynth_mel.py:120 --, 8, 32 and all cores.  `value` is the BEST leg of the
-    sweep (more threads than the utterance has parallel work oversubscribe the BLAS calls and run slower); every leg is
-    listed.  Timing protocol of the reference CLI (bin/resynth_mel.py:86-88): wall clock around the synthesis call only,
-    one warm-up call first.  Only the numpy port was timed: torch-CPU and TensorFlow runs of the reference graph are not
-    available (no TensorFlow on the box; the product has no torch graph)."""
+    """The CPU port of the reference graph timed on the host cores on a bounded sample: one 3 s utterance (the reference's
+    own CPU-runnable case, configs[0]).  Two variants of the same float32 graph: the numpy port
+    (oracle/mbexwn_oracle.py, matrix products on the host BLAS; 2 threads -- the reference CLI's default `-nt 2`,
+    bin/resynth_mel.py:120 -- and 8) and the torch-CPU port (oracle/mbexwn_oracle_torch.py: the WaveNet, 98 % of the FLOPs,
+    on torch's MKL / oneDNN ops; 8, 32, 64 threads and all cores).  `value` is the BEST leg (more threads than the utterance
+    has parallel work oversubscribe and run slower); every leg is listed.  Timing protocol of the reference CLI
+    (bin/resynth_mel.py:86-88): wall clock around the synthesis call only, one warm-up call first.  TensorFlow itself cannot
+    run here (not installable, no network)."""
+    import torch
     from oracle.mbexwn_oracle import OracleModel
+    from oracle.mbexwn_oracle_torch import TorchOracleModel
     from threadpoolctl import threadpool_limits
     frames = int(round(seconds * 80))
-    om = OracleModel(cfg, raw, wt, dtype=np.float32)
     rng = np.random.default_rng(42)
     mel, noise = synthetic_batch(rng, 1, frames, 20)
     legs = {}
     all_cores = os.cpu_count() or 1
-    sweep = sorted({tt for tt in (2, 8, 32, all_cores) if tt <= all_cores} | {min(2, all_cores)})
-    for threads in sweep:
+
+    def leg(om, budget_s):
+        om.forward(mel[:, :16], noise[:, :320])             # warm-up (weight folding, thread start)
+        times = []
+        budget = time.time() + budget_s                     # bounded: a few seconds of CPU work per leg
+        while len(times) < 7 and (len(times) < 2 or time.time() < budget):
+            t0 = time.time()
+            om.forward(mel, noise)
+            times.append(time.time() - t0)
+        return float(np.median(times)), len(times)
+
+    om_np = OracleModel(cfg, raw, wt, dtype=np.float32)
+    for threads in sorted({tt for tt in (2, 8) if tt <= all_cores} | {min(2, all_cores)}):
         with threadpool_limits(limits=threads):
-            om.forward(mel[:, :16], noise[:, :320])         # warm-up (weight folding, BLAS thread start)
-            times = []
-            budget = time.time() + 6.0                      # bounded: ~6 s of CPU work per leg, <= 4 legs
-            while len(times) < 7 and (len(times) < 2 or time.time() < budget):
-                t0 = time.time()
-                om.forward(mel, noise)
-                times.append(time.time() - t0)
-        med = float(np.median(times))
-        legs[f"threads_{threads}"] = {"value": frames * 300 / med, "x_realtime": frames * 300 / med / 24000.0,
-                                      "cores": threads, "runs": len(times)}
-    top = max(legs.values(), key=lambda leg: leg["value"])
+            med, runs = leg(om_np, 4.0)
+        legs[f"numpy_threads_{threads}"] = {"value": frames * 300 / med, "x_realtime": frames * 300 / med / 24000.0,
+                                            "cores": threads, "runs": runs, "port": "numpy"}
+    om_t = TorchOracleModel(cfg, raw, wt)
+    before = torch.get_num_threads()
+    for threads in sorted({tt for tt in (8, 32, 64, all_cores) if tt <= all_cores}):
+        torch.set_num_threads(threads)
+        with threadpool_limits(limits=threads):
+            med, runs = leg(om_t, 3.0)
+        legs[f"torch_threads_{threads}"] = {"value": frames * 300 / med, "x_realtime": frames * 300 / med / 24000.0,
+                                            "cores": threads, "runs": runs, "port": "torch"}
+    torch.set_num_threads(before)
+    top_name, top = max(legs.items(), key=lambda kv: kv[1]["value"])
     return {"value": top["value"], "unit": "audio samples/s", "cores": top["cores"], "kind": "port",
-            "sample": f"1 utterance x {seconds:g} s (80x{frames} mel), numpy float32 oracle, best of a thread sweep "
-                      f"{sweep} (median of {top['runs']} runs after 1 warm-up per leg), time.time() around the synthesis "
-                      f"call only (reference bin/resynth_mel.py:86-88)",
+            "sample": f"1 utterance x {seconds:g} s (80x{frames} mel), float32 CPU port of the reference graph, best leg "
+                      f"({top_name}) of a sweep over the numpy port (2, 8 threads) and the torch-CPU port (8 .. all cores), "
+                      f"median of {top['runs']} runs after 1 warm-up per leg, time.time() around the synthesis call only "
+                      f"(reference bin/resynth_mel.py:86-88)",
             "x_realtime": top["x_realtime"], "legs": legs, "host_cores": all_cores,
             "reference_claim": "README.md:222-223: about 2x real time on one laptop core (TF-CPU)"}
 

@@ -77,3 +77,20 @@ def test_float32_oracle_mode(golden_dir):
     audio = om.forward(gold["small/mell"], gold["small/noise"])
     assert audio.dtype == np.float32
     assert _maxdiff(audio, gold["small/audio"]) < 2e-4
+
+
+def test_torch_cpu_port_matches_the_float64_oracle():
+    """oracle/mbexwn_oracle_torch.py (the CPU baseline of bench.py: the WaveNet on torch-CPU float32 ops, the rest the numpy
+    float32 port) against the float64 oracle, at the path's tolerance; canonical model and a gfu variant."""
+    import numpy as np
+    from helpers import build_case, synthetic_inputs
+    from oracle.mbexwn_oracle import OracleModel
+    from oracle.mbexwn_oracle_torch import TorchOracleModel
+    for over in ({"mbexwn_config:pp_mod_subnet:n_channels": 64}, {"mbexwn_config:pp_mod_subnet:n_channels": 32,
+                                                                  "mbexwn_config:pp_mod_subnet:activation": "gfu"}):
+        cfg, raw, wt = build_case("SPEECH", over)
+        mel, noise = synthetic_inputs(3, 2, 21)
+        ref = OracleModel(cfg, raw, wt).forward(mel, noise)
+        got = TorchOracleModel(cfg, raw, wt).forward(mel, noise)
+        assert got.dtype == np.float32
+        assert np.max(np.abs(got - ref)) <= 1e-4 * max(1.0, float(np.abs(ref).max()))
