@@ -297,7 +297,7 @@ def split_report(ress, ctxs):
     flop = 3 * 2.0 * rows * C * (C + n_out)
     hbm = rows * (3 * C + 2 * n_out) * 4.0
     g_ms, g_n = ctxs["stages"]["gate"]
-    ress["precision"] = ("gate layers 1..L-1 and res/skip layers 1..L-2: fp16 x 3 (hi hi + 2^-11 (hi lo' + lo' hi)) on "
+    ress["precision"] = ("gate layers 1..L-1 and res/skip layers 0..L-2: fp16 x 3 (hi hi + 2^-11 (hi lo' + lo' hi)) on "
                          "v_mfma_f32_16x16x32_f16, float32 accumulation; everything else float32")
     ress["gate_split_launch_ms"] = g_ms / g_n if g_n else None
     if g_n:
@@ -306,9 +306,9 @@ def split_report(ress, ctxs):
                                  "avg_launch_ms": g_ms / g_n, "flop_executed": gflop,
                                  "achieved": gflop / (g_ms / g_n * 1e-3) / 1e12, "peak": FP16_MATRIX_PEAK_TFLOPS,
                                  "unit": "TFLOP/s", "frac": gflop / (g_ms / g_n * 1e-3) / 1e12 / FP16_MATRIX_PEAK_TFLOPS,
-                                 "note": "against the fp16 matrix peak; the kernel is bound by its LDS operand reads and "
-                                         "the float32 -> (hi, lo') conversion pass, not by the matrix pipe"}
-    ress["res_skip_ms_per_forward"] = rs_ms / n_fwd + (sp_ms / sp_n * (L - 2) if sp_n else 0.0)
+                                 "note": "against the fp16 matrix peak; the kernel is bound by its LDS operand reads "
+                                         "(256 B per clock and CU), not by the matrix pipe"}
+    ress["res_skip_ms_per_forward"] = rs_ms / n_fwd + (sp_ms / n_fwd if sp_n else 0.0)
     ress["res_skip_split_launch_ms"] = split_ms
     if split_ms:
         ress["roofline"] = {"kernel": "wn_resskip_f16_kernel", "bound": "hbm", "avg_launch_ms": split_ms,

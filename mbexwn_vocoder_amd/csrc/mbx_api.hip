@@ -152,6 +152,7 @@ struct Workspace {
     float *sub0, *sub1, *sub2, *sub3, *sub4, *sub5, *f0_wide, *f0, *cum, *chunk_last, *pulse, *cond, *h, *a, *skip, *wn_out, *sub, *exc, *ceps, *frames;
     float *mb_h, *mb_a, *mb_skip, *mb_y0, *mb_y1, *mb_cond[MBX_MAX_WN_BLOCKS];   // several WaveNet blocks only
     float *pulse_ana;   // PQMF analysis of the pulse signal (pulse_pqmf_taps > 0): the WaveNet's excitation rows
+    float *h16;         // split half precision: the hidden state as fp16 planes (ConvArgs::h_split), round_up(C, 8) words per row
     int *ceps_index;
     size_t total;
 };
@@ -190,6 +191,7 @@ Workspace carve(const mbx_handle *hd, char *base, int B, int T) {
     w.h = take(B * nsteps * c.wn_channels);
     w.a = take(B * nsteps * (c.wn_channels + 16));   // layer 0 appends the excitation channels to its rows (wn_gate0.hip)
     w.skip = take(B * nsteps * c.wn_channels);
+    w.h16 = take(hd->split_f16_gate ? B * nsteps * (size_t)((c.wn_channels + 7) / 8 * 8) : 0);
     w.wn_out = take(B * nsteps * c.wn_out_channels);
     w.sub = take(B * nsteps * c.subbands);
     w.exc = take(BT * c.hop_size);
@@ -1263,6 +1265,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                              find(hd, "wn.start.b")->ptr, C, w.h + sp.row0 * C, nsteps * C, stream);
     }
     auto lerp = hd->lerp[cond_up];
+    bool planes_valid = false;        // split half precision: the last res/skip launch also wrote h as fp16 planes (w.h16)
     for (int l = 0; l < L; ++l) {
         const std::string ls = std::to_string(l);
         const int d = c.wn_dilations[l];
@@ -1355,6 +1358,11 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
             if (hd->split_f16_gate && !st_in && !st_out && gs.cphase == 0 && gs.out_rows == 0) {
                 mbx::ConvArgs gh = g;
                 gh.w = find(hd, "wn.conv1D_" + ls + ".gate_f16")->ptr;
+                if (planes_valid) {                                  // the res/skip layer in front left h as fp16 planes
+                    gh.h_split = w.h16;
+                    gh.h_split_ld = (C + 7) / 8 * 8;
+                    gh.h_split_bstride = nsteps * (long long)gh.h_split_ld;
+                }
                 done = mbx::launch_wn_gate_f16(gh, stream);
             }
             const bool use4 = !done && hd->winograd == 4 && !st_in && !st_out;
@@ -1400,18 +1408,27 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                 r.skip_bstride = nsteps * n_out;
                 r.hs_bstride = nsteps * C;
                 r.skip_init = (l == 0);
-                ScopedEvents ev(hd, (hd->split_f16 && !ext) ? PROF_RES_SKIP_F16 : PROF_RES_SKIP, stream);
+                ScopedEvents ev(hd, (hd->split_f16 && (!ext || find(hd, "wn.res_skip_0.fold_start_f16"))) ? PROF_RES_SKIP_F16 : PROF_RES_SKIP, stream);
                 // large launches (>= two rounds of the 512 resident 128-row blocks): one block owns all columns of its rows.
                 // Like the gate kernels' block shape this follows the launch size only under the default policy: a pinned
                 // form (MBX_CONV_DIRECT, MBX_CONV_F23, batch_invariant, streams) pins the kernel, so results do not depend on the batch they ran in.
                 bool done = false;
                 // opt-in split half precision (mbx_config.wn_precision): every launch size, the layers whose input is a gate
                 // output alone (not layer 0 with the folded start convolution, whose rows carry the excitation as well)
-                if (hd->split_f16 && !ext) {
+                const DevTensor *f16w = hd->split_f16 ? find(hd, "wn.res_skip_" + ls + (ext ? ".fold_start_f16" : ".fold_f16")) : nullptr;
+                if (f16w && f16w->count == (long long)((cin_l + 31) / 32) * 12 * 1024) {
                     mbx::ConvArgs rh = r;
-                    rh.w = find(hd, "wn.res_skip_" + ls + ".fold_f16")->ptr;
+                    rh.w = f16w->ptr;
                     rh.gate_act = c.wn_gate_activation;
+                    if (hd->split_f16_gate && !active_frames) {      // the next layer's gate reads the new hidden state as fp16 planes
+                        rh.h_split = w.h16;
+                        rh.h_split_ld = (C + 7) / 8 * 8;
+                        rh.h_split_bstride = nsteps * (long long)rh.h_split_ld;
+                    }
                     done = mbx::launch_wn_resskip_f16(rh, stream);
+                    planes_valid = done && rh.h_split != nullptr;
+                } else {
+                    planes_valid = false;
                 }
                 const DevTensor *fww = done ? nullptr : find(hd, "wn.res_skip_" + ls + (ext ? ".fold_start_wide" : ".fold_wide"));
                 const long long wide_blocks = ((nsteps + 127) / 128) * B;
@@ -1740,7 +1757,9 @@ mbx_status mbx_conv_form(const mbx_handle *hd, mbx_conv_form_info *info) {
     info->batch_invariant = (hd->winograd != 4 || hd->winograd4_always) ? 1 : 0;
     info->fold_skip = hd->fold_skip;
     info->fold_start = hd->fold_start;
-    info->split_f16_layers = hd->split_f16 ? std::max(0, hd->cfg.wn_layers - 2) : 0;
+    info->split_f16_layers = 0;
+    for (int l = 0; hd->split_f16 && l + 1 < hd->cfg.wn_layers; ++l)
+        info->split_f16_layers += find(hd, "wn.res_skip_" + std::to_string(l) + (l == 0 && hd->fold_start ? ".fold_start_f16" : ".fold_f16")) != nullptr;
     info->split_f16_gate_layers = hd->split_f16_gate ? std::max(0, hd->cfg.wn_layers - 1) : 0;
     info->err_f43 = hd->calib_err43;
     info->err_f23 = hd->calib_err23;

@@ -22,6 +22,9 @@
 //      (engine.pack_gate_f16_weights), 24 KB per step, copied verbatim by LDS-DMA into one of two stages.
 // Per step: wait for the step's requests, barrier, convert X -> Y, barrier, request the next step (X is free, the other
 // weight stage too), multiply.  X + Y + 2 weight stages + conditioning tile + tables: 128.5 KB, one block per CU.
+// PLANES = true: the producer (wn_resskip_f16_kernel) has written the hidden state as fp16 planes already (ConvArgs::h_split:
+// per row hi and lo' halves): the rows are requested straight into the operand layout, X becomes a second operand stage, the
+// conversion and one barrier per step go, and a step's requests are in flight during the whole step before it.
 #include <cstdlib>
 #include <type_traits>
 #include "mbx_kernels.h"
@@ -68,6 +71,7 @@ __device__ __forceinline__ void gh_split4(const f32x4 &x, f16x4 &h, f16x4 &l) {
     }
 }
 
+template <bool PLANES>
 __global__ __launch_bounds__(512, 2) void wn_gate_f16_kernel(ConvArgs p, int log2d) {
     typedef __attribute__((address_space(3))) float lds_float;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -97,8 +101,9 @@ __global__ __launch_bounds__(512, 2) void wn_gate_f16_kernel(ConvArgs p, int log
     // (lane >> 3), chunk position lane & 7), dealt round-robin over the 8 waves, and 24 pieces of weights, 3 per wave
     const float *wtile = p.w + (long long)nt * nk * GH_B_FLOATS;
     const unsigned b_voff = 16u * (unsigned)lane;
-    auto issue_a = [&](int kt) {
-        const unsigned adst = lds_base + 4u * (unsigned)GH_X;
+    const _Float16 *pb = PLANES ? reinterpret_cast<const _Float16 *>(p.h_split + (long long)b * p.h_split_bstride) : nullptr;
+    auto issue_a = [&](int kt, int stage) {
+        const unsigned adst = lds_base + 4u * (unsigned)(PLANES ? (stage ? GH_X : GH_Y) : GH_X);
         const int ci0 = kt * GH_BK;
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
@@ -106,9 +111,19 @@ __global__ __launch_bounds__(512, 2) void wn_gate_f16_kernel(ConvArgs p, int log
             if (piece >= GH_AROWS / 8) break;
             const int r = 8 * piece + (lane >> 3);                 // staged row: source row m0 - 16 + r
             const int src_row = m0 - GH_HALO + r;
-            const int ch = ci0 + 4 * (lane & 7);                   // 4-channel chunk lane & 7 of the step
-            const bool ok = src_row >= 0 && src_row < rows && ch < p.cin;
-            gh_lds_dma16(ok ? xb + (long long)src_row * p.ldx + ch : p.zeros, adst + 1024u * (unsigned)piece);
+            if (PLANES) {
+                // chunk position lane & 7 of the operand tile holds logical chunk c8 = pos ^ key: hi (c8 < 4) or lo' (c8 >= 4)
+                // halves of the channels 8 (c8 & 3) .. + 7 of the step
+                const int c8 = (lane & 7) ^ ((r >> 1) & 7);
+                const int ch = ci0 + 8 * (c8 & 3);
+                const bool ok = src_row >= 0 && src_row < rows && ch < p.cin;
+                const _Float16 *src = pb + (long long)src_row * (2 * p.h_split_ld) + (c8 >> 2) * p.h_split_ld + ch;
+                gh_lds_dma16(ok ? reinterpret_cast<const float *>(src) : p.zeros, adst + 1024u * (unsigned)piece);
+            } else {
+                const int ch = ci0 + 4 * (lane & 7);               // 4-channel chunk lane & 7 of the step
+                const bool ok = src_row >= 0 && src_row < rows && ch < p.cin;
+                gh_lds_dma16(ok ? xb + (long long)src_row * p.ldx + ch : p.zeros, adst + 1024u * (unsigned)piece);
+            }
         }
     };
     auto issue_b = [&](int kt, int stage) {
@@ -133,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void wn_gate_f16_kernel(ConvArgs p, int log
         gh_lds_dma16(chn < C ? cbase + (long long)t * (2 * C) + (cq >> 3) * C + chn : p.zeros,
                      lds_base + 4u * (unsigned)GH_COND + 1024u * (unsigned)wave);
     }
-    issue_a(0);
+    issue_a(0, 0);
     issue_b(0, 0);
 
     // lane n of column tile (e, tanh | sigmoid) holds gate channel n0 + 2 n + e
@@ -169,32 +184,40 @@ __global__ __launch_bounds__(512, 2) void wn_gate_f16_kernel(ConvArgs p, int log
         const int stage = kt & 1;
         // every request this wave has in flight belongs to step kt (and, in step 0, to the conditioning tile)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                       // X and this step's weights are complete; nobody reads Y or the other stage
-        // the next step's weights can go to the other stage at once (its readers passed the barrier)
-        if (kt + 1 < nk) issue_b(kt + 1, stage ^ 1);
-        // ---- X -> Y: thread t converts the 16-byte chunks t, t + 512, ... (chunk q: staged row q >> 3, channels 4 (q & 7) ..);
-        // all reads first, so that their latencies overlap
-        f32x4 xv[5];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int q = tid + 512 * i;
-            xv[i] = xs[q < GH_AROWS * 8 ? q : tid];
-        }
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int q = tid + 512 * i;
-            if (q < GH_AROWS * 8) {
-                const int r = q >> 3, c4 = q & 7;
-                f16x4 hh, ll;
-                gh_split4(xv[i], hh, ll);
-                const int key = (r >> 1) & 7;
-                char *yr = ys + 128 * r + 8 * (c4 & 1);
-                *reinterpret_cast<f16x4 *>(yr + 16 * ((c4 >> 1) ^ key)) = hh;
-                *reinterpret_cast<f16x4 *>(yr + 16 * ((4 + (c4 >> 1)) ^ key)) = ll;
+        __syncthreads();                       // this step's operands are complete; nobody reads the other stages any more
+        if (PLANES) {
+            if (kt + 1 < nk) {
+                issue_a(kt + 1, stage ^ 1);
+                issue_b(kt + 1, stage ^ 1);
             }
+            ys = reinterpret_cast<char *>(lds + (stage ? GH_X : GH_Y));
+        } else {
+            // the next step's weights can go to the other stage at once (its readers passed the barrier)
+            if (kt + 1 < nk) issue_b(kt + 1, stage ^ 1);
+            // ---- X -> Y: thread t converts the 16-byte chunks t, t + 512, ... (chunk q: staged row q >> 3, channels 4 (q & 7) ..);
+            // all reads first, so that their latencies overlap
+            f32x4 xv[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int q = tid + 512 * i;
+                xv[i] = xs[q < GH_AROWS * 8 ? q : tid];
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int q = tid + 512 * i;
+                if (q < GH_AROWS * 8) {
+                    const int r = q >> 3, c4 = q & 7;
+                    f16x4 hh, ll;
+                    gh_split4(xv[i], hh, ll);
+                    const int key = (r >> 1) & 7;
+                    char *yr = ys + 128 * r + 8 * (c4 & 1);
+                    *reinterpret_cast<f16x4 *>(yr + 16 * ((c4 >> 1) ^ key)) = hh;
+                    *reinterpret_cast<f16x4 *>(yr + 16 * ((4 + (c4 >> 1)) ^ key)) = ll;
+                }
+            }
+            __syncthreads();                   // Y is complete, X is free
+            if (kt + 1 < nk) issue_a(kt + 1, 0);
         }
-        __syncthreads();                       // Y is complete, X is free
-        if (kt + 1 < nk) issue_a(kt + 1);
         const f16x8 *bs = bbase + stage * (GH_B_FLOATS / 4);
 #pragma unroll
         for (int tap = 0; tap < 3; ++tap) {
@@ -257,11 +280,15 @@ bool launch_wn_gate_f16(const ConvArgs &a, hipStream_t stream) {
                     a.cout == 2 * a.channels && (uintptr_t)a.x % 16 == 0 && (uintptr_t)a.w % 16 == 0 && a.zeros && a.cond &&
                     (uintptr_t)a.cond % 16 == 0 && a.cond_bstride % 4 == 0 && a.cond_up >= 1 && a.cond_up <= 64 &&
                     (GH_ROWS + a.cond_up - 2) / a.cond_up + 2 <= GH_COND_ROWS && a.lerp_w0 && a.lerp_w1 &&
-                    a.cond_phase == 0 && a.out_rows == 0 && a.max_rows < (1 << 24);
+                    a.cond_phase == 0 && a.out_rows == 0 && a.max_rows < (1 << 24) &&
+                    (!a.h_split || (a.h_split_ld % 8 == 0 && a.h_split_ld >= a.channels && a.h_split_bstride % 4 == 0 &&
+                                    (uintptr_t)a.h_split % 16 == 0));
     if (!ok) return false;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(wn_gate_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(wn_gate_f16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GH_LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(wn_gate_f16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GH_LDS_FLOATS * (int)sizeof(float)) != hipSuccess)
             return false;
         attr_set = true;
@@ -271,7 +298,10 @@ bool launch_wn_gate_f16(const ConvArgs &a, hipStream_t stream) {
     r.m_tiles_per_item = (a.max_rows + GH_ROWS - 1) / GH_ROWS;
     r.m_tiles_total = r.m_tiles_per_item * a.batch;
     const long long blocks = 8LL * ((r.m_tiles_total + 7) / 8) * r.n_tiles;
-    hipLaunchKernelGGL(wn_gate_f16_kernel, dim3((unsigned)blocks), dim3(512), GH_LDS_FLOATS * sizeof(float), stream, r, log2d);
+    if (a.h_split)
+        hipLaunchKernelGGL(wn_gate_f16_kernel<true>, dim3((unsigned)blocks), dim3(512), GH_LDS_FLOATS * sizeof(float), stream, r, log2d);
+    else
+        hipLaunchKernelGGL(wn_gate_f16_kernel<false>, dim3((unsigned)blocks), dim3(512), GH_LDS_FLOATS * sizeof(float), stream, r, log2d);
     return true;
 }
 

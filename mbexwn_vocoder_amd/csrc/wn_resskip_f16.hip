@@ -8,8 +8,9 @@
 // drops only lo lo (2^-22 relative), every fp16 x fp16 product is exact in the float32 accumulator, and the 2^11 keeps the
 // low parts in fp16's normal range: the result has the error of a plain float32 contraction (emulated on the canonical
 // K = 960 contraction: 2.7e-6 against 3.1e-6).  One accumulator holds 2^11 times the result: the
-// hi x hi product takes the activation's high part times 2^11 (exact in fp16: the gate output `a` lies in (-1, 1), which
-// is why the glu gate, whose linear half is unbounded, does not get this mode), the old value and the bias enter times
+// hi x hi product takes the activation's high part times 2^11 (exact in fp16 for |x| < 32: the gate output `a` lies in
+// (-1, 1) -- which is why the glu gate, whose linear half is unbounded, does not get this mode -- and the excitation channels
+// that layer 0's rows carry behind it, pulse samples and the noise draw, are O(1)), the old value and the bias enter times
 // 2^11, and the epilogue multiplies by 2^-11 -- powers of two, so no rounding is added.  The weights are split on the
 // host (engine.pack_resskip_f16_weights).
 //
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(512, 4) void wn_resskip_f16_kernel(ConvArgs p) {
         const bool col_ok = col < p.cout;
         const int colc = min(col, p.cout - 2);
         const bool to_h = colc < C;
-        const bool accumulate = col_ok && (to_h || !p.skip_init);
+        const bool accumulate = col_ok && (to_h ? !p.h_init : !p.skip_init);
         float2 bias = make_float2(0.f, 0.f);
         if (p.bias) bias = *reinterpret_cast<const float2 *>(p.bias + colc);
         const float *src = to_h ? hb + colc : sb + (colc - C);
@@ -169,10 +170,32 @@ __global__ __launch_bounds__(512, 4) void wn_resskip_f16_kernel(ConvArgs p) {
         }
     }
 
-    // ---- epilogue: new value = 2^-11 x accumulator
+    // ---- epilogue: new value = 2^-11 x accumulator; with h_split the new hidden state also goes out as fp16 planes (hi,
+    // lo' = (x - hi) 2^11) for the split gate kernel of the next layer, the plane padding behind C as zeros
+    _Float16 *planes = p.h_split ? reinterpret_cast<_Float16 *>(p.h_split + (long long)b * p.h_split_bstride) : nullptr;
+    const int pld = 2 * p.h_split_ld;              // halves per row of the planes
 #pragma unroll
     for (int pr = 0; pr < RH_NP; ++pr) {
         const int col = 32 * (pair0 + pr) + 2 * r16;
+        if (planes && col < p.h_split_ld) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int row = row0 + v;
+                if (row < rows) {
+                    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                    f16x2 hh = {(_Float16)0.f, (_Float16)0.f}, ll = hh;
+                    if (col < C) {
+                        const float x0 = acc[2 * pr][v] * (1.0f / 2048.0f), x1 = acc[2 * pr + 1][v] * (1.0f / 2048.0f);
+                        hh[0] = (_Float16)x0;
+                        hh[1] = (_Float16)x1;
+                        ll[0] = (_Float16)__builtin_fmaf(x0, 2048.0f, -2048.0f * (float)hh[0]);
+                        ll[1] = (_Float16)__builtin_fmaf(x1, 2048.0f, -2048.0f * (float)hh[1]);
+                    }
+                    *reinterpret_cast<f16x2 *>(planes + (long long)row * pld + col) = hh;
+                    *reinterpret_cast<f16x2 *>(planes + (long long)row * pld + p.h_split_ld + col) = ll;
+                }
+            }
+        }
         if (col >= p.cout) continue;
         const bool to_h = col < C;
         float *dst = to_h ? hb + col : sb + (col - C);
@@ -190,7 +213,8 @@ __global__ __launch_bounds__(512, 4) void wn_resskip_f16_kernel(ConvArgs p) {
 // a.w must point at the image of engine.pack_resskip_f16_weights (ceil(cin/32), 12, 1024 floats); returns false if the
 // layer does not fit (the caller then runs the float32 kernels)
 bool launch_wn_resskip_f16(const ConvArgs &a, hipStream_t stream) {
-    const bool ok = a.ks == 1 && a.cin == a.channels && !a.h_init && !a.last_layer && a.skip_ld > 0 && a.cout <= 384 &&
+    const bool ok = a.ks == 1 && (a.h_init ? a.cin >= a.channels : a.cin == a.channels) && !a.last_layer && a.skip_ld > 0 && a.cout <= 384 &&
+                    (!a.h_split || (a.h_split_ld % 8 == 0 && a.h_split_ld >= a.channels && a.h_split_ld <= a.cout + 32 && a.h_split_bstride % 4 == 0)) &&
                     a.gate_act != 3 &&          // glu: the layer's input is not bounded by 1
                     a.cin % 4 == 0 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 && a.channels % 2 == 0 && a.skip_ld % 2 == 0 &&
                     a.cout % 2 == 0 && a.cout <= a.channels + a.skip_ld && (uintptr_t)a.x % 16 == 0 &&

@@ -577,7 +577,7 @@ def fold_skip_weights(folded, n_layers, channels, split_f16=False):
     return out
 
 
-def fold_start_weights(folded, dims, fold_skip):
+def fold_start_weights(folded, dims, fold_skip, split_f16=False):
     """Fold the WaveNet's start convolution (1x1, reference custom_AE_layers.py:177-182,280) into layer 0.
 
     With x' = [x | 1 | 0] (8 channels; x = pulse channels (+ noise), the constant channel carries the start bias) and
@@ -616,6 +616,8 @@ def fold_start_weights(folded, dims, fold_skip):
         ext[C:C + 8, :C] = wsp
         out["wn.res_skip_0.fold_start"] = pack_resskip_weights(ext[None])
         out["wn.res_skip_0.fold_start_wide"] = pack_resskip_wide_weights(ext[None])
+        if split_f16 and C + n_out <= 384:
+            out["wn.res_skip_0.fold_start_f16"] = pack_resskip_f16_weights(ext[None])
         if C + n_out <= 384:
             out["wn.res_skip_0.fold_start_wave"] = pack_resskip_wave_weights(ext[None])
     return out
@@ -642,7 +644,7 @@ def tensor_table(config, raw_weights, wavetables, split_f16=False):
         out["wn.end.packed"] = pack_end_weights(out["wn.end.w"])
         fs = fold_skip_weights(out, dims.wn_layers, dims.wn_channels, split_f16=split_f16)
         if dims.wn_kernel_size == 3:
-            out.update(fold_start_weights(out, dims, fs))
+            out.update(fold_start_weights(out, dims, fs, split_f16=split_f16))
         fs.pop("__proj_0", None)
         out.update(fs)
     for ll in range(0 if dims.wn_multi else dims.wn_layers):
@@ -697,7 +699,7 @@ class MBExWNEngine:
         :meth:`conv_form_info`, :meth:`calibrate`), "direct", "f23" or "f43"; ``batch_invariant=True`` pins the kernels so
         that an utterance's bits do not depend on the batch it ran in; ``keep_skip`` / ``keep_start`` keep the un-folded
         graph; ``tune`` holds measurement knobs (make_config).  ``precision="split_f16"`` is an opt-in experiment (never
-        the default): the res/skip layers behind the first one contract on the 16-bit matrix pipe with fp16-split operands
+        the default): the res/skip layers (and the gate layers behind the first one) contract on the 16-bit matrix pipe with fp16-split operands
         (three products, float32 accumulation; csrc/wn_resskip_f16.hip)."""
         import torch
         if not torch.cuda.is_available():
