@@ -1,4 +1,4 @@
-"""Gate-kernel time per launch for the F(4,3) block shapes at several launch sizes (MBX_WG_SMALL pins the shape of
+"""Gate-kernel time per launch for the F(4,3) block shapes at several launch sizes (tune_gate_shape pins the shape of
 launches below 4 x 768 full blocks; larger launches always take the 256-row shape).  Run on the GPU box:
     python scripts/experiments/gate_shapes.py"""
 import os
@@ -13,11 +13,10 @@ import bench  # noqa: E402
 
 def main():
     import torch
-    sizes = [(1, 240), (1, 400), (1, 800), (1, 1200), (2, 800), (3, 800), (4, 800), (6, 800), (8, 800)]
-    for shape in ("0", "1"):
-        os.environ["MBX_WG_SMALL"] = shape
+    sizes = [(1, 80), (1, 160), (1, 240), (1, 320), (1, 400), (1, 480), (1, 800), (1, 1200), (2, 800), (4, 800), (8, 800)]
+    for shape in (1, 2):
         bench._ENGINES.clear()
-        cfg, raw, wt, dims, eng = bench.build_engine("SPEECH")
+        cfg, raw, wt, dims, eng = bench.build_engine("SPEECH", None, tune={"gate_shape": shape})
         row = []
         for batch, frames in sizes:
             rng = np.random.default_rng(1)
@@ -32,7 +31,7 @@ def main():
             ms, cnt = eng.profile_read("gate")
             eng.profile_enable(False)
             row.append(f"{batch}x{frames}: {ms / cnt * 1e3:7.1f} us ({eng.gate_form(batch, frames)[13:] or 'f43'})")
-        print(f"MBX_WG_SMALL={shape}  " + "  ".join(row))
+        print(f"tune_gate_shape={shape}  " + "  ".join(row), flush=True)
         eng.close()
 
 

@@ -503,6 +503,11 @@ _GEOMETRIES = {
                      _M + "pulse_rate_factor": 2, _M + "pulse_channels": 5,
                      _M + "multi_band_config": {"subbands": 10, "taps": 80, "cutoff_ratio": 0.06, "beta": 9.0},
                      _W + "cond_lin_upsampling": 10, _W + "n_channels": 64, _W + "n_layers": 3, _M + "ps_max_ceps_coefs": 120},
+    # the wave-per-frame STFT filter without its pruned first passes (more than 256 cepstral coefficients; a window of more
+    # than 1 280 samples), and with the energy-preserving gain (coefficient 0 kept, wave-wide sum of |H|^2)
+    "ceps400": {_M + "ps_max_ceps_coefs": 400, _W + "n_channels": 32, _W + "n_layers": 2},
+    "win1600": {_P + "win_size": 1600, _P + "hop_size": 300, _W + "n_channels": 32, _W + "n_layers": 2,
+                _M + "spect_filters_preserve_energy": True},
     "mel40_out44": {_P + "mel_channels": 40, _W + "n_out_channels": 44, _W + "n_channels": 40, _W + "n_layers": 3},
     "kernel5": {_W + "kernel_size": 5, _W + "n_channels": 32, _W + "n_layers": 3},
 }
