@@ -392,8 +392,8 @@ def roofline(ctx, workload):
                  "(ablation: arithmetic 81 us, block prologue 49, stores 29 of 158 us at 16 x 10 s)",
         "tail": "32-byte row pieces per lane and a dependent chain of 32x32x2 MFMAs per wave; a row-owning variant reached "
                 "113 us but changes the summation order between launch sizes",
-        "stft_filter": "vector instructions of three FFT-1024 per frame (PMC: 77 % of VALU issue cycles; a radix-16 "
-                       "register-pass version took the same 196 us at two waves per SIMD)",
+        "stft_filter": "vector instructions of three FFT-1024 per frame: one wave per frame, radix 16 / 16 / 4 in registers, "
+                       "2 900 instructions per frame at two waves per SIMD (round 3: block per frame, 4 x 1 785, 196 us)",
         "wavetable": "the float32 phase chain: 1 000 dependent adds per chunk, kept in the reference's order",
         "pqmf": "latency of a rows x 135 x 15 product per launch",
         "overlap_add": "HBM",
