@@ -13,9 +13,7 @@
  *   - every function returns an mbx_status; mbx_last_error() gives the thread-local message
  *   - the caller owns all buffers (mel, noise, audio, workspace: DEVICE memory of the handle's device)
  *   - a handle owns the folded weights and the constant tables; one handle per device; a handle is
- *     not re-entrant; calls only enqueue work on the given stream and never synchronise.  (Whole-item forwards of 4 096
- *     mel frames or more run the VTF-net on a second stream owned by the handle, forked behind the given stream and joined
- *     back into it inside the same call: for the caller everything is ordered on the given stream, as before.)
+ *     not re-entrant; calls only enqueue work on the given stream and never synchronise
  *   - all tensors are float32, channels-last, row-major
  *
  * The library reads NO environment variable: everything that changes numerics or the kernel choice is a field of
