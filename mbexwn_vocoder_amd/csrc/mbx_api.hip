@@ -19,7 +19,6 @@
 #include "mbx_kernels.h"
 
 namespace {
-constexpr long long SIDE_STREAM_FRAMES = 4096;   // mel frames of a launch from which the VTF-net runs on the side stream
 
 thread_local std::string g_last_error;
 
@@ -83,10 +82,6 @@ struct mbx_handle {
     std::map<int, std::pair<float *, float *>> lerp;   // interpolation factor -> (w0, w1)
     float *twiddle = nullptr;
     float *zeros = nullptr;   // 256 bytes of zeros (padding source of the LDS-DMA GEMMs)
-    // large launches: the VTF-net (its cepstrum is needed behind the WaveNet only) runs on a stream of the handle's own beside
-    // the F0 chain, the oscillator and the first layers (fork / join with two events, created at the first use)
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float *poly = nullptr;
     float *poly_t = nullptr;          // the same table as the MFMA B operand: (4 * ceil(K / 4), 16), K = poly_ndm * subbands, zero padded
     int poly_ndm = 0, poly_dm_min = 0;
@@ -820,12 +815,6 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
 mbx_status mbx_destroy(mbx_handle *handle) {
     if (!handle) return MBX_OK;
     if (handle->arena) (void)hipFree(handle->arena);
-    if (handle->side) {
-        (void)hipStreamSynchronize(handle->side);
-        (void)hipStreamDestroy(handle->side);
-    }
-    if (handle->ev_fork) (void)hipEventDestroy(handle->ev_fork);
-    if (handle->ev_join) (void)hipEventDestroy(handle->ev_join);
     for (auto &pool : handle->ev_pool)
         for (auto &pr : pool) {
             (void)hipEventDestroy(pr.first);
@@ -1099,7 +1088,6 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     // custom_pulsed_generator.py:793-800) and F0-net (reference :773-791) are independent chains on the mel input:
     // the n-th convolution of each goes into one launch (launch_conv1d_group; matters at small batch, where the
     // mel-rate convolutions are latency-bound)
-    bool vtf_on_side = false;
     {
         ScopedEvents ev(hd, PROF_FRONTEND, stream);
         // a carried front end computes the frames [fe_end - fe_frames, fe_end) of every item only (all items then have
@@ -1127,25 +1115,6 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
             cond.window_stride(T, c.mel_channels);
         }
         if (f0_in) f0.finished = true;
-        // Large launches (measured at 16 x 10 s): the mel-rate launches are throughput-bound there, while the F0 chain behind
-        // them (F0 head, interpolation, phase sums, oscillator) is a row of short latency-bound kernels that leave the chip
-        // idle: the VTF-net's convolutions fill that time from a second stream.  (At one utterance the grouped launches cost
-        // the same with or without the VTF member and the extra launches and events lose: DESIGN.md section 9.)
-        vtf_on_side = !vtf.finished && !fe_frames && !active_frames && !st_in && !st_out && hd->blocks.empty() &&
-                      (long long)B * T >= SIDE_STREAM_FRAMES;
-        if (vtf_on_side) {
-            if (!hd->side && hipStreamCreateWithFlags(&hd->side, hipStreamNonBlocking) != hipSuccess) vtf_on_side = false;
-            if (vtf_on_side && !hd->ev_fork && hipEventCreateWithFlags(&hd->ev_fork, hipEventDisableTiming) != hipSuccess) vtf_on_side = false;
-            if (vtf_on_side && !hd->ev_join && hipEventCreateWithFlags(&hd->ev_join, hipEventDisableTiming) != hipSuccess) vtf_on_side = false;
-        }
-        if (vtf_on_side) {
-            if (hipEventRecord(hd->ev_fork, stream) != hipSuccess || hipStreamWaitEvent(hd->side, hd->ev_fork, 0) != hipSuccess)
-                return fail(MBX_ERR_HIP, "fork of the VTF-net stream failed");
-            vtf.stream = hd->side;
-            mbx::ConvArgs one;
-            while (vtf.next_conv(one)) mbx::launch_conv1d_group(&one, 1, hd->side);
-            if (hipEventRecord(hd->ev_join, hd->side) != hipSuccess) return fail(MBX_ERR_HIP, "join of the VTF-net stream failed");
-        }
         for (;;) {
             mbx::ConvArgs group[3];
             int n = 0;
@@ -1546,8 +1515,6 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         const mbx_status wst = hd->blocks.empty() ? single_block() : run_wavenet_blocks(hd, w, B, T, n_frames, noise, stream);
         if (wst != MBX_OK) return wst;
     }
-    // the cepstrum of the VTF-net is needed from here on
-    if (vtf_on_side && hipStreamWaitEvent(stream, hd->ev_join, 0) != hipSuccess) return fail(MBX_ERR_HIP, "join of the VTF-net stream failed");
     // ---- sub-band gains instead of the STFT-domain filter (ps_use_stft: false; reference :857-884, 670, 916-917)
     if (c.ps_subband_gain) {
         if (active_frames || st_in || st_out) return fail(MBX_ERR_UNSUPPORTED, "ps_use_stft: false models run whole items only");
