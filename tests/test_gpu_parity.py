@@ -516,6 +516,28 @@ def test_padded_batch_equals_one_at_a_time(torch):
         assert np.all(batch_out[ii, ll * 300:] == 0.0)
 
 
+def test_large_launch_equals_single_runs_under_batch_invariant(torch):
+    """A launch of more than 4 096 mel frames (the mel-rate convolutions take their large-launch tile kernel, the bandwidth
+    stages their full grids) under batch_invariant (one set of WaveNet kernels at every size): a ragged batch of 9 x 500 frames
+    must give, bit for bit, what each item gives alone; three times, with other work queued on the stream in between."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    cfg, raw, wt = build_case("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 2})
+    eng = MBExWNEngine(cfg, raw, wt, conv_form="f43", batch_invariant=True)
+    lengths = [500, 471, 500, 123, 500, 500, 1, 388, 500]
+    mel, noise = synthetic_inputs(41, len(lengths), 500)
+    nf = torch.as_tensor(lengths, dtype=torch.int32).cuda()
+    singles = [eng.forward(dev(torch, mel[ii:ii + 1, :ll]), noise=dev(torch, noise[ii:ii + 1, :ll * 20])).cpu().numpy()[0]
+               for ii, ll in enumerate(lengths)]
+    for rep in range(3):
+        eng.forward(dev(torch, mel[::-1].copy()), n_frames=nf, noise=dev(torch, noise[::-1].copy()))
+        out = eng.forward(dev(torch, mel), n_frames=nf, noise=dev(torch, noise)).cpu().numpy()
+        for ii, ll in enumerate(lengths):
+            assert np.array_equal(out[ii, :ll * 300], singles[ii]), f"run {rep}: item {ii} differs from its single run"
+            assert np.all(out[ii, ll * 300:] == 0.0)
+    ref = orc.OracleModel(cfg, raw, wt).forward(mel[3:4, :123], noise[3:4, :123 * 20])[0]
+    assert _maxdiff(out[3, :123 * 300], ref) <= _tol(ref, E2E_TOL)
+
+
 @pytest.mark.parametrize("batch,frames", [(2, 30), (1, 800), (16, 800)])
 def test_deterministic(torch, batch, frames):
     """Same input, same bits -- also at the BASELINE sizes, where the large-launch kernels (F(4,3) with its three-stage
