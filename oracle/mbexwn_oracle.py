@@ -491,8 +491,9 @@ class OracleModel:
         return self.pqmf_synthesis(y)                                             # :920-921
 
     # ------------------------------------------------------------------ envelope (A12)
-    def cepstral_window_index(self, f0):
-        """custom_pulsed_generator.py:507-525 (float32 like the reference; returns int indices (B,T))."""
+    def cepstral_window_index(self, f0, return_position=False):
+        """custom_pulsed_generator.py:507-525 (float32 like the reference; returns int indices (B,T)).  return_position: also the
+        fractional row position the index is rounded from (the selection is the nearest row: discontinuous at the midpoints)."""
         ft = self.f32
         f0 = np.asarray(f0, dtype=ft)
         half = self.f0_smooth.shape[0] // 2
@@ -506,7 +507,9 @@ class OracleModel:
         lg = (ft(1 / np.log(10)) * np.log(sm)).astype(ft)
         lg = np.minimum(np.maximum(lg, self.ceps_log10f0[0]), self.ceps_log10f0[-1])
         ratio = (lg - self.ceps_log10f0[0]) / (self.ceps_log10f0[-1] - self.ceps_log10f0[0])
-        return np.rint(ratio * ft(self.ceps_log10f0.shape[0] - 1)).astype(np.int64)   # tf.round: half to even
+        pos = ratio * ft(self.ceps_log10f0.shape[0] - 1)
+        idx = np.rint(pos).astype(np.int64)                                            # tf.round: half to even
+        return (idx, pos) if return_position else idx
 
     def generate_specenv(self, mel, f0, window_index=None):
         """custom_pulsed_generator.py:793-855 -> complex (B,T,fft/2+1)."""

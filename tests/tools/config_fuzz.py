@@ -3,7 +3,10 @@
 
 Known non-bug outliers (fuzz_case.py shows them stage by stage): with add_subharm_chans the channels sin(2 pi phase / ii) of
 the WRAPPED phase jump wherever the phase wraps (the reference's own design); an F0 contour that differs by 3e-4 Hz can wrap
-one sample earlier, which moves that jump by a sample and shows as ~1e-2 in the audio around it (seed 30000 + 363)."""
+one sample earlier, which moves that jump by a sample and shows as ~1e-2 in the audio around it (seed 30000 + 363).  A
+second class of that kind (once in 1 100 draws, seed 52000 + 271): the lifter row of a frame is the nearest of 30 rows to its
+smoothed log F0, and a contour within rounding of a midpoint selects the neighbouring row -- accepted (ROW) only if the frame
+sits at a midpoint in the oracle and the audio meets the tolerance against the oracle run with the engine's rows."""
 import os, sys, traceback
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
@@ -129,6 +132,28 @@ for case in range(n_cases):
             note = f" [direct form {worst_d:.1e}, calibration {eng.conv_form_info()['err_f43']:.1e} <= {eng.conv_form_info()['threshold']:.1e}]"
             ok = worst <= 1.25 * worst_d and worst <= 16 * yard
             del eng_d
+        if not ok and getattr(om, "ceps_windows", None) is not None and not (cfg["mbexwn_config"].get("ps_off") or not cfg["mbexwn_config"].get("ps_use_stft", True)):
+            # a second known class: the lifter row of a frame is the NEAREST of n rows to the frame's smoothed log F0 (reference
+            # custom_pulsed_generator.py:507-525) -- discontinuous at the midpoints.  Accepted only if every frame whose row differs
+            # sits within 2e-3 rows of a midpoint in the oracle AND the audio meets the plain tolerance against the oracle run
+            # with the engine's rows
+            ix_hip = eng.stage("ceps_index").cpu().numpy().view(np.int32)
+            worst_r, flips, borderline = 0.0, 0, True
+            for ii, ll in enumerate(lengths):
+                nz = noise[ii:ii + 1, :ll * rpf] if dims.noise_sigma else None
+                m64 = mel[ii:ii + 1, :ll]
+                f0_ref = om.generate_f0(np.asarray(m64).astype(om.dtype))
+                ix_ref, pos = om.cepstral_window_index(f0_ref, return_position=True)
+                diff = np.nonzero(ix_hip[ii, :ll] != ix_ref[0])[0]
+                flips += len(diff)
+                borderline &= bool(np.all(np.abs(np.abs(pos[0, diff] - np.floor(pos[0, diff])) - 0.5) < 2e-3))
+                exc_ref = om.generate_excitation(np.asarray(m64).astype(om.dtype), f0_ref, nz)
+                env = om.generate_specenv(np.asarray(m64).astype(om.dtype), f0_ref, window_index=ix_hip[ii:ii + 1, :ll].astype(np.int64))
+                ref_r = om.istft(om.stft(exc_ref, ll) * env, f0_ref.shape[1] * int(om.sample_rate // om.pulse_rate))[0, :ll * 300]
+                worst_r = max(worst_r, float(np.abs(got[ii, :ll * 300] - ref_r).max()) / max(1.0, float(np.abs(ref_r).max())))
+            if flips and borderline and worst_r <= 1e-4:
+                ok = "row"
+                note += f" [{flips} lifter row(s) at a midpoint; with the engine's rows {worst_r:.1e}]"
         if not ok and dims.wt_subharm:
             # the known class (see the docstring): the wrapped phases of the two F0 contours differ by a whole turn somewhere
             ph_hip = eng.wavetable(eng.stage("f0"))[1].cpu().numpy()
@@ -138,7 +163,7 @@ for case in range(n_cases):
                 if np.any(np.abs(ph_hip[ii, :ph_ref.shape[0]] - ph_ref) > 0.5):
                     ok = "wrap"
         fails += not ok
-        print(case, "OK  " if ok is True else ("WRAP" if ok else "FAIL"), f"{worst:.1e}", f"(f32 port {yard:.1e}){note}", "form", form + "->" + eng.conv_form_info()["form"], "B", B, "T", T, {kk.split(':')[-1]: vv for kk, vv in over.items()}, flush=True)
+        print(case, "OK  " if ok is True else ({"wrap": "WRAP", "row": "ROW "}.get(ok, "FAIL")), f"{worst:.1e}", f"(f32 port {yard:.1e}){note}", "form", form + "->" + eng.conv_form_info()["form"], "B", B, "T", T, {kk.split(':')[-1]: vv for kk, vv in over.items()}, flush=True)
         del eng
     except Exception:                                        # noqa: BLE001
         fails += 1

@@ -52,3 +52,14 @@ for ii, ll in enumerate(lengths):
     flips = np.nonzero(np.abs(ph_hip[:ll*dims.pulse_per_frame] - ph_ref[:ll*dims.pulse_per_frame]) > 0.5)[0]
     print("   largest excitation difference at sample", worst, "= pulse sample", worst * dims.pulse_per_frame // 300,
           "| pulse samples where the wrapped phases differ by a whole turn:", flips[:10])
+    # the STFT filter: the error of the audio frame by frame, and the size of the envelope the oracle applies
+    if "envelope" in s64 and om64.ceps_windows is not None:
+        # the lifter row of a frame is the NEAREST of n_ceps_windows rows to the frame's smoothed log F0: a discontinuous function,
+        # a contour that lands within rounding of a midpoint selects the neighbouring row (in the engine or in the oracle)
+        ix_hip = eng.stage("ceps_index").cpu().numpy().view(np.int32)[ii, :ll]
+        ix_64, ix_32 = om64.cepstral_window_index(s64["f0"])[0], om32.cepstral_window_index(s32["f0"])[0]
+        print("   lifter rows that differ from the float64 oracle's: hip", np.nonzero(ix_hip != ix_64)[0], "float32 port", np.nonzero(ix_32 != ix_64)[0])
+    if "envelope" in s64:
+        env = np.abs(s64["envelope"][0])
+        print("   max |H|", f"{env.max():.2e}", "min |H|", f"{env.min():.2e}", "| audio error per frame:",
+              " ".join(f"{np.abs(got[ii, t*300:(t+1)*300]-a64[0, t*300:(t+1)*300]).max():.0e}" for t in range(ll)))
