@@ -177,11 +177,11 @@ def test_stft_filter(torch, frames):
     assert _maxdiff(got, ref) <= _tol(ref, STAGE_TOL)
 
 
-@pytest.mark.parametrize("scale", [0.5, 3.0])
+@pytest.mark.parametrize("scale", [0.5, 5.0])
 def test_stft_filter_large_cepstra(torch, scale):
     """The wave-per-frame kernel evaluates exp(R tanh(Re S) + j Im S) with short forms of its own (hardware exp2, a three-term
-    Cody-Waite reduction for sin / cos: csrc/stft_filter.hip): cepstra 10 and 60 times the usual size -- log spectra of +-40
-    and +-250, i.e. phases of tens to hundreds of radians and a fully saturated tanh -- must still match the float64 oracle at
+    Cody-Waite reduction for sin / cos: csrc/stft_filter.hip): cepstra 10 and 100 times the usual size -- phases of +-8 and
+    +-80 radians and a fully saturated tanh -- must still match the float64 oracle at
     the stage tolerance (the envelope's magnitude is bounded by exp(R), its phase error is an absolute error in radians)."""
     eng, om = get_engine("small", *SMALL)[:2]
     rng = np.random.default_rng(17)
@@ -193,12 +193,11 @@ def test_stft_filter_large_cepstra(torch, scale):
     full = np.zeros((B, frames, om.fft_size))
     full[:, :, 1:240] = x[:, :, 1:]
     spec = np.fft.rfft(full, axis=-1)
-    assert np.abs(spec.imag).max() > (20.0 if scale < 1 else 100.0)
+    assert np.abs(spec.imag).max() > (5.0 if scale < 1 else 50.0)
     env = np.exp(om.max_log_range * np.tanh(spec.real) + 1j * spec.imag)
     ref = om.istft(om.stft(exc.astype(np.float64), frames) * env, frames * 300)
     got = eng.stft_filter(dev(torch, exc), dev(torch, ceps), dev(torch, idx, torch.int32)).cpu().numpy()
-    # float32 carries the phase itself (|Im S| ~ 100 rad) to 1e-5 rad only: the tolerance scales with it
-    tol = _tol(ref, STAGE_TOL) * max(1.0, float(np.abs(spec.imag).max()) / 8.0)
+    tol = _tol(ref, STAGE_TOL)      # (measured: 1.4e-4 on amplitude 374 and 6.5e-4 on amplitude 494 with 86 rad phases)
     print(f"\nstft filter, cepstra x {scale}: max |Im S| {np.abs(spec.imag).max():.0f} rad, max|ref| {np.abs(ref).max():.1f}, "
           f"error {_maxdiff(got, ref):.2e} (tolerance {tol:.1e})")
     assert _maxdiff(got, ref) <= tol
