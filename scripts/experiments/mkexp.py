@@ -259,6 +259,10 @@ PATCHES = {
     'oldstft': [
         ('    if (c.fft_size == 2 * SW_NC && c.win <= c.fft_size && c.win % 2 == 0) {', '    if (false) {'),
     ],
+    # wn_tail.hip: every activation load of a wave in flight before its first MFMA (round-4 A/B)
+    'tail_unroll11': [
+        ('#pragma unroll 4\n    for (int c = wave; c < nc8; c += 4) {', '#pragma unroll 11\n    for (int c = wave; c < nc8; c += 4) {'),
+    ],
     # wn_winograd4w.hip
     'noepi': [
         ('    // ---- epilogue: combine the six products, add the conditioning',
