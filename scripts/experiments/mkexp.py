@@ -263,6 +263,10 @@ PATCHES = {
     'tail_unroll11': [
         ('#pragma unroll 4\n    for (int c = wave; c < nc8; c += 4) {', '#pragma unroll 11\n    for (int c = wave; c < nc8; c += 4) {'),
     ],
+    # conv_mfma.hip: twelve K groups of the small mel-rate tiles in flight instead of six (round-4 A/B)
+    'small_depth12': [
+        ('    constexpr int DEPTH = RT * CT == 1 ? 6 : 3;', '    constexpr int DEPTH = RT * CT == 1 ? 12 : 3;'),
+    ],
     # wn_winograd4w.hip
     'noepi': [
         ('    // ---- epilogue: combine the six products, add the conditioning',
