@@ -289,6 +289,56 @@ print("RCCL_OK")
     res = subprocess.run([sys.executable, "-c", code, ROOT, model_dir], env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "RCCL_OK" in res.stdout, res.stderr[-2000:]
 
+@pytest.mark.timeout(600)
+def test_two_ranks_share_the_one_gpu_sharded_synthesis(model_dir, tmp_path):
+    """world_size 2 with REAL kernels on the one GPU this box has: two fresh processes, each with its own handle on cuda:0,
+    synthesise their LPT shards of 13 ragged utterances at the same time and gather them on rank 0 (gloo on host tensors:
+    RCCL refuses two ranks on one device, so the collective itself is the CPU one here; the device-resident RCCL gather runs
+    with one rank in the tests above).  Rank 0 must end up with every utterance, bit-equal to its single run."""
+    code = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from helpers import synthetic_inputs
+from mbexwn_vocoder_amd.mel_inverter import MELInverter
+from mbexwn_vocoder_amd.sharding import ShardedSynthesizer, lpt_partition
+rank, world = int(sys.argv[3]), 2
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.cuda.set_device(0)
+eng = MELInverter(sys.argv[2]).model
+lengths = [int(vv) for vv in np.random.default_rng(4).integers(2, 60, size=13)]
+mels, noises = zip(*[(mm[0], nn[0]) for mm, nn in (synthetic_inputs(100 + ll, 1, ll) for ll in lengths)])
+def fwd(mel, nfr, noise):
+    return eng.forward(torch.as_tensor(mel).cuda(), n_frames=torch.as_tensor(nfr).cuda(), noise=torch.as_tensor(noise).cuda()).cpu().numpy()
+syn = ShardedSynthesizer(fwd, 300, 20, rank=rank, world_size=world, max_batch=3)
+dist.barrier()                                   # both ranks compute at the same time
+got = syn.run(list(mels), list(noises))          # default: gathered on rank 0
+mine = lpt_partition(lengths, world)[rank]
+assert len(mine) > 0
+if rank == 0:
+    assert got is not None and len(got) == len(lengths)
+    for ii, (mm, nn) in enumerate(zip(mels, noises)):
+        single = fwd(mm[None], np.asarray([mm.shape[0]], np.int32), nn[None])[0]
+        assert np.array_equal(got[ii], single), ii
+else:
+    assert got is None
+dist.barrier()
+dist.destroy_process_group()
+print("TWO_RANKS_OK", rank)
+"""
+    import socket
+    with socket.socket() as ss:
+        ss.bind(("127.0.0.1", 0))
+        port = ss.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    procs = [subprocess.Popen([sys.executable, "-c", code, ROOT, model_dir, str(rank)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for rank in range(2)]
+    outs = [pp.communicate(timeout=540) for pp in procs]
+    for rank, (pp, (so, se)) in enumerate(zip(procs, outs)):
+        assert pp.returncode == 0 and f"TWO_RANKS_OK {rank}" in so, se[-2000:]
+
+
 @pytest.mark.parametrize("case", ["plain", "rmsnorm"])
 def test_infer_and_infer_components_against_the_reference_methods(case):
     """engine.infer / infer_components against the reference's own PaNWaveNet.infer / infer_components bodies
