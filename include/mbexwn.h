@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MBX_ABI_VERSION 7
+#define MBX_ABI_VERSION 8
 #define MBX_MAX_SUBNET_OPS 32
 #define MBX_MAX_WN_LAYERS 64
 #define MBX_MAX_PRECOND 8
@@ -210,7 +210,9 @@ typedef struct {
      * MBX_PRECISION_SPLIT_F16: an opt-in experiment -- the res/skip layers and (whole-item forwards) the gate layers behind
      * the first one run their contractions on the 16-bit matrix pipe with every float32 operand split into two fp16 parts
      * (three products, float32 accumulation: float32-class error; csrc/wn_resskip_f16.hip, csrc/wn_gate_f16.hip; needs the
-     * "*.fold_f16" / "*.gate_f16" weight images; not with the glu gate; |h| must stay inside fp16's range) */
+     * "*.fold_f16" / "*.gate_f16" weight images; not with the glu gate; |h| must stay inside fp16's range).  mbx_create
+     * measures the handle in split precision against the float32 direct form on the calibration input and keeps the split
+     * kernels only within the calibration threshold (mbx_conv_form_info.err_split / split_rejected) */
     int32_t wn_precision;
     int32_t reserved7[1];
 } mbx_config;
@@ -250,6 +252,9 @@ typedef struct {
     float err_f43, err_f23;   /* max |audio(form) - audio(direct)| of the calibration run; < 0: form not available */
     float ref_max;            /* max |audio(direct)| of the calibration run */
     float threshold;          /* calib_fraction * 1e-4 * max(1, ref_max): a form is accepted at or below it */
+    float err_split;          /* ABI 8: max |audio(this handle in split precision) - audio(float32 direct form)| of the calibration
+                               * run (mbx_create runs it for every handle that asks for MBX_PRECISION_SPLIT_F16); < 0: not measured */
+    int32_t split_rejected;   /* 1: that error was above the threshold (or not finite): the handle runs float32 after all */
 } mbx_conv_form_info;
 mbx_status mbx_conv_form(const mbx_handle *handle, mbx_conv_form_info *info);
 

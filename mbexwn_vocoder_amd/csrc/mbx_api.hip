@@ -107,6 +107,8 @@ struct mbx_handle {
     int resskip_split = 0;           // mbx_config.tune_resskip_split
     bool split_f16 = false;          // mbx_config.wn_precision == MBX_PRECISION_SPLIT_F16 and the images are there
     bool split_f16_gate = false;     // ... for the gate layers too (wn_gate_f16.hip)
+    float calib_err_split = -1.f;    // max |audio(split precision) - audio(float32 direct form)| of the calibration run
+    int split_rejected = 0;          // the calibration switched the split precision off (error above the threshold, or not finite)
     int winograd = 0;            // gate layer form in effect: 0 direct, 2 Winograd F(2,3), 4 Winograd F(4,3) (needs the packed weights)
     // what mbx_conv_form reports
     int calibrated = 0;
@@ -451,7 +453,7 @@ extern "C" {
 // the form of the dilated convolution (mbx_config.wn_conv_form) and its calibration: defined behind forward_impl
 static bool form_available(const mbx_handle *hd, int form);
 static void set_form(mbx_handle *hd, int form);
-static mbx_status calibrate_on_synthetic_mel(mbx_handle *hd);
+static mbx_status calibrate_on_synthetic_mel(mbx_handle *hd, bool forms);
 
 const char *mbx_last_error(void) { return g_last_error.c_str(); }
 
@@ -802,9 +804,10 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
         if (form == MBX_CONV_F43 && !can43) form = can23 ? MBX_CONV_F23 : MBX_CONV_DIRECT;
         if (form == MBX_CONV_F23 && !can23) form = MBX_CONV_DIRECT;
         set_form(hd, form);
-        if (autoform && form != MBX_CONV_DIRECT) {
-            // MBX_CONV_AUTO: the Winograd forms must earn their place on this handle's own weights
-            st = calibrate_on_synthetic_mel(hd);
+        if ((autoform && form != MBX_CONV_DIRECT) || hd->split_f16) {
+            // MBX_CONV_AUTO: the Winograd forms must earn their place on this handle's own weights -- and so must the opt-in
+            // split precision, whatever the form (an overflow of fp16's range by the hidden state shows here as well)
+            st = calibrate_on_synthetic_mel(hd, autoform && form != MBX_CONV_DIRECT);
             if (st != MBX_OK) return bail(st);
         }
     }
@@ -1636,8 +1639,10 @@ static int current_form(const mbx_handle *hd) {
 // the direct form's by at most calib_fraction of the parity budget 1e-4 * max(1, |audio|) is adopted.  The difference
 // between two float32 forms measures the rounding of the less exact one (F(4,3): ~5x the direct form's, growing with the
 // amplitude of the residual stream).  Synchronises.
+// forms: compare the convolution forms and adopt the fastest one within the threshold (MBX_CONV_AUTO at mbx_create,
+// mbx_calibrate); false: only the split-precision check of a handle whose form the configuration pins
 static mbx_status calibrate_run(mbx_handle *hd, const float *mel, const int32_t *n_frames, int B, int T, const float *noise,
-                                void *workspace, size_t workspace_bytes, hipStream_t stream, int kind) {
+                                void *workspace, size_t workspace_bytes, hipStream_t stream, int kind, bool forms = true) {
     const size_t n = (size_t)B * T * hd->cfg.hop_size;
     float *audio_dev = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&audio_dev), n * sizeof(float)));
@@ -1645,6 +1650,10 @@ static mbx_status calibrate_run(mbx_handle *hd, const float *mel, const int32_t 
     const bool was_profiling = hd->profiling;
     hd->profiling = false;
     const int form_before = current_form(hd);
+    // the opt-in split precision is measured like a form: every reference and form run below is float32; the handle's
+    // configuration in split precision is then held to the same threshold against the float32 direct form
+    const bool split_req = hd->split_f16, split_gate_req = hd->split_f16_gate;
+    hd->split_f16 = hd->split_f16_gate = false;
     auto run = [&](int form, std::vector<float> &host) -> mbx_status {
         set_form(hd, form);
         mbx_status st = forward_impl(hd, mel, n_frames, B, T, noise, audio_dev, workspace, workspace_bytes, stream);
@@ -1657,7 +1666,11 @@ static mbx_status calibrate_run(mbx_handle *hd, const float *mel, const int32_t 
     auto done = [&](mbx_status st) {
         (void)hipFree(audio_dev);
         hd->profiling = was_profiling;
-        if (st != MBX_OK) set_form(hd, form_before);
+        if (st != MBX_OK) {
+            set_form(hd, form_before);
+            hd->split_f16 = split_req;
+            hd->split_f16_gate = split_gate_req;
+        }
         return st;
     };
     mbx_status st = run(MBX_CONV_DIRECT, ref);
@@ -1671,10 +1684,10 @@ static mbx_status calibrate_run(mbx_handle *hd, const float *mel, const int32_t 
     const float frac = hd->cfg.calib_fraction > 0.f ? hd->cfg.calib_fraction : 0.25f;
     const float threshold = frac * 1e-4f * std::max(1.f, ref_max);
     float err[2] = {-1.f, -1.f};
-    const int forms[2] = {MBX_CONV_F43, MBX_CONV_F23};
-    for (int k = 0; k < 2; ++k) {
-        if (!form_available(hd, forms[k])) continue;
-        st = run(forms[k], got);
+    const int form_list[2] = {MBX_CONV_F43, MBX_CONV_F23};
+    for (int k = 0; k < 2 && forms; ++k) {
+        if (!form_available(hd, form_list[k])) continue;
+        st = run(form_list[k], got);
         if (st != MBX_OK) return done(st);
         float e = 0.f;
         for (size_t i = 0; i < n; ++i) {
@@ -1683,15 +1696,33 @@ static mbx_status calibrate_run(mbx_handle *hd, const float *mel, const int32_t 
         }
         err[k] = e;
     }
-    int form = MBX_CONV_DIRECT;
-    if (finite && err[0] >= 0.f && err[0] <= threshold) form = MBX_CONV_F43;
-    else if (finite && err[1] >= 0.f && err[1] <= threshold) form = MBX_CONV_F23;
+    int form = forms ? MBX_CONV_DIRECT : form_before;
+    if (forms && finite && err[0] >= 0.f && err[0] <= threshold) form = MBX_CONV_F43;
+    else if (forms && finite && err[1] >= 0.f && err[1] <= threshold) form = MBX_CONV_F23;
     set_form(hd, form);
-    hd->calibrated = kind;
-    hd->calib_err43 = err[0];
-    hd->calib_err23 = err[1];
+    if (forms) {
+        hd->calibrated = kind;
+        hd->calib_err43 = err[0];
+        hd->calib_err23 = err[1];
+    }
     hd->calib_ref = ref_max;
     hd->calib_threshold = threshold;
+    if (split_req) {
+        // the handle as it will run (its form, split precision on) against the float32 direct form
+        hd->split_f16 = true;
+        hd->split_f16_gate = split_gate_req;
+        st = run(form, got);
+        if (st != MBX_OK) return done(st);
+        float e = 0.f;
+        for (size_t i = 0; i < n; ++i) {
+            const float d = std::fabs(got[i] - ref[i]);
+            e = std::isfinite(d) ? std::max(e, d) : INFINITY;
+        }
+        hd->calib_err_split = e;
+        // (the split precision rides on the form's own error: its budget is what the threshold leaves)
+        hd->split_rejected = !(finite && e <= threshold);
+        if (hd->split_rejected) hd->split_f16 = hd->split_f16_gate = false;
+    }
     return done(MBX_OK);
 }
 
@@ -1699,7 +1730,7 @@ static mbx_status calibrate_run(mbx_handle *hd, const float *mel, const int32_t 
 // of the level statistics the models are fed with (N(-5, 2^2) log amplitudes, clipped like scale_mel's output), one a
 // smooth loud sweep that drives the conditioning towards the saturated side of the gates -- and a seeded noise draw.
 // What is measured is this handle's own weights on plausible input, not the user's data: mbx_calibrate does that.
-static mbx_status calibrate_on_synthetic_mel(mbx_handle *hd) {
+static mbx_status calibrate_on_synthetic_mel(mbx_handle *hd, bool forms) {
     const mbx_config &c = hd->cfg;
     const int B = 2, T = 40;
     uint64_t rs = 0x9E3779B97F4A7C15ull;
@@ -1734,7 +1765,7 @@ static mbx_status calibrate_on_synthetic_mel(mbx_handle *hd) {
         hipMemcpy(mel_dev, mel.data(), mel.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(noise_dev, noise.data(), noise.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
         return release(fail(MBX_ERR_HIP, "calibration: device allocation / upload failed"));
-    return release(calibrate_run(hd, mel_dev, nullptr, B, T, c.noise_sigma != 0.f ? noise_dev : nullptr, ws, ws_bytes, nullptr, 1));
+    return release(calibrate_run(hd, mel_dev, nullptr, B, T, c.noise_sigma != 0.f ? noise_dev : nullptr, ws, ws_bytes, nullptr, 1, forms));
 }
 
 mbx_status mbx_calibrate(mbx_handle *hd, const float *mel, const int32_t *n_frames, int32_t batch, int32_t max_frames,
@@ -1761,6 +1792,8 @@ mbx_status mbx_conv_form(const mbx_handle *hd, mbx_conv_form_info *info) {
     for (int l = 0; hd->split_f16 && l + 1 < hd->cfg.wn_layers; ++l)
         info->split_f16_layers += find(hd, "wn.res_skip_" + std::to_string(l) + (l == 0 && hd->fold_start ? ".fold_start_f16" : ".fold_f16")) != nullptr;
     info->split_f16_gate_layers = hd->split_f16_gate ? std::max(0, hd->cfg.wn_layers - 1) : 0;
+    info->err_split = hd->calib_err_split;
+    info->split_rejected = hd->split_rejected;
     info->err_f43 = hd->calib_err43;
     info->err_f23 = hd->calib_err23;
     info->ref_max = hd->calib_ref;

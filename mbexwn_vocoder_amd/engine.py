@@ -19,7 +19,7 @@ from .config import ModelDims
 from .subnet import build_subnet
 from .weights import fold_weights, merge_channel_groups
 
-MBX_ABI_VERSION = 7
+MBX_ABI_VERSION = 8
 MBX_MAX_SUBNET_OPS = 32
 MBX_MAX_WN_LAYERS = 64
 MBX_MAX_PRECOND = 8
@@ -82,7 +82,8 @@ class mbx_conv_form_info(ctypes.Structure):
                 ("stream_form", ctypes.c_int32), ("calibrated", ctypes.c_int32), ("batch_invariant", ctypes.c_int32),
                 ("fold_skip", ctypes.c_int32), ("fold_start", ctypes.c_int32), ("split_f16_layers", ctypes.c_int32),
                 ("split_f16_gate_layers", ctypes.c_int32), ("err_f43", ctypes.c_float),
-                ("err_f23", ctypes.c_float), ("ref_max", ctypes.c_float), ("threshold", ctypes.c_float)]
+                ("err_f23", ctypes.c_float), ("ref_max", ctypes.c_float), ("threshold", ctypes.c_float),
+                ("err_split", ctypes.c_float), ("split_rejected", ctypes.c_int32)]
 
 
 CONV_FORMS = {"auto": 0, "direct": 1, "f23": 2, "f43": 3}
@@ -958,7 +959,9 @@ class MBExWNEngine:
         ``stream_form`` ("auto" | "direct" | "f23" | "f43"), ``calibrated`` (0 no, 1 on the built-in synthetic mel at
         creation, 2 on caller data), ``batch_invariant``, ``fold_skip``, ``fold_start``, and the calibration's numbers
         ``err_f43`` / ``err_f23`` (max |audio(form) - audio(direct)|, None: form not available), ``ref_max``,
-        ``threshold``."""
+        ``threshold``; with ``precision="split_f16"`` also ``err_split`` (max |audio(this handle in split precision) -
+        audio(float32 direct form)| of the calibration run at creation) and ``split_rejected`` (True: that error was above the
+        threshold or not finite, the handle runs float32 after all: ``split_f16_layers`` is 0 then)."""
         info = mbx_conv_form_info()
         info.struct_size = ctypes.sizeof(mbx_conv_form_info)
         _check(self._lib.mbx_conv_form(self._handle, ctypes.byref(info)))
@@ -969,7 +972,9 @@ class MBExWNEngine:
                 "split_f16_gate_layers": int(info.split_f16_gate_layers),
                 "err_f43": None if info.err_f43 < 0 else float(info.err_f43),
                 "err_f23": None if info.err_f23 < 0 else float(info.err_f23),
-                "ref_max": float(info.ref_max), "threshold": float(info.threshold)}
+                "ref_max": float(info.ref_max), "threshold": float(info.threshold),
+                "err_split": None if info.err_split < 0 else float(info.err_split),
+                "split_rejected": bool(info.split_rejected)}
 
     def calibrate(self, mel, n_frames=None, noise=None):
         """mbx_calibrate: repeat the form calibration on the caller's own mel batch (device tensors as for

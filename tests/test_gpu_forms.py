@@ -1,4 +1,4 @@
-"""The form of the dilated convolution as a guarded part of the ABI (mbx_config.wn_conv_form / batch_invariant, ABI 7).
+"""The form of the dilated convolution as a guarded part of the ABI (mbx_config.wn_conv_form / batch_invariant, ABI 7; ABI 8 adds the calibration of the split precision).
 
 The Winograd forms multiply the pre-activation rounding error (F(2,3) ~2x, F(4,3) ~5x the direct form's) and that error
 grows with the amplitude of the residual stream, so the default ("auto") must earn F(4,3) on the handle's own weights: the
@@ -215,6 +215,37 @@ def test_split_f16_res_skip_layers(torch, voice):
     cfg_g, raw_g, wt_g = build_case(voice, {"mbexwn_config:pp_mod_subnet:activation": "glu"})
     with pytest.raises(NotImplementedError):
         MBExWNEngine(cfg_g, raw_g, wt_g, precision="split_f16")
+
+
+def test_split_f16_is_calibrated_and_rejected_when_it_does_not_hold(torch):
+    """The opt-in split precision has to earn its place like a convolution form: mbx_create measures the handle as it will run
+    (its form, split precision on) against the float32 direct form on the calibration input and keeps the split kernels only
+    within the same threshold (mbx_conv_form_info.err_split / split_rejected, ABI 8).  Canonical weights: accepted, error far
+    below the threshold.  Res/skip biases of 1e5: the hidden state leaves fp16's range in the first layer, the split gate's
+    operands are infinite -- the handle must notice, run float32 after all and give the float32 handle's bits."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    cfg, raw, wt = build_case("SING", {})
+    mel, noise = synthetic_inputs(29, 2, 40)
+    for form in ("auto", "direct"):          # with and without the form calibration in the same run
+        eng = MBExWNEngine(cfg, raw, wt, conv_form=form, precision="split_f16")
+        info = eng.conv_form_info()
+        assert info["split_rejected"] is False and info["split_f16_layers"] == 4 and info["split_f16_gate_layers"] == 4
+        assert info["err_split"] is not None and 0.0 < info["err_split"] <= info["threshold"], info
+        if form == "auto":
+            assert info["calibrated"] == 1 and info["err_f43"] is not None and info["err_f43"] > 0.0      # the forms were measured in float32
+        print(f"\nsplit f16 calibration ({form}): err_split {info['err_split']:.2e}, threshold {info['threshold']:.2e}, err_f43 {info['err_f43']}")
+        eng.close()
+    hot = dict(raw)
+    for key, val in raw.items():
+        if key.startswith("wn.res_skip_") and key.endswith(".bias"):
+            hot[key] = (val + np.float32(1e5)).astype(np.float32)
+    e16 = MBExWNEngine(cfg, hot, wt, conv_form="direct", precision="split_f16")
+    e32 = MBExWNEngine(cfg, hot, wt, conv_form="direct")
+    info = e16.conv_form_info()
+    assert info["split_rejected"] is True and info["split_f16_layers"] == 0 and info["split_f16_gate_layers"] == 0, info
+    a16 = e16.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
+    a32 = e32.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
+    assert np.all(np.isfinite(a32)) and np.array_equal(a16, a32)
 
 
 def test_split_f16_large_launch_against_the_float32_handle(torch):
