@@ -16,12 +16,16 @@ namespace mbx {
 
 __device__ __forceinline__ float mod1(float x) { return x - floorf(x); }   // x >= 0: identical to fmod(x, 1)
 
-// (1) one wavefront per (item, chunk): the 64 lanes load the chunk coalesced and convert to phase velocity,
-// lane 0 then runs the sequential float32 sum out of LDS (4 values per ds_read_b128), and the lanes write
-// the running sums back coalesced.  The chain of 1000 dependent adds is the floor of this stage: measured (rocprofv3, one
-// 10 s utterance = 80 independent chains) 17 us per launch, of which about 5 us are what any launch costs and 2-3 us the
-// coalesced load / store phases; i.e. ~20 cycles per dependent v_add_f32 of a lone wave, which no re-ordering that keeps
-// the reference's rounding can shorten.
+// (1) one wavefront per (item, chunk).  The running sum of a chunk must be formed in the reference's order, one float32 add
+// after the other (tf.cumsum), so the chain of up to 1 000 dependent adds is the floor of this stage.  Round 4: the chain runs
+// ACROSS THE LANES of the wave instead of in lane 0: lane l of group g holds sample 64 g + l (coalesced load, phase velocity);
+// the group starts with acc = carry + x in every lane (final in lane 0), and 63 times `v_add_f32_dpp acc, acc, x wave_shr:1`
+// -- every lane l >= 1 takes the sum of lane l - 1 and adds its own sample; lane 0, whose source lane does not exist, is
+// not written -- so that after step t lanes 0 .. t hold their final sums (a lane's later rewrites repeat the same add on
+// the same final inputs).  One instruction per sample, nothing else on the chain: no LDS image, no per-sample moves; the
+// carry into the next group is a v_readlane of lane 63 and the sums leave as one coalesced store per group.  Same adds in
+// the same order on the same values as the lane-0 loop it replaces (17 us per launch for one 10 s utterance, ~20 cycles
+// per add with its LDS reads / writes and moves).
 constexpr int PHASE_MAX_CHUNK = 1024;   // multiple of 16
 
 // Streaming: an item may start in the middle of a reference chunk.  `st` (optional) gives, per item, the window
@@ -47,8 +51,6 @@ __global__ __launch_bounds__(64) void phase_chunk_kernel(const float *__restrict
                                                           int n_max, int chunk, float pulse_rate,
                                                           float *__restrict__ cum, float *__restrict__ chunk_last,
                                                           int chunks_max, const StreamState *__restrict__ st) {
-    __shared__ __attribute__((aligned(16))) float vin[PHASE_MAX_CHUNK];
-    __shared__ __attribute__((aligned(16))) float vout[PHASE_MAX_CHUNK];
     const int b = blockIdx.y;
     const int c = blockIdx.x;
     const int n = item_rows(n_frames, b, samples_per_frame, n_max);
@@ -59,36 +61,30 @@ __global__ __launch_bounds__(64) void phase_chunk_kernel(const float *__restrict
     const float *fb = f0 + (long long)b * bstride;
     float *cb = cum + (long long)b * bstride;
     const int len = end - begin;
-    const int padded = (len + 15) & ~15;
-    // phase velocity = frequency / sample_rate (tf_wavetable.py:516); the reference zero-pads the last chunk
-    for (int i = threadIdx.x; i < padded; i += 64) vin[i] = i < len ? fb[begin + i] / pulse_rate : 0.f;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // separate input / output images, 16 values per trip, and the 16 values of the NEXT trip requested from LDS before
-        // the dependent chain of float32 adds (the only serial part) of this trip starts: the chain never waits for a read
-        float acc = acc0;
-        float4 q[4], nx[4];
+    const int lane = threadIdx.x;
+    constexpr int G = PHASE_MAX_CHUNK / 64;
+    // phase velocity = frequency / sample_rate (tf_wavetable.py:516); the reference zero-pads the last chunk (adding the
+    // padding zeros leaves the sum unchanged)
+    float x[G];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const float4 *>(&vin[4 * u]);
-        for (int i = 0; i < padded; i += 16) {
-            const int ni = min(i + 16, padded - 16);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) nx[u] = *reinterpret_cast<const float4 *>(&vin[ni + 4 * u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc = acc + q[u].x; q[u].x = acc;
-                acc = acc + q[u].y; q[u].y = acc;
-                acc = acc + q[u].z; q[u].z = acc;
-                acc = acc + q[u].w; q[u].w = acc;
-                *reinterpret_cast<float4 *>(&vout[i + 4 * u]) = q[u];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) q[u] = nx[u];
-        }
-        chunk_last[(long long)b * chunks_max + c] = acc;   // adding the padding zeros leaves the sum unchanged
+    for (int g = 0; g < G; ++g) {
+        const int i = 64 * g + lane;
+        x[g] = i < len ? fb[begin + i] / pulse_rate : 0.f;
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < len; i += 64) cb[begin + i] = vout[i];
+    float carry = acc0;                                      // wave-uniform
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (64 * g < len) {                                  // wave-uniform: all 64 lanes are active inside
+            float acc = carry + x[g];
+            asm volatile(".rept 63\n\ts_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t.endr\n\ts_nop 4"
+                         : "+v"(acc)
+                         : "v"(x[g]));
+            carry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), 63));
+            const int i = 64 * g + lane;
+            if (i < len) cb[begin + i] = acc;
+        }
+    }
+    if (lane == 0) chunk_last[(long long)b * chunks_max + c] = carry;
 }
 
 // (2)+(3) one thread per sample.  The offset of chunk c = (sum_{j < c} (last_j mod 1)) mod 1, summed in chunk order
