@@ -267,6 +267,12 @@ PATCHES = {
     'small_depth12': [
         ('    constexpr int DEPTH = RT * CT == 1 ? 6 : 3;', '    constexpr int DEPTH = RT * CT == 1 ? 12 : 3;'),
     ],
+    'small_depth8': [
+        ('    constexpr int DEPTH = RT * CT == 1 ? 6 : 3;', '    constexpr int DEPTH = RT * CT == 1 ? 8 : 3;'),
+    ],
+    'small_depth4': [
+        ('    constexpr int DEPTH = RT * CT == 1 ? 6 : 3;', '    constexpr int DEPTH = RT * CT == 1 ? 4 : 3;'),
+    ],
     # wn_winograd4w.hip
     'noepi': [
         ('    // ---- epilogue: combine the six products, add the conditioning',
