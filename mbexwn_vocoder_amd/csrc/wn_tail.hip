@@ -34,26 +34,52 @@ __global__ __launch_bounds__(256) void wn_tail_kernel(const float *skip, long lo
     if (m0 >= rows) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 31, lk = lane >> 5;
-    for (int i = tid; i < n_out * M; i += 256) wp[i] = w_post[i];
-    if (tid < M) wp[32 * 16 + tid] = b_post ? b_post[tid] : 0.f;
 
     const int nc8 = (C + 7) / 8;                  // groups of 8 input channels (4 k steps x 2 lane halves)
     const float *xr = skip + (long long)b * skip_bstride + (long long)min(m0 + lrow, rows - 1) * C + 4 * lk;
     const float4 *wv = reinterpret_cast<const float4 *>(w_end_packed) + lane;
+    // what the epilogue adds to this thread's four outputs (bias, contributions of the earlier layers): requested here, with
+    // everything else, from clamped addresses and masked afterwards.  (As `cond ? load : 0` the compiler puts every load into a
+    // branch of its own and waits for it alone: the K loop was "one load, s_waitcnt vmcnt(0), four MFMAs" per group, and the
+    // epilogue eight serial round trips behind the block's barrier -- read off the ISA in round 4.)
+    const int e_rr = tid >> 3, e_nb = (tid & 7) * 4;
+    const float *ya = y_acc ? y_acc + (long long)b * y_bstride + (long long)min(m0 + e_rr, rows - 1) * n_out : nullptr;
+    float e_b[4], e_y[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = min(e_nb + q, n_out - 1);
+        const float bb = b_end ? b_end[n] : 0.f, yy = ya ? ya[n] : 0.f;      // (wave-uniform conditions)
+        e_b[q] = e_nb + q < n_out ? bb : 0.f;
+        e_y[q] = e_nb + q < n_out ? yy : 0.f;
+    }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 4
-    for (int c = wave; c < nc8; c += 4) {
-        // C % 8 == 4: the upper lane half of the last group has no channels (its weights are zero, its address is not read)
-        const bool in_row = 8 * c + 4 * lk < C;
-        const float4 a = in_row ? *reinterpret_cast<const float4 *>(xr + 8 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 w = wv[c * 64];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w.w, acc, 0, 0, 0);
+    // groups of this wave in batches of TL_BATCH: all loads of a batch in flight, then its MFMAs
+    constexpr int TL_BATCH = 6;
+    for (int c0 = wave; c0 < nc8; c0 += 4 * TL_BATCH) {
+        float4 a[TL_BATCH], w[TL_BATCH];
+#pragma unroll
+        for (int i = 0; i < TL_BATCH; ++i) {
+            const int c = min(c0 + 4 * i, nc8 - 1);
+            // C % 8 == 4: the upper lane half of the last group has no channels: its weights are zero, the row's last four
+            // channels are read in their place (finite values x 0)
+            a[i] = *reinterpret_cast<const float4 *>(xr + min(8 * c, C - 4 - 4 * lk));
+            w[i] = wv[c * 64];
+        }
+#pragma unroll
+        for (int i = 0; i < TL_BATCH; ++i) {
+            if (c0 + 4 * i < nc8) {                          // wave-uniform
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, w[i].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, w[i].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, w[i].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, w[i].w, acc, 0, 0, 0);
+            }
+        }
     }
+    // the post-net's weights (read behind the second barrier): staged here, behind the K loop's requests
+    for (int i = tid; i < n_out * M; i += 256) wp[i] = w_post[i];
+    if (tid < M) wp[32 * 16 + tid] = b_post ? b_post[tid] : 0.f;
     // lane (column lrow) holds rows (r & 3) + 8 (r >> 2) + 4 lk of this wave's partial 32 x 32 result
     float *tw = tile + wave * 32 * 33;
 #pragma unroll
@@ -61,15 +87,13 @@ __global__ __launch_bounds__(256) void wn_tail_kernel(const float *skip, long lo
     __syncthreads();
     // sum of the four partial results + bias -> y (stage output) and tile 0
     {
-        const int rr = tid >> 3, nb = (tid & 7) * 4;
+        const int rr = e_rr, nb = e_nb;
         float *yb = y + (long long)b * y_bstride + (long long)(m0 + rr) * n_out;
-        const float *ya = y_acc ? y_acc + (long long)b * y_bstride + (long long)min(m0 + rr, rows - 1) * n_out : nullptr;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int n = nb + q;
             const int o = rr * 33 + n;
-            const float v = ((tile[o] + tile[32 * 33 + o]) + (tile[2 * 32 * 33 + o] + tile[3 * 32 * 33 + o])) +
-                            ((b_end && n < n_out) ? b_end[n] : 0.f) + ((ya && n < n_out) ? ya[n] : 0.f);
+            const float v = ((tile[o] + tile[32 * 33 + o]) + (tile[2 * 32 * 33 + o] + tile[3 * 32 * 33 + o])) + e_b[q] + e_y[q];
             tile[o] = v;
             if (n < n_out && m0 + rr < rows) yb[n] = v;
         }
