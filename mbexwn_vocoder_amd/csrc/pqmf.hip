@@ -36,10 +36,24 @@ __global__ __launch_bounds__(256) void pqmf_kernel(const float *x, long long x_b
     float *xs = smem;                      // (n_rows, M) + 4: M * x, zero outside the item
     const float *xb = x + (long long)b * x_bstride;
     const float gain = (float)M;
-    for (int i = threadIdx.x; i < n_rows * M + 4; i += blockDim.x) {
+    // (n_rows * M + 4 <= 64 * 16 + 192 + 4 elements = at most five per thread.  All requests first, from clamped addresses,
+    // selected afterwards: as `cond ? load : 0` inside the loop every element was a branch with its own s_waitcnt vmcnt(0),
+    // five serial round trips per block)
+    constexpr int XS_ITERS = 5;
+    float xv[XS_ITERS];
+#pragma unroll
+    for (int it = 0; it < XS_ITERS; ++it) {
+        const int i = threadIdx.x + 256 * it;
         const int r = i / M, k = i - r * M;
+        const int m = min(max(q0 + dm_min + r, 0), steps - 1);
+        xv[it] = xb[(long long)m * M + k];
+    }
+#pragma unroll
+    for (int it = 0; it < XS_ITERS; ++it) {
+        const int i = threadIdx.x + 256 * it;
+        const int r = i / M;
         const int m = q0 + dm_min + r;
-        xs[i] = (r < n_rows && m >= 0 && m < steps) ? gain * xb[(long long)m * M + k] : 0.f;
+        if (i < n_rows * M + 4) xs[i] = (r < n_rows && m >= 0 && m < steps) ? gain * xv[it] : 0.f;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l16 = lane & 15, kq = lane >> 4;

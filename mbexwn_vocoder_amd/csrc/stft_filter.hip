@@ -518,7 +518,20 @@ __global__ void overlap_add_kernel(StftConsts c, const float *frames, const int 
             const int p = i + c.win / 2;
             const int t_hi = min(T - 1, p / c.hop);
             const int t_lo = p < c.win ? 0 : (p - c.win) / c.hop + 1;
-            for (int t = t_lo; t <= t_hi; ++t) acc += fb[(long long)t * c.win + (p - t * c.hop)];
+            if (c.win <= 4 * c.hop) {
+                // at most four frames cover a sample: all four requests first (clamped frame, masked afterwards), added in frame
+                // order -- the loop below waits for every load on its own (a trip count the compiler does not know)
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int t = min(t_lo + j, t_hi);
+                    v[j] = fb[(long long)t * c.win + (p - t * c.hop)];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc += t_lo + j <= t_hi ? v[j] : 0.f;
+            } else {
+                for (int t = t_lo; t <= t_hi; ++t) acc += fb[(long long)t * c.win + (p - t * c.hop)];
+            }
         }
         ab[i] = acc;
     }

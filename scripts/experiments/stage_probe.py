@@ -28,7 +28,7 @@ for _ in range(reps):
     eng.forward(mel, noise=noise)
 torch.cuda.synchronize()
 out = {}
-for kk in ("gate", "res_skip", "frontend", "start", "tail", "stft_filter"):
+for kk in ("gate", "res_skip", "frontend", "wavetable", "start", "tail", "pqmf", "stft_filter", "overlap_add"):
     ms, n = eng.profile_read(kk)
     out[kk] = round(ms / n * 1e3, 1) if n else None
 eng.profile_enable(False)
