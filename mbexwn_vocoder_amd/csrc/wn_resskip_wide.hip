@@ -85,13 +85,19 @@ __global__ __launch_bounds__(512, 4) void wn_resskip_wide_kernel(ConvArgs p) {
     const int whole_slices = p.cin / RW_BK;
     const unsigned b_voff = 16u * (unsigned)lane;
     const int bk0 = min(wave, NP - 1), bk1 = min(wave + 4, NP - 1);
-    auto issue = [&](int kt, int stage) {
+    // FAST (whole-row tile, cin a multiple of the slice): only requests with a wave-uniform base and a 32-bit lane offset.  The
+    // body below is instantiated twice and a block takes one copy: with the masked path (a 64-bit address per lane, a select
+    // against the zero buffer) in the same loop the 128-register budget spilled an address that was reloaded from scratch
+    // in EVERY slice -- and the compiler's s_waitcnt vmcnt(0) for that reload drained the two slices of LDS-DMA in flight
+    // (read off the ISA in round 4)
+    auto issue = [&](auto fastc, int kt, int stage) {
+        constexpr bool FAST = decltype(fastc)::value;
         const int ci0 = kt * RW_BK;
         const unsigned adst = lds_base + 4u * (unsigned)(stage * STAGE);
         const unsigned bdst = adst + 4u * (unsigned)RW_A_FLOATS;
         const float *bbase = p.w + (long long)kt * (SPLIT * B_FLOATS) + pair0 * 256;
         if (wave < 4) {
-            if (fast_rows && kt < whole_slices) {
+            if (FAST || (fast_rows && kt < whole_slices)) {
                 rw_lds_dma16_s(xb + ci0, a_voff, adst + 1024u * (unsigned)wave);
             } else {
                 const bool ok = a_ok && (ci0 + 4 * (int)a_hi < p.cin);
@@ -104,8 +110,7 @@ __global__ __launch_bounds__(512, 4) void wn_resskip_wide_kernel(ConvArgs p) {
             rw_lds_dma16_s(bbase + bk1 * 256, b_voff, bdst + 1024u * (unsigned)bk1);
         }
     };
-    issue(0, 0);
-
+    const bool blk_fast = fast_rows && whole_slices * RW_BK == p.cin;
     // ---- accumulators start from old value + bias (h columns accumulate unless h_init, skip columns unless skip_init)
     // register v of column tile ct: row m0 + 16 wave + 4 kq + v, column 32 (ct >> 1) + 2 r16 + (ct & 1)
     f32x4 acc[2 * NP];
@@ -115,31 +120,54 @@ __global__ __launch_bounds__(512, 4) void wn_resskip_wide_kernel(ConvArgs p) {
     float *sb = p.skip + (long long)b * skip_bstride;
     const int row0 = m0 + 16 * wave + 4 * kq;
     const int row_last = rows - 1;
+    auto body = [&](auto fastc) {
+    issue(fastc, 0, 0);
+    // Groups of PG column pairs: ALL requests of a group first -- its biases and old values, from clamped addresses -- then the
+    // arithmetic.  (Round 4, read off the ISA: written pair by pair, the
+    // compiler formed `col_ok ? bias : 0` right behind the bias load, i.e. an s_waitcnt vmcnt(0) in every pair that also
+    // drained the previous pair's row loads: eleven serial round trips in front of a block's first MFMA.)
+    const float *bias_src = p.bias ? p.bias : p.zeros;
+    constexpr int PG = 4;                                          // pairs per group (4: 26 spilled registers at the 128 budget)
 #pragma unroll
-    for (int pr = 0; pr < NP; ++pr) {
-        // unconditional loads from clamped addresses (no branch, all requests in flight), selected afterwards
-        const int col = 32 * (pair0 + pr) + 2 * r16;               // even: both columns of the lane on the same side of C
-        const bool col_ok = col < p.cout;
-        const int colc = min(col, p.cout - 2);
-        const bool to_h = colc < C;
-        const bool accumulate = col_ok && (to_h ? !p.h_init : !p.skip_init);
-        float2 bias = make_float2(0.f, 0.f);
-        if (p.bias) bias = *reinterpret_cast<const float2 *>(p.bias + colc);
-        const float *src = to_h ? hb + colc : sb + (colc - C);
-        const int ld = to_h ? C : skip_ld;
+    for (int g0 = 0; g0 < NP; g0 += PG) {
+        float2 bias4[PG], old4[PG][4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int row = min(row0 + v, row_last);
-            const float2 old = *reinterpret_cast<const float2 *>(src + (long long)row * ld);
-            acc[2 * pr][v] = (accumulate ? old.x : 0.f) + (col_ok ? bias.x : 0.f);
-            acc[2 * pr + 1][v] = (accumulate ? old.y : 0.f) + (col_ok ? bias.y : 0.f);
+        for (int j = 0; j < PG; ++j) {
+            const int pr = g0 + j;
+            if (pr < NP) {
+                const int col = 32 * (pair0 + pr) + 2 * r16;       // even: both columns of the lane on the same side of C
+                const int colc = min(col, p.cout - 2);
+                const bool to_h = colc < C;
+                bias4[j] = *reinterpret_cast<const float2 *>(bias_src + (p.bias ? colc : 0));
+                const float *src = to_h ? hb + colc : sb + (colc - C);
+                const int ld = to_h ? C : skip_ld;
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    old4[j][v] = *reinterpret_cast<const float2 *>(src + (long long)min(row0 + v, row_last) * ld);
+            }
         }
-        if (pr % 4 == 3) RW_FENCE();               // at most 16 pre-loads (32 registers) in flight
+        RW_FENCE();
+#pragma unroll
+        for (int j = 0; j < PG; ++j) {
+            const int pr = g0 + j;
+            if (pr < NP) {
+                const int col = 32 * (pair0 + pr) + 2 * r16;
+                const bool col_ok = col < p.cout;
+                const bool to_h = min(col, p.cout - 2) < C;
+                const bool accumulate = col_ok && (to_h ? !p.h_init : !p.skip_init);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    acc[2 * pr][v] = (accumulate ? old4[j][v].x : 0.f) + (col_ok ? bias4[j].x : 0.f);
+                    acc[2 * pr + 1][v] = (accumulate ? old4[j][v].y : 0.f) + (col_ok ? bias4[j].y : 0.f);
+                }
+            }
+        }
+        RW_FENCE();
     }
     // slices 1, 2 are requested behind slice 0 and the accumulator pre-loads: waiting for all but the 4 youngest
     // requests below leaves exactly them in flight
-    if (nk > 1) issue(1, 1);
-    if (nk > 2) issue(2, 2);
+    if (nk > 1) issue(fastc, 1, 1);
+    if (nk > 2) issue(fastc, 2, 2);
 
     // A operand: row 16 wave + r16, channels 2 kq, 2 kq + 1
     const int arow = 16 * wave + r16;
@@ -184,7 +212,7 @@ __global__ __launch_bounds__(512, 4) void wn_resskip_wide_kernel(ConvArgs p) {
         if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");       // slice kt+2 may still be in flight
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 3 < nk) issue(kt + 3, S);
+        if (kt + 3 < nk) issue(fastc, kt + 3, S);
         RW_FENCE();
         mfma4(rw_int<NP - 2>());
         mfma4(rw_int<NP - 1>());
@@ -215,6 +243,10 @@ __global__ __launch_bounds__(512, 4) void wn_resskip_wide_kernel(ConvArgs p) {
             if (kt + 1 < nk) slice(rw_int<1>(), kt + 1);
         }
     }
+
+    };      // body
+    if (blk_fast) body(std::true_type{});
+    else body(std::false_type{});
 
     // ---- epilogue: the accumulators are the new values
 #pragma unroll
