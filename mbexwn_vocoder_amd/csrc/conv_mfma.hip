@@ -608,28 +608,38 @@ __device__ __forceinline__ void conv1d_small_tile(const ConvArgs &p, int bx, int
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
 
+    // Requests only (clamped addresses); the masks are applied by mask_group when the batch is consumed.  (Round 4, read off
+    // the ISA: with `ok ? t : 0` right behind each load the compiler waited for every group's five loads before it issued the
+    // next group's -- six serial round trips per batch of six groups "in flight".)
     auto load_group = [&](int g, float4 (&av)[RT], float (&bv)[CT][4]) {
         const int tap = g / groups_per_tap;
         const int ci = (g - tap * groups_per_tap) * 8 + 4 * lk;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const int src = map_row(m0 + 32 * rt + lrow - p.pad_l + tap * p.dil, rows, p.pad_mode);
-            const float4 t = *reinterpret_cast<const float4 *>(xb + (long long)max(src, 0) * p.ldx + ci);
-            const bool ok = src >= 0;
-            av[rt].x = ok ? t.x : 0.f;
-            av[rt].y = ok ? t.y : 0.f;
-            av[rt].z = ok ? t.z : 0.f;
-            av[rt].w = ok ? t.w : 0.f;
+            av[rt] = *reinterpret_cast<const float4 *>(xb + (long long)max(src, 0) * p.ldx + ci);
         }
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const float *wk = wcol[ct] + (long long)(tap * p.cin + ci) * p.cout;
 #pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                const float t2 = wk[(long long)st * p.cout];
-                bv[ct][st] = col_ok[ct] ? t2 : 0.f;
-            }
+            for (int st = 0; st < 4; ++st) bv[ct][st] = wk[(long long)st * p.cout];
         }
+    };
+    auto mask_group = [&](int g, float4 (&av)[RT], float (&bv)[CT][4]) {
+        const int tap = g / groups_per_tap;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const bool ok = map_row(m0 + 32 * rt + lrow - p.pad_l + tap * p.dil, rows, p.pad_mode) >= 0;
+            av[rt].x = ok ? av[rt].x : 0.f;
+            av[rt].y = ok ? av[rt].y : 0.f;
+            av[rt].z = ok ? av[rt].z : 0.f;
+            av[rt].w = ok ? av[rt].w : 0.f;
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int st = 0; st < 4; ++st) bv[ct][st] = col_ok[ct] ? bv[ct][st] : 0.f;
     };
 
     // the loads of a batch of DEPTH groups are all in flight while the previous batch feeds the matrix pipe
@@ -640,6 +650,9 @@ __device__ __forceinline__ void conv1d_small_tile(const ConvArgs &p, int bx, int
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
         if (g_begin + d < g_end) load_group(g_begin + d, a_cur[d], b_cur[d]);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (g_begin + d < g_end) mask_group(g_begin + d, a_cur[d], b_cur[d]);
     for (int g = g_begin; g < g_end; g += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d)
@@ -660,6 +673,9 @@ __device__ __forceinline__ void conv1d_small_tile(const ConvArgs &p, int bx, int
                     }
             }
         }
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+            if (g + DEPTH + d < g_end) mask_group(g + DEPTH + d, a_nxt[d], b_nxt[d]);
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
 #pragma unroll
