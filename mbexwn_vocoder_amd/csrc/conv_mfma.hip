@@ -644,7 +644,7 @@ __device__ __forceinline__ void conv1d_small_tile(const ConvArgs &p, int bx, int
 
     // the loads of a batch of DEPTH groups are all in flight while the previous batch feeds the matrix pipe
     // (one group = 4 MFMAs per tile = 0.1 us, an L2 round trip is several times that)
-    constexpr int DEPTH = RT * CT == 1 ? 6 : 3;
+    constexpr int DEPTH = RT * CT == 1 ? 4 : 3;          // (round 4, with the loads really batched: 2: 47.8, 3: 45.9, 4: 45.7, 6: 47.1, 9: 48.8, 12: 54 us front end of 3 s)
     float4 a_cur[DEPTH][RT], a_nxt[DEPTH][RT];
     float b_cur[DEPTH][CT][4], b_nxt[DEPTH][CT][4];
 #pragma unroll
