@@ -132,6 +132,9 @@ __global__ void wavetable_kernel(WaveTableConsts k, const float *f0, long long b
         }
         const int rel = i - start;
         const int c = rel < first_len ? 0 : 1 + (rel - first_len) / k.chunk;
+        // both per-sample inputs requested together (behind the branches below the compiler asks for f0 only when the phase
+        // has arrived: one more round trip in front of the table look-up)
+        const float cum_i = cb[i], f = fb[i];
         float off;
         if (table) {
             off = offs[c];
@@ -140,7 +143,7 @@ __global__ void wavetable_kernel(WaveTableConsts k, const float *f0, long long b
             for (int j = 0; j < c; ++j) off = off + mod1(lb[j]);
             off = mod1(off);
         }
-        const float phase = mod1(cb[i] + off);
+        const float phase = mod1(cum_i + off);
         if (phase_out) phase_out[(long long)b * bstride + i] = phase;
         // wrapped_phase * 2 * pi in float32, left to right (tf_wavetable.py:521)
         const float w2pi = (phase * 2.f) * 3.14159265358979323846f;
@@ -155,7 +158,6 @@ __global__ void wavetable_kernel(WaveTableConsts k, const float *f0, long long b
         const float rem = pos - base;
         const int idx = (int)base;
         // grid mix (tf_wavetable.py:539-548): q = ln(clip(f0 / nominalF0)) / ln(grid); weights max(1-|q-r|, 0)
-        const float f = fb[i];
         const float ratio = fmaxf(k.min_tf, fminf(k.max_tf, f / k.nominal_f0));
         const float q = logf(ratio) * k.grid_norm;
         int r0 = (int)floorf(q);
@@ -204,7 +206,10 @@ void launch_wavetable(const WaveTableConsts &c, const float *f0, long long bstri
     const int chunks_max = (n_max + c.chunk - 1) / c.chunk + 1;
     hipLaunchKernelGGL(phase_chunk_kernel, dim3(chunks_max, batch), dim3(64), 0, stream, f0, bstride,
                        n_frames, samples_per_frame, n_max, c.chunk, c.pulse_rate, cum, chunk_last, chunks_max, st_in);
-    const int blocks = min((n_max + 255) / 256, 1024);
+    // every block forms the chunk offsets of its item first (one lane, a chain of c_hi adds: ~3 us for a 10 s item): about one
+    // resident round of blocks over the whole batch, each striding over its samples, instead of one block per 256 samples
+    // (16 x 10 s: 15 008 blocks = 7 rounds of that chain -> 2 048 blocks)
+    const int blocks = min((n_max + 255) / 256, max(1, 2048 / batch));
     hipLaunchKernelGGL(wavetable_kernel, dim3(blocks, batch), dim3(256), 0, stream, c, f0, bstride, n_frames,
                        samples_per_frame, n_max, cum, chunk_last, chunks_max, pulse, phase_out, st_in);
     if (st_in && st_out)
