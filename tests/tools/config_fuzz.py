@@ -129,7 +129,9 @@ for case in range(n_cases):
                 nz = noise[ii:ii + 1, :ll * rpf] if dims.noise_sigma else None
                 ref = om.forward(mel[ii:ii + 1, :ll], nz)[0]
                 worst_d = max(worst_d, float(np.abs(got_d[ii, :ll * 300] - ref).max()) / max(1.0, float(np.abs(ref).max())))
-            note = f" [direct form {worst_d:.1e}, calibration {eng.conv_form_info()['err_f43']:.1e} <= {eng.conv_form_info()['threshold']:.1e}]"
+            info = eng.conv_form_info()
+            cal = f"{info['err_f43']:.1e} <= {info['threshold']:.1e}" if info["err_f43"] is not None else "not run"
+            note = f" [direct form {worst_d:.1e}, calibration {cal}]"
             ok = worst <= 1.25 * worst_d and worst <= 16 * yard
             del eng_d
         if not ok and getattr(om, "ceps_windows", None) is not None and not (cfg["mbexwn_config"].get("ps_off") or not cfg["mbexwn_config"].get("ps_use_stft", True)):

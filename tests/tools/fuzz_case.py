@@ -53,7 +53,7 @@ for ii, ll in enumerate(lengths):
     print("   largest excitation difference at sample", worst, "= pulse sample", worst * dims.pulse_per_frame // 300,
           "| pulse samples where the wrapped phases differ by a whole turn:", flips[:10])
     # the STFT filter: the error of the audio frame by frame, and the size of the envelope the oracle applies
-    if "envelope" in s64 and om64.ceps_windows is not None:
+    if "envelope" in s64 and getattr(om64, "ceps_windows", None) is not None:
         # the lifter row of a frame is the NEAREST of n_ceps_windows rows to the frame's smoothed log F0: a discontinuous function,
         # a contour that lands within rounding of a midpoint selects the neighbouring row (in the engine or in the oracle)
         ix_hip = eng.stage("ceps_index").cpu().numpy().view(np.int32)[ii, :ll]
