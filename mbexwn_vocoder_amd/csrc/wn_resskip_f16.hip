@@ -126,24 +126,38 @@ __global__ __launch_bounds__(512, 4) void wn_resskip_f16_kernel(ConvArgs p) {
     float *sb = p.skip + (long long)b * skip_bstride;
     const int row0 = m0 + 16 * wave + 4 * kq;
     const int row_last = rows - 1;
+    // (groups of three pairs: all requests of a group first, then the arithmetic -- pair by pair the compiler waits for every
+    // bias load on its own, which also drains the previous pair's row loads: wn_resskip_wide.hip)
+    const float *bias_src = p.bias ? p.bias : p.zeros;
 #pragma unroll
-    for (int pr = 0; pr < RH_NP; ++pr) {
-        const int col = 32 * (pair0 + pr) + 2 * r16;
-        const bool col_ok = col < p.cout;
-        const int colc = min(col, p.cout - 2);
-        const bool to_h = colc < C;
-        const bool accumulate = col_ok && (to_h ? !p.h_init : !p.skip_init);
-        float2 bias = make_float2(0.f, 0.f);
-        if (p.bias) bias = *reinterpret_cast<const float2 *>(p.bias + colc);
-        const float *src = to_h ? hb + colc : sb + (colc - C);
-        const int ld = to_h ? C : skip_ld;
+    for (int g0 = 0; g0 < RH_NP; g0 += 3) {
+        float2 bias3[3], old3[3][4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int row = min(row0 + v, row_last);
-            const float2 old = *reinterpret_cast<const float2 *>(src + (long long)row * ld);
-            acc[2 * pr][v] = 2048.0f * ((accumulate ? old.x : 0.f) + (col_ok ? bias.x : 0.f));
-            acc[2 * pr + 1][v] = 2048.0f * ((accumulate ? old.y : 0.f) + (col_ok ? bias.y : 0.f));
+        for (int j = 0; j < 3; ++j) {
+            const int pr = g0 + j;
+            const int colc = min(32 * (pair0 + pr) + 2 * r16, p.cout - 2);
+            const bool to_h = colc < C;
+            bias3[j] = *reinterpret_cast<const float2 *>(bias_src + (p.bias ? colc : 0));
+            const float *src = to_h ? hb + colc : sb + (colc - C);
+            const int ld = to_h ? C : skip_ld;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) old3[j][v] = *reinterpret_cast<const float2 *>(src + (long long)min(row0 + v, row_last) * ld);
         }
+        RH_FENCE();
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int pr = g0 + j;
+            const int col = 32 * (pair0 + pr) + 2 * r16;
+            const bool col_ok = col < p.cout;
+            const bool to_h = min(col, p.cout - 2) < C;
+            const bool accumulate = col_ok && (to_h ? !p.h_init : !p.skip_init);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                acc[2 * pr][v] = 2048.0f * ((accumulate ? old3[j][v].x : 0.f) + (col_ok ? bias3[j].x : 0.f));
+                acc[2 * pr + 1][v] = 2048.0f * ((accumulate ? old3[j][v].y : 0.f) + (col_ok ? bias3[j].y : 0.f));
+            }
+        }
+        RH_FENCE();
     }
     const f16x8 *bptr = reinterpret_cast<const f16x8 *>(lds) + lane;      // + stage * (RH_STAGE / 4) + (4 pr + image) * 64
     const f32x4 *aptr = reinterpret_cast<const f32x4 *>(lds) + RH_B_FLOATS / 4 + wave * 128 + lane;
