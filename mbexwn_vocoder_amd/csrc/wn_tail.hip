@@ -44,6 +44,10 @@ __global__ __launch_bounds__(256) void wn_tail_kernel(const float *skip, long lo
     // epilogue eight serial round trips behind the block's barrier -- read off the ISA in round 4.)
     const int e_rr = tid >> 3, e_nb = (tid & 7) * 4;
     const float *ya = y_acc ? y_acc + (long long)b * y_bstride + (long long)min(m0 + e_rr, rows - 1) * n_out : nullptr;
+    // ... and the post-net's weights (n_out * M <= 512: two per thread) and biases, stored to LDS behind the K loop
+    const int n_wp = n_out * M;
+    const float wp0 = w_post[min(tid, n_wp - 1)], wp1 = w_post[min(tid + 256, n_wp - 1)];
+    const float bp = b_post ? b_post[min(tid, M - 1)] : 0.f;
     float e_b[4], e_y[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -78,8 +82,9 @@ __global__ __launch_bounds__(256) void wn_tail_kernel(const float *skip, long lo
         }
     }
     // the post-net's weights (read behind the second barrier): staged here, behind the K loop's requests
-    for (int i = tid; i < n_out * M; i += 256) wp[i] = w_post[i];
-    if (tid < M) wp[32 * 16 + tid] = b_post ? b_post[tid] : 0.f;
+    if (tid < n_wp) wp[tid] = wp0;
+    if (tid + 256 < n_wp) wp[tid + 256] = wp1;
+    if (tid < M) wp[32 * 16 + tid] = bp;
     // lane (column lrow) holds rows (r & 3) + 8 (r >> 2) + 4 lk of this wave's partial 32 x 32 result
     float *tw = tile + wave * 32 * 33;
 #pragma unroll
