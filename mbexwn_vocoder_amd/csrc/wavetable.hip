@@ -68,9 +68,12 @@ __global__ __launch_bounds__(64) void phase_chunk_kernel(const float *__restrict
     float x[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
+        // (clamped address, masked afterwards: as `i < len ? load : 0` every group's load sits in a branch with a wait of its own)
         const int i = 64 * g + lane;
-        x[g] = i < len ? fb[begin + i] / pulse_rate : 0.f;
+        x[g] = fb[begin + min(i, len - 1)];
     }
+#pragma unroll
+    for (int g = 0; g < G; ++g) x[g] = 64 * g + lane < len ? x[g] / pulse_rate : 0.f;
     float carry = acc0;                                      // wave-uniform
 #pragma unroll
     for (int g = 0; g < G; ++g) {
