@@ -341,16 +341,35 @@ __global__ __launch_bounds__(256, 2) void stft_filter_wave_kernel(StftConsts c, 
     const int b = blockIdx.y;
     const int T = item_rows(n_frames, b, 1, max_frames);
     if (blockIdx.x * 4 >= T) return;
-    for (int i = tid; i < SW_NC; i += 256) s_tw[i] = reinterpret_cast<const cf *>(c.twiddle)[i];
-    for (int i = tid; i < 128 * NMX; i += 256) {
-        s_hann[i] = i < c.win ? c.hann[i] : 0.f;
-        s_inv_win[i] = i < c.win ? c.inv_win[i] * (1.0f / (float)SW_NC) : 0.f;       // with the inverse transform's 1 / nc (a power of two)
-    }
     {
+        // the block's tables: all requests first (clamped addresses), then the stores -- written as plain copy loops every
+        // iteration waits for its own load (nine serial round trips in front of a block's first transform)
+        constexpr int NW = (128 * NMX + 255) / 256;
+        const cf *twg = reinterpret_cast<const cf *>(c.twiddle);
+        cf twv[SW_NC / 256];
+        float hv[NW], iv[NW];
+#pragma unroll
+        for (int k = 0; k < SW_NC / 256; ++k) twv[k] = twg[tid + 256 * k];
         // exp(-2 pi i n / 256) = entry 8 n of the 2048-circle (second half circle: negated)
-        cf w = reinterpret_cast<const cf *>(c.twiddle)[(8 * tid) & (SW_NC - 1)];
+        cf w = twg[(8 * tid) & (SW_NC - 1)];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int i = min(tid + 256 * k, c.win - 1);
+            hv[k] = c.hann[i];
+            iv[k] = c.inv_win[i];
+        }
+#pragma unroll
+        for (int k = 0; k < SW_NC / 256; ++k) s_tw[tid + 256 * k] = twv[k];
         if (8 * tid >= SW_NC) w = -w;
         s_t256[tid] = w;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int i = tid + 256 * k;
+            if (i < 128 * NMX) {
+                s_hann[i] = i < c.win ? hv[k] : 0.f;
+                s_inv_win[i] = i < c.win ? iv[k] * (1.0f / (float)SW_NC) : 0.f;   // with the inverse transform's 1 / nc (a power of two)
+            }
+        }
     }
     __syncthreads();                                            // (no block-wide synchronisation below this line)
     cf *buf = s_buf[wave];
