@@ -975,7 +975,12 @@ void launch_conv1d_group(const ConvArgs *convs, int n, hipStream_t stream) {
     int small[3], n_small = 0;
     for (int i = 0; i < n && i < 3; ++i)
         if (convs[i].max_rows > 0 && convs[i].batch > 0 && small_conv_eligible(convs[i])) small[n_small++] = i;
-    if (n > 3 || n_small < 2) {
+    // large launches: LDS-staged 64 x 128 tiles (conv1d_mel_tile: same sums in the same order), also for a single convolution
+    // (the conditioning chains of the WaveNet blocks behind the first one come one by one)
+    long long work = 0;
+    for (int k = 0; k < n_small; ++k) work += (long long)convs[small[k]].max_rows * convs[small[k]].batch;
+    const bool big = work >= 3 * 4096;
+    if (n > 3 || n_small < 1 || (n_small < 2 && !big)) {
         for (int i = 0; i < n; ++i) launch_conv1d(convs[i], EPI_LINEAR, stream);
         return;
     }
@@ -987,10 +992,6 @@ void launch_conv1d_group(const ConvArgs *convs, int n, hipStream_t stream) {
                 small[i] = small[j];
                 small[j] = t;
             }
-    // large launches: LDS-staged 64 x 128 tiles (conv1d_mel_tile: same sums in the same order)
-    long long work = 0;
-    for (int k = 0; k < n_small; ++k) work += (long long)convs[small[k]].max_rows * convs[small[k]].batch;
-    const bool big = work >= 3 * 4096;
     constexpr int MEL_RT = 2;                        // 64-row tiles
     const int tile_m = big ? 32 * MEL_RT : 32, tile_n = big ? MT_COLS : 32;
     SmallConvGroup g;
