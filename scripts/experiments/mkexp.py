@@ -273,6 +273,21 @@ PATCHES = {
     'small_depth4': [
         ('    constexpr int DEPTH = RT * CT == 1 ? 6 : 3;', '    constexpr int DEPTH = RT * CT == 1 ? 4 : 3;'),
     ],
+    # conv_mfma.hip, large-launch mel-rate tile kernel (timing only): no weight loads / no activation loads / no stores to LDS
+    'mt_now': [
+        ('            for (int st = 0; st < 4; ++st) b_reg[i][st] = (wk + (long long)st * p.cout)[b_voff];',
+         '            for (int st = 0; st < 4; ++st) b_reg[i][st] = 0.25f + (float)b_voff;'),
+    ],
+    'mt_noa': [
+        ('            if (src >= 0) t = *reinterpret_cast<const float4 *>(xb + (long long)src * p.ldx + ci);',
+         '            if (src >= 0) t = make_float4((float)src, 1.f, 2.f, (float)ci);'),
+    ],
+    'mt_nolds': [
+        ('        for (int i = 0; i < RT; ++i) *reinterpret_cast<float4 *>(al + a_lds + 256 * i) = a_reg[i];',
+         '        for (int i = 0; i < RT; ++i) if (a_reg[i].x == 123.456f) *reinterpret_cast<float4 *>(al + a_lds + 256 * i) = a_reg[i];'),
+        ('            *reinterpret_cast<float4 *>(bl + b_lds + i * (MT_COLS * 8)) = make_float4(b_reg[i][0], b_reg[i][1], b_reg[i][2], b_reg[i][3]);',
+         '            if (b_reg[i][0] == 123.456f) *reinterpret_cast<float4 *>(bl + b_lds + i * (MT_COLS * 8)) = make_float4(b_reg[i][0], b_reg[i][1], b_reg[i][2], b_reg[i][3]);'),
+    ],
     # wn_winograd4w.hip
     'noepi': [
         ('    // ---- epilogue: combine the six products, add the conditioning',
