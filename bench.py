@@ -118,7 +118,7 @@ def cpu_baseline(cfg, raw, wt, seconds=3.0):
     own CPU-runnable case, configs[0]).  Two variants of the same float32 graph: the numpy port
     (oracle/mbexwn_oracle.py, matrix products on the host BLAS; 2 threads -- the reference CLI's default `-nt 2`,
     bin/resynth_mel.py:120 -- and 8) and the torch-CPU port (oracle/mbexwn_oracle_torch.py: the WaveNet, 98 % of the FLOPs,
-    on torch's MKL / oneDNN ops; 8 and 16 threads).  `value` is the BEST leg; every leg is listed.  No leg uses more than 16
+    on torch's MKL / oneDNN ops; 2, 8 and 16 threads).  `value` is the BEST leg; every leg is listed.  No leg uses more than 16
     threads: a one-GPU box of the pool has a CPU share of 16 cores whatever os.cpu_count() says (measured there: 32 / 64 /
     256 torch threads ran at 14 / 10 / 0.2 x real time against 26-29 x at 8).  Timing protocol of the reference CLI
     (bin/resynth_mel.py:86-88): wall clock around the synthesis call only, one warm-up call first.  TensorFlow itself cannot
@@ -151,7 +151,7 @@ def cpu_baseline(cfg, raw, wt, seconds=3.0):
                                             "cores": threads, "runs": runs, "port": "numpy"}
     om_t = TorchOracleModel(cfg, raw, wt)
     before = torch.get_num_threads()
-    for threads in sorted({tt for tt in (8, 16) if tt <= all_cores}):
+    for threads in sorted({tt for tt in (2, 8, 16) if tt <= all_cores} | {min(2, all_cores)}):   # 2 = the reference CLI's -nt default
         torch.set_num_threads(threads)
         with threadpool_limits(limits=threads):
             med, runs = leg(om_t, 3.0)
@@ -161,10 +161,12 @@ def cpu_baseline(cfg, raw, wt, seconds=3.0):
     top_name, top = max(legs.items(), key=lambda kv: kv[1]["value"])
     return {"value": top["value"], "unit": "audio samples/s", "cores": top["cores"], "kind": "port",
             "sample": f"1 utterance x {seconds:g} s (80x{frames} mel), float32 CPU port of the reference graph, best leg "
-                      f"({top_name}) of a sweep over the numpy port (2, 8, 16 threads) and the torch-CPU port (8, 16 threads), "
+                      f"({top_name}) of a sweep over the numpy port and the torch-CPU port (2, 8, 16 threads each), "
                       f"median of {top['runs']} runs after 1 warm-up per leg, time.time() around the synthesis call only "
                       f"(reference bin/resynth_mel.py:86-88)",
             "x_realtime": top["x_realtime"], "legs": legs, "host_cores": all_cores,
+            # the reference CLI's default thread count (-nt 2, bin/resynth_mel.py:120): the better of the two ports at 2 threads
+            "x_realtime_nt2": max((vv["x_realtime"] for vv in legs.values() if vv["cores"] == min(2, all_cores)), default=None),
             "reference_claim": "README.md:222-223: about 2x real time on one laptop core (TF-CPU)"}
 
 
@@ -287,12 +289,13 @@ def split_report(ress, ctxs):
     ress.update(max_abs_delta_timed(
         [(f"item {ii}", ctxs["timed_out"][ii], ctxs["mel_h"][ii], ctxs["noise_h"][ii]) for ii in ctxs["delta_items"]],
         ctxs["cfg"], ctxs["raw"], ctxs["wt"], "config-3 batch, gate and res/skip layers in split half precision"))
-    rs_ms, rs_n = ctxs["stages"]["res_skip"]              # layer 0 (float32: its rows carry the excitation too)
-    sp_ms, sp_n = ctxs["stages"]["res_skip_f16"]          # layers 1 .. L-2: three fp16 products each
+    rs_ms, rs_n = ctxs["stages"]["res_skip"]              # float32 res/skip launches, if any (layers whose image is missing)
+    sp_ms, sp_n = ctxs["stages"]["res_skip_f16"]          # layers 0 .. L-2: three fp16 products each
     dd = ctxs["dims"]
     rows = ctxs["batch"] * ctxs["frames"] * dd.steps_per_frame
     L, C, n_out = dd.wn_layers, dd.wn_channels, dd.wn_out_channels
-    n_fwd = max(1, rs_n)
+    g0_n = ctxs["stages"]["gate0"][1]                     # one launch of the folded first layer per forward
+    n_fwd = max(1, g0_n if g0_n else (sp_n + rs_n) // max(1, L - 1))
     split_ms = sp_ms / sp_n if sp_n else None
     flop = 3 * 2.0 * rows * C * (C + n_out)
     hbm = rows * (3 * C + 2 * n_out) * 4.0
@@ -746,6 +749,11 @@ def main():
                 line.update(max_abs_delta_small(ctx["eng"], ctx["cfg"], ctx["raw"], ctx["wt"], ctx["mel_h"], ctx["noise_h"], torch))
         if secondary:
             line["secondary"] = secondary
+            # the five BASELINE configs (+ the two builder secondaries) at a glance, as scalars of `config` -- the part of the
+            # line a record keeper that drops nested objects and long strings still holds
+            summary = compact_summary(line, main_res, secondary)
+            line["config"].update(summary)
+            line["config"]["all"] = dict(summary)
         if not args.no_cpu_baseline:
             cfg, raw, wt = build_engine(voice)[:3]
             line["cpu_baseline"] = cpu_baseline(cfg, raw, wt)
@@ -759,6 +767,44 @@ def main():
         if bad:
             print(f"bench.py: max|delta| out of tolerance: {', '.join(bad)}", file=sys.stderr)
             raise SystemExit(3)
+
+
+def _delta_ratios(node, path="line"):
+    """(path, max_abs_delta / its tolerance) of every max|delta| figure anywhere in the line."""
+    found = []
+    if isinstance(node, dict):
+        for kk, vv in node.items():
+            if kk in ("max_abs_delta", "max_abs_delta_small") and isinstance(node.get(kk + "_tolerance"), float):
+                found.append((f"{path}.{kk}", vv / node[kk + "_tolerance"]))
+            elif isinstance(vv, dict):
+                found.extend(_delta_ratios(vv, f"{path}.{kk}"))
+    return found
+
+
+def compact_summary(line, main_res, secondary):
+    """Short numeric keys: ms per step (per tick for config 5, device p50) of every workload of the default run, the
+    max|delta| of each against the float64 oracle, and whether all of them are inside the tolerance."""
+    def ms(name):
+        return round(secondary[name]["ms_per_step"], 4) if name in secondary else None
+
+    def dd(name):
+        vv = secondary.get(name, {}).get("max_abs_delta")
+        return float(f"{vv:.3e}") if vv is not None else None
+    ratios = _delta_ratios(line)
+    flags = [ok for _, ok in _delta_flags(line)]
+    c5a, c5b = secondary.get("config5_sp_stream64", {}), secondary.get("config5_sp_stream64_80ms", {})
+    return {"c1_ms": ms("config1_sp_b1_3s"), "c2_ms": ms("config2_sp_b1_10s"), "c3_ms": round(main_res["ms_per_step"], 4),
+            "c4_ms": ms("config4_vo_256utt"),
+            "c5_80ms_tick_ms": round(c5b["tick_ms_device_p50"], 4) if c5b else None,
+            "c5_80ms_tick_host_ms": round(c5b["tick_ms_host_inclusive_p50"], 4) if c5b else None,
+            "c5_100ms_tick_ms": round(c5a["tick_ms_device_p50"], 4) if c5a else None,
+            "c5_100ms_tick_host_ms": round(c5a["tick_ms_host_inclusive_p50"], 4) if c5a else None,
+            "split_f16_ms": ms("config3_split_f16"), "blocks2_ms": ms("variant_blocks2"),
+            "c1_delta": dd("config1_sp_b1_3s"), "c2_delta": dd("config2_sp_b1_10s"),
+            "c3_delta": float(f"{line['max_abs_delta']:.3e}") if "max_abs_delta" in line else None,
+            "c4_delta": dd("config4_vo_256utt"), "split_f16_delta": dd("config3_split_f16"),
+            "deltas_ok": bool(flags) and all(ok is True for ok in flags), "deltas_checked": len(flags),
+            "worst_delta_over_tol": round(max(rr for _, rr in ratios), 4) if ratios else None}
 
 
 def _delta_flags(node, path="line"):

@@ -1416,8 +1416,8 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                 // Like the gate kernels' block shape this follows the launch size only under the default policy: a pinned
                 // form (MBX_CONV_DIRECT, MBX_CONV_F23, batch_invariant, streams) pins the kernel, so results do not depend on the batch they ran in.
                 bool done = false;
-                // opt-in split half precision (mbx_config.wn_precision): every launch size, the layers whose input is a gate
-                // output alone (not layer 0 with the folded start convolution, whose rows carry the excitation as well)
+                // opt-in split half precision (mbx_config.wn_precision): every launch size, every layer whose split image the
+                // host supplied (layer 0 with the folded start convolution too: its rows [a0 | x'] have the image *.fold_start_f16)
                 const DevTensor *f16w = hd->split_f16 ? find(hd, "wn.res_skip_" + ls + (ext ? ".fold_start_f16" : ".fold_f16")) : nullptr;
                 if (f16w && f16w->count == (long long)((cin_l + 31) / 32) * 12 * 1024) {
                     mbx::ConvArgs rh = r;
@@ -1666,6 +1666,9 @@ static mbx_status calibrate_run(mbx_handle *hd, const float *mel, const int32_t 
     auto done = [&](mbx_status st) {
         (void)hipFree(audio_dev);
         hd->profiling = was_profiling;
+        // the calibration forwards filled the stage table with pointers into their own (temporary, or by now overwritten)
+        // workspace and strides of the calibration batch: mbx_stage answers "unknown stage" until the caller's next forward
+        hd->stages.clear();
         if (st != MBX_OK) {
             set_form(hd, form_before);
             hd->split_f16 = split_req;

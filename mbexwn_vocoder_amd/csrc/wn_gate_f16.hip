@@ -284,14 +284,18 @@ bool launch_wn_gate_f16(const ConvArgs &a, hipStream_t stream) {
                     (!a.h_split || (a.h_split_ld % 8 == 0 && a.h_split_ld >= a.channels && a.h_split_bstride % 4 == 0 &&
                                     (uintptr_t)a.h_split % 16 == 0));
     if (!ok) return false;
-    static bool attr_set = false;
+    // the attribute belongs to the (function, device) pair: a process may hold handles on several devices
+    static unsigned long long attr_devices = 0;       // bit d: set for device d (devices >= 64: set at every launch)
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const bool attr_set = dev >= 0 && dev < 64 && ((attr_devices >> dev) & 1ull);
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(wn_gate_f16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GH_LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(wn_gate_f16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GH_LDS_FLOATS * (int)sizeof(float)) != hipSuccess)
             return false;
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_devices |= 1ull << dev;
     }
     ConvArgs r = a;
     r.n_tiles = (a.channels + 31) / 32;

@@ -239,8 +239,18 @@ def experiment_overrides():
     (the library itself reads no environment variable): MBX_WINOGRAD=0|2|4|44 -> conv_form direct / f23 / f43 / f43 +
     batch_invariant, MBX_FOLD_SKIP=0 / MBX_FOLD_START=0 -> keep_skip / keep_start, MBX_WG_SMALL=0|1 -> tune_gate_shape 1|2,
     MBX_RV_TILES=n -> tune_resskip_wave_tiles (0 = never), MBX_RV_SPLIT=1|2|3 -> tune_resskip_split.  Only consulted for
-    policy arguments the caller left unset; every variable in effect is named on stderr."""
+    policy arguments the caller left unset, and only when the process opts in with MBX_EXPERIMENT=1 (the experiment scripts
+    do): a stray MBX_WINOGRAD in a user's shell must not change the numerics of a default engine.  Every variable in effect
+    -- or ignored for want of the opt-in -- is named on stderr."""
     env, out = os.environ, {}
+    knobs = ("MBX_WINOGRAD", "MBX_FOLD_SKIP", "MBX_FOLD_START", "MBX_WG_SMALL", "MBX_RV_TILES", "MBX_RV_SPLIT")
+    if env.get("MBX_EXPERIMENT", "0") != "1":
+        stray = [kk for kk in knobs if kk in env]
+        if stray:
+            import sys
+            print(f"mbexwn_vocoder_amd: ignoring {' '.join(f'{kk}={env[kk]}' for kk in stray)} (experiment variables need "
+                  f"MBX_EXPERIMENT=1)", file=sys.stderr)
+        return out
     if "MBX_WINOGRAD" in env:
         mode = int(env["MBX_WINOGRAD"])
         out["conv_form"] = {0: "direct", 2: "f23", 4: "f43", 44: "f43"}[mode]
@@ -261,8 +271,7 @@ def experiment_overrides():
         out["tune"] = tune
     if out:
         import sys
-        names = [kk for kk in ("MBX_WINOGRAD", "MBX_FOLD_SKIP", "MBX_FOLD_START", "MBX_WG_SMALL", "MBX_RV_TILES", "MBX_RV_SPLIT")
-                 if kk in env]
+        names = [kk for kk in knobs if kk in env]
         print(f"mbexwn_vocoder_amd: experiment variables in effect: {' '.join(f'{kk}={env[kk]}' for kk in names)}",
               file=sys.stderr)
     return out

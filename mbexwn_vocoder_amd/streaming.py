@@ -151,6 +151,13 @@ class StreamingSynthesizer:
         other schedule runs launch by launch (still with the carried sub-bands, per-layer state and phase)."""
         self.engine = engine
         self.dims = engine.dims
+        # stream windows run the float32 F(2,3) / direct gate kernels whatever the handle's precision: an engine with the
+        # opt-in split half precision would synthesise offline with other kernels than its streams, and the documented
+        # bit-equality between a stream and the offline synthesis would silently not hold
+        info = engine.conv_form_info()
+        if info.get("split_f16_layers", 0) > 0 or info.get("split_f16_gate_layers", 0) > 0:
+            raise ValueError("StreamingSynthesizer needs a float32 engine: this one runs its whole-item forwards in split half "
+                             "precision (precision='split_f16'), streams would not be bit-equal to its offline synthesis")
         self.schedule = [int(chunk_frames)] if np.isscalar(chunk_frames) else [int(cc) for cc in chunk_frames]
         if not self.schedule or min(self.schedule) < 1:
             raise ValueError("chunk_frames must be a positive int or a non-empty schedule of positive ints")

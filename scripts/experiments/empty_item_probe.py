@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One-off probe (GPU box): items of zero frames inside a batch, every convolution form."""
 import os, sys
+os.environ["MBX_EXPERIMENT"] = "1"      # opt in to the MBX_* experiment variables (engine.experiment_overrides)
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))

@@ -251,10 +251,8 @@ PATCHES = {
         ('            if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res;',
          '            if (ch_ok && row < rows && res.x == 123.456f) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res;'),
     ],
-    # mbx_api.hip: the VTF-net stays on the caller's stream (round-4 A/B of the side stream)
-    'noside': [
-        ('constexpr long long SIDE_STREAM_FRAMES = 4096;', 'constexpr long long SIDE_STREAM_FRAMES = 1LL << 40;'),
-    ],
+    # (the round-4 'noside' A/B of the VTF-net side stream patched a constant of commit 42f4fb7; the side stream was removed
+    # with ab37db2, so the A/B is reproduced from that commit: git checkout 42f4fb7 -- mbexwn_vocoder_amd/csrc/mbx_api.hip)
     # stft_filter.hip: the block-per-frame kernel at fft_size 2048 as well (round-4 A/B of the wave-per-frame kernel)
     'oldstft': [
         ('    if (c.fft_size == 2 * SW_NC && c.win <= c.fft_size && c.win % 2 == 0) {', '    if (false) {'),

@@ -3,6 +3,7 @@
 (MBX_WINOGRAD=0), which address differently; the two must agree over the whole length.  Not part of the test suite (tens of
 GB of workspace); tests/test_gpu_parity.py::test_item_longer_than_4_gib_of_activation_rows is the permanent, smaller case."""
 import os
+os.environ["MBX_EXPERIMENT"] = "1"      # opt in to the MBX_* experiment variables (engine.experiment_overrides)
 import sys
 
 import numpy as np

@@ -2,6 +2,7 @@
 """One-off soak (GPU box): long-running streams (ring wrap-arounds, input-row drops, thousands of graph replays) against the
 offline synthesis of the same utterances in the streams' convolution form: bit equality is the criterion."""
 import os
+os.environ["MBX_EXPERIMENT"] = "1"      # opt in to the MBX_* experiment variables (engine.experiment_overrides)
 import sys
 import time
 

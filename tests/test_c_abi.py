@@ -58,7 +58,7 @@ def test_policy_fields_and_experiment_variables(monkeypatch, capsys):
     arguments -- or, for the experiment scripts, from the MBX_* variables, naming them on stderr."""
     from helpers import build_case
     cfg, raw, wt = build_case("SPEECH", {})
-    for kk in ("MBX_WINOGRAD", "MBX_FOLD_SKIP", "MBX_FOLD_START", "MBX_WG_SMALL", "MBX_RV_TILES", "MBX_RV_SPLIT"):
+    for kk in ("MBX_WINOGRAD", "MBX_FOLD_SKIP", "MBX_FOLD_START", "MBX_WG_SMALL", "MBX_RV_TILES", "MBX_RV_SPLIT", "MBX_EXPERIMENT"):
         monkeypatch.delenv(kk, raising=False)
     cc, _ = engine.make_config(cfg, wt)
     assert (cc.wn_conv_form, cc.batch_invariant, cc.wn_keep_skip, cc.wn_keep_start, cc.tune_gate_shape) == (0, 0, 0, 0, 0)
@@ -68,6 +68,11 @@ def test_policy_fields_and_experiment_variables(monkeypatch, capsys):
     monkeypatch.setenv("MBX_WINOGRAD", "44")
     monkeypatch.setenv("MBX_FOLD_START", "0")
     monkeypatch.setenv("MBX_WG_SMALL", "1")
+    monkeypatch.delenv("MBX_EXPERIMENT", raising=False)
+    cc, _ = engine.make_config(cfg, wt)                                # without the opt-in the variables are ignored, loudly
+    assert (cc.wn_conv_form, cc.batch_invariant, cc.wn_keep_start, cc.tune_gate_shape) == (0, 0, 0, 0)
+    assert "ignoring MBX_WINOGRAD=44" in capsys.readouterr().err
+    monkeypatch.setenv("MBX_EXPERIMENT", "1")
     cc, _ = engine.make_config(cfg, wt)
     assert (cc.wn_conv_form, cc.batch_invariant, cc.wn_keep_start, cc.tune_gate_shape) == (3, 1, 1, 2)
     assert "MBX_WINOGRAD=44" in capsys.readouterr().err

@@ -168,6 +168,28 @@ def test_calibrate_on_caller_data(torch):
     assert strict.conv_form_info()["form"] == "direct" and strict.conv_form_info()["calibrated"] == 1
 
 
+def test_stage_table_is_empty_after_a_calibration(torch):
+    """The calibration forwards of mbx_create / mbx_calibrate run on a workspace of their own (or overwrite the caller's):
+    mbx_stage must not hand out pointers into it -- it answers "unknown stage" until the caller's next forward."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    cfg, raw, wt = build_case("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3})
+    eng = MBExWNEngine(cfg, raw, wt)                           # conv_form "auto": calibrated at creation
+    assert eng.conv_form_info()["calibrated"] == 1
+    eng._last_shape = (1, 8)
+    with pytest.raises(Exception, match="unknown stage"):
+        eng.stage("f0")
+    mel, noise = synthetic_inputs(5, 2, 24)
+    eng.forward(dev(torch, mel), noise=dev(torch, noise))
+    assert eng.stage("f0").shape == (2, 24 * eng.dims.pulse_per_frame)
+    eng.calibrate(dev(torch, mel), noise=dev(torch, noise))
+    with pytest.raises(Exception, match="unknown stage"):
+        eng.stage("f0")
+    with pytest.raises(ValueError, match="float32 engine"):    # streams of a split-precision engine would not match its offline runs
+        from mbexwn_vocoder_amd.streaming import StreamingSynthesizer
+        cfg2, raw2, wt2 = build_case("SING", {})
+        StreamingSynthesizer(MBExWNEngine(cfg2, raw2, wt2, precision="split_f16"), chunk_frames=8)
+
+
 def test_handle_without_images_runs_the_direct_form(torch):
     from mbexwn_vocoder_amd.engine import MBExWNEngine
     cfg, raw, wt = build_case("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 3})

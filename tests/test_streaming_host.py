@@ -70,6 +70,9 @@ class _FakeEngine:
     def layer_state_info(self):
         return 0, 0, 0
 
+    def conv_form_info(self):
+        return {"split_f16_layers": 0, "split_f16_gate_layers": 0}
+
     def forward(self, mel, n_frames=None, noise=None, stream_state=None, **_):
         import torch
         hop, spf = self.dims.hop_size, self.dims.steps_per_frame
