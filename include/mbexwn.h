@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MBX_ABI_VERSION 8
+#define MBX_ABI_VERSION 9
 #define MBX_MAX_SUBNET_OPS 32
 #define MBX_MAX_WN_LAYERS 64
 #define MBX_MAX_PRECOND 8
@@ -92,6 +92,8 @@ typedef struct {
  * Streaming calls (state_in / state_out) run F(2,3) unless the handle's form is the direct one. */
 #define MBX_PRECISION_F32 0
 #define MBX_PRECISION_SPLIT_F16 1
+#define MBX_F0_ACC_F64 0
+#define MBX_F0_ACC_F32 1
 #define MBX_CONV_AUTO 0
 #define MBX_CONV_DIRECT 1
 #define MBX_CONV_F23 2
@@ -214,7 +216,14 @@ typedef struct {
      * measures the handle in split precision against the float32 direct form on the calibration input and keeps the split
      * kernels only within the calibration threshold (mbx_conv_form_info.err_split / split_rejected) */
     int32_t wn_precision;
-    int32_t reserved7[1];
+    /* ABI 9 (the former reserved word; 0 keeps its meaning "default"): arithmetic of the F0-net, the one stage whose output
+     * the graph integrates (phase = running sum of f0 / pulse_rate, reference tf_wavetable.py:429-492), so that its rounding
+     * moves every pulse behind it.  MBX_F0_ACC_F64 (0, default): float32 inputs, weights and hidden layers as in the
+     * reference, every contraction accumulated in float64 (v_mfma_f64_16x16x4_f64) and rounded to float32 once; the head
+     * (final 1x1 convolution, interpolation to the pulse rate, final activation, map onto [f0_min, f0_max]; reference
+     * custom_pulsed_generator.py:126-146, 773-791) one float64 kernel.  MBX_F0_ACC_F32 (1): the float32 kernels of the
+     * other mel-rate sub-nets (ABI <= 8 behaviour; contour error ~1e-3 Hz against ~2e-5 Hz) */
+    int32_t f0_accumulate;
 } mbx_config;
 
 /* A named HOST tensor handed over at creation (weights already weight-norm folded, tables).

@@ -727,6 +727,194 @@ __device__ __forceinline__ void conv1d_small_tile(const ConvArgs &p, int bx, int
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The F0-net's convolutions in float64 (ConvArgs::precise; mbx_config.f0_accumulate, the default).
+// The F0 contour is the one quantity of the graph that is INTEGRATED (phase = running float32 sum of f0 / pulse_rate,
+// reference tf_wavetable.py:429-492): a contour that differs from the exact one in the last bit of a few samples sends the
+// float32 phase chain down another rounding path, the difference stays for the rest of the utterance and moves every pulse
+// behind it -- measured end to end it, not the WaveNet, spent the float32 error budget, and the error grew with the length
+// of the utterance (scripts/experiments/f0_error_probe.py).  The net is mel-rate and < 1 % of the
+// work, so it runs on v_mfma_f64_16x16x4_f64.  Three operand modes of one tile:
+//   x float32, W float32           float64 accumulation only (sub-net shapes outside the full-float64 pattern, handles
+//                                  without the *.w64 tensors): one rounding to float32 per output
+//   x float32, W float64 (w64)     first layer of the full-float64 chain: reads the mel input, writes float64 (out64)
+//   x float64 (x64), W float64     hidden layers of the chain
+// The float64 weights are the exact weight-norm fold g v / |v| (host, engine.tensor_table "<layer>.w64").
+// Same skeleton as conv1d_small_tile: operands straight from L2, K in groups of 16 channels of a tap split over the block's
+// four waves, the quarters summed through LDS in wave order -- every output is summed in the same order whatever RT x CT, so a
+// padded batch stays bit-identical to one-at-a-time runs.  Lane (r = lane & 15, kq = lane >> 4) loads A[r][16g + 4kq .. + 3]
+// for four MFMA steps (step s contracts the channels 16g + 4kq' + s, kq' = 0..3) and W[16g + 4kq + s][col r].
+// C/D layout of the f64 MFMA (MI355X_MICROARCH.md): col = lane & 15, row = (lane >> 4) + 4 * reg.
+// Needs cin % 4 == 0 and 16-byte aligned rows (checked by the launcher; other shapes keep the float32 kernels).
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+template <bool F64> struct F64Operand;
+template <> struct F64Operand<false> {
+    typedef float scalar;
+    typedef float4 quad;
+};
+template <> struct F64Operand<true> {
+    typedef double scalar;
+    typedef double4 quad;
+};
+
+template <int RT, int CT, bool XF64, bool WF64>
+__device__ __forceinline__ void conv1d_f64_tile(const ConvArgs &p, int bx, int by, int b, double *red) {
+    typedef typename F64Operand<XF64>::scalar xs_t;
+    typedef typename F64Operand<XF64>::quad xq_t;
+    typedef typename F64Operand<WF64>::scalar ws_t;
+    const int rows = item_rows(p.n_frames, b, p.rows_per_frame, p.max_rows);
+    const int m0 = bx * 16 * RT;
+    if (m0 >= rows) return;
+    const int n0 = by * 16 * CT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const xs_t *xb = (XF64 ? reinterpret_cast<const xs_t *>(p.x64) : reinterpret_cast<const xs_t *>(p.x)) + (long long)b * p.x_bstride;
+    const ws_t *wbase = WF64 ? reinterpret_cast<const ws_t *>(p.w64) : reinterpret_cast<const ws_t *>(p.w);
+    const int groups_per_tap = (p.cin + 15) >> 4;          // groups of 16 input channels (the last one of a tap may be short)
+    const int n_groups = p.ks * groups_per_tap;
+    const int g_begin = (n_groups * wave) / 4, g_end = (n_groups * (wave + 1)) / 4;
+    bool col_ok[CT];
+    const ws_t *wcol[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int col = n0 + 16 * ct + r16;
+        col_ok[ct] = col < p.cout;
+        wcol[ct] = wbase + min(col, p.cout - 1);
+    }
+    f64x4 acc[RT][CT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[rt][ct][r] = 0.0;
+
+    // requests only (clamped addresses); the masks follow when the batch is consumed (see conv1d_small_tile)
+    auto load_group = [&](int g, xq_t (&av)[RT], ws_t (&bv)[CT][4]) {
+        const int tap = g / groups_per_tap;
+        const int ci = min((g - tap * groups_per_tap) * 16 + 4 * kq, p.cin - 4);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int src = map_row(m0 + 16 * rt + r16 - p.pad_l + tap * p.dil, rows, p.pad_mode);
+            av[rt] = *reinterpret_cast<const xq_t *>(xb + (long long)max(src, 0) * p.ldx + ci);
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const ws_t *wk = wcol[ct] + (long long)(tap * p.cin + ci) * p.cout;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) bv[ct][st] = wk[(long long)st * p.cout];
+        }
+    };
+    auto mask_group = [&](int g, xq_t (&av)[RT]) {
+        const int tap = g / groups_per_tap;
+        const bool ci_ok = (g - tap * groups_per_tap) * 16 + 4 * kq < p.cin;      // short last group of a tap
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const bool ok = ci_ok && map_row(m0 + 16 * rt + r16 - p.pad_l + tap * p.dil, rows, p.pad_mode) >= 0;
+            av[rt].x = ok ? av[rt].x : (xs_t)0;
+            av[rt].y = ok ? av[rt].y : (xs_t)0;
+            av[rt].z = ok ? av[rt].z : (xs_t)0;
+            av[rt].w = ok ? av[rt].w : (xs_t)0;
+        }
+    };
+    // groups in flight beside the one being multiplied: a 16 x 16 tile spends 4 MFMAs (256 cycles) on a group, an L2 round
+    // trip is several times that; a 32 x 32 tile 16 MFMAs
+    constexpr int DEPTH = RT * CT == 1 ? (XF64 ? 3 : 4) : (XF64 ? 1 : 2);
+    xq_t a_cur[DEPTH][RT], a_nxt[DEPTH][RT];
+    ws_t b_cur[DEPTH][CT][4], b_nxt[DEPTH][CT][4];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (g_begin + d < g_end) load_group(g_begin + d, a_cur[d], b_cur[d]);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (g_begin + d < g_end) mask_group(g_begin + d, a_cur[d]);
+    for (int g = g_begin; g < g_end; g += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+            if (g + DEPTH + d < g_end) load_group(g + DEPTH + d, a_nxt[d], b_nxt[d]);
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (g + d < g_end) {
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const xs_t af = st == 0 ? a_cur[d][rt].x : st == 1 ? a_cur[d][rt].y : st == 2 ? a_cur[d][rt].z : a_cur[d][rt].w;
+                        const double a64 = (double)af;
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct)
+                            acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a64, (double)b_cur[d][ct][st], acc[rt][ct], 0, 0, 0);
+                    }
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+            if (g + DEPTH + d < g_end) mask_group(g + DEPTH + d, a_nxt[d]);
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) a_cur[d][rt] = a_nxt[d][rt];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int st = 0; st < 4; ++st) b_cur[d][ct][st] = b_nxt[d][ct][st];
+        }
+    }
+    // the four K quarters: every wave parks its partial tiles in LDS, tile t is finished by wave t % 4, which adds the
+    // quarters in wave order (and, writing float32, rounds ONCE)
+    auto slot = [&](int w, int tile, int r) { return red + (((w * RT * CT + tile) * 4 + r) * 64 + lane); };
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int tile = rt * CT + ct;
+            if (wave != (tile & 3)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) *slot(wave, tile, r) = acc[rt][ct][r];
+            }
+        }
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int tile = rt * CT + ct;
+            if (wave != (tile & 3) || !col_ok[ct]) continue;
+            const int col = n0 + 16 * ct + r16;
+            const double bias = p.bias ? (double)p.bias[col] : 0.0;
+            const double slope = (double)(p.alpha ? p.alpha[col] : p.leaky);
+            const bool act = p.alpha != nullptr || p.use_leaky;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + 16 * rt + kq + 4 * r;
+                if (row < rows) {
+                    double q[4];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) q[w] = w == (tile & 3) ? acc[rt][ct][r] : *slot(w, tile, r);
+                    double v = ((q[0] + q[1]) + q[2]) + q[3] + bias;
+                    if (act) v = v > 0.0 ? v : slope * v;
+                    const long long at = (long long)b * p.out_bstride + (long long)row * p.ldo + col;
+                    if (p.out64) p.out64[at] = v;
+                    else p.out[at] = (float)v;
+                }
+            }
+        }
+}
+
+// operand mode of a float64 member: wave-uniform (kernel arguments)
+template <int RT, int CT>
+__device__ __forceinline__ void conv1d_f64_dispatch(const ConvArgs &p, int bx, int by, int b, double *red) {
+    if (p.x64) conv1d_f64_tile<RT, CT, true, true>(p, bx, by, b, red);
+    else if (p.w64) conv1d_f64_tile<RT, CT, false, true>(p, bx, by, b, red);
+    else conv1d_f64_tile<RT, CT, false, false>(p, bx, by, b, red);
+}
+
+__global__ __launch_bounds__(256) void conv1d_f64_kernel(ConvArgs p) {
+    __shared__ double red[4 * 4 * 64];
+    conv1d_f64_dispatch<1, 1>(p, blockIdx.x, blockIdx.y, blockIdx.z, red);
+}
+
 __global__ __launch_bounds__(256) void conv1d_small_kernel(ConvArgs p) {
     __shared__ float red[4 * 16 * 64];
     conv1d_small_tile<1, 1>(p, blockIdx.x, blockIdx.y, blockIdx.z, red);
@@ -743,13 +931,14 @@ struct SmallConvGroup {
 
 template <int RT, int CT>
 __global__ __launch_bounds__(256) void conv1d_small_group_kernel(SmallConvGroup g) {
-    __shared__ float red[4 * RT * CT * 16 * 64];
+    __shared__ __attribute__((aligned(16))) float red[4 * RT * CT * 16 * 64];      // (the f64 tile needs 4 * 4 * 64 doubles of it)
     const int id = blockIdx.x;
     const int k = (id >= g.start[1]) + (id >= g.start[2]);
     const int local = id - g.start[k];
     const int bx = local % g.gx[k];
     const int t = local / g.gx[k];
-    conv1d_small_tile<RT, CT>(g.c[k], bx, t % g.gy[k], t / g.gy[k], red);
+    if (g.c[k].precise) conv1d_f64_dispatch<1, 1>(g.c[k], bx, t % g.gy[k], t / g.gy[k], reinterpret_cast<double *>(red));   // 16 x 16 tiles
+    else conv1d_small_tile<RT, CT>(g.c[k], bx, t % g.gy[k], t / g.gy[k], red);
 }
 
 // The same convolutions at large launches (batch 16 x 10 s: 12 800 rows): an LDS-staged tile kernel with the summation
@@ -927,7 +1116,8 @@ __global__ __launch_bounds__(256, RT <= 2 ? 3 : 2) void conv1d_mel_group_kernel(
     const int local = id - g.start[k];
     const int bx = local % g.gx[k];
     const int t = local / g.gx[k];
-    conv1d_mel_tile<RT>(g.c[k], bx, t % g.gy[k], t / g.gy[k], lds);
+    if (g.c[k].precise) conv1d_f64_dispatch<2, 2>(g.c[k], bx, t % g.gy[k], t / g.gy[k], reinterpret_cast<double *>(lds));     // 32 x 32 tiles
+    else conv1d_mel_tile<RT>(g.c[k], bx, t % g.gy[k], t / g.gy[k], lds);
 }
 
 template <int WM, int WN, int TM, int TN, int EPI, int BK = 16>
@@ -964,7 +1154,14 @@ static bool launch_dma(const ConvArgs &a, hipStream_t stream) {
     return true;
 }
 
+static bool f64_conv_eligible(const ConvArgs &a) {
+    // (the launch sequence only sets x64 / w64 / out64 when the shape is regular: rows of 4 k channels, 32-byte aligned)
+    if (a.x64) return a.precise && a.w64 && a.cin % 4 == 0 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 && (uintptr_t)a.x64 % 32 == 0;
+    return a.precise && a.cin % 4 == 0 && a.cin >= 4 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 && (uintptr_t)a.x % 16 == 0;
+}
+
 static bool small_conv_eligible(const ConvArgs &a) {
+    if (f64_conv_eligible(a)) return true;              // a member of the shared mel-rate launches as well
     // no row limit: the mel-rate convolutions then sum K in the same order at every launch size, which keeps a padded
     // batch bit-identical to one-at-a-time runs (the F0 contour feeds the phase accumulator: rounding there is audible
     // in the last bits everywhere downstream)
@@ -1000,8 +1197,11 @@ void launch_conv1d_group(const ConvArgs *convs, int n, hipStream_t stream) {
         g.start[k] = total;
         if (k < n_small) {
             g.c[k] = convs[small[k]];
-            g.gx[k] = (g.c[k].max_rows + tile_m - 1) / tile_m;
-            g.gy[k] = (g.c[k].cout + tile_n - 1) / tile_n;
+            g.c[k].precise = f64_conv_eligible(g.c[k]) ? 1 : 0;
+            // float64-accumulating members (the F0-net): 16 x 16 tiles in the small launches, 32 x 32 in the large ones
+            const int tm = g.c[k].precise ? (big ? 32 : 16) : tile_m, tn = g.c[k].precise ? (big ? 32 : 16) : tile_n;
+            g.gx[k] = (g.c[k].max_rows + tm - 1) / tm;
+            g.gy[k] = (g.c[k].cout + tn - 1) / tn;
             total += g.gx[k] * g.gy[k] * g.c[k].batch;
         } else {
             g.c[k] = convs[small[0]];
@@ -1033,6 +1233,10 @@ void launch_conv1d(const ConvArgs &a, int epilogue, hipStream_t stream) {
         ConvArgs r = a;
         r.acc_preloaded = 1;
         launch_cfg<2, 2, 1, 2, EPI_RESSKIP>(r, stream);
+    } else if (f64_conv_eligible(a)) {
+        // F0-net convolution on its own (float64 accumulation): split-K 16x16 tiles at every size
+        dim3 grid((a.max_rows + 15) / 16, (a.cout + 15) / 16, a.batch);
+        hipLaunchKernelGGL(conv1d_f64_kernel, grid, dim3(256), 0, stream, a);
     } else if (small_conv_eligible(a)) {
         // mel-rate sub-nets at small batch: latency bound, split-K 32x32 tiles
         dim3 grid((a.max_rows + 31) / 32, (a.cout + 31) / 32, a.batch);

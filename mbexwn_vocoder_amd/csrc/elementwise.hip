@@ -52,6 +52,85 @@ void launch_lin_interp(const float *x, long long x_bstride, const int *n_frames,
                        rows_per_frame, max_rows, channels, up, w0, w1, act, scale, offset, y, y_bstride);
 }
 
+// Head of the F0-net in float64 (mbx_config.f0_accumulate, the default): final 1x1 convolution cin -> 1, linear interpolation
+// to the pulse rate, final activation and the affine map onto [f_min, f_max] -- reference custom_pulsed_generator.py:126-146
+// (final layer, missing up-sampling factor, final activation), :773-791 (generate_f0), custom_AE_layers.py:91-99 (soft_sigmoid).
+// The contour feeds the phase integrator: every step here is float64 on the float32 hidden layer and the float32 constants
+// (weights, bias, the interpolator's float32 weight vectors), rounded to float32 ONCE.  Block = 64 rows of the hidden layer
+// (+ the row behind them for the interpolation): four threads per row sum every fourth channel each in a fixed order.
+__device__ __forceinline__ double apply_act64(double x, int act) {
+    switch (act) {
+        case 1: return 0.5 + 0.5 * x / (1.0 + fabs(x));
+        case 2: return tanh(x);
+        case 3: return 1.0 / (1.0 + exp(-x));
+        case 4: return x / (1.0 + fabs(x));
+        case 5: return x / (1.0 + sqrt(fabs(x)));
+        case 6: return exp(x);
+        case 7: return fmax(x, 0.0);
+        default: return x;
+    }
+}
+
+constexpr int F0H_ROWS = 64;
+
+template <typename XT, typename WT>
+__global__ __launch_bounds__(256) void f0_head_kernel(const XT *x, long long x_bstride, int cin, const int *n_frames,
+                                                      int rows_per_frame, int max_rows, const WT *w, const float *bias,
+                                                      int up, const float *w0, const float *w1, int act, float scale,
+                                                      float offset, float *y, long long y_bstride) {
+    __shared__ double xs[F0H_ROWS + 1];
+    const int b = blockIdx.y;
+    const int rows = item_rows(n_frames, b, rows_per_frame, max_rows);
+    const int m0 = blockIdx.x * F0H_ROWS;
+    if (m0 >= rows) return;
+    const XT *xb = x + (long long)b * x_bstride;
+    const int tid = threadIdx.x, part = tid & 3;
+    auto dot = [&](int row) {
+        const XT *xr = xb + (long long)min(row, rows - 1) * cin;
+        double s = 0.0;
+        for (int c = part; c < cin; c += 4) s = fma((double)xr[c], (double)w[c], s);
+        // (s0 + s1) + (s2 + s3) over the row's four threads
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        return s + (bias ? (double)bias[0] : 0.0);
+    };
+    const double mine = dot(m0 + (tid >> 2));
+    if (part == 0) xs[tid >> 2] = mine;
+    if (tid < 64) {                                   // (whole wave: the shuffles need their partners)
+        const double last = dot(m0 + F0H_ROWS);
+        if (tid == 0) xs[F0H_ROWS] = last;
+    }
+    __syncthreads();
+    const int n_here = min(F0H_ROWS, rows - m0);
+    float *yb = y + (long long)b * y_bstride;
+    for (int i = tid; i < n_here * up; i += 256) {
+        const int t = i / up, u = i - t * up;
+        const int tn = min(m0 + t + 1, rows - 1) - m0;
+        double v = xs[t] * (double)w0[u] + xs[tn] * (double)w1[u];
+        v = apply_act64(v, act) * (double)scale + (double)offset;
+        yb[(long long)(m0 + t) * up + u] = (float)v;
+    }
+}
+
+void launch_f0_head(const float *x32, const double *x64, long long x_bstride, int cin, const int *n_frames, int rows_per_frame,
+                    int max_rows, int batch, const float *w32, const double *w64, const float *bias, int up, const float *w0,
+                    const float *w1, int act, float scale, float offset, float *y, long long y_bstride, hipStream_t stream) {
+    if (max_rows <= 0 || batch <= 0) return;
+    const dim3 grid((max_rows + F0H_ROWS - 1) / F0H_ROWS, batch);
+    if (x64 && w64)
+        hipLaunchKernelGGL((f0_head_kernel<double, double>), grid, dim3(256), 0, stream, x64, x_bstride, cin, n_frames,
+                           rows_per_frame, max_rows, w64, bias, up, w0, w1, act, scale, offset, y, y_bstride);
+    else if (x64)
+        hipLaunchKernelGGL((f0_head_kernel<double, float>), grid, dim3(256), 0, stream, x64, x_bstride, cin, n_frames,
+                           rows_per_frame, max_rows, w32, bias, up, w0, w1, act, scale, offset, y, y_bstride);
+    else if (w64)
+        hipLaunchKernelGGL((f0_head_kernel<float, double>), grid, dim3(256), 0, stream, x32, x_bstride, cin, n_frames,
+                           rows_per_frame, max_rows, w64, bias, up, w0, w1, act, scale, offset, y, y_bstride);
+    else
+        hipLaunchKernelGGL((f0_head_kernel<float, float>), grid, dim3(256), 0, stream, x32, x_bstride, cin, n_frames,
+                           rows_per_frame, max_rows, w32, bias, up, w0, w1, act, scale, offset, y, y_bstride);
+}
+
 __global__ void activation_kernel(const float *x, long long x_bstride, const int *n_frames, int rows_per_frame,
                                   int max_rows, int channels, int act, float scale, float offset, float *y,
                                   long long y_bstride) {

@@ -89,6 +89,8 @@ struct mbx_handle {
     // derived
     int f0_time_factor = 1, vtf_time_factor = 1;
     long long subnet_buf_per_frame = 0;   // floats per frame of one ping-pong buffer
+    bool f0_full64 = false;               // mbx_config.f0_accumulate == MBX_F0_ACC_F64 and the F0-net has the shape (conv [prelu | leaky])* head
+                                          // with its "<layer>.w64" tensors: float64 weights and hidden layers (f0_chain_is_full64)
     std::vector<mbx_subnet_op> cond_ops;  // pre-conditioning convolutions + the conditioning layer (empty: conditioning disabled)
     long long cond_buf_per_frame = 0;     // floats per frame of a ping-pong buffer of that chain (0: no pre-conditioning layers)
     // several WaveNet blocks (mbx_config.n_wn_blocks > 1; empty: the single-block path)
@@ -151,6 +153,7 @@ mbx_status analyse_subnet(const mbx_subnet_op *ops, int n_ops, int cin, long lon
 
 struct Workspace {
     float *mel_norm, *nm_a, *nm_b;
+    double *f0h0, *f0h1;   // float64 hidden layers of the F0-net (mbx_handle::f0_full64)
     float *sub0, *sub1, *sub2, *sub3, *sub4, *sub5, *f0_wide, *f0, *cum, *chunk_last, *pulse, *cond, *h, *a, *skip, *wn_out, *sub, *exc, *ceps, *frames;
     float *mb_h, *mb_a, *mb_skip, *mb_y0, *mb_y1, *mb_cond[MBX_MAX_WN_BLOCKS];   // several WaveNet blocks only
     float *pulse_ana;   // PQMF analysis of the pulse signal (pulse_pqmf_taps > 0): the WaveNet's excitation rows
@@ -179,6 +182,8 @@ Workspace carve(const mbx_handle *hd, char *base, int B, int T) {
     w.sub1 = take(BT * hd->subnet_buf_per_frame);
     w.sub2 = take(BT * hd->subnet_buf_per_frame);   // VTF-net ping-pong (its convolutions share launches with the F0-net's)
     w.sub3 = take(BT * hd->subnet_buf_per_frame);
+    w.f0h0 = reinterpret_cast<double *>(take(hd->f0_full64 ? 2 * BT * hd->subnet_buf_per_frame : 0));
+    w.f0h1 = reinterpret_cast<double *>(take(hd->f0_full64 ? 2 * BT * hd->subnet_buf_per_frame : 0));
     w.sub4 = take(BT * hd->cond_buf_per_frame);     // pre-conditioning layers (usually none: zero floats)
     w.sub5 = take(BT * hd->cond_buf_per_frame);
     // an F0-net with a bare ["L", up] entry runs at a multiple of the pulse rate and is cut to it (reference
@@ -238,6 +243,38 @@ mbx::ConvArgs conv_args(const float *x, long long x_bstride, int ldx, const int 
     return a;
 }
 
+// Head of the F0-net: [conv 1x1 -> 1 channel] [lin] ([act]) at the end of the op list (reference
+// custom_pulsed_generator.py:126-146): one float64 kernel (launch_f0_head) under mbx_config.f0_accumulate == MBX_F0_ACC_F64
+bool is_f0_head(const mbx_subnet_op *ops, int n_ops, int i) {
+    const int n_tail = n_ops - i;
+    return ops[i].kind == MBX_OP_CONV && ops[i].ks == 1 && ops[i].cout == 1 && ops[i].up == 1 && (n_tail == 2 || n_tail == 3) &&
+           ops[i + 1].kind == MBX_OP_LIN && (n_tail == 2 || ops[i + 2].kind == MBX_OP_ACT);
+}
+
+const double *f64_weights(const mbx_handle *hd, const mbx_subnet_op &op) {
+    const DevTensor *t = find(hd, std::string(op.name) + ".w64");
+    if (!t || t->count != 2LL * op.ks * op.cin * op.cout || (reinterpret_cast<uintptr_t>(t->ptr) & 7)) return nullptr;
+    return reinterpret_cast<const double *>(t->ptr);
+}
+
+// The whole F0-net in float64 (weights, hidden layers, head): its op list is (conv [prelu | leaky])* head, every layer has
+// its float64 weights "<layer>.w64" and rows of whole float4 / double4 groups.  Other shapes of the grammar keep float32
+// weights and hidden layers and accumulate in float64 (ConvArgs::precise alone).
+bool f0_chain_is_full64(const mbx_handle *hd) {
+    const mbx_config &c = hd->cfg;
+    if (c.f0_accumulate != MBX_F0_ACC_F64 || c.n_f0_ops < 3) return false;
+    int k = 0;
+    while (k < c.n_f0_ops) {
+        const mbx_subnet_op &op = c.f0_ops[k];
+        if (op.kind != MBX_OP_CONV || op.up != 1 || op.cin % 4 || !f64_weights(hd, op)) return false;
+        if (is_f0_head(c.f0_ops, c.n_f0_ops, k)) return k > 0;
+        if (op.cout % 4) return false;
+        ++k;
+        if (k < c.n_f0_ops && (c.f0_ops[k].kind == MBX_OP_PRELU || c.f0_ops[k].kind == MBX_OP_LEAKY)) ++k;
+    }
+    return false;
+}
+
 // Executes a sub-net op list (reference custom_pulsed_generator.py:38-148 flattened by the host).
 // in (B, T, cin) -> final (B, T*factor, cout); optional affine y*scale+offset applied after the last op.
 // Resumable: next_conv() launches the element-wise ops up to the next convolution and hands that convolution back
@@ -258,6 +295,11 @@ struct SubnetRun {
     long long stride_frames = 0;   // > 0: frames between batch items of the input and of the final output (a sub-window of a
                                    // longer window is being computed: mbx_forward_options.fe_new_frames); 0: T
     bool affine_done, finished = false;
+    bool precise = false;          // the F0-net under mbx_config.f0_accumulate == MBX_F0_ACC_F64: float64 accumulation in its
+                                   // convolutions (ConvArgs::precise) and its head -- final 1x1 convolution to one channel,
+                                   // interpolation, final activation, affine map -- as one float64 kernel
+    double *buf64_0 = nullptr, *buf64_1 = nullptr;   // ... with float64 weights and hidden layers (mbx_handle::f0_full64)
+    const double *cur64 = nullptr;                   // the current tensor when it is a float64 one (cur is null then)
     mbx_status status = MBX_OK;
     void window_stride(long long frames, int cin) {
         stride_frames = frames;
@@ -287,11 +329,42 @@ struct SubnetRun {
                 const DevTensor *w = find(hd, std::string(op.name) + ".w");
                 const DevTensor *bias = find(hd, std::string(op.name) + ".b");
                 if (!w || !bias) return stop(fail(MBX_ERR_INVALID_ARGUMENT, std::string("missing tensor ") + op.name + ".w/.b"));
+                // float64 head: [conv 1x1 -> 1 channel] [lin] ([act]) at the end of the list
+                const int n_tail = n_ops - i;
+                if (precise && is_f0_head(ops, n_ops, i)) {
+                    const mbx_subnet_op &lin = ops[i + 1];
+                    auto it = hd->lerp.find(lin.up);
+                    if (it == hd->lerp.end()) return stop(fail(MBX_ERR_INVALID_ARGUMENT, "interpolation table missing"));
+                    const long long out_bstride = (stride_frames ? stride_frames : (long long)T) * rpf * lin.up;
+                    mbx::launch_f0_head(cur, cur64, cur_bstride, op.cin, n_frames, rpf, T * rpf, B, w->ptr,
+                                        buf64_0 ? f64_weights(hd, op) : nullptr, bias->ptr, lin.up,
+                                        it->second.first, it->second.second, n_tail == 3 ? ops[i + 2].act : MBX_ACT_LINEAR,
+                                        affine_done ? 1.f : scale, affine_done ? 0.f : offset, final_out, out_bstride, stream);
+                    cur64 = nullptr;
+                    affine_done = true;
+                    cur = final_out;
+                    chan = 1;
+                    rpf *= lin.up;
+                    cur_bstride = out_bstride;
+                    i = n_ops;
+                    break;
+                }
                 float *out = (i == last_writer) ? final_out : (pp ? buf1 : buf0);
                 pp ^= 1;
                 const long long out_bstride = ((i == last_writer && stride_frames) ? stride_frames : (long long)T) * rpf * op.cout;
                 mbx::ConvArgs a = conv_args(cur, cur_bstride, chan, n_frames, rpf, T * rpf, B, w, bias, op.ks, op.cin,
                                             op.cout, 1, op.pad_l, op.pad_mode, out, out_bstride, op.cout);
+                a.precise = precise ? 1 : 0;
+                if (buf64_0) {             // full-float64 chain (the op list was checked at mbx_create: f0_chain_is_full64)
+                    double *out64 = (pp ^ 1) ? buf64_1 : buf64_0;       // (pp was toggled above)
+                    a.w64 = f64_weights(hd, op);
+                    a.x64 = cur64;
+                    a.out64 = out64;
+                    if (cur64) a.x = nullptr;
+                    a.out = nullptr;
+                    cur64 = out64;
+                    out = nullptr;
+                }
                 if (i + 1 < n_ops && ops[i + 1].kind == MBX_OP_PRELU && op.up == 1) {
                     const DevTensor *al = find(hd, std::string(ops[i + 1].name) + ".alpha");
                     if (!al) return stop(fail(MBX_ERR_INVALID_ARGUMENT, std::string("missing tensor ") + ops[i + 1].name + ".alpha"));
@@ -748,6 +821,9 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
     if (!c.ps_off && (hd->vtf_time_factor != 1 || vtf_out != c.n_ceps))
         return bail(fail(MBX_ERR_INVALID_ARGUMENT, "VTF sub-net must end with n_ceps channels at the mel frame rate"));
     hd->subnet_buf_per_frame = std::max(pf0, pvtf);
+    if (c.f0_accumulate != MBX_F0_ACC_F64 && c.f0_accumulate != MBX_F0_ACC_F32)
+        return bail(fail(MBX_ERR_INVALID_ARGUMENT, "f0_accumulate must be MBX_F0_ACC_F64 or MBX_F0_ACC_F32"));
+    hd->f0_full64 = f0_chain_is_full64(hd);
     if (c.wn_conv_form < MBX_CONV_AUTO || c.wn_conv_form > MBX_CONV_F43)
         return bail(fail(MBX_ERR_INVALID_ARGUMENT, "wn_conv_form must be MBX_CONV_AUTO, _DIRECT, _F23 or _F43"));
     if (c.tune_gate_shape < 0 || c.tune_gate_shape > 2 || c.tune_resskip_split < 0 || c.tune_resskip_split > 3 ||
@@ -1111,6 +1187,13 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         const bool f0_wide = hd->f0_time_factor > c.pulse_per_frame;
         SubnetRun f0(hd, c.f0_ops, c.n_f0_ops, mel_fe, c.mel_channels, nf_fe, B, Tf, w.sub0, w.sub1,
                      f0_wide ? w.f0_wide : w.f0 + f_off * c.pulse_per_frame, true, c.f0_max - c.f0_min, c.f0_min, stream);
+        f0.precise = c.f0_accumulate == MBX_F0_ACC_F64;
+        // (a mel pointer that is not 16-byte aligned keeps the float32 hidden layers: the first layer then runs whatever
+        // kernel takes its rows, and that kernel writes float32)
+        if (hd->f0_full64 && (reinterpret_cast<uintptr_t>(mel_fe) & 15) == 0 && c.mel_channels % 4 == 0) {
+            f0.buf64_0 = w.f0h0;
+            f0.buf64_1 = w.f0h1;
+        }
         if (c.ps_off) vtf.finished = true;             // no VTF-net (the cepstrum buffer stays unused)
         if (fe_frames) {
             vtf.window_stride(T, c.mel_channels);

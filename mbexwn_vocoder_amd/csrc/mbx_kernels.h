@@ -96,6 +96,11 @@ struct ConvArgs {
     long long h_split_bstride;   // float32 words between batch items
     int h_split_ld;
     int tune_split;           // wave-tiled res/skip kernel: 1..3 pins its column split (mbx_config.tune_resskip_split; same bits), 0: by launch size
+    // EPI_LINEAR, the F0-net (conv1d_f64_tile): contraction on v_mfma_f64_16x16x4_f64
+    int precise;              // 1: float64 accumulation; with only this set x, w and out are the float32 ones above (one rounding per output)
+    const double *x64;        // input as float64 (same strides, counted in elements) instead of x; needs w64
+    const double *w64;        // weights (ks*cin, cout) as float64 instead of w
+    double *out64;            // output as float64 (same strides) instead of out
 };
 
 void launch_conv1d(const ConvArgs &a, int epilogue, hipStream_t stream);
@@ -161,6 +166,13 @@ bool launch_wn_tail(const float *skip, long long skip_bstride, const int *n_fram
 void launch_lin_interp(const float *x, long long x_bstride, const int *n_frames, int rows_per_frame, int max_rows,
                        int batch, int channels, int up, const float *w0, const float *w1, int act, float scale,
                        float offset, float *y, long long y_bstride, hipStream_t stream);
+// Head of the F0-net in float64 (elementwise.hip::f0_head_kernel): 1x1 convolution cin -> 1 (+ bias), linear interpolation by
+// `up`, final activation, y * scale + offset -- float32 in, one rounding to float32 at the end
+// (reference custom_pulsed_generator.py:126-146, 773-791; custom_AE_layers.py:91-99)
+// x32 or x64: the hidden layer as float32 or float64; w32 or w64 likewise
+void launch_f0_head(const float *x32, const double *x64, long long x_bstride, int cin, const int *n_frames, int rows_per_frame,
+                    int max_rows, int batch, const float *w32, const double *w64, const float *bias, int up, const float *w0,
+                    const float *w1, int act, float scale, float offset, float *y, long long y_bstride, hipStream_t stream);
 // y = act(x)*scale + offset on (B, rows, C)
 // sub-band rows carried between the ticks of a stream (elementwise.hip); desc (batch, 5) int32 on the device
 void launch_sub_carry(float *sub, long long sub_bstride, float *store, long long slot_stride, const int *desc, int batch,

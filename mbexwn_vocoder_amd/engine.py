@@ -19,7 +19,7 @@ from .config import ModelDims
 from .subnet import build_subnet
 from .weights import fold_weights, merge_channel_groups
 
-MBX_ABI_VERSION = 8
+MBX_ABI_VERSION = 9
 MBX_MAX_SUBNET_OPS = 32
 MBX_MAX_WN_LAYERS = 64
 MBX_MAX_PRECOND = 8
@@ -74,7 +74,7 @@ class mbx_config(ctypes.Structure):
                 ("wn_keep_start", ctypes.c_int32), ("calib_fraction", ctypes.c_float), ("tune_gate_shape", ctypes.c_int32),
                 ("tune_resskip_wave_tiles", ctypes.c_int32), ("tune_resskip_split", ctypes.c_int32),
                 ("nm_use_pinv", ctypes.c_int32), ("nm_win_norm", ctypes.c_float), ("wn_precision", ctypes.c_int32),
-                ("reserved7", ctypes.c_int32 * 1)]
+                ("f0_accumulate", ctypes.c_int32)]
 
 
 class mbx_conv_form_info(ctypes.Structure):
@@ -278,10 +278,11 @@ def experiment_overrides():
 
 
 PRECISIONS = {"f32": 0, "split_f16": 1}
+F0_ACCUMULATE = {"f64": 0, "f32": 1}       # mbx_config.f0_accumulate: MBX_F0_ACC_F64 (default) / MBX_F0_ACC_F32
 
 
 def make_config(config, wavetables, conv_form=None, batch_invariant=None, keep_skip=None, keep_start=None,
-                calib_fraction=None, tune=None, precision="f32"):
+                calib_fraction=None, tune=None, precision="f32", f0_accumulate="f64"):
     """mbx_config of a model.  Policy arguments (None = default, or the experiment variable if one is set):
     conv_form "auto" | "direct" | "f23" | "f43" (mbx_config.wn_conv_form), batch_invariant, keep_skip, keep_start,
     calib_fraction, tune = {"gate_shape": 0|1|2, "resskip_wave_tiles": n, "resskip_split": 0..3}."""
@@ -370,6 +371,9 @@ def make_config(config, wavetables, conv_form=None, batch_invariant=None, keep_s
     if precision not in PRECISIONS:
         raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
     cc.wn_precision = PRECISIONS[precision]
+    if f0_accumulate not in F0_ACCUMULATE:
+        raise ValueError(f"f0_accumulate must be one of {sorted(F0_ACCUMULATE)}")
+    cc.f0_accumulate = F0_ACCUMULATE[f0_accumulate]
     return cc, dims
 
 
@@ -642,6 +646,13 @@ def tensor_table(config, raw_weights, wavetables, split_f16=False):
     wn_norm = mb.get("pp_mod_subnet", {}).get("use_weight_norm", None)
     out = dict(merge_channel_groups(fold_weights(raw_weights, wavenet_weight_norm=wn_norm,
                                                  wavenet_equalized_lr=dims.wn_equalized_lr), dims))
+    # F0-net: the exact (float64) weight-norm fold of every layer, handed over as pairs of float32 words
+    # (mbx_config.f0_accumulate = MBX_F0_ACC_F64: csrc/conv_mfma.hip::conv1d_f64_tile reads them as doubles)
+    from .weights import fold_weight_norm_f64
+    for key in raw_weights:
+        if key.startswith("PulsPar_Layer_") and key.endswith(".v") and key[:-2] + ".g" in raw_weights:
+            w64 = np.ascontiguousarray(fold_weight_norm_f64(raw_weights[key], raw_weights[key[:-2] + ".g"]))
+            out[key[:-2] + ".w64"] = w64.view(np.float32).reshape(w64.shape + (2,))
     _, syn = tb.pqmf_filters(int(mbc["subbands"]), int(mbc["taps"]), float(mbc["cutoff_ratio"]), float(mbc["beta"]),
                              mbc.get("max_band", None))
     out["table.pqmf_syn"] = syn
@@ -700,7 +711,8 @@ class MBExWNEngine:
     """Device-resident MBExWN generator. One instance per GPU (one process per GPU)."""
 
     def __init__(self, config, raw_weights, wavetables=None, device=None, weight_images=True, conv_form=None,
-                 batch_invariant=None, keep_skip=None, keep_start=None, calib_fraction=None, tune=None, precision="f32"):
+                 batch_invariant=None, keep_skip=None, keep_start=None, calib_fraction=None, tune=None, precision="f32",
+                 f0_accumulate="f64"):
         """``weight_images=False`` hands mbx_create only the folded weights and the tables (what a minimal binding of the
         C ABI would do): the engine then runs its generic kernels instead of the specialised ones.
 
@@ -710,7 +722,9 @@ class MBExWNEngine:
         that an utterance's bits do not depend on the batch it ran in; ``keep_skip`` / ``keep_start`` keep the un-folded
         graph; ``tune`` holds measurement knobs (make_config).  ``precision="split_f16"`` is an opt-in experiment (never
         the default): the res/skip layers (and the gate layers behind the first one) contract on the 16-bit matrix pipe with fp16-split operands
-        (three products, float32 accumulation; csrc/wn_resskip_f16.hip)."""
+        (three products, float32 accumulation; csrc/wn_resskip_f16.hip).  ``f0_accumulate`` = "f64" (default: the F0-net's
+        contractions accumulate in float64 and round once -- its contour feeds the phase integrator) or "f32" (the float32
+        kernels of the other mel-rate sub-nets: the behaviour up to ABI 8, kept for A/B measurements)."""
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("MBExWNEngine needs an AMD GPU (no CPU fallback for the mel-inversion path)")
@@ -724,13 +738,13 @@ class MBExWNEngine:
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         cconf, self.dims = make_config(config, wavetables, conv_form=conv_form, batch_invariant=batch_invariant,
                                        keep_skip=keep_skip, keep_start=keep_start, calib_fraction=calib_fraction, tune=tune,
-                                       precision=precision)
+                                       precision=precision, f0_accumulate=f0_accumulate)
         self._tune_gate_shape = cconf.tune_gate_shape
         self.normalizes_rms = cconf.nm_iters > 0            # row A14: done on the device inside mbx_forward
         self._tensors = tensor_table(config, raw_weights, wavetables, split_f16=precision == "split_f16")   # keep the host arrays alive
         if not weight_images:
             self._tensors = {kk: vv for kk, vv in self._tensors.items()
-                             if kk.startswith("table.") or kk.rsplit(".", 1)[-1] in ("w", "b", "alpha")}
+                             if kk.startswith("table.") or kk.rsplit(".", 1)[-1] in ("w", "b", "alpha", "w64")}
         arr = (mbx_tensor * len(self._tensors))()
         for ii, (name, val) in enumerate(self._tensors.items()):
             arr[ii].name = name.encode()

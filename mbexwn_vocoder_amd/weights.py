@@ -116,6 +116,15 @@ def fold_weight_norm(v, g):
     return (np.asarray(g, dtype=np.float32) * (v * inv)).astype(np.float32)
 
 
+def fold_weight_norm_f64(v, g):
+    """The same fold W = g v / sqrt(max(sum_{k,ci} v^2, 1e-12)) (reference conv_layers.py:149-153) evaluated in float64 on the
+    float32 variables: the weights of the F0-net under mbx_config.f0_accumulate = MBX_F0_ACC_F64 ("<layer>.w64",
+    csrc/conv_mfma.hip::conv1d_f64_tile) -- the contour feeds the phase integrator, so its net runs on the exact fold."""
+    v = np.asarray(v, dtype=np.float64)
+    sq = np.sum(v * v, axis=(0, 1), keepdims=True)
+    return np.asarray(g, dtype=np.float64) * (v / np.sqrt(np.maximum(sq, 1e-12)))
+
+
 # layers the reference may build without weight normalisation: only the WaveNet's own (pp_mod_subnet.use_weight_norm,
 # reference custom_AE_layers.py:124,177-260); the F0 / VTF sub-nets and the post-net are always weight-normed
 # (reference custom_pulsed_generator.py:84-136, 491)
