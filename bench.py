@@ -201,6 +201,17 @@ def max_abs_delta_timed(samples, cfg, raw, wt, what):
                                     f"on the {nf}-frame prefixes (prefix property, margin {nf - keep} frames)"}
 
 
+def max_abs_delta_full(ctx, what):
+    """max|delta| of a single utterance over its WHOLE length: the buffer the timed steps wrote against the float64 oracle run
+    on the whole utterance (no prefix property involved)."""
+    got, mel, noise = ctx["timed_full"], ctx["mel_h"][:1], ctx["noise_h"][:1]
+    dd, pk = _delta_vs_oracle(got[None], ctx["cfg"], ctx["raw"], ctx["wt"], mel, noise, mel.shape[1])
+    return {"max_abs_delta_full": dd, "max_abs_delta_full_tolerance": DELTA_TOL * max(1.0, pk),
+            "max_abs_delta_full_ok": bool(dd <= DELTA_TOL * max(1.0, pk)),
+            "max_abs_delta_full_sample": f"output buffer of the timed steps ({what}): all {mel.shape[1]} frames "
+                                         f"({mel.shape[1] / 80:g} s) of the utterance, float32 HIP vs float64 numpy oracle"}
+
+
 def max_abs_delta_small(eng, cfg, raw, wt, mel_h, noise_h, torch):
     """The same comparison on a separate small launch (1 x DELTA_FRAMES frames: the small-launch kernels -- channel-split
     F(4,3) gate, narrow res/skip, split-K mel-rate convolutions), outside the timed region."""
@@ -260,6 +271,9 @@ def run_batch(args, name, rank, world, fence, torch, profile, steps=None, warmup
     delta_items = sorted({0, batch - 1})
     keep = min(DELTA_FRAMES, frames) * dims.hop_size
     timed_out = {ii: out[ii, :keep].cpu().numpy() for ii in delta_items} if rank == 0 else {}
+    # single utterances: the whole item as well (max|delta| over the full length: the phase integrator makes a contour error
+    # grow with the length of the utterance, which a prefix check cannot see)
+    timed_full = out[0].cpu().numpy() if rank == 0 and batch == 1 else None
     samples = world * batch * frames * dims.hop_size * steps
     res = {"workload": f"{name}: MW-{voice[:2]}-FD canonical (C={dims.wn_channels}, L={dims.wn_layers}), batch {batch} x "
                        f"{frames / 80:g} s per GPU, 80x{frames} synthetic mel, seeded synthetic weights",
@@ -267,7 +281,7 @@ def run_batch(args, name, rank, world, fence, torch, profile, steps=None, warmup
            "ms_per_step": elapsed / steps * 1e3, "steps": steps, "scaling": "weak",
            "gate_form": eng.gate_form(batch, frames), "conv_form": eng.conv_form_info()}
     ctx = {"cfg": cfg, "raw": raw, "wt": wt, "dims": dims, "eng": eng, "mel_h": mel_h, "noise_h": noise_h, "batch": batch,
-           "frames": frames, "timed_out": timed_out, "delta_items": delta_items, "stages": None}
+           "frames": frames, "timed_out": timed_out, "timed_full": timed_full, "delta_items": delta_items, "stages": None}
     if profile:
         # per-stage device times from HIP events on the launch stream, in a separate pass so that the events do not sit
         # inside the throughput measurement
@@ -699,11 +713,13 @@ def main():
         if rank == 0:
             res2.update(max_abs_delta_timed([("item 0", ctx2["timed_out"][0], ctx2["mel_h"][0], ctx2["noise_h"][0])],
                                             ctx2["cfg"], ctx2["raw"], ctx2["wt"], "config 2 batch"))
+            res2.update(max_abs_delta_full(ctx2, "config 2 batch"))
         secondary["config2_sp_b1_10s"] = res2
         res1, ctx1 = run_batch(args, "config1_sp_b1_3s", rank, world, fence, torch, profile=False, steps=short_steps)
         if rank == 0:
             res1.update(max_abs_delta_timed([("item 0", ctx1["timed_out"][0], ctx1["mel_h"][0], ctx1["noise_h"][0])],
                                             ctx1["cfg"], ctx1["raw"], ctx1["wt"], "config 1 batch"))
+            res1.update(max_abs_delta_full(ctx1, "config 1 batch"))
         secondary["config1_sp_b1_3s"] = res1
         # the generic path (two WaveNet blocks, in-block upsampling): builder-run secondary, not a BASELINE config
         resb, ctxb = run_batch(args, "variant_blocks2", rank, world, fence, torch, profile=True, steps=min(args.steps, 5), warmup=1)
@@ -774,7 +790,7 @@ def _delta_ratios(node, path="line"):
     found = []
     if isinstance(node, dict):
         for kk, vv in node.items():
-            if kk in ("max_abs_delta", "max_abs_delta_small") and isinstance(node.get(kk + "_tolerance"), float):
+            if kk in ("max_abs_delta", "max_abs_delta_small", "max_abs_delta_full") and isinstance(node.get(kk + "_tolerance"), float):
                 found.append((f"{path}.{kk}", vv / node[kk + "_tolerance"]))
             elif isinstance(vv, dict):
                 found.extend(_delta_ratios(vv, f"{path}.{kk}"))
@@ -801,6 +817,8 @@ def compact_summary(line, main_res, secondary):
             "c5_100ms_tick_host_ms": round(c5a["tick_ms_host_inclusive_p50"], 4) if c5a else None,
             "split_f16_ms": ms("config3_split_f16"), "blocks2_ms": ms("variant_blocks2"),
             "c1_delta": dd("config1_sp_b1_3s"), "c2_delta": dd("config2_sp_b1_10s"),
+            "c1_delta_full_3s": float(f"{secondary['config1_sp_b1_3s']['max_abs_delta_full']:.3e}") if "max_abs_delta_full" in secondary.get("config1_sp_b1_3s", {}) else None,
+            "c2_delta_full_10s": float(f"{secondary['config2_sp_b1_10s']['max_abs_delta_full']:.3e}") if "max_abs_delta_full" in secondary.get("config2_sp_b1_10s", {}) else None,
             "c3_delta": float(f"{line['max_abs_delta']:.3e}") if "max_abs_delta" in line else None,
             "c4_delta": dd("config4_vo_256utt"), "split_f16_delta": dd("config3_split_f16"),
             "deltas_ok": bool(flags) and all(ok is True for ok in flags), "deltas_checked": len(flags),

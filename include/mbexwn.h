@@ -440,6 +440,15 @@ mbx_status mbx_conv1d(mbx_handle *handle, const float *x, int32_t batch, int32_t
                       const float *w, const float *b, const float *alpha, int32_t ks, int32_t cout,
                       int32_t dilation, int32_t pad_l, int32_t pad_mode, float *y, void *hip_stream);
 
+/* The same convolution with float64 accumulation (float32 operands, exact products, float64 sums on
+ * v_mfma_f64_16x16x4_f64, one rounding to float32 per output): the arithmetic of the F0-net's layers under
+ * mbx_config.f0_accumulate = MBX_F0_ACC_F64 where the net keeps float32 weights and hidden layers (stage parity of
+ * csrc/conv_mfma.hip::conv1d_f64_tile).  Needs cin % 4 == 0; launches of >= 12 288 rows take the 32 x 32 tiles of the large
+ * mel-rate launches, smaller ones the 16 x 16 tiles -- same bits. */
+mbx_status mbx_conv1d_f64acc(mbx_handle *handle, const float *x, int32_t batch, int32_t n_rows, int32_t cin,
+                             const float *w, const float *b, const float *alpha, int32_t ks, int32_t cout,
+                             int32_t dilation, int32_t pad_l, int32_t pad_mode, float *y, void *hip_stream);
+
 /* TF2C_LinInterpLayer(num_pad_end=1, drop_last=True) (reference support_layers.py:99-121):
  * x (batch, n_rows, channels) -> y (batch, n_rows*up, channels) */
 mbx_status mbx_lin_interp(mbx_handle *handle, const float *x, int32_t batch, int32_t n_rows, int32_t channels,

@@ -2046,6 +2046,27 @@ mbx_status mbx_conv1d(mbx_handle *hd, const float *x, int32_t batch, int32_t n_r
     return e == hipSuccess ? MBX_OK : fail(MBX_ERR_HIP, hipGetErrorString(e));
 }
 
+mbx_status mbx_conv1d_f64acc(mbx_handle *hd, const float *x, int32_t batch, int32_t n_rows, int32_t cin, const float *w,
+                             const float *b, const float *alpha, int32_t ks, int32_t cout, int32_t dilation, int32_t pad_l,
+                             int32_t pad_mode, float *y, void *hip_stream) {
+    if (!hd || !x || !w || !y || batch <= 0 || n_rows <= 0 || cin <= 0 || cout <= 0 || ks <= 0 || dilation <= 0)
+        return fail(MBX_ERR_INVALID_ARGUMENT, "bad argument");
+    if (pad_mode < MBX_PAD_ZERO || pad_mode > MBX_PAD_EDGE) return fail(MBX_ERR_INVALID_ARGUMENT, "bad pad_mode");
+    if (cin % 4 || (reinterpret_cast<uintptr_t>(x) & 15))
+        return fail(MBX_ERR_UNSUPPORTED, "the float64-accumulating convolution needs cin % 4 == 0 and a 16-byte aligned input");
+    DeviceGuard guard(hd->device);
+    DevTensor wt, bt;
+    wt.ptr = const_cast<float *>(w);
+    bt.ptr = const_cast<float *>(b);
+    mbx::ConvArgs a = conv_args(x, (long long)n_rows * cin, cin, nullptr, 1, n_rows, batch, &wt, b ? &bt : nullptr, ks,
+                                cin, cout, dilation, pad_l, pad_mode, y, (long long)n_rows * cout, cout);
+    a.alpha = alpha;
+    a.precise = 1;
+    mbx::launch_conv1d_group(&a, 1, static_cast<hipStream_t>(hip_stream));
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MBX_OK : fail(MBX_ERR_HIP, hipGetErrorString(e));
+}
+
 mbx_status mbx_lin_interp(mbx_handle *hd, const float *x, int32_t batch, int32_t n_rows, int32_t channels, int32_t up,
                           float *y, void *hip_stream) {
     if (!hd || !x || !y || batch <= 0 || n_rows <= 0 || channels <= 0) return fail(MBX_ERR_INVALID_ARGUMENT, "bad argument");

@@ -165,6 +165,8 @@ def load_library():
     lib.mbx_pqmf_synthesis.argtypes = [vp, fp, i32, i32, fp, vp]
     lib.mbx_conv1d.restype = i32
     lib.mbx_conv1d.argtypes = [vp, fp, i32, i32, i32, fp, fp, fp, i32, i32, i32, i32, i32, fp, vp]
+    lib.mbx_conv1d_f64acc.restype = i32
+    lib.mbx_conv1d_f64acc.argtypes = [vp, fp, i32, i32, i32, fp, fp, fp, i32, i32, i32, i32, i32, fp, vp]
     lib.mbx_lin_interp.restype = i32
     lib.mbx_lin_interp.argtypes = [vp, fp, i32, i32, i32, i32, fp, vp]
     lib.mbx_wavetable.restype = i32
@@ -181,7 +183,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = ["mbx_last_error", "mbx_create", "mbx_destroy", "mbx_conv_form", "mbx_calibrate", "mbx_workspace_size", "mbx_forward",
                     "mbx_forward_stream", "mbx_forward_ex", "mbx_layer_state_info", "mbx_window_advance", "mbx_stage",
-                    "mbx_profile_enable", "mbx_profile_read", "mbx_pqmf_synthesis", "mbx_conv1d", "mbx_lin_interp", "mbx_wavetable", "mbx_stft_filter", "mbx_norm_mel", "mbx_mel_analysis"]
+                    "mbx_profile_enable", "mbx_profile_read", "mbx_pqmf_synthesis", "mbx_conv1d", "mbx_conv1d_f64acc", "mbx_lin_interp", "mbx_wavetable", "mbx_stft_filter", "mbx_norm_mel", "mbx_mel_analysis"]
 
 
 def _check(status):
@@ -1170,16 +1172,18 @@ class MBExWNEngine:
         _check(self._lib.mbx_pqmf_synthesis(self._handle, x.data_ptr(), B, S, y.data_ptr(), self._stream()))
         return y
 
-    def conv1d(self, x, w, b=None, alpha=None, dilation=1, pad_l=0, pad_mode=0):
+    def conv1d(self, x, w, b=None, alpha=None, dilation=1, pad_l=0, pad_mode=0, f64_accumulate=False):
+        """mbx_conv1d, or mbx_conv1d_f64acc with ``f64_accumulate`` (float64 sums, one rounding per output)."""
         torch = self._torch
         x, w = x.contiguous(), w.contiguous()
         B, R, cin = x.shape
         ks, _, cout = w.shape
         y = torch.empty((B, R, cout), dtype=torch.float32, device=self.device)
-        _check(self._lib.mbx_conv1d(self._handle, x.data_ptr(), B, R, cin, w.data_ptr(),
-                                    b.data_ptr() if b is not None else None,
-                                    alpha.data_ptr() if alpha is not None else None, ks, cout, dilation, pad_l,
-                                    pad_mode, y.data_ptr(), self._stream()))
+        fn = self._lib.mbx_conv1d_f64acc if f64_accumulate else self._lib.mbx_conv1d
+        _check(fn(self._handle, x.data_ptr(), B, R, cin, w.data_ptr(),
+                  b.data_ptr() if b is not None else None,
+                  alpha.data_ptr() if alpha is not None else None, ks, cout, dilation, pad_l,
+                  pad_mode, y.data_ptr(), self._stream()))
         return y
 
     def lin_interp(self, x, up):

@@ -111,6 +111,13 @@ def test_default_form_is_safe_on_stressed_weights(torch, name, gain, bias_mean, 
     assert np.isfinite(row["auto"]) and np.isfinite(row["wn_auto"])
     assert row["wn_auto"] <= max(row["wn_tol"], 1.25 * row["wn_direct"]), f"WaveNet of the default handle ({row['auto_form']}): {row}"
     assert row["auto"] <= max(tol, 1.25 * row["direct"]), f"default handle ({row['auto_form']}): {row}"
+    if name != "gain16":
+        # round 5: with the F0-net in float64 the contour no longer spends the budget -- the default handle meets the plain
+        # tolerance in every case but the one whose WaveNet amplifies by 100 (ill-conditioned in float32 in every form: the
+        # numpy float32 port is off by 3.8 there), and is at least as exact as a plain float32 port of the graph wherever
+        # that port's error is above the float32 floor of the output stages
+        assert row["auto"] <= tol, f"default handle ({row['auto_form']}): {row}"
+        assert row["auto"] <= max(row["f32_port"], 2e-5 * max(1.0, row["ref_max"])), f"default handle vs the float32 port: {row}"
     # the calibration's purpose: a form whose own rounding breaks the WaveNet's tolerance is not the one auto keeps
     if row["wn_" + row["auto_form"]] > row["wn_tol"]:
         assert row["auto_form"] == "direct", row
