@@ -171,6 +171,14 @@ PATCHES = {
         ('#pragma unroll 4\n    for (int c = wave; c < nc8; c += 4) {',
          '    const int per_ = (nc8 + 3) / 4;\n#pragma unroll 4\n    for (int c = wave * per_; c < min(nc8, (wave + 1) * per_); ++c) {'),
     ],
+    # wn_winograd4w.hip (256-row kernel), round 5: de-phase experiment; s_memrealtime ticks = 10 ns
+    'dpA17': [('    const int rw = wave;                                    // row part of this wave\n', '    const int rw = wave;                                    // row part of this wave\n    {   // EXPERIMENT (round 5): de-phase the co-resident blocks of a CU -- first-round blocks of slot k start k * DELAY late\n        const int slot_ = (int)(blockIdx.x >> 3) / 32;\n        if (blockIdx.x < 768 && slot_ > 0) {\n            const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();\n            while (__builtin_amdgcn_s_memrealtime() - t0_ < (unsigned long long)slot_ * 1700ull) __builtin_amdgcn_s_sleep(32);\n        }\n    }\n')],
+    'dpA26': [('    const int rw = wave;                                    // row part of this wave\n', '    const int rw = wave;                                    // row part of this wave\n    {   // EXPERIMENT (round 5): de-phase the co-resident blocks of a CU -- first-round blocks of slot k start k * DELAY late\n        const int slot_ = (int)(blockIdx.x >> 3) / 32;\n        if (blockIdx.x < 768 && slot_ > 0) {\n            const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();\n            while (__builtin_amdgcn_s_memrealtime() - t0_ < (unsigned long long)slot_ * 2600ull) __builtin_amdgcn_s_sleep(32);\n        }\n    }\n')],
+    'dpA34': [('    const int rw = wave;                                    // row part of this wave\n', '    const int rw = wave;                                    // row part of this wave\n    {   // EXPERIMENT (round 5): de-phase the co-resident blocks of a CU -- first-round blocks of slot k start k * DELAY late\n        const int slot_ = (int)(blockIdx.x >> 3) / 32;\n        if (blockIdx.x < 768 && slot_ > 0) {\n            const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();\n            while (__builtin_amdgcn_s_memrealtime() - t0_ < (unsigned long long)slot_ * 3400ull) __builtin_amdgcn_s_sleep(32);\n        }\n    }\n')],
+    'dpA51': [('    const int rw = wave;                                    // row part of this wave\n', '    const int rw = wave;                                    // row part of this wave\n    {   // EXPERIMENT (round 5): de-phase the co-resident blocks of a CU -- first-round blocks of slot k start k * DELAY late\n        const int slot_ = (int)(blockIdx.x >> 3) / 32;\n        if (blockIdx.x < 768 && slot_ > 0) {\n            const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();\n            while (__builtin_amdgcn_s_memrealtime() - t0_ < (unsigned long long)slot_ * 5100ull) __builtin_amdgcn_s_sleep(32);\n        }\n    }\n')],
+    'dpB34': [('    const int rw = wave;                                    // row part of this wave\n', '    const int rw = wave;                                    // row part of this wave\n    {   // EXPERIMENT (round 5): de-phase the co-resident blocks of a CU -- first-round blocks of slot k start k * DELAY late\n        const int slot_ = (int)(blockIdx.x >> 3) % 3;\n        if (blockIdx.x < 768 && slot_ > 0) {\n            const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();\n            while (__builtin_amdgcn_s_memrealtime() - t0_ < (unsigned long long)slot_ * 3400ull) __builtin_amdgcn_s_sleep(32);\n        }\n    }\n')],
+    'dpB17': [('    const int rw = wave;                                    // row part of this wave\n', '    const int rw = wave;                                    // row part of this wave\n    {   // EXPERIMENT (round 5): de-phase the co-resident blocks of a CU -- first-round blocks of slot k start k * DELAY late\n        const int slot_ = (int)(blockIdx.x >> 3) % 3;\n        if (blockIdx.x < 768 && slot_ > 0) {\n            const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();\n            while (__builtin_amdgcn_s_memrealtime() - t0_ < (unsigned long long)slot_ * 1700ull) __builtin_amdgcn_s_sleep(32);\n        }\n    }\n')],
+    'dpALL8': [('    const int rw = wave;                                    // row part of this wave\n', '    const int rw = wave;                                    // row part of this wave\n    {   // EXPERIMENT (round 5): de-phase the co-resident blocks of a CU -- first-round blocks of slot k start k * DELAY late\n        const int slot_ = (int)(blockIdx.x >> 3) % 3;\n        if (blockIdx.x < 1073741824 && slot_ > 0) {\n            const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();\n            while (__builtin_amdgcn_s_memrealtime() - t0_ < (unsigned long long)slot_ * 800ull) __builtin_amdgcn_s_sleep(32);\n        }\n    }\n')],
     'base': [],
     # wn_winograd4w.hip
     'nodma': [
