@@ -102,7 +102,11 @@ __device__ __forceinline__ float2 ww_sub(float2 a, float2 b) { return make_float
 template <int N>
 using ww_int = std::integral_constant<int, N>;
 
-template <int CR>
+// GA: the gate activation as a compile-time constant (0 = gtu, the canonical models) or -1 = ConvArgs::gate_act at run time.
+// With the run-time kind every wn_gate_act call of the epilogue sits behind wave-uniform branches, which cut the epilogue
+// into 32 scheduling regions -- each with its own LDS round trip (s_waitcnt lgkmcnt(0)) in front of a few dozen
+// instructions: 32 000 cycles per block (round 5, in-kernel stamps: 14 of a block's 94 us).
+template <int CR, int GA>
 __global__ __launch_bounds__(256, CR <= 28 ? 3 : 2) void wn_gate_winograd4w_kernel(ConvArgs p, int log2d) {
     using SH = WwShape<CR>;
     constexpr int ROWS = SH::ROWS, NSTAGE = SH::NSTAGE, STAGE = SH::STAGE, A_FLOATS = SH::A_FLOATS, PHASE = SH::PHASE;
@@ -349,12 +353,34 @@ __global__ __launch_bounds__(256, CR <= 28 ? 3 : 2) void wn_gate_winograd4w_kern
     const float *cl = lds + SH::COND;
     float *obase = p.out + (long long)b * p.out_bstride + n0 + 2 * r16;
     const float *clane = cl + 2 * r16;
-    // everything up to the store is unconditional (every table and conditioning address is valid), so the LDS reads of
-    // all rows can be in flight together; only the store is predicated
+    // Round 5 (read off the ISA): with the predicated store behind every output the compiler kept each output in a region
+    // of its own -- table entry, wait, six conditioning reads, wait, arithmetic, store: 48 serial LDS round trips per block
+    // under the LDS traffic of the co-resident blocks' K loops.  Now: all 16 table entries of the lane are requested first;
+    // per register vi the 24 conditioning / weight reads of its four outputs are requested together, the four results are
+    // formed outside any branch (the empty asm keeps them there) and only then stored.  Same arithmetic, same bits.
+    int etab[4][4];
 #pragma unroll
     for (int vi = 0; vi < 4; ++vi) {
         const int gi = 16 * rw + 4 * kq + vi;                                    // group held by this register
         const int lr0 = ((gi >> log2d) << (log2d + 2)) + (gi & (d - 1));         // its first row, relative to m0
+#pragma unroll
+        for (int o = 0; o < 4; ++o) etab[vi][o] = reinterpret_cast<const int *>(lds + SH::TAB)[lr0 + (o << log2d)];
+    }
+#pragma unroll
+    for (int vi = 0; vi < 4; ++vi) {
+        const int gi = 16 * rw + 4 * kq + vi;
+        const int lr0 = ((gi >> log2d) << (log2d + 2)) + (gi & (d - 1));
+        float2 w[4], ct0[4], ct1[4], cs0[4], cs1[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int e = etab[vi][o];
+            w[o] = make_float2(lds[SH::LERP + (e & 255)], lds[SH::LERP + 64 + (e & 255)]);
+            const float *c0 = clane + (e >> 8);
+            ct0[o] = *reinterpret_cast<const float2 *>(c0);
+            ct1[o] = *reinterpret_cast<const float2 *>(c0 + 64);
+            cs0[o] = *reinterpret_cast<const float2 *>(c0 + 32);
+            cs1[o] = *reinterpret_cast<const float2 *>(c0 + 96);
+        }
         float y[4][4];                                                           // [column tile][output]
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -365,19 +391,19 @@ __global__ __launch_bounds__(256, CR <= 28 ? 3 : 2) void wn_gate_winograd4w_kern
             y[c][2] = fmaf(4.f, s34, s12);
             y[c][3] = fmaf(8.f, d34, d12) + acc[5][c][vi];
         }
+        float2 res[4];
+        const int kind = GA < 0 ? p.gate_act : GA;
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            const int lr = lr0 + (o << log2d);
-            const int row = m0 + lr;
-            const int e = reinterpret_cast<const int *>(lds + SH::TAB)[lr];
-            const float2 w = make_float2(lds[SH::LERP + (e & 255)], lds[SH::LERP + 64 + (e & 255)]);
-            const float *c0 = clane + (e >> 8);
-            const float2 ct0 = *reinterpret_cast<const float2 *>(c0), ct1 = *reinterpret_cast<const float2 *>(c0 + 64);
-            const float2 cs0 = *reinterpret_cast<const float2 *>(c0 + 32), cs1 = *reinterpret_cast<const float2 *>(c0 + 96);
-            float2 res;
-            res.x = wn_gate_act(p.gate_act, y[0][o] + (ct0.x * w.x + ct1.x * w.y), y[1][o] + (cs0.x * w.x + cs1.x * w.y));
-            res.y = wn_gate_act(p.gate_act, y[2][o] + (ct0.y * w.x + ct1.y * w.y), y[3][o] + (cs0.y * w.x + cs1.y * w.y));
-            if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res;
+            // (the interpolation as an explicit fma: both block shapes must round it the same way)
+            res[o].x = wn_gate_act(kind, y[0][o] + fmaf(ct0[o].x, w[o].x, ct1[o].x * w[o].y), y[1][o] + fmaf(cs0[o].x, w[o].x, cs1[o].x * w[o].y));
+            res[o].y = wn_gate_act(kind, y[2][o] + fmaf(ct0[o].y, w[o].x, ct1[o].y * w[o].y), y[3][o] + fmaf(cs0[o].y, w[o].x, cs1[o].y * w[o].y));
+            asm volatile("" : "+v"(res[o].x), "+v"(res[o].y));
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int row = m0 + lr0 + (o << log2d);
+            if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res[o];
         }
     }
 }
@@ -432,6 +458,7 @@ __device__ __forceinline__ void wp_comb(int PH, const float2 (&x)[6], float2 (&u
     }
 }
 
+template <int GA>
 __global__ __launch_bounds__(256, 3) void wn_gate_winograd4p_kernel(ConvArgs p, int log2d) {
     using SH = WpShape;
     constexpr int ROWS = SH::ROWS, NSTAGE = SH::NSTAGE, STAGE = SH::STAGE, A_FLOATS = SH::A_FLOATS, PHASE = SH::PHASE;
@@ -674,8 +701,9 @@ __global__ __launch_bounds__(256, 3) void wn_gate_winograd4p_kernel(ConvArgs p, 
             const float2 ct0 = *reinterpret_cast<const float2 *>(c0), ct1 = *reinterpret_cast<const float2 *>(c0 + 64);
             const float2 cs0 = *reinterpret_cast<const float2 *>(c0 + 32), cs1 = *reinterpret_cast<const float2 *>(c0 + 96);
             float2 res;
-            res.x = wn_gate_act(p.gate_act, y[0][o] + (ct0.x * w.x + ct1.x * w.y), y[1][o] + (cs0.x * w.x + cs1.x * w.y));
-            res.y = wn_gate_act(p.gate_act, y[2][o] + (ct0.y * w.x + ct1.y * w.y), y[3][o] + (cs0.y * w.x + cs1.y * w.y));
+            const int kind = GA < 0 ? p.gate_act : GA;
+            res.x = wn_gate_act(kind, y[0][o] + fmaf(ct0.x, w.x, ct1.x * w.y), y[1][o] + fmaf(cs0.x, w.x, cs1.x * w.y));
+            res.y = wn_gate_act(kind, y[2][o] + fmaf(ct0.y, w.x, ct1.y * w.y), y[3][o] + fmaf(cs0.y, w.x, cs1.y * w.y));
             if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res;
         }
     }
@@ -702,9 +730,14 @@ bool launch_wn_gate_winograd4w(const ConvArgs &a, bool split, hipStream_t stream
     r.m_tiles_per_item = (a.max_rows + rows_blk - 1) / rows_blk;
     r.m_tiles_total = r.m_tiles_per_item * a.batch;
     const long long blocks = 8LL * ((r.m_tiles_total + 7) / 8) * r.n_tiles;
-    if (split) hipLaunchKernelGGL(wn_gate_winograd4p_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, r, log2d);
-    else if (cond_rows <= 28) hipLaunchKernelGGL(wn_gate_winograd4w_kernel<28>, dim3((unsigned)blocks), dim3(256), 0, stream, r, log2d);
-    else hipLaunchKernelGGL(wn_gate_winograd4w_kernel<56>, dim3((unsigned)blocks), dim3(256), 0, stream, r, log2d);
+    const dim3 grid((unsigned)blocks), blk(256);
+    const bool gtu = a.gate_act == 0;
+    if (split && gtu) hipLaunchKernelGGL(wn_gate_winograd4p_kernel<0>, grid, blk, 0, stream, r, log2d);
+    else if (split) hipLaunchKernelGGL(wn_gate_winograd4p_kernel<-1>, grid, blk, 0, stream, r, log2d);
+    else if (cond_rows <= 28 && gtu) hipLaunchKernelGGL((wn_gate_winograd4w_kernel<28, 0>), grid, blk, 0, stream, r, log2d);
+    else if (cond_rows <= 28) hipLaunchKernelGGL((wn_gate_winograd4w_kernel<28, -1>), grid, blk, 0, stream, r, log2d);
+    else if (gtu) hipLaunchKernelGGL((wn_gate_winograd4w_kernel<56, 0>), grid, blk, 0, stream, r, log2d);
+    else hipLaunchKernelGGL((wn_gate_winograd4w_kernel<56, -1>), grid, blk, 0, stream, r, log2d);
     return true;
 }
 

@@ -179,6 +179,58 @@ PATCHES = {
     'dpB34': [('    const int rw = wave;                                    // row part of this wave\n', '    const int rw = wave;                                    // row part of this wave\n    {   // EXPERIMENT (round 5): de-phase the co-resident blocks of a CU -- first-round blocks of slot k start k * DELAY late\n        const int slot_ = (int)(blockIdx.x >> 3) % 3;\n        if (blockIdx.x < 768 && slot_ > 0) {\n            const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();\n            while (__builtin_amdgcn_s_memrealtime() - t0_ < (unsigned long long)slot_ * 3400ull) __builtin_amdgcn_s_sleep(32);\n        }\n    }\n')],
     'dpB17': [('    const int rw = wave;                                    // row part of this wave\n', '    const int rw = wave;                                    // row part of this wave\n    {   // EXPERIMENT (round 5): de-phase the co-resident blocks of a CU -- first-round blocks of slot k start k * DELAY late\n        const int slot_ = (int)(blockIdx.x >> 3) % 3;\n        if (blockIdx.x < 768 && slot_ > 0) {\n            const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();\n            while (__builtin_amdgcn_s_memrealtime() - t0_ < (unsigned long long)slot_ * 1700ull) __builtin_amdgcn_s_sleep(32);\n        }\n    }\n')],
     'dpALL8': [('    const int rw = wave;                                    // row part of this wave\n', '    const int rw = wave;                                    // row part of this wave\n    {   // EXPERIMENT (round 5): de-phase the co-resident blocks of a CU -- first-round blocks of slot k start k * DELAY late\n        const int slot_ = (int)(blockIdx.x >> 3) % 3;\n        if (blockIdx.x < 1073741824 && slot_ > 0) {\n            const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();\n            while (__builtin_amdgcn_s_memrealtime() - t0_ < (unsigned long long)slot_ * 800ull) __builtin_amdgcn_s_sleep(32);\n        }\n    }\n')],
+    # wn_winograd4w.hip (256-row kernel), round 5: in-kernel stamps (s_memtime = shader cycles, s_memrealtime = 10 ns) of every
+    # wave of the LAST gate launch of a forward: kernel start, first stage landed, K loop done, end -- and (stampB) the cycles
+    # spent between "products 0..4 issued" and "barrier passed" summed over the slices.  Read back by gate_phase_account.py
+    # through the variant library's own export mbx_exp_stamps.
+    'stampA': [
+        ('namespace mbx {\n\ntypedef float f32x4 __attribute__((ext_vector_type(4)));',
+         'namespace mbx {\n\n__device__ unsigned long long g_ww_stamps[16384 * 4 * 8];\n#define WW_STAMP(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }\n#define WW_RSTAMP(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memrealtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }\n\ntypedef float f32x4 __attribute__((ext_vector_type(4)));'),
+        ('    const int rw = wave;                                    // row part of this wave\n',
+         '    const int rw = wave;                                    // row part of this wave\n    unsigned long long ts0_, ts1_, ts2_, ts3_, tr0_, tr3_, tbar_ = 0;\n    WW_STAMP(ts0_);\n    WW_RSTAMP(tr0_);\n'),
+        ('    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");\n    __syncthreads();\n    load_x(ww_int<0>());',
+         '    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");\n    __syncthreads();\n    WW_STAMP(ts1_);\n    load_x(ww_int<0>());'),
+        ('    // ---- epilogue: combine the six products, add the conditioning, gate, store the four outputs of the group\n    const float *cl = lds + SH::COND;',
+         '    WW_STAMP(ts2_);\n    // ---- epilogue: combine the six products, add the conditioning, gate, store the four outputs of the group\n    const float *cl = lds + SH::COND;'),
+        ('            if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res[o];\n        }\n    }\n}\n\n// ---------------------------------------------------------------------------------------------------------------------\n// <128 rows, products split>',
+         '            if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res[o];\n        }\n    }\n    WW_STAMP(ts3_);\n    WW_RSTAMP(tr3_);\n    if (lane == 0 && blockIdx.x < 16384) {\n        unsigned long long *o_ = g_ww_stamps + ((long long)blockIdx.x * 4 + wave) * 8;\n        o_[0] = ts0_; o_[1] = ts1_; o_[2] = ts2_; o_[3] = ts3_; o_[4] = tr0_; o_[5] = tr3_; o_[6] = tbar_;\n        o_[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg((4) | (31 << 11));\n    }\n}\n\n// ---------------------------------------------------------------------------------------------------------------------\n// <128 rows, products split>'),
+        ('}  // namespace mbx\n',
+         '}  // namespace mbx\n\nextern "C" int mbx_exp_stamps(void *dst, size_t bytes) {\n    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mbx::g_ww_stamps), bytes, 0, hipMemcpyDeviceToHost);\n}\n'),
+    ],
+    'stampB': [
+        ('        // ---- product 5 behind the barrier; fill st+1 must have landed\n        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n        __syncthreads();\n',
+         '        // ---- product 5 behind the barrier; fill st+1 must have landed\n        unsigned long long tb0_, tb1_;\n        WW_STAMP(tb0_);\n        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n        __syncthreads();\n        WW_STAMP(tb1_);\n        tbar_ += tb1_ - tb0_;\n'),
+    ],
+    # (with stampA) finer stamps inside the prologue: o_[6] = cycles from kernel start to "all LDS-DMA requests issued",
+    # the upper half of o_[7]'s low word is not used: stamps go to tbar_ as (issued - start) | (tables written - start) << 20 | (first wait passed - start) << 40
+    'stampC': [
+        ('    // lane n of column tile (e, tanh | sigmoid) holds gate channel n0 + 2 n + e\n',
+         '    unsigned long long tsa_, tsb_, tsc_;\n    WW_STAMP(tsa_);\n    // lane n of column tile (e, tanh | sigmoid) holds gate channel n0 + 2 n + e\n'),
+        ('    // A operand: group of this lane Q = 16*rw + r16',
+         '    WW_STAMP(tsb_);\n    // A operand: group of this lane Q = 16*rw + r16'),
+        ('    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");\n    __syncthreads();\n    WW_STAMP(ts1_);',
+         '    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");\n    WW_STAMP(tsc_);\n    __syncthreads();\n    WW_STAMP(ts1_);\n    tbar_ = ((tsa_ - ts0_) & 0xFFFFF) | (((tsb_ - ts0_) & 0xFFFFF) << 20) | (((tsc_ - ts0_) & 0xFFFFF) << 40);'),
+    ],
+    # wn_winograd4w.hip, round 5: the prologue and the epilogue at raised wave priority (their instructions compete with the
+    # MFMA streams of the two co-resident blocks: stamps show ~16-20 cycles per instruction there)
+    'prioPE': [
+        ('    const int rw = wave;                                    // row part of this wave\n',
+         '    const int rw = wave;                                    // row part of this wave\n    __builtin_amdgcn_s_setprio(3);\n'),
+        ('    load_x(ww_int<0>());\n    load_b(ww_int<0>(), ww_int<0>());\n    comb(ww_int<0>());\n    {\n        int st = 0;',
+         '    __builtin_amdgcn_s_setprio(0);\n    load_x(ww_int<0>());\n    load_b(ww_int<0>(), ww_int<0>());\n    comb(ww_int<0>());\n    {\n        int st = 0;'),
+        ('    // ---- epilogue: combine the six products, add the conditioning, gate, store the four outputs of the group\n',
+         '    __builtin_amdgcn_s_setprio(3);\n    // ---- epilogue: combine the six products, add the conditioning, gate, store the four outputs of the group\n'),
+    ],
+    'prioP': [
+        ('    const int rw = wave;                                    // row part of this wave\n',
+         '    const int rw = wave;                                    // row part of this wave\n    __builtin_amdgcn_s_setprio(3);\n'),
+        ('    load_x(ww_int<0>());\n    load_b(ww_int<0>(), ww_int<0>());\n    comb(ww_int<0>());\n    {\n        int st = 0;',
+         '    __builtin_amdgcn_s_setprio(0);\n    load_x(ww_int<0>());\n    load_b(ww_int<0>(), ww_int<0>());\n    comb(ww_int<0>());\n    {\n        int st = 0;'),
+    ],
+    'prioE': [
+        ('    // ---- epilogue: combine the six products, add the conditioning, gate, store the four outputs of the group\n',
+         '    __builtin_amdgcn_s_setprio(3);\n    // ---- epilogue: combine the six products, add the conditioning, gate, store the four outputs of the group\n'),
+    ],
     'base': [],
     # wn_winograd4w.hip
     'nodma': [
