@@ -73,6 +73,8 @@ __device__ __forceinline__ void w2_lds_dma16_s(const float *sbase, unsigned voff
 template <int N>
 using w2_int = std::integral_constant<int, N>;
 
+// GA: gate activation as a compile-time constant (0 = gtu) or -1 = ConvArgs::gate_act (see wn_winograd4w.hip)
+template <int GA>
 __global__ __launch_bounds__(256, 4) void wn_gate_winograd2w_kernel(ConvArgs p, int log2d) {
     constexpr int NSTAGE = W2_NSTAGE;
     typedef __attribute__((address_space(3))) float lds_float;
@@ -304,32 +306,61 @@ __global__ __launch_bounds__(256, 4) void wn_gate_winograd2w_kernel(ConvArgs p, 
     const float *cl = lds + W2_COND + wave * (W2_COND_ROWS * 64) + 2 * r16;
     float *obase = p.out + (long long)b * p.out_bstride + n0 + 2 * r16;
     const float inv_up = 1.0f / (float)cond_up;
+    // Round 5 (read off the ISA): the interpolation weights of an output were two global loads behind the branches of the
+    // run-time gate kind, each output a region of its own with a full wait (vmcnt(0) lgkmcnt(0)) -- eight serial L2 round
+    // trips per block, and a streaming tick's blocks all run in one round, where nothing hides them.  Now: positions and
+    // weight requests of all eight outputs first, the conditioning reads of a register's two outputs together, results
+    // formed outside the store branches.  Same arithmetic, same bits.
+    int t2s[4][2];
+    float w0s[4][2], w1s[4][2];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         const int pi = 4 * kq + v;                                               // pair held by this register
         const int lr0 = ((pi >> log2d) << (log2d + 1)) + (pi & (d - 1));         // its first row, relative to m0
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int crow = m0 + lr0 + (o << log2d) + cphase;
+            int t2 = (int)((float)crow * inv_up);                                // crow / cond_up (rows < 2^24)
+            int uu = crow - t2 * cond_up;
+            if (uu < 0) { --t2; uu += cond_up; }
+            if (uu >= cond_up) { ++t2; uu -= cond_up; }
+            t2s[v][o] = min(max(t2 - t2base, 0), W2_COND_ROWS - 2) * 64;
+            w0s[v][o] = p.lerp_w0[uu];
+            w1s[v][o] = p.lerp_w1[uu];
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int pi = 4 * kq + v;
+        const int lr0 = ((pi >> log2d) << (log2d + 1)) + (pi & (d - 1));
+        float2 ct0[2], ct1[2], cs0[2], cs1[2];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const float *c0 = cl + t2s[v][o];
+            ct0[o] = *reinterpret_cast<const float2 *>(c0);
+            ct1[o] = *reinterpret_cast<const float2 *>(c0 + 64);
+            cs0[o] = *reinterpret_cast<const float2 *>(c0 + 32);
+            cs1[o] = *reinterpret_cast<const float2 *>(c0 + 96);
+        }
         float y[4][2];                                                           // [column tile][output]
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             y[c][0] = (acc[0][c][v] + acc[1][c][v]) + acc[2][c][v];
             y[c][1] = (acc[1][c][v] - acc[2][c][v]) - acc[3][c][v];
         }
+        float2 res[2];
+        const int kind = GA < 0 ? p.gate_act : GA;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const float w0 = w0s[v][o], w1 = w1s[v][o];
+            res[o].x = wn_gate_act(kind, y[0][o] + fmaf(ct0[o].x, w0, ct1[o].x * w1), y[1][o] + fmaf(cs0[o].x, w0, cs1[o].x * w1));
+            res[o].y = wn_gate_act(kind, y[2][o] + fmaf(ct0[o].y, w0, ct1[o].y * w1), y[3][o] + fmaf(cs0[o].y, w0, cs1[o].y * w1));
+            asm volatile("" : "+v"(res[o].x), "+v"(res[o].y));
+        }
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
             const int row = m0 + lr0 + (o << log2d);
-            const int crow = row + cphase;
-            int t2 = (int)((float)crow * inv_up);                                // crow / cond_up (rows < 2^24)
-            int uu = crow - t2 * cond_up;
-            if (uu < 0) { --t2; uu += cond_up; }
-            if (uu >= cond_up) { ++t2; uu -= cond_up; }
-            const float w0 = p.lerp_w0[uu], w1 = p.lerp_w1[uu];
-            const float *c0 = cl + min(max(t2 - t2base, 0), W2_COND_ROWS - 2) * 64;
-            const float2 ct0 = *reinterpret_cast<const float2 *>(c0), ct1 = *reinterpret_cast<const float2 *>(c0 + 64);
-            const float2 cs0 = *reinterpret_cast<const float2 *>(c0 + 32), cs1 = *reinterpret_cast<const float2 *>(c0 + 96);
-            float2 res;
-            res.x = wn_gate_act(p.gate_act, y[0][o] + (ct0.x * w0 + ct1.x * w1), y[1][o] + (cs0.x * w0 + cs1.x * w1));
-            res.y = wn_gate_act(p.gate_act, y[2][o] + (ct0.y * w0 + ct1.y * w1), y[3][o] + (cs0.y * w0 + cs1.y * w1));
-            if (ch_ok && row < out_hi) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res;
+            if (ch_ok && row < out_hi) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res[o];
         }
     }
 }
@@ -359,7 +390,8 @@ bool launch_wn_gate_winograd2w(const ConvArgs &a, hipStream_t stream) {
     r.m_tiles_total = r.m_tiles_per_item * a.batch;
     const long long groups = (r.m_tiles_total + 3) / 4;
     const long long blocks = 8LL * ((groups + 7) / 8) * r.n_tiles;
-    hipLaunchKernelGGL(wn_gate_winograd2w_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, r, log2d);
+    if (a.gate_act == 0) hipLaunchKernelGGL(wn_gate_winograd2w_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, r, log2d);
+    else hipLaunchKernelGGL(wn_gate_winograd2w_kernel<-1>, dim3((unsigned)blocks), dim3(256), 0, stream, r, log2d);
     return true;
 }
 

@@ -675,10 +675,31 @@ __global__ __launch_bounds__(256, 3) void wn_gate_winograd4p_kernel(ConvArgs p, 
     const float *cl = lds + SH::COND;
     float *obase = p.out + (long long)b * p.out_bstride + n0 + 2 * r16;
     const float *clane = cl + 2 * r16;
+    // (as in the 256-row kernel: table entries first, the conditioning reads of a register's outputs together, results formed
+    // outside the store branches)
+    int etab[4][2];
 #pragma unroll
     for (int vi = 0; vi < 4; ++vi) {
         const int gi = 16 * rw + 4 * kq + vi;                                    // group held by this register
         const int lr0 = ((gi >> log2d) << (log2d + 2)) + (gi & (d - 1));         // its first row, relative to m0
+#pragma unroll
+        for (int o = 0; o < 2; ++o) etab[vi][o] = reinterpret_cast<const int *>(lds + SH::TAB)[lr0 + ((2 * ph + o) << log2d)];
+    }
+#pragma unroll
+    for (int vi = 0; vi < 4; ++vi) {
+        const int gi = 16 * rw + 4 * kq + vi;
+        const int lr0 = ((gi >> log2d) << (log2d + 2)) + (gi & (d - 1));
+        float2 w[2], ct0[2], ct1[2], cs0[2], cs1[2];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int e = etab[vi][o];
+            w[o] = make_float2(lds[SH::LERP + (e & 255)], lds[SH::LERP + 64 + (e & 255)]);
+            const float *c0 = clane + (e >> 8);
+            ct0[o] = *reinterpret_cast<const float2 *>(c0);
+            ct1[o] = *reinterpret_cast<const float2 *>(c0 + 64);
+            cs0[o] = *reinterpret_cast<const float2 *>(c0 + 32);
+            cs1[o] = *reinterpret_cast<const float2 *>(c0 + 96);
+        }
         float y[4][2];                                                           // [column tile][this wave's two outputs]
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -691,20 +712,18 @@ __global__ __launch_bounds__(256, 3) void wn_gate_winograd4p_kernel(ConvArgs p, 
                 y[c][1] = fmaf(8.f, dv[c][vi], t.y) + acc[2][c][vi];             // d12 + 8 d34 + m5
             }
         }
+        float2 res[2];
+        const int kind = GA < 0 ? p.gate_act : GA;
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
-            const int lr = lr0 + ((2 * ph + o) << log2d);
-            const int row = m0 + lr;
-            const int e = reinterpret_cast<const int *>(lds + SH::TAB)[lr];
-            const float2 w = make_float2(lds[SH::LERP + (e & 255)], lds[SH::LERP + 64 + (e & 255)]);
-            const float *c0 = clane + (e >> 8);
-            const float2 ct0 = *reinterpret_cast<const float2 *>(c0), ct1 = *reinterpret_cast<const float2 *>(c0 + 64);
-            const float2 cs0 = *reinterpret_cast<const float2 *>(c0 + 32), cs1 = *reinterpret_cast<const float2 *>(c0 + 96);
-            float2 res;
-            const int kind = GA < 0 ? p.gate_act : GA;
-            res.x = wn_gate_act(kind, y[0][o] + fmaf(ct0.x, w.x, ct1.x * w.y), y[1][o] + fmaf(cs0.x, w.x, cs1.x * w.y));
-            res.y = wn_gate_act(kind, y[2][o] + fmaf(ct0.y, w.x, ct1.y * w.y), y[3][o] + fmaf(cs0.y, w.x, cs1.y * w.y));
-            if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res;
+            res[o].x = wn_gate_act(kind, y[0][o] + fmaf(ct0[o].x, w[o].x, ct1[o].x * w[o].y), y[1][o] + fmaf(cs0[o].x, w[o].x, cs1[o].x * w[o].y));
+            res[o].y = wn_gate_act(kind, y[2][o] + fmaf(ct0[o].y, w[o].x, ct1[o].y * w[o].y), y[3][o] + fmaf(cs0[o].y, w[o].x, cs1[o].y * w[o].y));
+            asm volatile("" : "+v"(res[o].x), "+v"(res[o].y));
+        }
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int row = m0 + lr0 + ((2 * ph + o) << log2d);
+            if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res[o];
         }
     }
 }

@@ -18,7 +18,13 @@ TMP = '/tmp/mbx_exp'
 os.makedirs(TMP, exist_ok=True)
 os.makedirs(f'{R}/scripts/experiments/libs', exist_ok=True)
 FILE = os.environ.get('EXP_FILE', 'wn_winograd4w.hip')
-src = open(f'{R}/mbexwn_vocoder_amd/csrc/{FILE}').read()
+# EXP_REV=<git revision>: the kernel source as of that revision (compiled against today's headers and linked with today's
+# other objects) -- same-box A/B of a kernel change: EXP_REV=HEAD~3 python mkexp.py old4w:base
+if os.environ.get('EXP_REV'):
+    src = subprocess.run(['git', 'show', f"{os.environ['EXP_REV']}:mbexwn_vocoder_amd/csrc/{FILE}"], cwd=R, capture_output=True,
+                         text=True, check=True).stdout
+else:
+    src = open(f'{R}/mbexwn_vocoder_amd/csrc/{FILE}').read()
 PATCHES = {
     # wn_gate0.hip
     'g0_nostore': [
