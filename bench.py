@@ -468,7 +468,7 @@ def run_sharded(args, name, rank, world, dist, fence, torch, steps=None, warmup=
                              dims.hop_size, dims.steps_per_frame, rank=rank, world_size=world, max_batch=16,
                              max_padded_frames=16 * 1200, device=torch.device("cuda", torch.cuda.current_device()),
                              force_collective=dist is not None)
-    from mbexwn_vocoder_amd.sharding import lpt_partition
+    from mbexwn_vocoder_amd.sharding import lpt_partition, plan_stats
     mine = set(lpt_partition(lengths, world)[rank])
     mels, noises = [], []
     for ii, ll in enumerate(lengths):       # only this rank's utterances are generated; the others are placeholders
@@ -515,7 +515,13 @@ def run_sharded(args, name, rank, world, dist, fence, torch, steps=None, warmup=
             "gather_exposed_ms_per_rank": [round(vv[1], 3) for vv in per_rank],
             "value": samples / elapsed, "x_realtime": samples / elapsed / 24000.0, "ms_per_step": elapsed / steps * 1e3,
             "steps": steps, "scaling": "strong", "parallelism": f"utterance-sharded x{world}",
-            "padding_overhead": padded / max(1, sum(lengths[ii] for ii in mine))}
+            "padding_overhead": padded / max(1, sum(lengths[ii] for ii in mine)),
+            # what the partition allows at 1 .. 8 ranks (computed, not measured: every rank derives the same plan):
+            # LPT makespan / mean load, and the bytes of the gather left behind a rank's last forward
+            "partition": {str(nn): {"lpt_makespan_over_mean_load": round(st["imbalance"], 5),
+                                    "micro_batches_per_rank": st["micro_batches"],
+                                    "exposed_gather_bytes_per_rank": st["exposed_gather_bytes"]}
+                          for nn, st in ((nn, plan_stats(lengths, nn, dims.hop_size, 16, 16 * 1200)) for nn in (1, 2, 4, 8))}}
 
 
 def run_streaming(args, name, rank, world, fence, torch, steps=None, warmup=None):

@@ -42,7 +42,7 @@ def write_audio(outfile, data, rate, format):
 
 
 def main(model_id, input_mell_files, output_dir, use_gpu=False, sigma=None, format=None, verbose=False, seed=42,
-         num_threads=2, quiet=False):
+         num_threads=2, quiet=False, calibrate=0):
     import torch
     if not torch.cuda.is_available():
         print("resynth_mel::error:: no GPU available; this build has no CPU path", file=sys.stderr)
@@ -62,9 +62,16 @@ def main(model_id, input_mell_files, output_dir, use_gpu=False, sigma=None, form
         np.random.seed(seed)
         torch.manual_seed(seed)
 
-    MelInv = mel_inverter.MELInverter(model_id_or_path=model_id)
+    MelInv = mel_inverter.MELInverter(model_id_or_path=model_id, verbose=verbose)
     if output_dir and not os.path.exists(output_dir):
         os.makedirs(output_dir)
+    if calibrate and input_mell_files:
+        # --calibrate N (this build): the form of the WaveNet's convolution is decided on the first N mels of the job
+        # (MELInverter.calibrate -> mbx_calibrate) instead of on the synthetic mel of the engine's creation
+        first = [MelInv.scale_mel(load_var(ff)) for ff in input_mell_files[:int(calibrate)]]
+        info = MelInv.calibrate(first, verbose=verbose)
+        if not quiet and not verbose:
+            print(f"calibrated on {len(first)} file(s): convolution form {info['form']}", file=sys.stderr)
 
     for mell_file in input_mell_files:
         outfile = os.path.join(output_dir or "", "syn_" + os.path.splitext(os.path.basename(mell_file))[0] + "." + format)
@@ -107,6 +114,9 @@ if __name__ == "__main__":
     parser.add_argument("-g", "--use_gpu", action="store_true", help="run on gpu (implied)")
     parser.add_argument("-v", "--verbose", action="store_true", help="display verbose progress info")
     parser.add_argument("-q", "--quiet", action="store_true", help="dont display progress")
+    parser.add_argument("--calibrate", default=0, type=int, metavar="N",
+                        help="decide the form of the WaveNet's convolution on the first N input files before synthesis "
+                             "(Def: %(default)s = keep the decision made at model load on a synthetic mel)")
     args = parser.parse_args()
 
     if not args.model_id:

@@ -15,8 +15,12 @@ log_to_db = 20 * np.log10(np.exp(1))   # reference vocoder/model/preprocess.py:7
 
 
 class MELInverter(object):
-    def __init__(self, model_id_or_path: Union[str, None] = None, verbose: bool = False):
+    def __init__(self, model_id_or_path: Union[str, None] = None, verbose: bool = False, calibrate: bool = False):
+        """As the reference's constructor (mel_inverter.py:22-41); ``calibrate`` (this build) is handed to
+        :meth:`load_model`."""
         self.model = None
+        self._calibrate_pending = False
+        self._verbose = verbose
         self.model_id_or_path = model_id_or_path
         self.config_file = None
         self.preprocess_config = None
@@ -34,7 +38,7 @@ class MELInverter(object):
         self.use_max_limit = False
 
         if model_id_or_path:
-            self.load_model(model_id_or_path=model_id_or_path, verbose=verbose)
+            self.load_model(model_id_or_path=model_id_or_path, verbose=verbose, calibrate=calibrate)
 
     @property
     def srate(self):
@@ -120,9 +124,43 @@ class MELInverter(object):
 
         ``noise`` optionally injects the N(0,1) draw of the noise channel (shape (B, T*steps_per_frame));
         by default it is drawn on the device, as the reference draws tf.random.normal."""
+        if self._calibrate_pending:                 # load_model(..., calibrate=True): the first real mel decides the form
+            self.calibrate([scaled_mell], verbose=self._verbose)
         syn_audio = self.model.infer(scaled_mell, sigma=None, synth_length=scaled_mell.shape[1] * self.hop_size,
                                      noise=noise).numpy()
         return syn_audio.ravel()
+
+    def calibrate(self, scaled_mells, verbose=False, max_frames=400, seed=42):
+        """Decide the form of the WaveNet's dilated convolution on REAL data (this build; C ABI mbx_calibrate).
+
+        The engine runs Winograd F(4,3) only where its own rounding stays within a quarter of the float32 parity budget of
+        the direct form; at creation that is measured on a seeded synthetic mel (mbx_create), which a louder or otherwise
+        unusual corpus need not resemble.  ``scaled_mells``: a list of ``scale_mel`` outputs (1, T, mel_channels), e.g. the
+        first utterances of the job; at most ``max_frames`` frames of each are used.  The same procedure (direct form,
+        F(4,3), F(2,3) on these inputs, the fastest form within the threshold is kept) then binds every later
+        ``synth_from_mel``.  Returns ``self.model.conv_form_info()``; ``verbose`` prints the decision."""
+        import torch
+        mels = [np.asarray(mm, dtype=np.float32).reshape(-1, mm.shape[-2], mm.shape[-1])[0][:max_frames] for mm in scaled_mells]
+        if not mels:
+            raise ValueError("calibrate() needs at least one mel spectrogram")
+        lengths = [int(mm.shape[0]) for mm in mels]
+        batch = np.zeros((len(mels), max(lengths), mels[0].shape[1]), dtype=np.float32)
+        for ii, mm in enumerate(mels):
+            batch[ii, :lengths[ii]] = mm
+        dims = self.model.dims
+        noise = np.random.default_rng(seed).normal(size=(len(mels), max(lengths) * dims.wn_in_rows_per_frame)).astype(np.float32)
+        dev = self.model.device
+        info = self.model.calibrate(torch.as_tensor(batch, device=dev),
+                                    n_frames=torch.as_tensor(lengths, dtype=torch.int32, device=dev),
+                                    noise=torch.as_tensor(noise, device=dev) if dims.noise_sigma else None)
+        self._calibrate_pending = False
+        if verbose:
+            e43 = "n/a" if info["err_f43"] is None else f"{info['err_f43']:.2e}"
+            e23 = "n/a" if info["err_f23"] is None else f"{info['err_f23']:.2e}"
+            print(f"    calibrated the convolution form on {len(mels)} mel spectrogram(s), {sum(lengths)} frames: {info['form']} "
+                  f"(|audio(F(4,3)) - audio(direct)| {e43}, F(2,3) {e23}, threshold {info['threshold']:.2e} on |audio| <= "
+                  f"{info['ref_max']:.2f})", file=sys.stderr)
+        return info
 
     def generate_mel_from_snd(self, snd, srate, on_device=False):
         """Audio -> ``.mell`` dictionary (reference mel_inverter.py:156-182); host side (analysis.py) or, with
@@ -166,9 +204,13 @@ class MELInverter(object):
         return data_dict
 
     # ------------------------------------------------------------------------------------------
-    def load_model(self, model_id_or_path, verbose=False):
+    def load_model(self, model_id_or_path, verbose=False, calibrate=False):
         """reference mel_inverter.py:184-239: resolve the model directory, read ``config.yaml``, build the
-        generator, restore the weights and copy the pre-processing parameters onto the instance."""
+        generator, restore the weights and copy the pre-processing parameters onto the instance.
+
+        ``calibrate=True`` (this build): the first mel handed to :meth:`synth_from_mel` goes through :meth:`calibrate`
+        before it is synthesised -- the form of the WaveNet's convolution is then decided on the job's own data instead
+        of on the synthetic mel of ``mbx_create`` (``resynth_mel.py --calibrate N`` does the same on the first N files)."""
         from . import get_config_file
         from .config import read_config
         from .engine import MBExWNEngine
@@ -198,6 +240,12 @@ class MELInverter(object):
         else:
             raise FileNotFoundError(f"error::no weights found under {model_dir} (expected weights.npz or weights.tf.index)")
         self.model = MBExWNEngine(hparams, raw)
+        self._calibrate_pending = bool(calibrate)
+        self._verbose = bool(verbose)
+        if verbose:
+            info = self.model.conv_form_info()
+            print(f"convolution form {info['form']} (requested {info['requested']}, calibrated at creation on a synthetic mel: "
+                  f"{'yes' if info['calibrated'] == 1 else 'no'})", file=sys.stderr)
 
         self.mel_channels = self.preprocess_config["mel_channels"]
         self.hop_size = self.preprocess_config["hop_size"]

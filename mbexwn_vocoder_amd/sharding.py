@@ -41,6 +41,35 @@ def plan_batches(indices, lengths, max_batch=16, max_padded_frames=16 * 1200):
     return batches
 
 
+def plan_stats(lengths, world_size, hop_size, max_batch=16, max_padded_frames=16 * 1200, gather_chunk_floats=1 << 22):
+    """What the partition of a job looks like before it runs (every rank computes the same numbers):
+
+    ``imbalance``       LPT makespan / mean load (frames): 1.0 = perfectly even; the scaling efficiency the partition allows
+    ``padding``         padded frames / real frames of the micro-batches, per rank
+    ``micro_batches``   micro-batches per rank (sorted by falling length: the SMALLEST runs last)
+    ``exposed_gather_bytes``  per rank, the bytes of the result gather that cannot be issued before the rank's last forward
+                        has been packed (the gather is chunked and asynchronous: a piece goes to the collective as soon as
+                        the micro-batches that fill it are packed, so only the pieces the last micro-batch touches -- and the
+                        zero padding behind the rank's own audio up to the longest shard -- are left for the end)"""
+    lengths = [int(ll) for ll in lengths]
+    shards = lpt_partition(lengths, world_size)
+    loads = [sum(lengths[ii] for ii in ss) for ss in shards]
+    mean = sum(loads) / max(1, world_size)
+    flat = max(loads) * hop_size if loads else 0
+    chunk = max(1, int(gather_chunk_floats))
+    padding, n_batches, exposed = [], [], []
+    for rr, ss in enumerate(shards):
+        batches = plan_batches(ss, lengths, max_batch, max_padded_frames)
+        padded = sum(len(bb) * max(lengths[ii] for ii in bb) for bb in batches)
+        padding.append(padded / max(1, loads[rr]))
+        n_batches.append(len(batches))
+        last_audio = sum(lengths[ii] for ii in batches[-1]) * hop_size if batches else 0
+        before_last = loads[rr] * hop_size - last_audio                       # floats packed before the last forward
+        exposed.append(4 * (flat - (before_last // chunk) * chunk))
+    return {"imbalance": (max(loads) / mean) if mean else 1.0, "loads_frames": loads, "padding": padding,
+            "micro_batches": n_batches, "exposed_gather_bytes": exposed, "shard_buffer_bytes": 4 * flat}
+
+
 class ShardResult:
     """Audio of a sharded run, still where the forward pass left it (device tensors when the engine ran on a GPU).
 

@@ -138,6 +138,82 @@ def _worker4(rank, world, port, tmpdir):
         dist.destroy_process_group()
 
 
+def _config4_lengths():
+    """BASELINE config 4 as bench.py draws it: 256 utterances, U[2 s, 15 s] in frames."""
+    return [int(vv) for vv in np.random.default_rng(4242).integers(160, 1201, size=256)]
+
+
+def _utterance(ii, ll, channels=8):
+    rng = np.random.default_rng(1000 + ii)
+    return rng.normal(size=(ll, channels)).astype(np.float32), rng.normal(size=(ll * SPF,)).astype(np.float32)
+
+
+def _worker8(rank, world, port, tmpdir):
+    """world_size 8 on the real length distribution of config 4: every rank stages only its own utterances, the audio is
+    gathered on rank 0 (chunked, asynchronous), which checks every one of the 256 utterances against its own forward."""
+    import torch.distributed as dist
+    from mbexwn_vocoder_amd.sharding import plan_stats
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lengths = _config4_lengths()
+        mine = set(lpt_partition(lengths, world)[rank])
+        mels, noises = [], []
+        for ii, ll in enumerate(lengths):
+            if ii in mine:
+                mm, nn = _utterance(ii, ll)
+            else:                                            # placeholders: only the lengths of the others matter
+                mm, nn = np.zeros((ll, 8), dtype=np.float32), np.zeros((ll * SPF,), dtype=np.float32)
+            mels.append(mm)
+            noises.append(nn)
+        order = []
+
+        def counted(mel, n_frames, noise):
+            order.append(int(np.asarray(n_frames).sum()))
+            return fake_forward(mel, n_frames, noise)
+        syn = ShardedSynthesizer(counted, HOP, SPF, rank=rank, world_size=world, max_batch=16, max_padded_frames=16 * 1200)
+        plan = syn.stage(mels, noises)
+        res = syn.run_staged(plan, gather="rank0")
+        st = plan_stats(lengths, world, HOP, 16, 16 * 1200)
+        ok = st["imbalance"] <= 1.03 and st["micro_batches"][rank] == len(plan["batches"]) == len(order)
+        ok = ok and order == sorted(order, reverse=True)                     # the smallest micro-batch runs last
+        ok = ok and st["exposed_gather_bytes"][rank] <= st["shard_buffer_bytes"]
+        ok = ok and res.timing["chunks"] == -(-int(plan["flat"].numel()) // (1 << 22))
+        if rank == 0:
+            got = res.to_list()
+            seen = 0
+            for ii, ll in enumerate(lengths):
+                mm, nn = _utterance(ii, ll)
+                ref = fake_forward(mm[None], np.asarray([ll], np.int32), nn[None])[0]
+                ok = ok and got[ii] is not None and got[ii].shape == ref.shape and np.array_equal(got[ii], ref)
+                seen += 1
+            ok = ok and seen == 256 and sum(len(ss) for ss in res.shards) == 256
+        else:
+            ok = ok and all(pp is None for pp in res.parts)
+        with open(os.path.join(tmpdir, f"ok{rank}"), "w") as fo:
+            fo.write("1" if ok else "0")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_world_size_8_gloo_config4_length_distribution(tmp_path):
+    """The shape of the 8-GPU job of BASELINE config 4, on CPU ranks: 256 utterances U[2 s, 15 s], LPT imbalance <= 3 %,
+    two micro-batches per rank of which the smaller runs last, every utterance gathered exactly once on rank 0."""
+    import torch.multiprocessing as mp
+    from mbexwn_vocoder_amd.sharding import plan_stats
+    st = plan_stats(_config4_lengths(), 8, HOP, 16, 16 * 1200)
+    assert st["imbalance"] <= 1.03 and st["micro_batches"] == [2] * 8
+    assert max(st["exposed_gather_bytes"]) <= 0.5 * st["shard_buffer_bytes"]     # at most the last micro-batch's audio is left
+    with socket.socket() as ss:
+        ss.bind(("127.0.0.1", 0))
+        port = ss.getsockname()[1]
+    mp.spawn(_worker8, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    for rank in range(8):
+        assert (tmp_path / f"ok{rank}").read_text() == "1", f"rank {rank}"
+
+
 @pytest.mark.timeout(300)
 def test_world_size_4_gloo_uneven_shards_and_an_empty_rank(tmp_path):
     import torch.multiprocessing as mp
