@@ -129,6 +129,68 @@ def test_cli_config1_canonical_3s_against_the_oracle(tmp_path):
     assert err <= 1e-4 * max(1.0, float(np.abs(ref).max())), err
 
 
+def test_calibrate_on_real_data_through_the_drop_in_surface(tmp_path):
+    """MELInverter.load_model(calibrate=True) / resynth_mel.py --calibrate N: the form of the WaveNet's convolution is
+    decided on the job's own mels (mbx_calibrate) instead of on the synthetic mel of the engine's creation.  Stressed
+    weights (the WaveNet's gains x ~5, shifted biases: |h| ~ 25) for which the creation-time calibration keeps a Winograd
+    form while a loud mel -- quieter audio, hence a tighter threshold -- does not: after the calibration on that mel the
+    handle reports the safer form, and its audio is as exact as the direct form's."""
+    import torch
+    from mbexwn_vocoder_amd.config import read_config
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    from mbexwn_vocoder_amd.fileio import save_var
+    from mbexwn_vocoder_amd.mel_inverter import MELInverter, create_synthetic_model_dir
+    from mbexwn_vocoder_amd.tables import WaveTables
+    from mbexwn_vocoder_amd.weights import load_weights, save_weights
+    from oracle.mbexwn_oracle import OracleModel
+    from test_gpu_forms import stressed_weights
+    rank = {"direct": 0, "f23": 1, "f43": 2}
+    frames = 60
+    rng = np.random.default_rng(4242)
+    loud = np.clip(np.log(np.exp(rng.normal(-5.0, 2.0, size=(1, frames, 80))) + 1e-5) + 4.0, -11.5, 2.0).astype(np.float32)
+    noise = rng.normal(size=(1, frames * 20)).astype(np.float32)
+    found = None
+    for gain in (5.0, 4.7, 5.3, 4.4, 5.6):
+        mdir = create_synthetic_model_dir(str(tmp_path / f"stressed_{gain}"), "SING")
+        wpath = os.path.join(mdir, "weights.npz")
+        save_weights(wpath, stressed_weights(load_weights(wpath), gain, 0.3))
+        plain = MELInverter(mdir)
+        at_creation = plain.model.conv_form_info()
+        assert at_creation["calibrated"] == 1
+        inv = MELInverter(mdir, calibrate=True)
+        assert inv.model.conv_form_info()["form"] == at_creation["form"]          # nothing decided before the first mel
+        audio = inv.synth_from_mel(loud, noise=noise)
+        after = inv.model.conv_form_info()
+        assert after["calibrated"] == 2 and not inv._calibrate_pending
+        # the decision follows the numbers measured on the caller's data
+        want = "f43" if after["err_f43"] is not None and after["err_f43"] <= after["threshold"] else \
+            "f23" if after["err_f23"] is not None and after["err_f23"] <= after["threshold"] else "direct"
+        assert after["form"] == want
+        if rank[after["form"]] < rank[at_creation["form"]]:
+            found = (gain, mdir, at_creation, after, audio, plain.synth_from_mel(loud, noise=noise))
+            break
+    assert found, "no stress level at which the loud mel changes the creation-time decision"
+    gain, mdir, at_creation, after, audio, audio_uncal = found
+    cfg = read_config(os.path.join(mdir, "config.yaml"))
+    raw = load_weights(os.path.join(mdir, "weights.npz"))
+    wt = WaveTables(sample_rate=8000.0, **cfg["mbexwn_config"]["wavetable_config"])
+    ref = OracleModel(cfg, raw, wt).forward(loud, noise)[0]
+    direct = MBExWNEngine(cfg, raw, wt, conv_form="direct").forward(torch.as_tensor(loud).cuda(), noise=torch.as_tensor(noise).cuda()).cpu().numpy()[0]
+    err, err_uncal, err_direct = (float(np.abs(xx.astype(np.float64) - ref).max()) for xx in (audio, audio_uncal, direct))
+    print(f"gain {gain}: creation {at_creation['form']} -> calibrated on the loud mel {after['form']}; |audio - oracle| calibrated "
+          f"{err:.2e}, un-calibrated {err_uncal:.2e}, direct form {err_direct:.2e} on |audio| <= {np.abs(ref).max():.1f}")
+    assert err <= 1.25 * err_direct + 1e-7
+    # the CLI: --calibrate N decides on the first N files and says so under -v
+    dd = mell_dict(40, seed=3)
+    path = str(tmp_path / "utt.mell")
+    save_var(path, dd)
+    cli = os.path.join(ROOT, "mbexwn_vocoder_amd", "bin", "resynth_mel.py")
+    res = subprocess.run([sys.executable, cli, mdir, "-i", path, "-o", str(tmp_path / "out"), "--format", "wav", "-g", "-v",
+                          "--calibrate", "1"], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    assert "calibrated the convolution form on 1 mel spectrogram(s)" in res.stderr and "convolution form" in res.stderr
+
+
 def test_sharded_synthesis_matches_single_runs(model_dir):
     """config 4 in miniature: ragged utterances, LPT shards, padded micro-batches, per-item parity."""
     import torch
