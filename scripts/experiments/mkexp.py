@@ -237,6 +237,13 @@ PATCHES = {
         ('    // ---- epilogue: combine the six products, add the conditioning, gate, store the four outputs of the group\n',
          '    __builtin_amdgcn_s_setprio(3);\n    // ---- epilogue: combine the six products, add the conditioning, gate, store the four outputs of the group\n'),
     ],
+    # wn_resskip_wide.hip, round 5: the second resident block of every CU (first round: ids 256..511) starts late -- the blocks of a
+    # launch run in lockstep and their accumulator pre-loads / stores hit HBM in bursts
+    'rwd15': [('    const int m0 = mt * RW_ROWS;\n    if (m0 >= rows) return;\n', '    const int m0 = mt * RW_ROWS;\n    if (m0 >= rows) return;\n    if (blockIdx.x >= 256 && blockIdx.x < 512) {\n        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();\n        while (__builtin_amdgcn_s_memrealtime() - t0 < 1500ull) __builtin_amdgcn_s_sleep(32);\n    }\n')],
+    'rwd30': [('    const int m0 = mt * RW_ROWS;\n    if (m0 >= rows) return;\n', '    const int m0 = mt * RW_ROWS;\n    if (m0 >= rows) return;\n    if (blockIdx.x >= 256 && blockIdx.x < 512) {\n        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();\n        while (__builtin_amdgcn_s_memrealtime() - t0 < 3000ull) __builtin_amdgcn_s_sleep(32);\n    }\n')],
+    'rwd45': [('    const int m0 = mt * RW_ROWS;\n    if (m0 >= rows) return;\n', '    const int m0 = mt * RW_ROWS;\n    if (m0 >= rows) return;\n    if (blockIdx.x >= 256 && blockIdx.x < 512) {\n        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();\n        while (__builtin_amdgcn_s_memrealtime() - t0 < 4500ull) __builtin_amdgcn_s_sleep(32);\n    }\n')],
+    'rwd60': [('    const int m0 = mt * RW_ROWS;\n    if (m0 >= rows) return;\n', '    const int m0 = mt * RW_ROWS;\n    if (m0 >= rows) return;\n    if (blockIdx.x >= 256 && blockIdx.x < 512) {\n        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();\n        while (__builtin_amdgcn_s_memrealtime() - t0 < 6000ull) __builtin_amdgcn_s_sleep(32);\n    }\n')],
+    'rwspread': [('    const int m0 = mt * RW_ROWS;\n    if (m0 >= rows) return;\n', '    const int m0 = mt * RW_ROWS;\n    if (m0 >= rows) return;\n    if (blockIdx.x < 512) {\n        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();\n        const unsigned long long w_ = (unsigned long long)((blockIdx.x >> 3) & 7) * 750ull;\n        while (__builtin_amdgcn_s_memrealtime() - t0 < w_) __builtin_amdgcn_s_sleep(32);\n    }\n')],
     'base': [],
     # wn_winograd4w.hip
     'nodma': [
