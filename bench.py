@@ -402,7 +402,7 @@ def roofline(ctx, workload):
         "overlap_add": B * T * (win * 4 + hop * 4),                                # frames -> audio
         "wavetable": B * T * (ppf * 4 * 2),                                        # f0 -> pulse (phase + lookup)
     }
-    # what the measurements say limits each of these stages (profiles/README.md); the GB/s figure is
+    # what the measurements say limits each of these stages (NOTEBOOK.md R4 section 9, profiles/README.md); the GB/s figure is
     # their algorithmic traffic over the launch time whatever the limiter is
     limiter = {
         "gate0": "vector + transcendental issue of the gate activation, which shares the SIMD with its K = 24 fp32 MFMAs "

@@ -7,7 +7,7 @@
 //     x y  ~  hi_x hi_y + 2^-11 (hi_x lo'_y + lo'_x hi_y)
 // drops only lo lo (2^-22 relative), every fp16 x fp16 product is exact in the float32 accumulator, and the 2^11 keeps the
 // low parts in fp16's normal range: the result has the error of a plain float32 contraction (emulated on the canonical
-// K = 960 contraction: 2.7e-6 against 3.1e-6).  One accumulator holds 2^11 times the result: the
+// K = 960 contraction: 2.7e-6 against 3.1e-6; NOTEBOOK.md R4 section 9).  One accumulator holds 2^11 times the result: the
 // hi x hi product takes the activation's high part times 2^11 (exact in fp16 for |x| < 32: the gate output `a` lies in
 // (-1, 1) -- which is why the glu gate, whose linear half is unbounded, does not get this mode -- and the excitation channels
 // that layer 0's rows carry behind it, pulse samples and the noise draw, are O(1)), the old value and the bias enter times
