@@ -55,9 +55,9 @@ void launch_lin_interp(const float *x, long long x_bstride, const int *n_frames,
 // Head of the F0-net in float64 (mbx_config.f0_accumulate, the default): final 1x1 convolution cin -> 1, linear interpolation
 // to the pulse rate, final activation and the affine map onto [f_min, f_max] -- reference custom_pulsed_generator.py:126-146
 // (final layer, missing up-sampling factor, final activation), :773-791 (generate_f0), custom_AE_layers.py:91-99 (soft_sigmoid).
-// The contour feeds the phase integrator: every step here is float64 on the float32 hidden layer and the float32 constants
-// (weights, bias, the interpolator's float32 weight vectors), rounded to float32 ONCE.  Block = 64 rows of the hidden layer
-// (+ the row behind them for the interpolation): four threads per row sum every fourth channel each in a fixed order.
+// The contour feeds the phase integrator: every step here is float64 on the hidden layer and the float32 constants (bias, the
+// interpolator's float32 weight vectors), rounded to float32 ONCE.  Block = 16 rows of the hidden layer (+ the row behind
+// them for the interpolation): four threads per row sum every fourth channel each in a fixed order.
 __device__ __forceinline__ double apply_act64(double x, int act) {
     switch (act) {
         case 1: return 0.5 + 0.5 * x / (1.0 + fabs(x));
@@ -71,7 +71,7 @@ __device__ __forceinline__ double apply_act64(double x, int act) {
     }
 }
 
-constexpr int F0H_ROWS = 64;
+constexpr int F0H_ROWS = 16;     // (64: four blocks for a 3 s utterance, 13.5 us of float64 divisions on four CUs)
 
 template <typename XT, typename WT>
 __global__ __launch_bounds__(256) void f0_head_kernel(const XT *x, long long x_bstride, int cin, const int *n_frames,
@@ -94,11 +94,10 @@ __global__ __launch_bounds__(256) void f0_head_kernel(const XT *x, long long x_b
         s += __shfl_xor(s, 2);
         return s + (bias ? (double)bias[0] : 0.0);
     };
-    const double mine = dot(m0 + (tid >> 2));
-    if (part == 0) xs[tid >> 2] = mine;
-    if (tid < 64) {                                   // (whole wave: the shuffles need their partners)
-        const double last = dot(m0 + F0H_ROWS);
-        if (tid == 0) xs[F0H_ROWS] = last;
+    // rows m0 .. m0 + F0H_ROWS (the last one for the interpolation of the row in front of it): four threads each
+    if (tid < 4 * (F0H_ROWS + 1) + 60) {              // (whole waves: the shuffles need their partners)
+        const double mine = dot(m0 + (tid >> 2));
+        if (part == 0 && (tid >> 2) <= F0H_ROWS) xs[tid >> 2] = mine;
     }
     __syncthreads();
     const int n_here = min(F0H_ROWS, rows - m0);
