@@ -375,11 +375,12 @@ def roofline(ctx, workload):
     bandwidth-type stages against the HBM peak.  Algorithmic work per launch: DESIGN.md section 4."""
     dims, eng, batch, frames, stages = ctx["dims"], ctx["eng"], ctx["batch"], ctx["frames"], ctx["stages"]
     form = eng.gate_form(batch, frames)
-    executed = {"direct": 1.0, "winograd_f23": 2.0 / 3.0, "winograd_f43": 0.5, "winograd_f43_psplit": 0.5}[form]
+    executed = {"direct": 1.0, "winograd_f23": 2.0 / 3.0, "winograd_f43": 0.5, "winograd_f43_psplit": 0.5, "winograd_f43_hsplit": 0.5}[form]
     kernel = {"direct": "conv1d_mfma_dma_kernel<EPI_GATE> (dilated conv k=3 C->2C + cond + tanh*sigmoid)",
               "winograd_f23": "wn_gate_winograd2w_kernel (dilated conv k=3 C->2C in Winograd F(2,3) form on v_mfma_f32_16x16x4_f32, wave-granular tiles + cond + tanh*sigmoid)",
               "winograd_f43": "wn_gate_winograd4w_kernel (dilated conv k=3 C->2C in Winograd F(4,3) form on v_mfma_f32_16x16x4_f32 + cond + tanh*sigmoid)",
-              "winograd_f43_psplit": "wn_gate_winograd4p_kernel (same, 128-row blocks whose waves split the six products: same bits, finer units)"}[form]
+              "winograd_f43_psplit": "wn_gate_winograd4p_kernel (same, 128-row blocks whose waves split the six products: same bits, finer units)",
+              "winograd_f43_hsplit": "wn_gate_winograd4h_kernel (same, product-split blocks of half a column tile: same bits, finer still)"}[form]
     C, ks, L = dims.wn_channels, dims.wn_kernel_size, dims.wn_layers
     rows = batch * frames * dims.steps_per_frame
     gate_ms, gate_n = stages["gate"]

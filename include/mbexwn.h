@@ -198,7 +198,8 @@ typedef struct {
     int32_t wn_keep_start;       /* 1: keep the start convolution and the full first layer (default: folded into layer 0) */
     float calib_fraction;        /* MBX_CONV_AUTO: share of the parity budget the form's own rounding may take; 0 = 0.25 */
     /* measurement knobs, none changes what a kernel computes for a given kernel choice (scripts/experiments):
-     *   tune_gate_shape        0: by launch size, 1: 256-row F(4,3) blocks, 2: 128-row product-split blocks (same bits)
+     *   tune_gate_shape        0: by launch size, 1: 256-row F(4,3) blocks, 2: 128-row product-split blocks, 3: product-split
+     *                          blocks of half a column tile (same bits, all three)
      *   tune_resskip_wave_tiles 0: default (2048); n > 0: res/skip launches of at most n 16-row tiles run the wave-tiled
      *                          kernel; -1: never
      *   tune_resskip_split     0: by launch size, 1..3: column split of the wave-tiled res/skip kernel (same bits) */

@@ -104,7 +104,7 @@ struct mbx_handle {
     bool fold_skip = false;      // skip path folded into the end convolution (needs the *.fold tensors)
     bool fold_start = false;     // start convolution folded into layer 0 (needs fold_skip and the *.start_fold / *.fold_start tensors)
     bool winograd4_always = false;   // mbx_config.batch_invariant with F(4,3): the large-launch kernel shapes at every size
-    int gate_small_shape = -1;       // mbx_config.tune_gate_shape: pins the F(4,3) block shape of small launches (0: 256-row | 1: product-split; same bits)
+    int gate_small_shape = -1;       // mbx_config.tune_gate_shape: pins the F(4,3) block shape of small launches (0: 256-row | 1: product-split | 2: product-split, half column tiles; same bits)
     long long resskip_wave_tiles = 2048;   // default policy: res/skip launches of at most this many 16-row tiles run the wave-tiled kernel
     int resskip_split = 0;           // mbx_config.tune_resskip_split
     bool split_f16 = false;          // mbx_config.wn_precision == MBX_PRECISION_SPLIT_F16 and the images are there
@@ -826,7 +826,7 @@ mbx_status mbx_create(const mbx_config *config, const mbx_tensor *tensors, int32
     hd->f0_full64 = f0_chain_is_full64(hd);
     if (c.wn_conv_form < MBX_CONV_AUTO || c.wn_conv_form > MBX_CONV_F43)
         return bail(fail(MBX_ERR_INVALID_ARGUMENT, "wn_conv_form must be MBX_CONV_AUTO, _DIRECT, _F23 or _F43"));
-    if (c.tune_gate_shape < 0 || c.tune_gate_shape > 2 || c.tune_resskip_split < 0 || c.tune_resskip_split > 3 ||
+    if (c.tune_gate_shape < 0 || c.tune_gate_shape > 3 || c.tune_resskip_split < 0 || c.tune_resskip_split > 3 ||
         c.tune_resskip_wave_tiles < -1 || c.calib_fraction < 0.f || c.calib_fraction > 1.f)
         return bail(fail(MBX_ERR_INVALID_ARGUMENT, "tune_* / calib_fraction out of range"));
     {
@@ -1041,7 +1041,7 @@ static mbx_status run_wavenet_blocks(mbx_handle *hd, const Workspace &w, int B, 
                     wino4->shape[2] == 3072) {
                     mbx::ConvArgs gw = g;
                     gw.w = wino4->ptr;
-                    done = mbx::launch_wn_gate_winograd4w(gw, false, stream);
+                    done = mbx::launch_wn_gate_winograd4w(gw, 0, stream);
                 }
                 if (!done) mbx::launch_conv1d(g, mbx::EPI_GATE, stream);
             }
@@ -1439,7 +1439,13 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
             // 256-row blocks and loses behind it, where both shapes divide evenly and the 128-row block's extra LDS-DMA traffic
             // per MFMA (the weight slice serves half the rows) and shorter slices tell
             bool split4 = !hd->winograd4_always && full_blocks <= 1024 && load_half <= load_full;
-            if (hd->gate_small_shape >= 0 && !hd->winograd4_always && full_blocks < 4 * 768) split4 = hd->gate_small_shape != 0;
+            // round 5: product-split blocks of HALF a column tile (one channel parity: twice the blocks of half the work) where
+            // even the product-split blocks leave the CUs unevenly loaded -- a 3 s utterance is 380 of them on 256 CUs, the
+            // worst CU works two while the average is 1.5; 760 half blocks give every CU three (same bits as the other shapes)
+            const double load_quarter = 0.25 * (double)((2 * half_blocks + 255) / 256);
+            int shape4 = split4 ? (load_quarter < load_half ? 2 : 1) : 0;
+            if (hd->gate_small_shape >= 0 && !hd->winograd4_always && full_blocks < 4 * 768) shape4 = hd->gate_small_shape;
+            split4 = shape4 != 0;
             // opt-in split half precision: whole-item forwards of the layers behind the folded first one
             if (hd->split_f16_gate && !st_in && !st_out && gs.cphase == 0 && gs.out_rows == 0) {
                 mbx::ConvArgs gh = g;
@@ -1458,7 +1464,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                 mbx::ConvArgs gw = g;
                 gw.w = wino4->ptr;
                 // (the product-split shape holds 16 conditioning rows: cond_up >= 10; the 256-row shape takes cond_up >= 5)
-                done = mbx::launch_wn_gate_winograd4w(gw, split4, stream) || (split4 && mbx::launch_wn_gate_winograd4w(gw, false, stream));
+                done = mbx::launch_wn_gate_winograd4w(gw, shape4, stream) || (split4 && mbx::launch_wn_gate_winograd4w(gw, 0, stream));
             }
             // F(2,3): wave-tiled kernel on v_mfma_f32_16x16x4_f32 (wn_winograd2w.hip): streams, per-layer regions, MBX_CONV_F23
             const DevTensor *wino = (!done && hd->winograd) ? find(hd, "wn.conv1D_" + ls + ".wino2w") : nullptr;

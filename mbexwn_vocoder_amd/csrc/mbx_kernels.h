@@ -109,7 +109,8 @@ void launch_conv1d_group(const ConvArgs *convs, int n, hipStream_t stream);
 // Winograd F(4,3) form on v_mfma_f32_16x16x4_f32, wave tile 16 groups x 64 columns (wn_winograd4w.hip); a.w = image of
 // engine.pack_winograd4w_weights (ceil(C/32), ceil(C/8), 3072); split: 128-row blocks whose waves split the six products
 // (same bits as the 256-row blocks)
-bool launch_wn_gate_winograd4w(const ConvArgs &a, bool split, hipStream_t stream);
+// shape: 0 = 256-row blocks, 1 = 128-row product-split blocks, 2 = product-split blocks of half a column tile (same bits, all three)
+bool launch_wn_gate_winograd4w(const ConvArgs &a, int shape, hipStream_t stream);
 // Winograd F(2,3) form on v_mfma_f32_16x16x4_f32 with wave-granular tiles (wn_winograd2w.hip: streams, per-layer regions,
 // MBX_CONV_F23); a.w = image of engine.pack_winograd2w_weights (ceil(C/32), ceil(C/8), 2048)
 bool launch_wn_gate_winograd2w(const ConvArgs &a, hipStream_t stream);

@@ -728,10 +728,293 @@ __global__ __launch_bounds__(256, 3) void wn_gate_winograd4p_kernel(ConvArgs p, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// <128 rows, products split, HALF a column tile> (round 5): the product-split block for launches that do not fill the chip
+// evenly.  A 3 s utterance is 380 product-split blocks on 256 CUs: 124 CUs work two blocks while 132 work one, and the launch
+// lasts as long as two.  Here a block owns the 16 gate channels of ONE channel parity e of its column tile (the packed weight
+// image is [product][parity e][lane][4]: the block stages the e-th kilobyte of every product and nothing else): twice the blocks
+// of half the matrix work -- 760 for 3 s, every CU gets three, the launch lasts as long as one and a half.  Same groups, same
+// products, same sums in the same order as the other two shapes: the SAME bits.  LDS 29.5 KB, 4+ blocks per CU.  The launcher
+// takes it when the worst CU's share shrinks (launch_wn_gate_winograd4w).
+struct WhShape {
+    static constexpr int ROWS = 128;
+    static constexpr int PHASE = ROWS / 4 + WW_HALO;            // 48
+    static constexpr int A_FLOATS = 4 * PHASE * WW_BK;          // 1536
+    static constexpr int B_FLOATS = 6 * 256;                    // one parity of the six products
+    static constexpr int STAGE = A_FLOATS + B_FLOATS;           // 3072 floats = 12 KB
+    static constexpr int NSTAGE = 2;
+    static constexpr int COND_ROWS = 16;
+    static constexpr int COND = NSTAGE * STAGE;
+    static constexpr int TAB = COND + COND_ROWS * 64;
+    static constexpr int LERP = TAB + ROWS;
+    static constexpr int LDS_FLOATS = LERP + 128;               // 6144 + 1024 + 128 + 128 = 7424 floats = 29 696 bytes
+};
+
+template <int GA>
+__global__ __launch_bounds__(256, 4) void wn_gate_winograd4h_kernel(ConvArgs p, int log2d) {
+    using SH = WhShape;
+    constexpr int ROWS = SH::ROWS, NSTAGE = SH::NSTAGE, STAGE = SH::STAGE, A_FLOATS = SH::A_FLOATS, PHASE = SH::PHASE;
+    typedef __attribute__((address_space(3))) float lds_float;
+    __shared__ __attribute__((aligned(16))) float lds[SH::LDS_FLOATS];
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float *)lds);
+
+    // p.n_tiles counts HALF column tiles here: nt2 = 2 * (column tile) + parity
+    const int id = blockIdx.x;
+    const int l = id >> 3;
+    const int g_ = (l / p.n_tiles) * 8 + (id & 7);
+    const int nt2 = l % p.n_tiles;
+    const int nt = nt2 >> 1, eh = nt2 & 1;
+    if (g_ >= p.m_tiles_total) return;
+    const int b = g_ / p.m_tiles_per_item;
+    const int mt = g_ - b * p.m_tiles_per_item;
+    const int rows = item_rows(p.n_frames, b, p.rows_per_frame, p.max_rows);
+    const int m0 = mt * ROWS;
+    if (m0 >= rows) return;
+    const int C = p.channels;
+    const int n0 = nt * 32;
+    const int d = 1 << log2d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rw = wave >> 1, ph = wave & 1;                // row half and product half of this wave
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int xrow0 = max(m0 - WW_HALO, 0);
+    const float *xb = p.x + (long long)b * p.x_bstride + (long long)xrow0 * p.ldx;
+    const int nk8 = (p.cin + WW_BK - 1) / WW_BK;
+
+    // ---- per-lane DMA sources of the activation rows (as in wn_gate_winograd4p_kernel)
+    unsigned a_voff[2];
+    unsigned a_bits = 0;
+    int a_inst[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        a_inst[i] = i == 0 ? wave : 4 + (wave & 1);         // chunks 4, 5: written by two waves each (same data)
+        const int pos = a_inst[i] * 64 + lane;
+        const int cell = pos >> 1;
+        const int phase = cell / PHASE, sidx = cell - phase * PHASE;
+        const int m = 4 * (sidx >> log2d) + phase;
+        const int row = (m << log2d) + (sidx & (d - 1)) + WW_HALO - d;
+        const int src = m0 - WW_HALO + row;
+        const int hi = (pos & 1) ^ ((cell >> 3) & 1);
+        if (row < ROWS + 2 * WW_HALO && src >= 0 && src < rows) a_bits |= 1u << i;
+        a_bits |= (unsigned)hi << (4 + i);
+        a_voff[i] = 4u * (unsigned)((min(max(src, 0), rows - 1) - xrow0) * p.ldx + 4 * hi);
+    }
+    const bool fast_rows = p.fast_dma && m0 >= WW_HALO && m0 + ROWS + WW_HALO <= rows;
+    const int whole_fills = p.cin / WW_BK;
+    const float *wtile = p.w + (long long)nt * nk8 * WW_B_FLOATS + eh * 256;      // product j of this parity: + 512 j
+    const unsigned b_voff = 16u * (unsigned)lane;
+    // LDS-DMA of slice st: 2 requests for the rows + 2 for the weights per wave (products wave and 4 + (wave & 1): the last two
+    // are requested twice, so that every wave has the same number of requests in flight)
+    auto issue = [&](int st, int stage) {
+        const int ci0 = st * WW_BK;
+        const unsigned sdst = lds_base + 4u * (unsigned)(stage * STAGE);
+        if (fast_rows && st < whole_fills) {
+            const float *abase = xb + ci0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) ww_lds_dma16_s(abase, a_voff[i], sdst + 1024u * (unsigned)a_inst[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ci = ci0 + 4 * (int)((a_bits >> (4 + i)) & 1u);
+                const bool ok = ((a_bits >> i) & 1u) & (ci < p.cin);
+                const float *src = reinterpret_cast<const float *>(reinterpret_cast<const char *>(xb + ci0) + a_voff[i]);
+                ww_lds_dma16(ok ? src : p.zeros, sdst + 1024u * (unsigned)a_inst[i]);
+            }
+        }
+        const float *bsrc = wtile + (long long)st * WW_B_FLOATS;
+        const int j0 = wave, j1 = 4 + (wave & 1);
+        ww_lds_dma16_s(bsrc + j0 * 512, b_voff, sdst + 4u * (unsigned)A_FLOATS + 1024u * (unsigned)j0);
+        ww_lds_dma16_s(bsrc + j1 * 512, b_voff, sdst + 4u * (unsigned)A_FLOATS + 1024u * (unsigned)j1);
+    };
+    // ---- conditioning rows of this block (16 x (32 tanh | 32 sigmoid) columns of the whole column tile): one request per wave
+    const int cond_up = p.cond_up;
+    const int t2base = m0 / cond_up;
+    {
+        const int n2 = rows / cond_up;
+        const float *cbase = p.cond + (long long)b * p.cond_bstride;
+        const int pos = wave * 64 + lane;
+        const int crow = pos >> 4, cq = pos & 15;
+        const int chn = n0 + 4 * (cq & 7);
+        const int t = min(t2base + crow, n2 - 1);
+        ww_lds_dma16(chn < C ? cbase + (long long)t * (2 * C) + (cq >> 3) * C + chn : p.zeros,
+                     lds_base + 4u * (unsigned)SH::COND + 1024u * (unsigned)wave);
+    }
+#pragma unroll
+    for (int s0 = 0; s0 < NSTAGE; ++s0)
+        if (s0 < nk8) issue(s0, s0);
+
+    const int chl = n0 + 2 * r16 + eh;                    // gate channel of this lane
+    const bool ch_ok = chl < C;
+    f32x4 acc[3][2];          // [product 3 ph + j][0 tanh | 1 sigmoid]
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float bv = (j == 1 && ph == 0 && p.bias && ch_ok) ? p.bias[c * C + chl] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[j][c][r] = bv;
+        }
+    if (tid < ROWS) {
+        const int row = m0 + tid;
+        const int t2 = row / cond_up;
+        const int u = row - t2 * cond_up;
+        reinterpret_cast<int *>(lds + SH::TAB)[tid] = (((t2 - t2base) * 64) << 8) | u;
+    }
+    if (tid < 64) {
+        lds[SH::LERP + tid] = tid < cond_up ? p.lerp_w0[tid] : 0.f;
+        lds[SH::LERP + 64 + tid] = tid < cond_up ? p.lerp_w1[tid] : 0.f;
+    }
+
+    const int grp = 16 * rw + r16;
+    const float *xptr[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int cell = (q & 3) * PHASE + grp + ((q >> 2) << log2d);
+        xptr[q] = lds + 8 * cell + 4 * ((kq >> 1) ^ ((cell >> 3) & 1)) + 2 * (kq & 1);
+    }
+    const float *bptr = lds + A_FLOATS + (ph * 3) * 256 + lane * 4;      // this wave's three products (one parity each)
+
+    float2 x[6];
+    float2 u[2];
+    float4 bw[3];
+    float2 ca, cb;
+
+    auto load_x = [&](auto sc) {
+        constexpr int S = decltype(sc)::value;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) x[q] = *reinterpret_cast<const float2 *>(xptr[q] + S * STAGE);
+    };
+    auto load_b = [&](auto sc, auto jc) {
+        constexpr int S = decltype(sc)::value, J = decltype(jc)::value;
+        bw[J] = *reinterpret_cast<const float4 *>(bptr + S * STAGE + J * 256);
+    };
+    auto mfma4 = [&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        f32x4 *ac = acc[J];
+        const float2 uu = u[J & 1];
+        const float4 b0 = bw[J];
+        ac[0] = WW_MFMA(uu.x, b0.x, ac[0]);
+        ac[1] = WW_MFMA(uu.x, b0.z, ac[1]);
+        ac[0] = WW_MFMA(uu.y, b0.y, ac[0]);
+        ac[1] = WW_MFMA(uu.y, b0.w, ac[1]);
+    };
+    auto fill = [&](auto sc, int st) {
+        constexpr int S = decltype(sc)::value;
+        ww_int<(S + 1) % NSTAGE> ns;
+        load_b(sc, ww_int<1>());
+        WW_FENCE();
+        wp_comb<1>(ph, x, u, ca, cb);
+        mfma4(ww_int<0>());
+        WW_FENCE();
+        load_b(sc, ww_int<2>());
+        WW_FENCE();
+        wp_comb<2>(ph, x, u, ca, cb);
+        mfma4(ww_int<1>());
+        WW_FENCE();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (st + NSTAGE < nk8) issue(st + NSTAGE, S);
+        load_x(ns);
+        load_b(ns, ww_int<0>());
+        WW_FENCE();
+        mfma4(ww_int<2>());
+        WW_FENCE();
+        wp_comb<0>(ph, x, u, ca, cb);
+        WW_FENCE();
+    };
+
+    // ---- the first slice and the conditioning tile have landed; the second slice may still be in flight
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __syncthreads();
+    load_x(ww_int<0>());
+    load_b(ww_int<0>(), ww_int<0>());
+    wp_comb<0>(ph, x, u, ca, cb);
+    {
+        int st = 0;
+        for (; st + 2 <= nk8; st += 2) {
+            fill(ww_int<0>(), st);
+            fill(ww_int<1>(), st + 1);
+        }
+        if (st < nk8) fill(ww_int<0>(), st);
+    }
+
+    // ---- the product halves of a row half meet through the stage memory (4 waves x 4 KB)
+    __syncthreads();
+    float sv[2][4], dv[2][4];
+    {
+        float2 *mine = reinterpret_cast<float2 *>(lds) + wave * 512 + lane;
+        const int ja = ph == 0 ? 1 : 0, jb = ph == 0 ? 2 : 1;          // m1, m2 | m3, m4 in this wave's accumulators
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                sv[c][v] = acc[ja][c][v] + acc[jb][c][v];
+                dv[c][v] = acc[ja][c][v] - acc[jb][c][v];
+                mine[(c * 4 + v) * 64] = make_float2(sv[c][v], dv[c][v]);
+            }
+    }
+    __syncthreads();
+    const float2 *theirs = reinterpret_cast<const float2 *>(lds) + (wave ^ 1) * 512 + lane;
+    const float *cl = lds + SH::COND;
+    float *obase = p.out + (long long)b * p.out_bstride + chl;
+    const float *clane = cl + 2 * r16 + eh;
+    int etab[4][2];
+#pragma unroll
+    for (int vi = 0; vi < 4; ++vi) {
+        const int gi = 16 * rw + 4 * kq + vi;                                    // group held by this register
+        const int lr0 = ((gi >> log2d) << (log2d + 2)) + (gi & (d - 1));         // its first row, relative to m0
+#pragma unroll
+        for (int o = 0; o < 2; ++o) etab[vi][o] = reinterpret_cast<const int *>(lds + SH::TAB)[lr0 + ((2 * ph + o) << log2d)];
+    }
+#pragma unroll
+    for (int vi = 0; vi < 4; ++vi) {
+        const int gi = 16 * rw + 4 * kq + vi;
+        const int lr0 = ((gi >> log2d) << (log2d + 2)) + (gi & (d - 1));
+        float2 w[2];
+        float ct0[2], ct1[2], cs0[2], cs1[2];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int e = etab[vi][o];
+            w[o] = make_float2(lds[SH::LERP + (e & 255)], lds[SH::LERP + 64 + (e & 255)]);
+            const float *c0 = clane + (e >> 8);
+            ct0[o] = c0[0];
+            ct1[o] = c0[64];
+            cs0[o] = c0[32];
+            cs1[o] = c0[96];
+        }
+        float y[2][2];                                                           // [tanh | sigmoid][this wave's two outputs]
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float2 t = theirs[(c * 4 + vi) * 64];                          // (s, d) of the other product half
+            if (ph == 0) {
+                y[c][0] = (acc[0][c][vi] + sv[c][vi]) + t.x;                     // (m0 + s12) + s34
+                y[c][1] = fmaf(2.f, t.y, dv[c][vi]);                             // d12 + 2 d34
+            } else {
+                y[c][0] = fmaf(4.f, sv[c][vi], t.x);                             // s12 + 4 s34
+                y[c][1] = fmaf(8.f, dv[c][vi], t.y) + acc[2][c][vi];             // d12 + 8 d34 + m5
+            }
+        }
+        float res[2];
+        const int kind = GA < 0 ? p.gate_act : GA;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            res[o] = wn_gate_act(kind, y[0][o] + fmaf(ct0[o], w[o].x, ct1[o] * w[o].y), y[1][o] + fmaf(cs0[o], w[o].x, cs1[o] * w[o].y));
+            asm volatile("" : "+v"(res[o]));
+        }
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int row = m0 + lr0 + ((2 * ph + o) << log2d);
+            if (ch_ok && row < rows) obase[(long long)row * p.ldo] = res[o];
+        }
+    }
+}
+
 // a.w must point at the host-packed F(4,3) weights (ceil(C/32), ceil(C/8), 3072) of engine.pack_winograd4w_weights;
 // split = the 128-row shape whose waves split the six products (same bits as the 256-row shape).  Returns false if the
 // layer does not fit.
-bool launch_wn_gate_winograd4w(const ConvArgs &a, bool split, hipStream_t stream) {
+// shape: 0 = 256-row blocks, 1 = 128-row product-split blocks, 2 = product-split blocks of half a column tile
+bool launch_wn_gate_winograd4w(const ConvArgs &a, int shape, hipStream_t stream) {
+    const bool split = shape != 0;
     int log2d = 0;
     while ((1 << log2d) < a.dil) ++log2d;
     const int rows_blk = split ? 128 : 256;
@@ -749,8 +1032,16 @@ bool launch_wn_gate_winograd4w(const ConvArgs &a, bool split, hipStream_t stream
     r.m_tiles_per_item = (a.max_rows + rows_blk - 1) / rows_blk;
     r.m_tiles_total = r.m_tiles_per_item * a.batch;
     const long long blocks = 8LL * ((r.m_tiles_total + 7) / 8) * r.n_tiles;
-    const dim3 grid((unsigned)blocks), blk(256);
+    const dim3 blk(256);
     const bool gtu = a.gate_act == 0;
+    if (shape == 2) {
+        r.n_tiles *= 2;                                   // half column tiles
+        const dim3 grid2((unsigned)(8LL * ((r.m_tiles_total + 7) / 8) * r.n_tiles));
+        if (gtu) hipLaunchKernelGGL(wn_gate_winograd4h_kernel<0>, grid2, blk, 0, stream, r, log2d);
+        else hipLaunchKernelGGL(wn_gate_winograd4h_kernel<-1>, grid2, blk, 0, stream, r, log2d);
+        return true;
+    }
+    const dim3 grid((unsigned)blocks);
     if (split && gtu) hipLaunchKernelGGL(wn_gate_winograd4p_kernel<0>, grid, blk, 0, stream, r, log2d);
     else if (split) hipLaunchKernelGGL(wn_gate_winograd4p_kernel<-1>, grid, blk, 0, stream, r, log2d);
     else if (cond_rows <= 28 && gtu) hipLaunchKernelGGL((wn_gate_winograd4w_kernel<28, 0>), grid, blk, 0, stream, r, log2d);

@@ -1021,7 +1021,8 @@ class MBExWNEngine:
         """Which implementation of the dilated convolution a forward of this size runs: the handle's form
         (mbx_conv_form) and, for F(4,3), the block shape the library's launch-size rule picks (csrc/mbx_api.hip: 256-row
         blocks, or 128-row blocks whose waves split the six products where those spread the work clearly more evenly over
-        the SIMDs; both give the same bits): "direct", "winograd_f23", "winograd_f43" or "winograd_f43_psplit"."""
+        the SIMDs, or product-split blocks of half a column tile where even those load the CUs unevenly; all three give the same
+        bits): "direct", "winograd_f23", "winograd_f43", "winograd_f43_psplit" or "winograd_f43_hsplit"."""
         info = self.conv_form_info()
         if info["form"] == "direct":
             return "direct"
@@ -1034,9 +1035,12 @@ class MBExWNEngine:
         if info["batch_invariant"]:
             return "winograd_f43"
         if self._tune_gate_shape and full_blocks < 4 * 768:
-            return "winograd_f43" if self._tune_gate_shape == 1 else "winograd_f43_psplit"
+            return {1: "winograd_f43", 2: "winograd_f43_psplit", 3: "winograd_f43_hsplit"}[self._tune_gate_shape]
         load_full, load_half = (full_blocks + 255) // 256, 0.5 * ((half_blocks + 255) // 256)
-        return "winograd_f43_psplit" if full_blocks <= 1024 and load_half <= load_full else "winograd_f43"
+        load_quarter = 0.25 * ((2 * half_blocks + 255) // 256)
+        if full_blocks <= 1024 and load_half <= load_full:
+            return "winograd_f43_hsplit" if load_quarter < load_half else "winograd_f43_psplit"
+        return "winograd_f43"
 
     @property
     def folds_start(self):

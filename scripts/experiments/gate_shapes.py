@@ -13,8 +13,8 @@ import bench  # noqa: E402
 
 def main():
     import torch
-    sizes = [(1, 80), (1, 160), (1, 240), (1, 320), (1, 400), (1, 480), (1, 800), (1, 1200), (2, 800), (4, 800), (8, 800)]
-    for shape in (1, 2):
+    sizes = [(1, 80), (1, 160), (1, 240), (1, 320), (1, 400), (1, 480), (1, 560), (1, 640), (1, 800), (1, 1200), (2, 800), (4, 800), (8, 800)]
+    for shape in (1, 2, 3, 0):            # 256-row, product-split, product-split half column tiles, the launch-size rule
         bench._ENGINES.clear()
         cfg, raw, wt, dims, eng = bench.build_engine("SPEECH", None, tune={"gate_shape": shape})
         row = []

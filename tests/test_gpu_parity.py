@@ -594,17 +594,18 @@ def test_f43_block_shapes_give_the_same_bits(torch, monkeypatch, voice):
     mel, noise = synthetic_inputs(77, 2, 240)
     nf = torch.as_tensor(lengths, dtype=torch.int32).cuda()
     outs = {}
-    for shape in ("0", "1"):
-        eng = MBExWNEngine(cfg, raw, wt, conv_form="f43", tune={"gate_shape": 1 if shape == "0" else 2})
-        assert eng.gate_form(2, 240) == {"0": "winograd_f43", "1": "winograd_f43_psplit"}[shape]
+    for shape in ("0", "1", "2"):
+        eng = MBExWNEngine(cfg, raw, wt, conv_form="f43", tune={"gate_shape": 1 + int(shape)})
+        assert eng.gate_form(2, 240) == {"0": "winograd_f43", "1": "winograd_f43_psplit", "2": "winograd_f43_hsplit"}[shape]
         outs[shape] = eng.forward(dev(torch, mel), n_frames=nf, noise=dev(torch, noise)).cpu().numpy()
         del eng
     assert np.array_equal(outs["0"], outs["1"]), "the product-split blocks must give the bits of the 256-row blocks"
+    assert np.array_equal(outs["0"], outs["2"]), "... and so must the product-split blocks of half a column tile"
     ref = orc.OracleModel(cfg, raw, wt).forward(mel[1:2, :133], noise[1:2, :133 * 20])[0]
     assert _maxdiff(outs["1"][1, :133 * 300], ref) <= _tol(ref, E2E_TOL)
     # the default policy picks one of the two equivalent shapes by how the work divides over the SIMDs
     eng = MBExWNEngine(cfg, raw, wt, conv_form="f43")
-    assert eng.gate_form(2, 240) in ("winograd_f43", "winograd_f43_psplit")
+    assert eng.gate_form(2, 240) in ("winograd_f43", "winograd_f43_psplit", "winograd_f43_hsplit")
     assert np.array_equal(eng.forward(dev(torch, mel), n_frames=nf, noise=dev(torch, noise)).cpu().numpy(), outs["1"])
 
 
