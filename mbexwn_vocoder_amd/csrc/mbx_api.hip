@@ -1439,11 +1439,15 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
             // 256-row blocks and loses behind it, where both shapes divide evenly and the 128-row block's extra LDS-DMA traffic
             // per MFMA (the weight slice serves half the rows) and shorter slices tell
             bool split4 = !hd->winograd4_always && full_blocks <= 1024 && load_half <= load_full;
-            // round 5: product-split blocks of HALF a column tile (one channel parity: twice the blocks of half the work) where
-            // even the product-split blocks leave the CUs unevenly loaded -- a 3 s utterance is 380 of them on 256 CUs, the
-            // worst CU works two while the average is 1.5; 760 half blocks give every CU three (same bits as the other shapes)
-            const double load_quarter = 0.25 * (double)((2 * half_blocks + 255) / 256);
-            int shape4 = split4 ? (load_quarter < load_half ? 2 : 1) : 0;
+            // round 5: product-split blocks of HALF a column tile (one channel parity: twice the blocks of half the work; same bits
+            // as the other shapes).  The idea: a 3 s utterance is 380 product-split blocks on 256 CUs, the worst CU works two
+            // while the average is 1.5; 760 half blocks give every CU three.
+            // Measured (scripts/experiments/gate_shapes.py, profiles/r05_gate_shapes.txt; one item of 1 / 2 / 3 / 4 / 5 / 10 s):
+            // 32.4 / 43.8 / 54.0 / 65.9 / 70.4 / 131.8 us against 32.1 / 48.5 / 48.8 / 64.3 / 63.5 / 100.7 us for the product-split
+            // blocks -- the estimate above was wrong: a block of half the matrix work lasts almost as long (40 barrier-separated
+            // slices whose round trips, not whose MFMAs, set its time), so the finer shape only pays where the product-split
+            // blocks leave CUs empty (<= 256 of them) and the half blocks do not (> 256): utterances around 2 s.
+            int shape4 = split4 ? ((half_blocks <= 256 && 2 * half_blocks > 256) ? 2 : 1) : 0;
             if (hd->gate_small_shape >= 0 && !hd->winograd4_always && full_blocks < 4 * 768) shape4 = hd->gate_small_shape;
             split4 = shape4 != 0;
             // opt-in split half precision: whole-item forwards of the layers behind the folded first one

@@ -734,8 +734,10 @@ __global__ __launch_bounds__(256, 3) void wn_gate_winograd4p_kernel(ConvArgs p, 
 // lasts as long as two.  Here a block owns the 16 gate channels of ONE channel parity e of its column tile (the packed weight
 // image is [product][parity e][lane][4]: the block stages the e-th kilobyte of every product and nothing else): twice the blocks
 // of half the matrix work -- 760 for 3 s, every CU gets three, the launch lasts as long as one and a half.  Same groups, same
-// products, same sums in the same order as the other two shapes: the SAME bits.  LDS 29.5 KB, 4+ blocks per CU.  The launcher
-// takes it when the worst CU's share shrinks (launch_wn_gate_winograd4w).
+// products, same sums in the same order as the other two shapes: the SAME bits.  LDS 29.5 KB, 4+ blocks per CU.
+// Measured (profiles/r05_gate_shapes.txt): 54.0 against 48.8 us at 3 s -- a block of half the matrix work lasts almost as long
+// (its 40 barrier-separated slices set its time, not its MFMAs) -- and 43.8 against 48.5 us at 2 s, where the product-split
+// blocks leave CUs empty: the launcher takes this shape there only (mbx_api.hip).
 struct WhShape {
     static constexpr int ROWS = 128;
     static constexpr int PHASE = ROWS / 4 + WW_HALO;            // 48

@@ -1037,9 +1037,8 @@ class MBExWNEngine:
         if self._tune_gate_shape and full_blocks < 4 * 768:
             return {1: "winograd_f43", 2: "winograd_f43_psplit", 3: "winograd_f43_hsplit"}[self._tune_gate_shape]
         load_full, load_half = (full_blocks + 255) // 256, 0.5 * ((half_blocks + 255) // 256)
-        load_quarter = 0.25 * ((2 * half_blocks + 255) // 256)
         if full_blocks <= 1024 and load_half <= load_full:
-            return "winograd_f43_hsplit" if load_quarter < load_half else "winograd_f43_psplit"
+            return "winograd_f43_hsplit" if half_blocks <= 256 < 2 * half_blocks else "winograd_f43_psplit"
         return "winograd_f43"
 
     @property
