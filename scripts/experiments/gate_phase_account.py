@@ -27,7 +27,7 @@ import bench  # noqa: E402
 def main():
     import torch
     from mbexwn_vocoder_amd import engine
-    batch, frames = 16, 800
+    batch, frames = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (16, 800)
     cfg, raw, wt, dims, eng = bench.build_engine("SING")
     lib = engine.load_library()
     lib.mbx_exp_stamps.restype = ctypes.c_int
@@ -67,9 +67,10 @@ def main():
     elif tbar.max() > 0:
         out["wait_and_barrier_in_loop"] = stats(tbar)
         out["wait_and_barrier_share_of_loop"] = float(np.median(tbar / np.maximum(ts2 - ts1, 1)))
-    # matrix-pipe time of a wave's loop: 40 slices x 48 MFMAs x 32 cycles
+    # matrix-pipe time of a wave's loop: 40 slices x 48 MFMAs x 32 cycles (product-split blocks: 24 MFMAs per wave and slice)
     nk8 = (dims.wn_channels + 7) // 8
-    out["mfma_cycles_per_block_wave"] = nk8 * 48 * 32
+    out["mfma_cycles_per_block_wave"] = nk8 * (24 if "stampP" in os.environ.get("MBX_LIB_PATH", "") else 48) * 32
+    out["batch_frames"] = [batch, frames]
     # per SIMD: resident waves over time.  HW_ID: wave_id [3:0], simd_id [5:4], cu_id [11:8], sh_id [12], se_id [15:13]; XCC_ID in the upper word
     simd = ((hw >> 32) & 15) << 16 | ((hw >> 13) & 7) << 12 | ((hw >> 12) & 1) << 11 | ((hw >> 8) & 15) << 4 | ((hw >> 4) & 3)
     cover, none_in_loop, resident, exposed_pe = [], [], [], []

@@ -244,6 +244,23 @@ PATCHES = {
     'rwd45': [('    const int m0 = mt * RW_ROWS;\n    if (m0 >= rows) return;\n', '    const int m0 = mt * RW_ROWS;\n    if (m0 >= rows) return;\n    if (blockIdx.x >= 256 && blockIdx.x < 512) {\n        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();\n        while (__builtin_amdgcn_s_memrealtime() - t0 < 4500ull) __builtin_amdgcn_s_sleep(32);\n    }\n')],
     'rwd60': [('    const int m0 = mt * RW_ROWS;\n    if (m0 >= rows) return;\n', '    const int m0 = mt * RW_ROWS;\n    if (m0 >= rows) return;\n    if (blockIdx.x >= 256 && blockIdx.x < 512) {\n        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();\n        while (__builtin_amdgcn_s_memrealtime() - t0 < 6000ull) __builtin_amdgcn_s_sleep(32);\n    }\n')],
     'rwspread': [('    const int m0 = mt * RW_ROWS;\n    if (m0 >= rows) return;\n', '    const int m0 = mt * RW_ROWS;\n    if (m0 >= rows) return;\n    if (blockIdx.x < 512) {\n        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();\n        const unsigned long long w_ = (unsigned long long)((blockIdx.x >> 3) & 7) * 750ull;\n        while (__builtin_amdgcn_s_memrealtime() - t0 < w_) __builtin_amdgcn_s_sleep(32);\n    }\n')],
+    # wn_winograd4w.hip, round 5: the same stamps in the 128-row product-split kernel (one utterance): gate_phase_account.py 1 240
+    'stampP': [
+        ('namespace mbx {\n\ntypedef float f32x4 __attribute__((ext_vector_type(4)));',
+         'namespace mbx {\n\n__device__ unsigned long long g_ww_stamps[16384 * 4 * 8];\n#define WW_STAMP(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }\n#define WW_RSTAMP(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memrealtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }\n\ntypedef float f32x4 __attribute__((ext_vector_type(4)));'),
+        ('    const int rw = wave >> 1, ph = wave & 1;                // row half and product half of this wave\n',
+         '    const int rw = wave >> 1, ph = wave & 1;                // row half and product half of this wave\n    unsigned long long ts0_, ts1_, ts2_, ts3_, tr0_, tr3_, tbar_ = 0;\n    WW_STAMP(ts0_);\n    WW_RSTAMP(tr0_);\n'),
+        ('    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");\n    __syncthreads();\n',
+         '    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");\n    __syncthreads();\n    WW_STAMP(ts1_);\n'),
+        ('        mfma8(ww_int<1>());\n        WW_FENCE();\n        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n        __syncthreads();\n',
+         '        mfma8(ww_int<1>());\n        WW_FENCE();\n        unsigned long long tb0_, tb1_;\n        WW_STAMP(tb0_);\n        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n        __syncthreads();\n        WW_STAMP(tb1_);\n        tbar_ += tb1_ - tb0_;\n'),
+        ('    // ---- the product halves of a row half meet (through the stage memory: 4 waves x 8 KB)',
+         '    WW_STAMP(ts2_);\n    // ---- the product halves of a row half meet (through the stage memory: 4 waves x 8 KB)'),
+        ('            if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res[o];\n        }\n    }\n}\n\n// ---------------------------------------------------------------------------------------------------------------------\n// <128 rows, products split, HALF a column tile>',
+         '            if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res[o];\n        }\n    }\n    WW_STAMP(ts3_);\n    WW_RSTAMP(tr3_);\n    if (lane == 0 && blockIdx.x < 16384) {\n        unsigned long long *o_ = g_ww_stamps + ((long long)blockIdx.x * 4 + wave) * 8;\n        o_[0] = ts0_; o_[1] = ts1_; o_[2] = ts2_; o_[3] = ts3_; o_[4] = tr0_; o_[5] = tr3_; o_[6] = tbar_;\n        o_[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg((4) | (31 << 11));\n    }\n}\n\n// ---------------------------------------------------------------------------------------------------------------------\n// <128 rows, products split, HALF a column tile>'),
+        ('}  // namespace mbx\n',
+         '}  // namespace mbx\n\nextern "C" int mbx_exp_stamps(void *dst, size_t bytes) {\n    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mbx::g_ww_stamps), bytes, 0, hipMemcpyDeviceToHost);\n}\n'),
+    ],
     'base': [],
     # wn_winograd4w.hip
     'nodma': [
