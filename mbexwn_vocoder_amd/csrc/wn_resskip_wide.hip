@@ -45,7 +45,8 @@ __device__ __forceinline__ void rw_lds_dma16_s(const float *sbase, unsigned voff
 template <int N>
 using rw_int = std::integral_constant<int, N>;
 
-template <int NP, int SPLIT>
+// HFULL: the first HFULL pairs of every block are known (launcher) to lie entirely inside the residual columns (32 (pr + 1) <= C)
+template <int NP, int SPLIT, int HFULL>
 __global__ __launch_bounds__(512, 4) void wn_resskip_wide_kernel(ConvArgs p) {
     constexpr int B_FLOATS = NP * 256;             // packed weights of one slice
     constexpr int STAGE = RW_A_FLOATS + B_FLOATS;
@@ -121,20 +122,43 @@ __global__ __launch_bounds__(512, 4) void wn_resskip_wide_kernel(ConvArgs p) {
     const int row0 = m0 + 16 * wave + 4 * kq;
     const int row_last = rows - 1;
     auto body = [&](auto fastc) {
+    // Round 5 (in-kernel stamps, profiles/r05_phase_resskip.json): the prologue was 61 500 of a block's 240 000 cycles -- slice 0
+    // requested, then the accumulator pre-loads in three groups, each waited for before the next was requested, then slices 1 and 2:
+    // four serial HBM round trips under load.  Now ONE: the three slices first, then every pre-load -- the first HFULL pairs (all
+    // 32 columns residual columns: a compile-time count, because a run-time branch around the stores sent the whole accumulator
+    // array to scratch) as single-word loads straight into their accumulator registers (four row pointers, the pair offset an
+    // immediate: no address registers to spill, no copies), the remaining pair(s) through the group code -- and only then the
+    // first use.  Same sums (old value + bias first, then the products): same bits.
     issue(fastc, 0, 0);
-    // Groups of PG column pairs: ALL requests of a group first -- its biases and old values, from clamped addresses -- then the
-    // arithmetic.  (Round 4, read off the ISA: written pair by pair, the
-    // compiler formed `col_ok ? bias : 0` right behind the bias load, i.e. an s_waitcnt vmcnt(0) in every pair that also
-    // drained the previous pair's row loads: eleven serial round trips in front of a block's first MFMA.)
+    if (nk > 1) issue(fastc, 1, 1);
+    if (nk > 2) issue(fastc, 2, 2);
     const float *bias_src = p.bias ? p.bias : p.zeros;
-    constexpr int PG = 4;                                          // pairs per group (4: 26 spilled registers at the 128 budget)
+    const float *hrow[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) hrow[v] = hb + (long long)min(row0 + v, row_last) * C + 2 * r16;
+    float2 hbias[HFULL > 0 ? HFULL : 1];
+    const bool keep_h = !p.h_init;
+#pragma unroll
+    for (int pr = 0; pr < HFULL; ++pr) {                           // (compile-time: no branch stands between the loads and their registers)
+        const int c0 = 32 * (pair0 + pr);
+        hbias[pr] = *reinterpret_cast<const float2 *>(bias_src + (p.bias ? c0 + 2 * r16 : 0));
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            acc[2 * pr][v] = hrow[v][c0];
+            acc[2 * pr + 1][v] = hrow[v][c0 + 1];
+        }
+    }
+    // the other pairs (columns of the output accumulator, the pair that straddles C): requests of a group first, from clamped
+    // addresses, then the arithmetic (written pair by pair the compiler formed `col_ok ? bias : 0` right behind each bias load:
+    // an s_waitcnt vmcnt(0) in every pair, round 4)
+    constexpr int PG = 4;
 #pragma unroll
     for (int g0 = 0; g0 < NP; g0 += PG) {
         float2 bias4[PG], old4[PG][4];
 #pragma unroll
         for (int j = 0; j < PG; ++j) {
             const int pr = g0 + j;
-            if (pr < NP) {
+            if (pr >= HFULL && pr < NP) {
                 const int col = 32 * (pair0 + pr) + 2 * r16;       // even: both columns of the lane on the same side of C
                 const int colc = min(col, p.cout - 2);
                 const bool to_h = colc < C;
@@ -150,7 +174,7 @@ __global__ __launch_bounds__(512, 4) void wn_resskip_wide_kernel(ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < PG; ++j) {
             const int pr = g0 + j;
-            if (pr < NP) {
+            if (pr >= HFULL && pr < NP) {
                 const int col = 32 * (pair0 + pr) + 2 * r16;
                 const bool col_ok = col < p.cout;
                 const bool to_h = min(col, p.cout - 2) < C;
@@ -164,10 +188,15 @@ __global__ __launch_bounds__(512, 4) void wn_resskip_wide_kernel(ConvArgs p) {
         }
         RW_FENCE();
     }
-    // slices 1, 2 are requested behind slice 0 and the accumulator pre-loads: waiting for all but the 4 youngest
-    // requests below leaves exactly them in flight
-    if (nk > 1) issue(fastc, 1, 1);
-    if (nk > 2) issue(fastc, 2, 2);
+#pragma unroll
+    for (int pr = 0; pr < HFULL; ++pr) {
+        const float bx = p.bias ? hbias[pr].x : 0.f, by = p.bias ? hbias[pr].y : 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            acc[2 * pr][v] = (keep_h ? acc[2 * pr][v] : 0.f) + bx;
+            acc[2 * pr + 1][v] = (keep_h ? acc[2 * pr + 1][v] : 0.f) + by;
+        }
+    }
 
     // A operand: row 16 wave + r16, channels 2 kq, 2 kq + 1
     const int arow = 16 * wave + r16;
@@ -282,8 +311,9 @@ bool launch_wn_resskip_wide(const ConvArgs &a, hipStream_t stream) {
     // 11 pairs (C = 320): one block owns all columns of its rows.  12 pairs (C = 340) would need 96 accumulator registers
     // per wave, which leaves one 8-wave block per CU (162 VGPRs; measured 0.53 of the peak): two blocks per row tile own
     // six pairs each instead and read the rows of `a` twice (the second read is an L2 hit)
-    if (np == 11) hipLaunchKernelGGL((wn_resskip_wide_kernel<11, 1>), dim3((unsigned)blocks), dim3(512), 0, stream, r);
-    else hipLaunchKernelGGL((wn_resskip_wide_kernel<6, 2>), dim3((unsigned)(2 * blocks)), dim3(512), 0, stream, r);
+    if (np == 11 && a.channels >= 320) hipLaunchKernelGGL((wn_resskip_wide_kernel<11, 1, 10>), dim3((unsigned)blocks), dim3(512), 0, stream, r);
+    else if (np == 11) hipLaunchKernelGGL((wn_resskip_wide_kernel<11, 1, 0>), dim3((unsigned)blocks), dim3(512), 0, stream, r);
+    else hipLaunchKernelGGL((wn_resskip_wide_kernel<6, 2, 0>), dim3((unsigned)(2 * blocks)), dim3(512), 0, stream, r);
     return true;
 }
 

@@ -41,9 +41,10 @@ def main():
     for _ in range(5):
         eng.forward(mel, noise=noise)
     torch.cuda.synchronize()
-    gms, gcnt = eng.profile_read("gate")
+    stage = os.environ.get("STAMP_STAGE", "gate")                 # "res_skip": stamps of wn_resskip_wide_kernel (mkexp.py rwstamp)
+    gms, gcnt = eng.profile_read(stage)
     eng.profile_enable(False)
-    buf = np.zeros((16384, 4, 8), dtype=np.uint64)
+    buf = np.zeros((16384, 4, 8) if stage == "gate" else (8192, 8, 8), dtype=np.uint64)
     rc = lib.mbx_exp_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes)
     assert rc == 0, rc
     ok = buf[:, :, 3] != 0
@@ -70,7 +71,10 @@ def main():
     # matrix-pipe time of a wave's loop: 40 slices x 48 MFMAs x 32 cycles (product-split blocks: 24 MFMAs per wave and slice)
     nk8 = (dims.wn_channels + 7) // 8
     out["mfma_cycles_per_block_wave"] = nk8 * (24 if "stampP" in os.environ.get("MBX_LIB_PATH", "") else 48) * 32
+    if stage == "res_skip":
+        out["mfma_cycles_per_block_wave"] = nk8 * 44 * 32
     out["batch_frames"] = [batch, frames]
+    out["stage"] = stage
     # per SIMD: resident waves over time.  HW_ID: wave_id [3:0], simd_id [5:4], cu_id [11:8], sh_id [12], se_id [15:13]; XCC_ID in the upper word
     simd = ((hw >> 32) & 15) << 16 | ((hw >> 13) & 7) << 12 | ((hw >> 12) & 1) << 11 | ((hw >> 8) & 15) << 4 | ((hw >> 4) & 3)
     cover, none_in_loop, resident, exposed_pe = [], [], [], []

@@ -261,6 +261,23 @@ PATCHES = {
         ('}  // namespace mbx\n',
          '}  // namespace mbx\n\nextern "C" int mbx_exp_stamps(void *dst, size_t bytes) {\n    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mbx::g_ww_stamps), bytes, 0, hipMemcpyDeviceToHost);\n}\n'),
     ],
+    # wn_resskip_wide.hip, round 5: in-kernel stamps of every wave (start, accumulators pre-loaded + first slice landed, K loop done,
+    # end; cycles between "MFMAs of a slice issued" and "barrier passed" summed over the slices): STAMP_STAGE=res_skip gate_phase_account.py
+    'rwstamp': [
+        ('namespace mbx {\n\ntypedef float f32x4 __attribute__((ext_vector_type(4)));',
+         'namespace mbx {\n\n__device__ unsigned long long g_ww_stamps[16384 * 4 * 8];\n#define WW_STAMP(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }\n#define WW_RSTAMP(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memrealtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }\n\ntypedef float f32x4 __attribute__((ext_vector_type(4)));'),
+        ('    const int r16 = lane & 15, kq = lane >> 4;\n    const float *xb = p.x + (long long)b * p.x_bstride + (long long)m0 * p.ldx;   // the block\'s first row: 32-bit offsets stay small\n',
+         '    const int r16 = lane & 15, kq = lane >> 4;\n    unsigned long long ts0_, ts1_ = 0, ts2_ = 0, ts3_, tr0_, tr3_, tbar_ = 0;\n    WW_STAMP(ts0_);\n    WW_RSTAMP(tr0_);\n    const float *xb = p.x + (long long)b * p.x_bstride + (long long)m0 * p.ldx;   // the block\'s first row: 32-bit offsets stay small\n'),
+        ('    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n    __syncthreads();\n    load_a(rw_int<0>());',
+         '    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n    __syncthreads();\n    WW_STAMP(ts1_);\n    load_a(rw_int<0>());'),
+        ('        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");       // slice kt+2 may still be in flight\n        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n        __syncthreads();\n',
+         '        unsigned long long tb0_, tb1_;\n        WW_STAMP(tb0_);\n        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");       // slice kt+2 may still be in flight\n        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n        __syncthreads();\n        WW_STAMP(tb1_);\n        tbar_ += tb1_ - tb0_;\n'),
+        ('    };      // body\n', '    WW_STAMP(ts2_);\n    };      // body\n'),
+        ('            if (row < rows) *reinterpret_cast<float2 *>(dst + (long long)row * ld) = make_float2(acc[2 * pr][v], acc[2 * pr + 1][v]);\n        }\n    }\n}\n',
+         '            if (row < rows) *reinterpret_cast<float2 *>(dst + (long long)row * ld) = make_float2(acc[2 * pr][v], acc[2 * pr + 1][v]);\n        }\n    }\n    WW_STAMP(ts3_);\n    WW_RSTAMP(tr3_);\n    if (lane == 0 && blockIdx.x < 8192) {\n        unsigned long long *o_ = g_ww_stamps + ((long long)blockIdx.x * 8 + wave) * 8;\n        o_[0] = ts0_; o_[1] = ts1_; o_[2] = ts2_; o_[3] = ts3_; o_[4] = tr0_; o_[5] = tr3_; o_[6] = tbar_;\n        o_[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg((4) | (31 << 11));\n    }\n}\n'),
+        ('}  // namespace mbx\n',
+         '}  // namespace mbx\n\nextern "C" int mbx_exp_stamps(void *dst, size_t bytes) {\n    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mbx::g_ww_stamps), bytes, 0, hipMemcpyDeviceToHost);\n}\n'),
+    ],
     'base': [],
     # wn_winograd4w.hip
     'nodma': [
