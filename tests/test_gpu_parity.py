@@ -305,6 +305,24 @@ def test_forward_matches_oracle(torch, key, spec, batch, frames):
     assert _maxdiff(got, ref) <= _tol(ref, E2E_TIGHT), "with the exact contour the end-to-end error is the WaveNet's and the filters'"
 
 
+def test_mel_pointer_that_is_not_16_byte_aligned(torch):
+    """The C ABI takes any float pointer.  The float64 F0 chain reads the mel rows as 16-byte pieces; a caller's mel that
+    starts in the middle of one (a view into a larger buffer) keeps float32 hidden layers -- whatever kernels take those rows
+    write float32 -- and the result stays inside the stated tolerance; the aligned run of the same data is the exact one."""
+    eng, om = get_engine("canon", *CANON)[:2]
+    mel, noise = synthetic_inputs(11, 1, 24)
+    base = torch.zeros(1 + mel.size, dtype=torch.float32, device="cuda")
+    base[1:] = dev(torch, mel).reshape(-1)
+    view = base[1:].view(1, 24, 80)
+    assert view.is_contiguous() and view.data_ptr() % 16 == 4
+    ref = om.forward(mel, noise)
+    got_u = eng.forward(view, noise=dev(torch, noise)).cpu().numpy()
+    got_a = eng.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
+    assert np.all(np.isfinite(got_u))
+    assert _maxdiff(got_u, ref) <= _tol(ref, E2E_TOL)
+    assert _maxdiff(got_a, ref) <= _tol(ref, E2E_TIGHT)
+
+
 def test_f0_contour_in_float64_keeps_the_error_from_growing_with_the_length(torch):
     """The contour feeds the float32 phase integrator (reference tf_wavetable.py:429-492): a contour that is off in the last
     bit of a few samples sends the phase chain down another rounding path for the rest of the utterance.  With the F0-net in
