@@ -249,25 +249,42 @@ __global__ __launch_bounds__(512, 2) void wn_gate_f16_kernel(ConvArgs p, int log
     const float *cl = lds + GH_COND;
     float *obase = p.out + (long long)b * p.out_bstride + n0 + 2 * r16;
     const float *clane = cl + 2 * r16;
+    // (round 5, as in the float32 gate kernels: table entries first, then the conditioning reads of a row tile together, results
+    // formed outside the store branches -- every output used to be a region of its own with its own LDS round trips)
+    int etab[2][4];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
+        for (int v = 0; v < 4; ++v) etab[rt][v] = reinterpret_cast<const int *>(lds + GH_TAB)[32 * wave + 16 * rt + 4 * kq + v];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        float2 w[4], ct0[4], ct1[4], cs0[4], cs1[4];
+#pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const int lr = 32 * wave + 16 * rt + 4 * kq + v;
-            const int row = m0 + lr;
-            const int e = reinterpret_cast<const int *>(lds + GH_TAB)[lr];
-            const float2 w = make_float2(lds[GH_LERP + (e & 255)], lds[GH_LERP + 64 + (e & 255)]);
+            const int e = etab[rt][v];
+            w[v] = make_float2(lds[GH_LERP + (e & 255)], lds[GH_LERP + 64 + (e & 255)]);
             const float *c0 = clane + (e >> 8);
-            const float2 ct0 = *reinterpret_cast<const float2 *>(c0), ct1 = *reinterpret_cast<const float2 *>(c0 + 64);
-            const float2 cs0 = *reinterpret_cast<const float2 *>(c0 + 32), cs1 = *reinterpret_cast<const float2 *>(c0 + 96);
+            ct0[v] = *reinterpret_cast<const float2 *>(c0);
+            ct1[v] = *reinterpret_cast<const float2 *>(c0 + 64);
+            cs0[v] = *reinterpret_cast<const float2 *>(c0 + 32);
+            cs1[v] = *reinterpret_cast<const float2 *>(c0 + 96);
+        }
+        float2 res[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
             float y[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) y[c] = fmaf(accx[rt][c][v], 1.0f / 2048.0f, accm[rt][c][v]);
-            float2 res;
-            res.x = wn_gate_act(p.gate_act, y[0] + (ct0.x * w.x + ct1.x * w.y), y[1] + (cs0.x * w.x + cs1.x * w.y));
-            res.y = wn_gate_act(p.gate_act, y[2] + (ct0.y * w.x + ct1.y * w.y), y[3] + (cs0.y * w.x + cs1.y * w.y));
-            if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res;
+            res[v].x = wn_gate_act(p.gate_act, y[0] + fmaf(ct0[v].x, w[v].x, ct1[v].x * w[v].y), y[1] + fmaf(cs0[v].x, w[v].x, cs1[v].x * w[v].y));
+            res[v].y = wn_gate_act(p.gate_act, y[2] + fmaf(ct0[v].y, w[v].x, ct1[v].y * w[v].y), y[3] + fmaf(cs0[v].y, w[v].x, cs1[v].y * w[v].y));
+            asm volatile("" : "+v"(res[v].x), "+v"(res[v].y));
         }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int row = m0 + 32 * wave + 16 * rt + 4 * kq + v;
+            if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res[v];
+        }
+    }
 }
 
 // a.w must point at the image of engine.pack_gate_f16_weights (ceil(C/32) column tiles, ceil(C/32) steps, 6144 floats);
