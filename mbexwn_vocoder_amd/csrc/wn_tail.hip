@@ -15,6 +15,7 @@
 // (engine.pack_end_weights, zero padded to 32 columns), one coalesced 16-byte load per lane.  The four partial 32 x 32
 // results are summed through LDS, which also puts whole rows in front of single lanes for the post-net.
 // HBM-bound: rows x C x 4 bytes.
+#include <algorithm>
 #include "mbx_kernels.h"
 
 namespace mbx {
@@ -123,6 +124,140 @@ __global__ __launch_bounds__(256) void wn_tail_kernel(const float *skip, long lo
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the same stage with every wave owning its rows.  The kernel above splits the channels over the four waves of a
+// block: four partial 32 x 32 results meet through LDS behind a barrier, and the post-net is a scalar loop -- 76 us of its
+// 129 us at 16 x 10 s remain when every global load is taken out (round-3 ablation), twice its 34 us of MFMA time.  Here:
+// block = 4 waves x 16 rows; a wave contracts ALL channels of its 16 rows (v_mfma_f32_16x16x4_f32, two 16-column tiles),
+// the activations straight from global memory (lane (row r16, kq) loads the 16 bytes of channels 16 j + 4 kq .. + 3: 64
+// contiguous bytes per row and instruction), the packed weight image of wn_tail_kernel -- read as [16-channel block j][kq]
+// [column][4 steps] -- staged once per block by LDS-DMA; no cross-wave sum.  The post-net is a second, 8-step MFMA chain on
+// the wave's own 16 x 32 result (transposed through a 2 KB LDS tile of the wave's own).  One kernel at every launch size:
+// results do not depend on the batch.
+__device__ __forceinline__ void tl_lds_dma16_s(const float *sbase, unsigned voff_bytes, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte_addr), "v"(voff_bytes), "s"(sbase)
+                 : "memory", "m0");
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int T2_ROWS = 64;
+constexpr int T2_YT = 16 * 33;                       // a wave's transposition tile (16 rows, pitch 33)
+
+template <int NJ>   // blocks of 16 channels a wave loads and multiplies: ceil(8 ceil(C / 8) / 16) <= NJ
+__global__ __launch_bounds__(256) void wn_tail2_kernel(const float *skip, long long skip_bstride, const int *n_frames,
+                                                       int rows_per_frame, int max_rows, int C, const float *w_end_packed,
+                                                       const float *b_end, int n_out, const float *w_post,
+                                                       const float *b_post, int M, const float *y_acc, float *y,
+                                                       long long y_bstride, float *sub, long long sub_bstride) {
+    typedef __attribute__((address_space(3))) float lds_float;
+    extern __shared__ __attribute__((aligned(16))) float t2lds[];
+    const int nc8 = (C + 7) / 8;                      // 8-channel groups of the image = kilobytes to stage
+    float *wimg = t2lds;                              // nc8 * 256 floats; after the K loop (behind a barrier) the same bytes hold:
+    float *ytile = t2lds;                             // 4 waves x T2_YT
+    float *wp = ytile + 4 * T2_YT;                    // 32 x 16 post weights (zero padded), then 16 post biases
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float *)t2lds);
+    const int b = blockIdx.y;
+    const int rows = item_rows(n_frames, b, rows_per_frame, max_rows);
+    const int m0 = blockIdx.x * T2_ROWS;
+    if (m0 >= rows) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;
+
+    // ---- the weight image: kilobyte c of the image -> kilobyte c of LDS, dealt round-robin over the waves
+    for (int c = wave; c < nc8; c += 4) tl_lds_dma16_s(w_end_packed + c * 256, 16u * (unsigned)lane, lds_base + 1024u * (unsigned)c);
+    const int nj = (8 * nc8 + 15) / 16;               // blocks of 16 channels
+    const int row_a = min(m0 + 16 * wave + r16, rows - 1);
+    const float *xr = skip + (long long)b * skip_bstride + (long long)row_a * C;
+    // what the epilogue adds to the lane's outputs: column n = r16 (+ 16 t), rows 4 kq + v of the wave's tile
+    float e_add[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = r16 + 16 * t;
+        const float bb = (b_end && n < n_out) ? b_end[n] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int row = min(m0 + 16 * wave + 4 * kq + v, rows - 1);
+            const float yy = (y_acc && n < n_out) ? y_acc[(long long)b * y_bstride + (long long)row * n_out + n] : 0.f;
+            e_add[t][v] = bb + yy;
+        }
+    }
+    f32x4 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[t][v] = 0.f;
+
+    // every activation of the wave's rows requested at once (NJ x 16 bytes a lane); the image's DMA is older than all of them,
+    // so "at most NJ loads outstanding" = the image has landed
+    float4 a[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int ch = 16 * min(j, nj - 1) + 4 * kq;
+        // pieces behind the row's last channel meet zero weights (the image is zero padded to a multiple of 8 channels;
+        // pieces behind the image are masked below): read the row's last four channels in their place (finite values)
+        a[j] = *reinterpret_cast<const float4 *>(xr + min(ch, C - 4));
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ) : "memory");
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if (j < nj) {                                  // (block-uniform)
+            const bool in_img = 16 * j + 4 * kq < 8 * nc8;
+            const float4 av = in_img ? a[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int g = min(4 * j + kq, 2 * nc8 - 1);              // [group c = g >> 1][lane half g & 1] of the image
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float4 bv = *reinterpret_cast<const float4 *>(wimg + (g * 32 + 16 * t + r16) * 4);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                                   // the image has been read by every wave: its bytes are free
+    // ---- post-net weights (n_out x M -> 32 x 16, zero padded) and biases
+    for (int i = tid; i < 32 * 16; i += 256) {
+        const int n = i >> 4, m = i & 15;
+        wp[i] = (n < n_out && m < M) ? w_post[n * M + m] : 0.f;
+    }
+    if (tid < 16) wp[512 + tid] = (b_post && tid < M) ? b_post[tid] : 0.f;
+    // ---- y = acc + bias + earlier layers (stage output), and the wave's 16 x 32 result row-major in its LDS tile
+    float *yt = ytile + wave * T2_YT;
+    float *yb = y + (long long)b * y_bstride;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = r16 + 16 * t;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int lr = 4 * kq + v;
+            const int row = m0 + 16 * wave + lr;
+            const float val = acc[t][v] + e_add[t][v];
+            yt[lr * 33 + n] = n < n_out ? val : 0.f;
+            if (n < n_out && row < rows) yb[(long long)row * n_out + n] = val;
+        }
+    }
+    // ---- post-net: (16 x 32) x (32 x 16) on the matrix cores; lane (row r16, kq) supplies y[r16][4 s + kq], (kq, column r16)
+    // supplies Wp[4 s + kq][r16]
+    __syncthreads();                                   // the post-net's weights are in place
+    f32x4 sacc;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) sacc[v] = 0.f;
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8)
+        sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(yt[r16 * 33 + 4 * s8 + kq], wp[(4 * s8 + kq) * 16 + r16], sacc, 0, 0, 0);
+    if (r16 < M) {
+        const float bp = wp[512 + r16];
+        float *sb = sub + (long long)b * sub_bstride;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int row = m0 + 16 * wave + 4 * kq + v;
+            if (row < rows) sb[(long long)row * M + r16] = sacc[v] + bp;
+        }
+    }
+}
+
 // returns false if the shapes do not fit (caller falls back to two generic convolutions)
 bool launch_wn_tail(const float *skip, long long skip_bstride, const int *n_frames, int rows_per_frame, int max_rows,
                     int batch, int C, const float *w_end_packed, const float *b_end, int n_out, const float *w_post,
@@ -132,6 +267,16 @@ bool launch_wn_tail(const float *skip, long long skip_bstride, const int *n_fram
         (uintptr_t)w_end_packed % 16 != 0)
         return false;
     if (max_rows <= 0 || batch <= 0) return true;
+    // rows owned by waves (wn_tail2_kernel): up to 352 channels (22 blocks of 16 in a lane's registers)
+    const int nc8 = (C + 7) / 8, nj = (8 * nc8 + 15) / 16;
+    const size_t lds2 = std::max((size_t)nc8 * 256, (size_t)(4 * T2_YT + 32 * 16 + 16)) * sizeof(float);
+    if (nj <= 22 && C >= 16) {
+        auto kern = nj <= 20 ? wn_tail2_kernel<20> : wn_tail2_kernel<22>;
+        hipLaunchKernelGGL(kern, dim3((max_rows + T2_ROWS - 1) / T2_ROWS, batch), dim3(256), lds2, stream, skip, skip_bstride,
+                           n_frames, rows_per_frame, max_rows, C, w_end_packed, b_end, n_out, w_post, b_post, M, y_acc, y,
+                           y_bstride, sub, sub_bstride);
+        return true;
+    }
     hipLaunchKernelGGL(wn_tail_kernel, dim3((max_rows + 31) / 32, batch), dim3(256), 0, stream, skip, skip_bstride,
                        n_frames, rows_per_frame, max_rows, C, w_end_packed, b_end, n_out, w_post, b_post, M, y_acc, y,
                        y_bstride, sub, sub_bstride);
