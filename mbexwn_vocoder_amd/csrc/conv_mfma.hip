@@ -954,15 +954,21 @@ constexpr int MT_B_FLOATS = MT_SLICE * MT_COLS * 8;
 template <int RT>
 __device__ __forceinline__ void conv1d_mel_tile(const ConvArgs &p, int bx, int by, int b, float *lds) {
     constexpr int MT_ROWS = 32 * RT, MT_A_FLOATS = MT_SLICE * MT_ROWS * 8;
-    const int rows = item_rows(p.n_frames, b, p.rows_per_frame, p.max_rows);
+    int rows = item_rows(p.n_frames, b, p.rows_per_frame, p.max_rows);
     const int m0 = bx * MT_ROWS;
     if (m0 >= rows) return;
     const int n0 = by * MT_COLS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 31, lk = lane >> 5;
+    // what the K loop reads of the arguments, held in scalar registers: the member's ConvArgs sits behind a runtime index in the
+    // kernel's argument block, and the compiler otherwise re-reads the fields in every slice (four serial scalar-memory round
+    // trips per slice in the round-4 ISA, each with nothing to hide behind at one or two waves per SIMD)
     const float *xb = p.x + (long long)b * p.x_bstride;
-    const int gpt = p.cin >> 3;                              // groups of 8 input channels per tap
-    const int n_groups = p.ks * gpt;
+    const float *wgt = p.w;
+    int gpt = p.cin >> 3;                                    // groups of 8 input channels per tap
+    int n_groups = p.ks * gpt;
+    int cout = p.cout, ldx = p.ldx, dil = p.dil, pad_l = p.pad_l, pad_mode = p.pad_mode;
+    asm volatile("" : "+s"(xb), "+s"(wgt), "+s"(gpt), "+s"(n_groups), "+s"(cout), "+s"(ldx), "+s"(dil), "+s"(pad_l), "+s"(pad_mode), "+s"(rows));
 
     // staging roles (index arithmetic that does not depend on the thread stays on the scalar unit: every vector
     // instruction a wave issues takes time from the matrix pipe).  A: thread -> (row, 16-byte chunk of the slice's 32
@@ -972,7 +978,7 @@ __device__ __forceinline__ void conv1d_mel_tile(const ConvArgs &p, int bx, int b
     // a column's result depends on its own weights only and is not stored, the groups are not read.
     const int a_row = tid >> 3, ja = (tid & 7) >> 1, ha = tid & 1;
     const int b_col = tid & 127, hb = tid >> 7;
-    const unsigned b_voff = (unsigned)(4 * hb * p.cout + min(n0 + b_col, p.cout - 1));
+    const unsigned b_voff = (unsigned)(4 * hb * cout + min(n0 + b_col, cout - 1));
     const int a_lds = (ja * MT_ROWS + a_row) * 8 + 4 * (ha ^ ((a_row >> 3) & 1));          // row + 32: + 256 floats, same swizzle
     const int b_lds = b_col * 8 + 4 * (hb ^ ((b_col >> 3) & 1));                           // group j: + j * 1024 floats
     auto load_slice = [&](int gs, int ng, float4 (&a_reg)[RT], float (&b_reg)[4][4]) {
@@ -986,16 +992,16 @@ __device__ __forceinline__ void conv1d_mel_tile(const ConvArgs &p, int bx, int b
         const int ci = cg * 8 + 4 * ha;
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
-            const int src = map_row(m0 + a_row + 32 * i - p.pad_l + tap * p.dil, rows, p.pad_mode);
+            const int src = map_row(m0 + a_row + 32 * i - pad_l + tap * dil, rows, pad_mode);
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (src >= 0) t = *reinterpret_cast<const float4 *>(xb + (long long)src * p.ldx + ci);
+            if (src >= 0) t = *reinterpret_cast<const float4 *>(xb + (long long)src * ldx + ci);
             a_reg[i] = t;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float *wk = p.w + (long long)(min(gs + i, n_groups - 1) * 8) * p.cout;   // scalar
+            const float *wk = wgt + (long long)(min(gs + i, n_groups - 1) * 8) * cout;   // scalar
 #pragma unroll
-            for (int st = 0; st < 4; ++st) b_reg[i][st] = (wk + (long long)st * p.cout)[b_voff];
+            for (int st = 0; st < 4; ++st) b_reg[i][st] = (wk + (long long)st * cout)[b_voff];
         }
     };
     auto store_slice = [&](int buf, const float4 (&a_reg)[RT], const float (&b_reg)[4][4]) {
@@ -1049,21 +1055,28 @@ __device__ __forceinline__ void conv1d_mel_tile(const ConvArgs &p, int bx, int b
         const bool quarter_done = q1 != q;
         const float *al = lds + buf * (MT_A_FLOATS + MT_B_FLOATS) + a_rd;
         const float *bl = lds + buf * (MT_A_FLOATS + MT_B_FLOATS) + MT_A_FLOATS + b_rd;
+        auto group = [&](int j) {
+            const float4 bv = *reinterpret_cast<const float4 *>(bl + j * (MT_COLS * 8));
 #pragma unroll
-        for (int j = 0; j < MT_SLICE; ++j) {
-            if (j < ng) {
-                const float4 bv = *reinterpret_cast<const float4 *>(bl + j * (MT_COLS * 8));
-#pragma unroll
-                for (int t = 0; t < RT; ++t) {
-                    const float4 av = *reinterpret_cast<const float4 *>(al + j * (MT_ROWS * 8) + t * 256);
-                    f32x16 c = cur[t];
-                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, c, 0, 0, 0);
-                    cur[t] = c;
-                }
+            for (int t = 0; t < RT; ++t) {
+                const float4 av = *reinterpret_cast<const float4 *>(al + j * (MT_ROWS * 8) + t * 256);
+                f32x16 c = cur[t];
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, c, 0, 0, 0);
+                cur[t] = c;
             }
+        };
+        if (ng == MT_SLICE) {
+            // a full slice as one basic block: the operand reads of a group are requested while the group before it multiplies
+            // (as four guarded groups every group waited for its own reads with the matrix pipe empty)
+#pragma unroll
+            for (int j = 0; j < MT_SLICE; ++j) group(j);
+        } else {
+#pragma unroll
+            for (int j = 0; j < MT_SLICE - 1; ++j)
+                if (j < ng) group(j);
         }
         if (quarter_done) {
             // (quarters between q and q1 are empty: they would add zeros)
@@ -1090,7 +1103,7 @@ __device__ __forceinline__ void conv1d_mel_tile(const ConvArgs &p, int bx, int b
     }
 
     const int col = n0 + bcol;
-    if (col >= p.cout) return;
+    if (col >= cout) return;
     const float bias = p.bias ? p.bias[col] : 0.f;
     const float slope = p.alpha ? p.alpha[col] : p.leaky;
     const bool act = p.alpha != nullptr || p.use_leaky;
@@ -1108,6 +1121,261 @@ __device__ __forceinline__ void conv1d_mel_tile(const ConvArgs &p, int bx, int b
         }
 }
 
+// Round 5: the same tile with the slices brought in by LDS-DMA and a K loop without vector bookkeeping.
+// What the round-4 kernel (conv1d_mel_tile above) lost, read off in-kernel stamps and ablations (NOTEBOOK.md, round 5): at 16 x
+// 10 s its members ran at 0.39 / 0.29 / 0.41 of the matrix peak although neither the loads (ablated: -6 %) nor the LDS traffic
+// bound them.  Two or three blocks share a CU; while one wave is inside its burst of 64-cycle MFMAs, every VECTOR instruction of
+// a co-resident wave waits for a gap between them (~one MFMA each).  A wave's non-MFMA phase of ~25 vector instructions per
+// slice (address arithmetic for 18 loads and 6 ds_writes, cursor selects the compiler put on the vector ALU, LDS addresses)
+// thereby took longer than the other wave's MFMA burst -- the SIMD idled 40 % of the time --, the four quarter folds (96 vector
+// instructions each) and the epilogue (300) likewise.  Here, per slice of two groups of 8 channels, a wave issues
+//   3 LDS-DMA requests (activations: 32 rows x 8 channels of its group and row tile; weights: four k rows x 128 columns),
+//   8 LDS reads, 16 MFMAs, one counted wait + one barrier,
+// and NO vector ALU instruction: the slice cursor lives in scalar registers (s_cmp / s_cselect through inline asm: the
+// compiler lowers a uniform bool -> int through v_cndmask + v_readfirstlane), the request addresses are scalar bases + per-lane
+// offsets computed once, the four stages of the ring are four unrolled loop bodies whose LDS offsets are immediates.  Folds are
+// packed adds (16 + 8 moves per fold), the epilogue 3.5 vector instructions per output.
+// Same MFMA steps in the same order, the same quarter fold: bit-identical to conv1d_small_tile (tests: the large launch against
+// the same rows in small launches).
+//   activations of a stage: [group j][row tile t][32 rows][2 halves of 4 channels], half h of row r at slot h ^ ((r >> 3) & 1)
+//                           (the 16 rows of a ds_read_b128 phase then hit all 16 bank quads)
+//   weights of a stage:     [16 k rows][128 columns], the row's 16-byte chunks rotated by 8 positions when (k >> 2) & 1 (the two
+//                           k rows of a ds_read_b32 -- lanes 0-31 and 32-63 -- then sit in different banks)
+constexpr int M2_NG = 2, M2_STAGES = 4;
+constexpr int M2_A_FLOATS = M2_NG * 64 * 8, M2_W_FLOATS = M2_NG * 8 * MT_COLS, M2_STAGE_FLOATS = M2_A_FLOATS + M2_W_FLOATS;
+static_assert(M2_STAGES * M2_STAGE_FLOATS * 4 <= 2 * (MT_SLICE * 64 * 8 + MT_B_FLOATS) * 4, "the group kernel's LDS array holds the ring");
+
+__device__ __forceinline__ void lds_dma16_s(const float *sbase, unsigned voff_bytes, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte_addr), "v"(voff_bytes), "s"(sbase) : "memory", "m0");
+}
+// scalar 0 / 1 flags and selects that stay on the scalar unit
+__device__ __forceinline__ int s_flag_ge(int a, int b) {
+    int r;
+    asm("s_cmp_ge_i32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(a), "s"(b) : "scc");
+    return r;
+}
+__device__ __forceinline__ int s_select(int flag, int a, int b) {          // flag ? a : b
+    int r;
+    asm("s_cmp_lg_u32 %1, 0\n\ts_cselect_b32 %0, %2, %3" : "=s"(r) : "s"(flag), "s"(a), "s"(b) : "scc");
+    return r;
+}
+__device__ __forceinline__ const float *s_ptr_add(const float *base, int byte_off) {
+    const unsigned long long u = (unsigned long long)(uintptr_t)base;
+    unsigned lo, hi;
+    asm("s_add_u32 %0, %2, %4\n\ts_addc_u32 %1, %3, 0" : "=&s"(lo), "=&s"(hi) : "s"((unsigned)u), "s"((unsigned)(u >> 32)), "s"(byte_off) : "scc");
+    return reinterpret_cast<const float *>((uintptr_t)(((unsigned long long)hi << 32) | lo));
+}
+
+// INTERIOR: every source row of the tile (all taps) lies inside the item -- the activation request is then a scalar base + the
+// lanes' constant offsets, and a slice is one basic block (the compiler interleaves its scalar code with the MFMAs)
+template <bool INTERIOR>
+__device__ __forceinline__ void conv1d_mel_tile_dma_body(const ConvArgs &p, int bx, int by, int b, float *lds, int rows) {
+    typedef __attribute__((address_space(3))) float lds_float;
+    const int m0 = bx * 64;
+    const int n0 = by * MT_COLS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lk = lane >> 5;
+    const int gpt = p.cin >> 3;                              // groups of 8 input channels per tap
+    const int n_groups = p.ks * gpt;
+    const int cout = p.cout, ldx = p.ldx;
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float *)lds);
+
+    // ---- DMA roles.  The wave fetches group jw = wave >> 1 of a slice: the activations of row tile tw = wave & 1 and the k
+    // rows 4 (wave & 1) .. + 3 of the group's eight.  (A slice of one group: the waves of group 1 fetch group 0 again -- the
+    // same three requests per wave and slice whatever the slice, which is what the counted waits count.)
+    const int jw = wave >> 1, tw = wave & 1;
+    const int d_row = lane >> 1, d_half = (lane & 1) ^ ((lane >> 4) & 1);            // slot lane & 1 of row lane >> 1 holds half d_half
+    const unsigned a_voff = (unsigned)(d_row * ldx + 4 * d_half) * 4u;               // interior of an item: row pitch x row + half
+    const unsigned a_dst = lds_base + (unsigned)((jw * 2 + tw) * 256) * 4u;          // + stage
+    // weights: instruction i covers k rows kin = 4 tw + 2 i + (lane >> 5) of the group; position lane & 31 of the row holds the
+    // chunk (position - 8 ((kin >> 2) & 1)) & 31 = columns n0 + 4 chunk .. + 3 (clamped: columns behind cout are not stored)
+    unsigned w_voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int kin = 4 * tw + 2 * i + (lane >> 5);
+        const int chunk = ((lane & 31) - 8 * ((kin >> 2) & 1)) & 31;
+        w_voff[i] = (unsigned)(kin * cout + min(n0 + 4 * chunk, cout - 4)) * 4u;
+    }
+    const unsigned w_dst = lds_base + (unsigned)(M2_A_FLOATS + (jw * 8 + 4 * tw) * MT_COLS) * 4u;      // + 1024 i + stage
+    // scalar bases: the tile's first source row at tap 0 (may lie outside the item: only used when the whole 32-row piece is
+    // inside) and the weight matrix; per slice a 32-bit byte offset is added (the launcher bounds both tensors by 2^31 bytes)
+    const int r_tile = m0 + 32 * tw - p.pad_l;
+    const float *xb = p.x + (long long)b * p.x_bstride;
+    const float *x_tile = xb + (long long)r_tile * ldx;
+    const float *wgt = p.w;
+    const int tap_rows = p.dil, tap_bytes = p.dil * ldx * 4, group_bytes = 8 * cout * 4;
+
+    // ---- the slice cursor (scalar registers only): quarter end qe, first group gs, its tap and channel group, and the byte
+    // offsets that go with them.  A cursor that has reached the last slice stays there: the requests behind the end fetch the
+    // last slice again into a free stage, so every iteration issues the same three requests and waits with the same count.
+    int c_q = 0, c_gs = 0, c_qe = n_groups >> 2, c_tap = 0, c_cg = 0;
+    auto cursor_groups = [&]() { return min(M2_NG, c_qe - c_gs); };
+    auto cursor_info = [&]() {                               // groups | quarter complete << 2: what the MFMA side needs of a slice
+        const int n = cursor_groups();
+        return n | (s_flag_ge(c_gs + n, c_qe) << 2);
+    };
+    auto advance = [&]() {
+        const int n = cursor_groups();
+        const int gs2 = c_gs + n;
+        int cg2 = c_cg + n, tap2 = c_tap;
+#pragma unroll
+        for (int i = 0; i < M2_NG; ++i) {                    // n <= M2_NG wraps at most (gpt >= 1)
+            const int wrap = s_flag_ge(cg2, gpt);
+            cg2 -= wrap * gpt;
+            tap2 += wrap;
+        }
+        const int next_q = s_flag_ge(gs2, c_qe);             // (quarters are never empty: n_groups >= 4)
+        const int q2 = c_q + next_q;
+        const int qe2 = s_select(next_q, (n_groups * (q2 + 1)) >> 2, c_qe);
+        const int last = s_flag_ge(gs2, n_groups);
+        c_gs = s_select(last, c_gs, gs2);
+        c_cg = s_select(last, c_cg, cg2);
+        c_tap = s_select(last, c_tap, tap2);
+        c_q = s_select(last, c_q, q2);
+        c_qe = s_select(last, c_qe, qe2);
+    };
+    auto issue = [&](int stage) {
+        const int ng = cursor_groups();
+        const int second = jw & s_flag_ge(ng, M2_NG);        // this wave fetches the slice's second group
+        const int wrap = second & s_flag_ge(c_cg + 1, gpt);
+        const int cg = s_select(wrap, 0, c_cg + second);
+        const int tap = c_tap + wrap;
+        const int g = c_gs + second;
+        const unsigned st_off = (unsigned)(stage * M2_STAGE_FLOATS) * 4u;
+        if (INTERIOR) {
+            lds_dma16_s(s_ptr_add(x_tile, tap * tap_bytes + cg * 32), a_voff, a_dst + st_off);
+        } else {                                             // first / last tile of an item: padding per row
+            const int src = map_row(r_tile + tap * tap_rows + d_row, rows, p.pad_mode);
+            lds_dma16(src >= 0 ? xb + (long long)src * ldx + cg * 8 + 4 * d_half : p.zeros, a_dst + st_off);
+        }
+        const float *wk = s_ptr_add(wgt, g * group_bytes);
+        lds_dma16_s(wk, w_voff[0], w_dst + st_off);
+        lds_dma16_s(wk, w_voff[1], w_dst + st_off + 1024u);
+    };
+
+    f32x16 cur[2], sum[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cur[t][r] = sum[t][r] = 0.f;
+
+    int n_slices = 0;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) n_slices += ((((n_groups * (qq + 1)) >> 2) - ((n_groups * qq) >> 2)) + M2_NG - 1) / M2_NG;
+    // ring of the slices in flight: what the MFMA side needs of them
+    int info0, info1, info2;
+    info0 = cursor_info();
+    issue(0);
+    advance();
+    info1 = cursor_info();
+    issue(1);
+    advance();
+    info2 = cursor_info();
+    issue(2);
+    advance();
+    // operand addresses of the MFMA lanes (floats, + stage): activations of (group j, tile t): + (2 j + t) 256; weights of
+    // (group j, step st): + j 1024 + st 128
+    const int bcol = 32 * wave + lrow;
+    const float *al = lds + lrow * 8 + 4 * (lk ^ ((lrow >> 3) & 1));
+    const float *bl = lds + M2_A_FLOATS + 4 * lk * MT_COLS + 4 * (((bcol >> 2) + 8 * lk) & 31) + (bcol & 3);
+
+    auto body = [&](auto stage_c) {
+        constexpr int ST = decltype(stage_c)::value;         // the stage of this slice; the request goes to the one before it
+        // the slice has landed: this wave's requests (all but those of the two slices behind it), then everybody's
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __syncthreads();                                     // ... and the stage read last in the slice before is free
+        // the operands of both groups are requested first (a slice of one group reads a stale second group and drops it): their
+        // LDS latency passes under the request code
+        float4 av[M2_NG][2];
+        float bv[M2_NG][4];
+#pragma unroll
+        for (int j = 0; j < M2_NG; ++j) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) av[j][t] = *reinterpret_cast<const float4 *>(al + ST * M2_STAGE_FLOATS + (2 * j + t) * 256);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) bv[j][st] = bl[ST * M2_STAGE_FLOATS + j * 8 * MT_COLS + st * MT_COLS];
+        }
+        const int info = info0;
+        info0 = info1;
+        info1 = info2;
+        info2 = cursor_info();
+        issue((ST + M2_STAGES - 1) % M2_STAGES);
+        advance();
+        auto group = [&](int j) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x16 c = cur[t];
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][t].x, bv[j][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][t].y, bv[j][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][t].z, bv[j][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][t].w, bv[j][3], c, 0, 0, 0);
+                cur[t] = c;
+            }
+        };
+        group(0);
+        if ((info & 3) == M2_NG) group(1);
+        if (info >> 2) {                                     // the quarter is complete: ((q0 + q1) + q2) + q3, q0 as 0 + q0 (the
+#pragma unroll                                               // chains start from +0, so q0 is never -0 and 0 + q0 has q0's bits)
+            for (int t = 0; t < 2; ++t) {
+                sum[t] = sum[t] + cur[t];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cur[t][r] = 0.f;
+            }
+        }
+    };
+    for (int sl = 0; sl < n_slices; sl += M2_STAGES) {
+        body(std::integral_constant<int, 0>{});
+        if (sl + 1 >= n_slices) break;
+        body(std::integral_constant<int, 1>{});
+        if (sl + 2 >= n_slices) break;
+        body(std::integral_constant<int, 2>{});
+        if (sl + 3 >= n_slices) break;
+        body(std::integral_constant<int, 3>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the requests behind the end have landed before the block leaves
+
+    const int col = n0 + bcol;
+    if (col >= cout) return;
+    const float bias = p.bias ? p.bias[col] : 0.f;
+    const float slope = p.alpha ? p.alpha[col] : p.leaky;
+    const bool act = p.alpha != nullptr || p.use_leaky;
+    float *ob = p.out + (long long)b * p.out_bstride;
+    if (m0 + 64 <= rows) {
+        // a full tile: one address per lane (row 4 lk of the tile, its column), the 32 rows of the lane at scalar multiples of
+        // the row pitch
+        float *o0 = ob + (long long)(m0 + 4 * lk) * p.ldo + col;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = sum[t][r] + bias;
+                if (act) v = v > 0.f ? v : slope * v;
+                o0[(long long)(32 * t + (r & 3) + 8 * (r >> 2)) * p.ldo] = v;
+            }
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (row < rows) {
+                float v = sum[t][r] + bias;
+                if (act) v = v > 0.f ? v : slope * v;
+                ob[(long long)row * p.ldo + col] = v;
+            }
+        }
+}
+
+__device__ __forceinline__ void conv1d_mel_tile_dma(const ConvArgs &p, int bx, int by, int b, float *lds) {
+    const int rows = __builtin_amdgcn_readfirstlane(item_rows(p.n_frames, b, p.rows_per_frame, p.max_rows));
+    const int m0 = bx * 64;
+    if (m0 >= rows) return;
+    if (m0 - p.pad_l >= 0 && m0 + 63 - p.pad_l + (p.ks - 1) * p.dil < rows) conv1d_mel_tile_dma_body<true>(p, bx, by, b, lds, rows);
+    else conv1d_mel_tile_dma_body<false>(p, bx, by, b, lds, rows);
+}
+
 template <int RT>
 __global__ __launch_bounds__(256, RT <= 2 ? 3 : 2) void conv1d_mel_group_kernel(SmallConvGroup g) {
     __shared__ __attribute__((aligned(16))) float lds[2 * (MT_SLICE * 32 * RT * 8 + MT_B_FLOATS)];
@@ -1117,6 +1385,7 @@ __global__ __launch_bounds__(256, RT <= 2 ? 3 : 2) void conv1d_mel_group_kernel(
     const int bx = local % g.gx[k];
     const int t = local / g.gx[k];
     if (g.c[k].precise) conv1d_f64_dispatch<2, 2>(g.c[k], bx, t % g.gy[k], t / g.gy[k], reinterpret_cast<double *>(lds));     // 32 x 32 tiles
+    else if (g.c[k].zeros) conv1d_mel_tile_dma(g.c[k], bx, t % g.gy[k], t / g.gy[k], lds);
     else conv1d_mel_tile<RT>(g.c[k], bx, t % g.gy[k], t / g.gy[k], lds);
 }
 
@@ -1198,6 +1467,8 @@ void launch_conv1d_group(const ConvArgs *convs, int n, hipStream_t stream) {
         if (k < n_small) {
             g.c[k] = convs[small[k]];
             g.c[k].precise = f64_conv_eligible(g.c[k]) ? 1 : 0;
+            // LDS-DMA tile (conv1d_mel_tile_dma): 16-byte weight chunks, at least one full chunk of columns
+            if (!(g.c[k].cout % 4 == 0 && g.c[k].cout >= 4 && (uintptr_t)g.c[k].w % 16 == 0)) g.c[k].zeros = nullptr;
             // float64-accumulating members (the F0-net): 16 x 16 tiles in the small launches, 32 x 32 in the large ones
             const int tm = g.c[k].precise ? (big ? 32 : 16) : tile_m, tn = g.c[k].precise ? (big ? 32 : 16) : tile_n;
             g.gx[k] = (g.c[k].max_rows + tm - 1) / tm;

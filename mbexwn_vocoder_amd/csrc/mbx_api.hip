@@ -355,6 +355,7 @@ struct SubnetRun {
                 mbx::ConvArgs a = conv_args(cur, cur_bstride, chan, n_frames, rpf, T * rpf, B, w, bias, op.ks, op.cin,
                                             op.cout, 1, op.pad_l, op.pad_mode, out, out_bstride, op.cout);
                 a.precise = precise ? 1 : 0;
+                a.zeros = hd->zeros;
                 if (buf64_0) {             // full-float64 chain (the op list was checked at mbx_create: f0_chain_is_full64)
                     double *out64 = (pp ^ 1) ? buf64_1 : buf64_0;       // (pp was toggled above)
                     a.w64 = f64_weights(hd, op);
@@ -2051,7 +2052,9 @@ mbx_status mbx_conv1d(mbx_handle *hd, const float *x, int32_t batch, int32_t n_r
     mbx::ConvArgs a = conv_args(x, (long long)n_rows * cin, cin, nullptr, 1, n_rows, batch, &wt, b ? &bt : nullptr, ks,
                                 cin, cout, dilation, pad_l, pad_mode, y, (long long)n_rows * cout, cout);
     a.alpha = alpha;
-    mbx::launch_conv1d(a, mbx::EPI_LINEAR, static_cast<hipStream_t>(hip_stream));
+    a.zeros = hd->zeros;
+    // the way the launch sequence issues its mel-rate convolutions: large launches take the LDS-staged tile kernel
+    mbx::launch_conv1d_group(&a, 1, static_cast<hipStream_t>(hip_stream));
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MBX_OK : fail(MBX_ERR_HIP, hipGetErrorString(e));
 }
