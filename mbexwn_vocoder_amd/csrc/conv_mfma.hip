@@ -943,186 +943,14 @@ __global__ __launch_bounds__(256) void conv1d_small_group_kernel(SmallConvGroup 
 
 // The same convolutions at large launches (batch 16 x 10 s: 12 800 rows): an LDS-staged tile kernel with the summation
 // order of conv1d_small_tile.  Block = 4 waves, 64 rows x 128 columns; wave w owns the columns 32 w .. 32 w + 31 of both
-// 32-row tiles.  K runs in slices of <= 4 groups of 8 channels that never cross a quarter boundary; a slice is staged
-// once per block (A: 64 rows x 32 channels, coalesced 128-byte rows; W: 32 x 128, transposed on the way so that one
-// ds_read_b128 yields the four k steps of a lane) in one of two LDS buffers while the other one feeds the MFMAs.  A wave
-// keeps two accumulator sets per tile: the chain of the quarter in progress and the running sum q0, q0 + q1, ... -- the
-// same left fold ((q0 + q1) + q2) + q3 + bias, the same MFMA steps in the same order, hence bit-identical results.
-constexpr int MT_COLS = 128, MT_SLICE = 4;                              // slice = MT_SLICE groups of 8 channels
-constexpr int MT_B_FLOATS = MT_SLICE * MT_COLS * 8;
+// 32-row tiles.  K runs in slices of groups of 8 channels that never cross a quarter boundary.  A wave keeps two accumulator
+// sets per tile: the chain of the quarter in progress and the running sum q0, q0 + q1, ... -- the same left fold
+// ((q0 + q1) + q2) + q3 + bias, the same MFMA steps in the same order, hence bit-identical results.
+// (Rounds 3-4 staged the slices through registers -- conv1d_mel_tile, removed in round 5: see below.)
+constexpr int MT_COLS = 128;
 
-template <int RT>
-__device__ __forceinline__ void conv1d_mel_tile(const ConvArgs &p, int bx, int by, int b, float *lds) {
-    constexpr int MT_ROWS = 32 * RT, MT_A_FLOATS = MT_SLICE * MT_ROWS * 8;
-    int rows = item_rows(p.n_frames, b, p.rows_per_frame, p.max_rows);
-    const int m0 = bx * MT_ROWS;
-    if (m0 >= rows) return;
-    const int n0 = by * MT_COLS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lrow = lane & 31, lk = lane >> 5;
-    // what the K loop reads of the arguments, held in scalar registers: the member's ConvArgs sits behind a runtime index in the
-    // kernel's argument block, and the compiler otherwise re-reads the fields in every slice (four serial scalar-memory round
-    // trips per slice in the round-4 ISA, each with nothing to hide behind at one or two waves per SIMD)
-    const float *xb = p.x + (long long)b * p.x_bstride;
-    const float *wgt = p.w;
-    int gpt = p.cin >> 3;                                    // groups of 8 input channels per tap
-    int n_groups = p.ks * gpt;
-    int cout = p.cout, ldx = p.ldx, dil = p.dil, pad_l = p.pad_l, pad_mode = p.pad_mode;
-    asm volatile("" : "+s"(xb), "+s"(wgt), "+s"(gpt), "+s"(n_groups), "+s"(cout), "+s"(ldx), "+s"(dil), "+s"(pad_l), "+s"(pad_mode), "+s"(rows));
-
-    // staging roles (index arithmetic that does not depend on the thread stays on the scalar unit: every vector
-    // instruction a wave issues takes time from the matrix pipe).  A: thread -> (row, 16-byte chunk of the slice's 32
-    // channels), rows a_row and a_row + 32, group ja = chunk >> 1.  W: thread -> (column, half hb of a group's 8 k steps)
-    // for each of the slice's groups: row (g 8 + 4 hb + st) of the (ks * cin, cout) matrix -- the tap needs no division.
-    // Columns behind cout and groups behind the slice's last one are staged with whatever the clamped address holds:
-    // a column's result depends on its own weights only and is not stored, the groups are not read.
-    const int a_row = tid >> 3, ja = (tid & 7) >> 1, ha = tid & 1;
-    const int b_col = tid & 127, hb = tid >> 7;
-    const unsigned b_voff = (unsigned)(4 * hb * cout + min(n0 + b_col, cout - 1));
-    const int a_lds = (ja * MT_ROWS + a_row) * 8 + 4 * (ha ^ ((a_row >> 3) & 1));          // row + 32: + 256 floats, same swizzle
-    const int b_lds = b_col * 8 + 4 * (hb ^ ((b_col >> 3) & 1));                           // group j: + j * 1024 floats
-    auto load_slice = [&](int gs, int ng, float4 (&a_reg)[RT], float (&b_reg)[4][4]) {
-        // group of this thread's A chunk: tap / channel offset from the slice's first group (scalar) + ja
-        const int tap_s = gs / gpt, cg_s = gs - tap_s * gpt;
-        int cg = cg_s + min(ja, ng - 1), tap = tap_s;
-        while (cg >= gpt) {                                  // at most ja iterations (gpt >= 1)
-            cg -= gpt;
-            ++tap;
-        }
-        const int ci = cg * 8 + 4 * ha;
-#pragma unroll
-        for (int i = 0; i < RT; ++i) {
-            const int src = map_row(m0 + a_row + 32 * i - pad_l + tap * dil, rows, pad_mode);
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (src >= 0) t = *reinterpret_cast<const float4 *>(xb + (long long)src * ldx + ci);
-            a_reg[i] = t;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float *wk = wgt + (long long)(min(gs + i, n_groups - 1) * 8) * cout;   // scalar
-#pragma unroll
-            for (int st = 0; st < 4; ++st) b_reg[i][st] = (wk + (long long)st * cout)[b_voff];
-        }
-    };
-    auto store_slice = [&](int buf, const float4 (&a_reg)[RT], const float (&b_reg)[4][4]) {
-        float *al = lds + buf * (MT_A_FLOATS + MT_B_FLOATS);
-        float *bl = al + MT_A_FLOATS;
-#pragma unroll
-        for (int i = 0; i < RT; ++i) *reinterpret_cast<float4 *>(al + a_lds + 256 * i) = a_reg[i];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4 *>(bl + b_lds + i * (MT_COLS * 8)) = make_float4(b_reg[i][0], b_reg[i][1], b_reg[i][2], b_reg[i][3]);
-    };
-
-    f32x16 cur[RT], sum[RT];
-#pragma unroll
-    for (int t = 0; t < RT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cur[t][r] = sum[t][r] = 0.f;
-
-    // slices in K order; (q, gs) = quarter and first group of the slice being computed.  The global loads run two slices
-    // ahead of the MFMAs (an L2 round trip is longer than one slice's 32 MFMAs): register set i & 1 holds slice i until it
-    // is written to the LDS buffer the slice before it has just been read from.
-    auto q_end = [&](int qq) { return (n_groups * (qq + 1)) / 4; };
-    auto advance = [&](int &qq, int &g0) {                   // next slice behind (qq, g0); qq == 4: none
-        g0 += min(MT_SLICE, q_end(qq) - g0);
-        while (qq < 4 && g0 >= q_end(qq)) ++qq;
-    };
-    float4 a_reg[2][RT];
-    float b_reg[2][4][4];
-    int q = 0, gs = 0;
-    while (q < 4 && gs >= q_end(q)) ++q;                     // (empty leading quarters do not occur: n_groups >= 4)
-    int q1 = q, gs1 = gs;
-    if (q < 4) {
-        load_slice(gs, min(MT_SLICE, q_end(q) - gs), a_reg[0], b_reg[0]);
-        advance(q1, gs1);
-        if (q1 < 4) load_slice(gs1, min(MT_SLICE, q_end(q1) - gs1), a_reg[1], b_reg[1]);
-        store_slice(0, a_reg[0], b_reg[0]);
-    }
-    __syncthreads();
-    const int bcol = 32 * wave + lrow;
-    const int a_rd = lrow * 8 + 4 * (lk ^ ((lrow >> 3) & 1));                              // tile t: + 256 floats, group j: + 512
-    const int b_rd = bcol * 8 + 4 * (lk ^ ((bcol >> 3) & 1));                              // group j: + 1024
-    int buf = 0;
-    auto step = [&](auto parity) {
-        constexpr int P = decltype(parity)::value;           // register set of the slice behind this one
-        const int ng = min(MT_SLICE, q_end(q) - gs);
-        int q2 = q1, gs2 = gs1;                              // slice two ahead goes into the set this slice came from
-        if (q1 < 4) {
-            advance(q2, gs2);
-            if (q2 < 4) load_slice(gs2, min(MT_SLICE, q_end(q2) - gs2), a_reg[P ^ 1], b_reg[P ^ 1]);
-        }
-        const bool quarter_done = q1 != q;
-        const float *al = lds + buf * (MT_A_FLOATS + MT_B_FLOATS) + a_rd;
-        const float *bl = lds + buf * (MT_A_FLOATS + MT_B_FLOATS) + MT_A_FLOATS + b_rd;
-        auto group = [&](int j) {
-            const float4 bv = *reinterpret_cast<const float4 *>(bl + j * (MT_COLS * 8));
-#pragma unroll
-            for (int t = 0; t < RT; ++t) {
-                const float4 av = *reinterpret_cast<const float4 *>(al + j * (MT_ROWS * 8) + t * 256);
-                f32x16 c = cur[t];
-                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, c, 0, 0, 0);
-                cur[t] = c;
-            }
-        };
-        if (ng == MT_SLICE) {
-            // a full slice as one basic block: the operand reads of a group are requested while the group before it multiplies
-            // (as four guarded groups every group waited for its own reads with the matrix pipe empty)
-#pragma unroll
-            for (int j = 0; j < MT_SLICE; ++j) group(j);
-        } else {
-#pragma unroll
-            for (int j = 0; j < MT_SLICE - 1; ++j)
-                if (j < ng) group(j);
-        }
-        if (quarter_done) {
-            // (quarters between q and q1 are empty: they would add zeros)
-#pragma unroll
-            for (int t = 0; t < RT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    sum[t][r] = q == 0 ? cur[t][r] : sum[t][r] + cur[t][r];
-                    cur[t][r] = 0.f;
-                }
-        }
-        if (q1 < 4) store_slice(buf ^ 1, a_reg[P], b_reg[P]);
-        __syncthreads();
-        buf ^= 1;
-        q = q1;
-        gs = gs1;
-        q1 = q2;
-        gs1 = gs2;
-    };
-    while (q < 4) {
-        step(std::integral_constant<int, 1>{});              // the slice behind the first one sits in set 1
-        if (q >= 4) break;
-        step(std::integral_constant<int, 0>{});
-    }
-
-    const int col = n0 + bcol;
-    if (col >= cout) return;
-    const float bias = p.bias ? p.bias[col] : 0.f;
-    const float slope = p.alpha ? p.alpha[col] : p.leaky;
-    const bool act = p.alpha != nullptr || p.use_leaky;
-    float *ob = p.out + (long long)b * p.out_bstride;
-#pragma unroll
-    for (int t = 0; t < RT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            if (row < rows) {
-                float v = sum[t][r] + bias;
-                if (act) v = v > 0.f ? v : slope * v;
-                ob[(long long)row * p.ldo + col] = v;
-            }
-        }
-}
-
-// Round 5: the same tile with the slices brought in by LDS-DMA and a K loop without vector bookkeeping.
-// What the round-4 kernel (conv1d_mel_tile above) lost, read off in-kernel stamps and ablations (NOTEBOOK.md, round 5): at 16 x
+// Round 5: the slices are brought in by LDS-DMA and the K loop has no vector bookkeeping.
+// What the round-4 kernel (conv1d_mel_tile, register-staged) lost, read off in-kernel stamps and ablations (NOTEBOOK.md, round 5): at 16 x
 // 10 s its members ran at 0.39 / 0.29 / 0.41 of the matrix peak although neither the loads (ablated: -6 %) nor the LDS traffic
 // bound them.  Two or three blocks share a CU; while one wave is inside its burst of 64-cycle MFMAs, every VECTOR instruction of
 // a co-resident wave waits for a gap between them (~one MFMA each).  A wave's non-MFMA phase of ~25 vector instructions per
@@ -1143,7 +971,6 @@ __device__ __forceinline__ void conv1d_mel_tile(const ConvArgs &p, int bx, int b
 //                           k rows of a ds_read_b32 -- lanes 0-31 and 32-63 -- then sit in different banks)
 constexpr int M2_NG = 2, M2_STAGES = 4;
 constexpr int M2_A_FLOATS = M2_NG * 64 * 8, M2_W_FLOATS = M2_NG * 8 * MT_COLS, M2_STAGE_FLOATS = M2_A_FLOATS + M2_W_FLOATS;
-static_assert(M2_STAGES * M2_STAGE_FLOATS * 4 <= 2 * (MT_SLICE * 64 * 8 + MT_B_FLOATS) * 4, "the group kernel's LDS array holds the ring");
 
 __device__ __forceinline__ void lds_dma16_s(const float *sbase, unsigned voff_bytes, unsigned lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte_addr), "v"(voff_bytes), "s"(sbase) : "memory", "m0");
@@ -1376,17 +1203,15 @@ __device__ __forceinline__ void conv1d_mel_tile_dma(const ConvArgs &p, int bx, i
     else conv1d_mel_tile_dma_body<false>(p, bx, by, b, lds, rows);
 }
 
-template <int RT>
-__global__ __launch_bounds__(256, RT <= 2 ? 3 : 2) void conv1d_mel_group_kernel(SmallConvGroup g) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * (MT_SLICE * 32 * RT * 8 + MT_B_FLOATS)];
+__global__ __launch_bounds__(256, 3) void conv1d_mel_group_kernel(SmallConvGroup g) {
+    __shared__ __attribute__((aligned(16))) float lds[M2_STAGES * M2_STAGE_FLOATS];
     const int id = blockIdx.x;
     const int k = (id >= g.start[1]) + (id >= g.start[2]);
     const int local = id - g.start[k];
     const int bx = local % g.gx[k];
     const int t = local / g.gx[k];
     if (g.c[k].precise) conv1d_f64_dispatch<2, 2>(g.c[k], bx, t % g.gy[k], t / g.gy[k], reinterpret_cast<double *>(lds));     // 32 x 32 tiles
-    else if (g.c[k].zeros) conv1d_mel_tile_dma(g.c[k], bx, t % g.gy[k], t / g.gy[k], lds);
-    else conv1d_mel_tile<RT>(g.c[k], bx, t % g.gy[k], t / g.gy[k], lds);
+    else conv1d_mel_tile_dma(g.c[k], bx, t % g.gy[k], t / g.gy[k], lds);
 }
 
 template <int WM, int WN, int TM, int TN, int EPI, int BK = 16>
@@ -1441,11 +1266,19 @@ void launch_conv1d_group(const ConvArgs *convs, int n, hipStream_t stream) {
     int small[3], n_small = 0;
     for (int i = 0; i < n && i < 3; ++i)
         if (convs[i].max_rows > 0 && convs[i].batch > 0 && small_conv_eligible(convs[i])) small[n_small++] = i;
-    // large launches: LDS-staged 64 x 128 tiles (conv1d_mel_tile: same sums in the same order), also for a single convolution
-    // (the conditioning chains of the WaveNet blocks behind the first one come one by one)
+    // large launches: LDS-staged 64 x 128 tiles (conv1d_mel_tile_dma: same sums in the same order), also for a single convolution
+    // (the conditioning chains of the WaveNet blocks behind the first one come one by one).  The tile's LDS-DMA needs 16-byte
+    // weight chunks, the zero page and tensors below 2^31 bytes (32-bit offsets); other shapes keep the small-launch kernel.
     long long work = 0;
-    for (int k = 0; k < n_small; ++k) work += (long long)convs[small[k]].max_rows * convs[small[k]].batch;
-    const bool big = work >= 3 * 4096;
+    bool dma_ok = true;
+    for (int k = 0; k < n_small; ++k) {
+        const ConvArgs &c = convs[small[k]];
+        work += (long long)c.max_rows * c.batch;
+        if (f64_conv_eligible(c)) continue;
+        dma_ok = dma_ok && c.zeros && c.cout % 4 == 0 && c.cout >= 4 && (uintptr_t)c.w % 16 == 0 &&
+                 (long long)c.ks * c.cin * c.cout * 4 < (1LL << 31) && ((long long)c.max_rows + c.ks * c.dil) * c.ldx * 4 < (1LL << 31);
+    }
+    const bool big = work >= 3 * 4096 && dma_ok;
     if (n > 3 || n_small < 1 || (n_small < 2 && !big)) {
         for (int i = 0; i < n; ++i) launch_conv1d(convs[i], EPI_LINEAR, stream);
         return;
@@ -1458,8 +1291,7 @@ void launch_conv1d_group(const ConvArgs *convs, int n, hipStream_t stream) {
                 small[i] = small[j];
                 small[j] = t;
             }
-    constexpr int MEL_RT = 2;                        // 64-row tiles
-    const int tile_m = big ? 32 * MEL_RT : 32, tile_n = big ? MT_COLS : 32;
+    const int tile_m = big ? 64 : 32, tile_n = big ? MT_COLS : 32;
     SmallConvGroup g;
     int total = 0;
     for (int k = 0; k < 3; ++k) {
@@ -1467,8 +1299,6 @@ void launch_conv1d_group(const ConvArgs *convs, int n, hipStream_t stream) {
         if (k < n_small) {
             g.c[k] = convs[small[k]];
             g.c[k].precise = f64_conv_eligible(g.c[k]) ? 1 : 0;
-            // LDS-DMA tile (conv1d_mel_tile_dma): 16-byte weight chunks, at least one full chunk of columns
-            if (!(g.c[k].cout % 4 == 0 && g.c[k].cout >= 4 && (uintptr_t)g.c[k].w % 16 == 0)) g.c[k].zeros = nullptr;
             // float64-accumulating members (the F0-net): 16 x 16 tiles in the small launches, 32 x 32 in the large ones
             const int tm = g.c[k].precise ? (big ? 32 : 16) : tile_m, tn = g.c[k].precise ? (big ? 32 : 16) : tile_n;
             g.gx[k] = (g.c[k].max_rows + tm - 1) / tm;
@@ -1481,7 +1311,7 @@ void launch_conv1d_group(const ConvArgs *convs, int n, hipStream_t stream) {
     }
     g.start[3] = total;
     for (int k = n_small; k < 3; ++k) g.start[k] = 0x7fffffff;
-    if (big) hipLaunchKernelGGL(conv1d_mel_group_kernel<MEL_RT>, dim3((unsigned)total), dim3(256), 0, stream, g);
+    if (big) hipLaunchKernelGGL(conv1d_mel_group_kernel, dim3((unsigned)total), dim3(256), 0, stream, g);
     else hipLaunchKernelGGL((conv1d_small_group_kernel<1, 1>), dim3((unsigned)total), dim3(256), 0, stream, g);
     for (int i = 0; i < n; ++i) {
         bool in_group = false;

@@ -378,58 +378,9 @@ PATCHES = {
     'small_depth4': [
         ('    constexpr int DEPTH = RT * CT == 1 ? 6 : 3;', '    constexpr int DEPTH = RT * CT == 1 ? 4 : 3;'),
     ],
-    # conv_mfma.hip, large-launch mel-rate tile kernel (timing only): no weight loads / no activation loads / no stores to LDS
-    'mt_now': [
-        ('            for (int st = 0; st < 4; ++st) b_reg[i][st] = (wk + (long long)st * cout)[b_voff];',
-         '            for (int st = 0; st < 4; ++st) b_reg[i][st] = 0.25f + (float)b_voff;'),
-    ],
-    'mt_noa': [
-        ('            if (src >= 0) t = *reinterpret_cast<const float4 *>(xb + (long long)src * ldx + ci);',
-         '            if (src >= 0) t = make_float4((float)src, 1.f, 2.f, (float)ci);'),
-    ],
-    'mt_nolds': [
-        ('        for (int i = 0; i < RT; ++i) *reinterpret_cast<float4 *>(al + a_lds + 256 * i) = a_reg[i];',
-         '        for (int i = 0; i < RT; ++i) if (a_reg[i].x == 123.456f) *reinterpret_cast<float4 *>(al + a_lds + 256 * i) = a_reg[i];'),
-        ('            *reinterpret_cast<float4 *>(bl + b_lds + i * (MT_COLS * 8)) = make_float4(b_reg[i][0], b_reg[i][1], b_reg[i][2], b_reg[i][3]);',
-         '            if (b_reg[i][0] == 123.456f) *reinterpret_cast<float4 *>(bl + b_lds + i * (MT_COLS * 8)) = make_float4(b_reg[i][0], b_reg[i][1], b_reg[i][2], b_reg[i][3]);'),
-    ],
-    'mt_nomfma': [     # the operand reads stay (one vector FMA per group keeps them alive), the matrix instructions go
-        ('                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, c, 0, 0, 0);\n                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, c, 0, 0, 0);\n                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, c, 0, 0, 0);\n                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, c, 0, 0, 0);\n                cur[t] = c;',
-         '                c[0] = fmaf(av.x, bv.x, fmaf(av.y, bv.y, fmaf(av.z, bv.z, fmaf(av.w, bv.w, c[0]))));\n                cur[t] = c;'),
-    ],
-    'mt_nobar': [      # no barrier behind a slice (races: timing only)
-        ('        if (q1 < 4) store_slice(buf ^ 1, a_reg[P], b_reg[P]);\n        __syncthreads();',
-         '        if (q1 < 4) store_slice(buf ^ 1, a_reg[P], b_reg[P]);'),
-    ],
-    'mt_noout': [      # no output stores
-        ('            if (row < rows) {\n                float v = sum[t][r] + bias;\n                if (act) v = v > 0.f ? v : slope * v;\n                ob[(long long)row * p.ldo + col] = v;',
-         '            if (row < rows) {\n                float v = sum[t][r] + bias;\n                if (act) v = v > 0.f ? v : slope * v;\n                if (v == 123.456f) ob[(long long)row * p.ldo + col] = v;'),
-    ],
+    # conv_mfma.hip: the ablations of the register-staged large-launch tile (mt_*: rounds 4-5) and of the first LDS-DMA version
+    # (m2_nomfma / nolds / nodma / nobar / inter) went with the code they patched; their results: profiles/r05_mel_tile_ablations.txt
     # conv_mfma.hip, conv1d_mel_tile_dma (timing only)
-    'm2_nomfma': [
-        ('                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].x, bv[0], c, 0, 0, 0);\n                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].y, bv[1], c, 0, 0, 0);\n                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].z, bv[2], c, 0, 0, 0);\n                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].w, bv[3], c, 0, 0, 0);',
-         '                c[0] = fmaf(av[t].x, bv[0], fmaf(av[t].y, bv[1], fmaf(av[t].z, bv[2], fmaf(av[t].w, bv[3], c[0]))));'),
-    ],
-    'm2_nolds': [      # operands from registers: no LDS reads
-        ('            for (int t = 0; t < 2; ++t) av[t] = *reinterpret_cast<const float4 *>(al + (2 * j + t) * 256);',
-         '            for (int t = 0; t < 2; ++t) av[t] = make_float4(1.f + (float)j, 2.f, 3.f, (float)stage);'),
-        ('            for (int st = 0; st < 4; ++st) bv[st] = bl[j * 8 * MT_COLS + st * MT_COLS];',
-         '            for (int st = 0; st < 4; ++st) bv[st] = 0.5f + (float)(st + stage);'),
-    ],
-    'm2_nodma': [      # no requests (and nothing to wait for)
-        ('        lds_dma16_s(wk, w_voff[0], w_dst + st_off);\n        lds_dma16_s(wk, w_voff[1], w_dst + st_off + 1024u);',
-         '        if (wk == nullptr) lds_dma16_s(wk, w_voff[0], w_dst + st_off);'),
-        ('            lds_dma16_s(xb + (long long)r0 * ldx + cg * 8, a_voff, a_dst + st_off);',
-         '            if (wgt == nullptr) lds_dma16_s(xb + (long long)r0 * ldx + cg * 8, a_voff, a_dst + st_off);'),
-    ],
-    'm2_nobar': [
-        ('        __syncthreads();                                     // ... and the stage read last in the slice before is free',
-         ''),
-    ],
-    'm2_inter': [      # the two row tiles' chains interleaved (same order per accumulator: same bits)
-        ('#pragma unroll\n            for (int t = 0; t < 2; ++t) {\n                f32x16 c = cur[t];\n                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].x, bv[0], c, 0, 0, 0);\n                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].y, bv[1], c, 0, 0, 0);\n                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].z, bv[2], c, 0, 0, 0);\n                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].w, bv[3], c, 0, 0, 0);\n                cur[t] = c;\n            }',
-         '            cur[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0].x, bv[0], cur[0], 0, 0, 0);\n            cur[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1].x, bv[0], cur[1], 0, 0, 0);\n            cur[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0].y, bv[1], cur[0], 0, 0, 0);\n            cur[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1].y, bv[1], cur[1], 0, 0, 0);\n            cur[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0].z, bv[2], cur[0], 0, 0, 0);\n            cur[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1].z, bv[2], cur[1], 0, 0, 0);\n            cur[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0].w, bv[3], cur[0], 0, 0, 0);\n            cur[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1].w, bv[3], cur[1], 0, 0, 0);'),
-    ],
     # conv_mfma.hip, conv1d_mel_tile_dma: cycles of a wave from start to "first slice requested", in wait + barrier, in request +
     # cursor code, in the operand reads + MFMAs, in the quarter folds, and in the epilogue (scripts/experiments/mel_tile_stamps.py)
     'm2_stamp': [      # start / end of every wave + where it ran (no stamps inside the loop)

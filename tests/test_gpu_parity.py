@@ -153,6 +153,41 @@ def test_conv1d_f64_tile_shapes_give_the_same_bits(torch):
     assert np.all(np.abs(tail - ref[:, 1:]) <= 0.5 * np.spacing(np.abs(ref[:, 1:]).astype(np.float32)) * 1.001 + 1e-300)
 
 
+@pytest.mark.parametrize("ks,cin,cout,mode,rows", [
+    (3, 80, 256, "CONSTANT", 800),       # the mel-rate convolutions of the front end (K = 240: quarters of 7 / 8 groups)
+    (3, 256, 256, "CONSTANT", 800),
+    (1, 256, 240, "CONSTANT", 800),      # columns that do not fill the second 128-column tile
+    (3, 80, 1280, "CONSTANT", 800),
+    (3, 80, 128, "SYMMETRIC", 777),      # padding per row in the first / last tile of an item; a short last tile
+    (3, 88, 132, "EDGE", 801),
+    (5, 24, 36, "CONSTANT", 790),        # taps that change inside a slice
+    (3, 16, 4, "CONSTANT", 800),         # one chunk of columns, quarters of 1 / 2 groups
+])
+def test_mel_tile_large_launch_same_bits(torch, ks, cin, cout, mode, rows):
+    """Large launches (>= 12 288 rows) run the mel-rate convolutions as LDS-DMA tiles of 64 x 128 (csrc/conv_mfma.hip::
+    conv1d_mel_tile_dma), small ones as 32 x 32 tiles with K split over the waves: the same MFMA steps in the same order and
+    the same fold of the K quarters, so a row's bits do not depend on the launch it ran in -- and both match the oracle."""
+    eng = get_engine("small", *SMALL)[0]
+    rng = np.random.default_rng(ks * 100000 + cin * 100 + cout)
+    B = 16
+    x = rng.normal(size=(B, rows, cin)).astype(np.float32)
+    w = (rng.normal(size=(ks, cin, cout)) / np.sqrt(ks * cin)).astype(np.float32)
+    b = rng.normal(size=(cout,)).astype(np.float32)
+    alpha = rng.uniform(0.05, 0.4, size=(cout,)).astype(np.float32)
+    if mode == "CONSTANT":
+        pl, pr = (ks - 1) // 2, (ks - 1) - (ks - 1) // 2
+    else:
+        pl, pr = (ks - 1) // 2 + ((ks - 1) % 2), (ks - 1) // 2
+    pm = {"CONSTANT": 0, "SYMMETRIC": 1, "EDGE": 2}[mode]
+    xd, wd, bd, ad = dev(torch, x), dev(torch, w), dev(torch, b), dev(torch, alpha)
+    big = eng.conv1d(xd, wd, bd, ad, pad_l=pl, pad_mode=pm).cpu().numpy()
+    small = np.concatenate([eng.conv1d(xd[i:i + 1], wd, bd, ad, pad_l=pl, pad_mode=pm).cpu().numpy() for i in range(B)])
+    assert np.array_equal(big, small)
+    ref = orc.prelu(orc.conv1d_valid(orc.pad_time(x[:2].astype(np.float64), pl, pr, mode), w.astype(np.float64), b.astype(np.float64)),
+                    alpha.astype(np.float64))
+    assert _maxdiff(big[:2], ref) <= _tol(ref, STAGE_TOL)
+
+
 @pytest.mark.parametrize("rows,channels,up", [(7, 1, 100), (5, 640, 10), (1, 3, 10)])
 def test_lin_interp(torch, rows, channels, up):
     eng = get_engine("small", *SMALL)[0]
