@@ -746,6 +746,24 @@ __device__ __forceinline__ void conv1d_small_tile(const ConvArgs &p, int bx, int
 // for four MFMA steps (step s contracts the channels 16g + 4kq' + s, kq' = 0..3) and W[16g + 4kq + s][col r].
 // C/D layout of the f64 MFMA (MI355X_MICROARCH.md): col = lane & 15, row = (lane >> 4) + 4 * reg.
 // Needs cin % 4 == 0 and 16-byte aligned rows (checked by the launcher; other shapes keep the float32 kernels).
+// scalar 0 / 1 flags and selects that stay on the scalar unit
+__device__ __forceinline__ int s_flag_ge(int a, int b) {
+    int r;
+    asm("s_cmp_ge_i32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(a), "s"(b) : "scc");
+    return r;
+}
+__device__ __forceinline__ int s_select(int flag, int a, int b) {          // flag ? a : b
+    int r;
+    asm("s_cmp_lg_u32 %1, 0\n\ts_cselect_b32 %0, %2, %3" : "=s"(r) : "s"(flag), "s"(a), "s"(b) : "scc");
+    return r;
+}
+__device__ __forceinline__ const float *s_ptr_add(const float *base, int byte_off) {
+    const unsigned long long u = (unsigned long long)(uintptr_t)base;
+    unsigned lo, hi;
+    asm("s_add_u32 %0, %2, %4\n\ts_addc_u32 %1, %3, 0" : "=&s"(lo), "=&s"(hi) : "s"((unsigned)u), "s"((unsigned)(u >> 32)), "s"(byte_off) : "scc");
+    return reinterpret_cast<const float *>((uintptr_t)(((unsigned long long)hi << 32) | lo));
+}
+
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 template <bool F64> struct F64Operand;
@@ -902,6 +920,172 @@ __device__ __forceinline__ void conv1d_f64_tile(const ConvArgs &p, int bx, int b
         }
 }
 
+// The 32 x 32 float64 tile of the large launches (round 5).  Same sums in the same order as conv1d_f64_tile -- wave w contracts
+// K quarter w of all four 16 x 16 sub-tiles, the quarters meet through LDS in wave order --, but the loop is written for the
+// issue budget of a CU it shares with fp32 MFMA blocks (every vector instruction of a wave waits for a gap in the co-resident
+// waves' MFMA bursts): tap / channel group of a quarter advance in scalar registers (no division per group), the operand
+// addresses are a per-lane base + one scalar offset per group, two loop bodies ping-pong the operand registers (no copies),
+// row masks only in the first / last tile of an item.
+template <bool XF64, bool WF64, bool INTERIOR>
+__device__ __forceinline__ void conv1d_f64_tile32_body(const ConvArgs &p, int bx, int by, int b, double *red, int rows) {
+    typedef typename F64Operand<XF64>::scalar xs_t;
+    typedef typename F64Operand<XF64>::quad xq_t;
+    typedef typename F64Operand<WF64>::scalar ws_t;
+    const int m0 = bx * 32, n0 = by * 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;
+    const xs_t *xb = (XF64 ? reinterpret_cast<const xs_t *>(p.x64) : reinterpret_cast<const xs_t *>(p.x)) + (long long)b * p.x_bstride;
+    const ws_t *wbase = WF64 ? reinterpret_cast<const ws_t *>(p.w64) : reinterpret_cast<const ws_t *>(p.w);
+    const int cin = p.cin, cout = p.cout, ldx = p.ldx;
+    const int gpt = (cin + 15) >> 4;                        // groups of 16 input channels per tap (the last one may be short)
+    const int n_groups = p.ks * gpt;
+    const int g_begin = (n_groups * wave) / 4, g_end = (n_groups * (wave + 1)) / 4;
+    const bool short_tail = (cin & 15) != 0;
+    bool col_ok[2];
+    const ws_t *wlane[2];                                   // W[4 kq][column] of the lane
+    const xs_t *xlane[2];                                   // x[tile row of the lane at tap 0][4 kq]
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int col = n0 + 16 * ct + r16;
+        col_ok[ct] = col < cout;
+        wlane[ct] = wbase + min(col, cout - 1) + (long long)(4 * kq) * cout;
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) xlane[rt] = xb + (long long)(m0 + 16 * rt + r16 - p.pad_l) * ldx + 4 * kq;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[rt][ct][r] = 0.0;
+
+    // scalar cursor of the quarter: tap and channel group of the next group to request
+    int c_tap = g_begin / gpt, c_cg = g_begin - c_tap * gpt;
+    c_tap = __builtin_amdgcn_readfirstlane(c_tap);
+    c_cg = __builtin_amdgcn_readfirstlane(c_cg);
+    auto request = [&](xq_t (&av)[2], ws_t (&bv)[2][4]) {   // the group at the cursor; the cursor moves on
+        // channels 16 cg + 4 kq .. + 3 of the lane; behind cin (short last group of a tap) the lane reads the tap's last four
+        // channels and is masked when the group is consumed
+        const int ci_lane = short_tail ? min(16 * c_cg + 4 * kq, cin - 4) - 4 * kq : 16 * c_cg;
+        if (INTERIOR) {
+            const long long xoff = (long long)c_tap * p.dil * ldx + ci_lane;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) av[rt] = *reinterpret_cast<const xq_t *>(xlane[rt] + xoff);
+        } else {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int src = map_row(m0 + 16 * rt + r16 - p.pad_l + c_tap * p.dil, rows, p.pad_mode);
+                av[rt] = *reinterpret_cast<const xq_t *>(xb + (long long)max(src, 0) * ldx + 4 * kq + ci_lane);
+            }
+        }
+        const long long woff = ((long long)c_tap * cin + ci_lane) * cout;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int st = 0; st < 4; ++st) bv[ct][st] = wlane[ct][woff + (long long)st * cout];
+        const int wrap = s_flag_ge(c_cg + 1, gpt);
+        c_cg = s_select(wrap, 0, c_cg + 1);
+        c_tap += wrap;
+    };
+    auto consume = [&](int tap, int cg, xq_t (&av)[2], ws_t (&bv)[2][4]) {
+        if (!INTERIOR || short_tail) {
+            const bool ci_ok = 16 * cg + 4 * kq < cin;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const bool ok = ci_ok && (INTERIOR || map_row(m0 + 16 * rt + r16 - p.pad_l + tap * p.dil, rows, p.pad_mode) >= 0);
+                av[rt].x = ok ? av[rt].x : (xs_t)0;
+                av[rt].y = ok ? av[rt].y : (xs_t)0;
+                av[rt].z = ok ? av[rt].z : (xs_t)0;
+                av[rt].w = ok ? av[rt].w : (xs_t)0;
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const xs_t af = st == 0 ? av[rt].x : st == 1 ? av[rt].y : st == 2 ? av[rt].z : av[rt].w;
+                const double a64 = (double)af;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a64, (double)bv[ct][st], acc[rt][ct], 0, 0, 0);
+            }
+    };
+    xq_t a0[2], a1[2];
+    ws_t b0[2][4], b1[2][4];
+    int t0 = c_tap, g0 = c_cg, t1 = 0, g1 = 0;               // tap / channel group of the groups held in set 0 / 1
+    if (g_begin < g_end) request(a0, b0);
+    for (int g = g_begin; g < g_end; g += 2) {
+        if (g + 1 < g_end) {
+            t1 = c_tap;
+            g1 = c_cg;
+            request(a1, b1);
+        }
+        consume(t0, g0, a0, b0);
+        if (g + 1 >= g_end) break;
+        if (g + 2 < g_end) {
+            t0 = c_tap;
+            g0 = c_cg;
+            request(a0, b0);
+        }
+        consume(t1, g1, a1, b1);
+    }
+    // the four K quarters: every wave parks its partial tiles in LDS, tile t is finished by wave t, which adds the quarters in
+    // wave order (and, writing float32, rounds ONCE)
+    auto slot = [&](int w, int tile, int r) { return red + (((w * 4 + tile) * 4 + r) * 64 + lane); };
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int tile = rt * 2 + ct;
+            if (wave != tile) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) *slot(wave, tile, r) = acc[rt][ct][r];
+            }
+        }
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int tile = rt * 2 + ct;
+            if (wave != tile || !col_ok[ct]) continue;
+            const int col = n0 + 16 * ct + r16;
+            const double bias = p.bias ? (double)p.bias[col] : 0.0;
+            const double slope = (double)(p.alpha ? p.alpha[col] : p.leaky);
+            const bool act = p.alpha != nullptr || p.use_leaky;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + 16 * rt + kq + 4 * r;
+                if (row < rows) {
+                    double q[4];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) q[w] = w == tile ? acc[rt][ct][r] : *slot(w, tile, r);
+                    double v = ((q[0] + q[1]) + q[2]) + q[3] + bias;
+                    if (act) v = v > 0.0 ? v : slope * v;
+                    const long long at = (long long)b * p.out_bstride + (long long)row * p.ldo + col;
+                    if (p.out64) p.out64[at] = v;
+                    else p.out[at] = (float)v;
+                }
+            }
+        }
+}
+
+template <bool XF64, bool WF64>
+__device__ __forceinline__ void conv1d_f64_tile32(const ConvArgs &p, int bx, int by, int b, double *red) {
+    const int rows = __builtin_amdgcn_readfirstlane(item_rows(p.n_frames, b, p.rows_per_frame, p.max_rows));
+    const int m0 = bx * 32;
+    if (m0 >= rows) return;
+    if (m0 - p.pad_l >= 0 && m0 + 31 - p.pad_l + (p.ks - 1) * p.dil < rows) conv1d_f64_tile32_body<XF64, WF64, true>(p, bx, by, b, red, rows);
+    else conv1d_f64_tile32_body<XF64, WF64, false>(p, bx, by, b, red, rows);
+}
+
+__device__ __forceinline__ void conv1d_f64_dispatch32(const ConvArgs &p, int bx, int by, int b, double *red) {
+    if (p.x64) conv1d_f64_tile32<true, true>(p, bx, by, b, red);
+    else if (p.w64) conv1d_f64_tile32<false, true>(p, bx, by, b, red);
+    else conv1d_f64_tile32<false, false>(p, bx, by, b, red);
+}
+
 // operand mode of a float64 member: wave-uniform (kernel arguments)
 template <int RT, int CT>
 __device__ __forceinline__ void conv1d_f64_dispatch(const ConvArgs &p, int bx, int by, int b, double *red) {
@@ -975,24 +1159,6 @@ constexpr int M2_A_FLOATS = M2_NG * 64 * 8, M2_W_FLOATS = M2_NG * 8 * MT_COLS, M
 __device__ __forceinline__ void lds_dma16_s(const float *sbase, unsigned voff_bytes, unsigned lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte_addr), "v"(voff_bytes), "s"(sbase) : "memory", "m0");
 }
-// scalar 0 / 1 flags and selects that stay on the scalar unit
-__device__ __forceinline__ int s_flag_ge(int a, int b) {
-    int r;
-    asm("s_cmp_ge_i32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(a), "s"(b) : "scc");
-    return r;
-}
-__device__ __forceinline__ int s_select(int flag, int a, int b) {          // flag ? a : b
-    int r;
-    asm("s_cmp_lg_u32 %1, 0\n\ts_cselect_b32 %0, %2, %3" : "=s"(r) : "s"(flag), "s"(a), "s"(b) : "scc");
-    return r;
-}
-__device__ __forceinline__ const float *s_ptr_add(const float *base, int byte_off) {
-    const unsigned long long u = (unsigned long long)(uintptr_t)base;
-    unsigned lo, hi;
-    asm("s_add_u32 %0, %2, %4\n\ts_addc_u32 %1, %3, 0" : "=&s"(lo), "=&s"(hi) : "s"((unsigned)u), "s"((unsigned)(u >> 32)), "s"(byte_off) : "scc");
-    return reinterpret_cast<const float *>((uintptr_t)(((unsigned long long)hi << 32) | lo));
-}
-
 // INTERIOR: every source row of the tile (all taps) lies inside the item -- the activation request is then a scalar base + the
 // lanes' constant offsets, and a slice is one basic block (the compiler interleaves its scalar code with the MFMAs)
 template <bool INTERIOR>
@@ -1210,7 +1376,7 @@ __global__ __launch_bounds__(256, 3) void conv1d_mel_group_kernel(SmallConvGroup
     const int local = id - g.start[k];
     const int bx = local % g.gx[k];
     const int t = local / g.gx[k];
-    if (g.c[k].precise) conv1d_f64_dispatch<2, 2>(g.c[k], bx, t % g.gy[k], t / g.gy[k], reinterpret_cast<double *>(lds));     // 32 x 32 tiles
+    if (g.c[k].precise) conv1d_f64_dispatch32(g.c[k], bx, t % g.gy[k], t / g.gy[k], reinterpret_cast<double *>(lds));     // 32 x 32 tiles
     else conv1d_mel_tile_dma(g.c[k], bx, t % g.gy[k], t / g.gy[k], lds);
 }
 
