@@ -727,6 +727,160 @@ __device__ __forceinline__ void conv1d_small_tile(const ConvArgs &p, int bx, int
         }
 }
 
+// scalar 0 / 1 flags and selects that stay on the scalar unit
+__device__ __forceinline__ int s_flag_ge(int a, int b) {
+    int r;
+    asm("s_cmp_ge_i32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(a), "s"(b) : "scc");
+    return r;
+}
+__device__ __forceinline__ int s_select(int flag, int a, int b) {          // flag ? a : b
+    int r;
+    asm("s_cmp_lg_u32 %1, 0\n\ts_cselect_b32 %0, %2, %3" : "=s"(r) : "s"(flag), "s"(a), "s"(b) : "scc");
+    return r;
+}
+__device__ __forceinline__ const float *s_ptr_add(const float *base, int byte_off) {
+    const unsigned long long u = (unsigned long long)(uintptr_t)base;
+    unsigned lo, hi;
+    asm("s_add_u32 %0, %2, %4\n\ts_addc_u32 %1, %3, 0" : "=&s"(lo), "=&s"(hi) : "s"((unsigned)u), "s"((unsigned)(u >> 32)), "s"(byte_off) : "scc");
+    return reinterpret_cast<const float *>((uintptr_t)(((unsigned long long)hi << 32) | lo));
+}
+
+// a load from global memory at (wave-uniform base + per-lane byte offset): said with a global address-space pointer, so that the
+// compiler emits global_load (scalar base + vector offset) and counts it with vmcnt only -- a pointer rebuilt from integers is
+// a generic one: flat_load, 64-bit vector address arithmetic per load and waits on lgkmcnt as well
+typedef float g_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float g_load_f32(const float *sbase, unsigned voff_bytes) {
+    typedef __attribute__((address_space(1))) const char g_char;
+    typedef __attribute__((address_space(1))) const float g_float;
+    return *reinterpret_cast<g_float *>((g_char *)sbase + voff_bytes);
+}
+__device__ __forceinline__ float4 g_load_f32x4(const float *sbase, unsigned voff_bytes) {
+    typedef __attribute__((address_space(1))) const char g_char;
+    typedef __attribute__((address_space(1))) const g_f32x4 g_quad;
+    const g_f32x4 v = *reinterpret_cast<g_quad *>((g_char *)sbase + voff_bytes);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+// Round 5: conv1d_small_tile<1, 1> rewritten for its issue budget (the same sums in the same order, hence the same bits).
+// A streaming tick is 64 items of a dozen rows, a 3 s utterance 240 rows: the launch is a few thousand short blocks, eight of
+// them resident per CU, and what a wave does between its MFMAs competes with the other waves' MFMAs for the SIMD (DESIGN.md
+// section 4).  The round-4 loop spent ~45 vector instructions per group of 4 MFMAs: the tap by division and map_row per
+// group, 64-bit address arithmetic for five loads, the row masks, and the copy of the prefetched batch into the current one.
+// Now: tap / channel group advance in scalar registers, a load is a scalar base + a per-lane 32-bit offset computed once (per
+// tap at the item's edges), the two operand sets ping-pong, the row mask is formed once per tap and skipped in the interior.
+template <bool INTERIOR>
+__device__ __forceinline__ void conv1d_small_tile32_body(const ConvArgs &p, int bx, int by, int b, float *red, int rows) {
+    const int m0 = bx * 32, n0 = by * 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lk = lane >> 5;
+    const float *xb = p.x + (long long)b * p.x_bstride;
+    const int cin = p.cin, cout = p.cout, ldx = p.ldx, dil = p.dil, pad_l = p.pad_l;
+    const int gpt = cin >> 3;                               // groups of 8 input channels per tap
+    const int n_groups = p.ks * gpt;
+    const int g_begin = (n_groups * wave) / 4, g_end = (n_groups * (wave + 1)) / 4;
+    const int col = n0 + lrow;
+    const bool col_ok = col < cout;
+    // weights: W[8 g + 4 lk + st][col] = scalar base of the group + the lane's offset of step st
+    unsigned w_voff[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) w_voff[st] = (unsigned)((4 * lk + st) * cout + min(col, cout - 1)) * 4u;
+    // activations: x[source row of the lane at the tap][8 cg + 4 lk ..] = scalar base (item + channel group; in the interior +
+    // tap) + the lane's offset; at the item's edges the offset holds the mapped row of the tap and `a_ok` says whether it exists
+    unsigned a_voff = (unsigned)((m0 + lrow - pad_l) * ldx + 4 * lk) * 4u;       // interior: relative to tap 0 (never negative there)
+    bool a_ok = true;
+    int c_tap = __builtin_amdgcn_readfirstlane(g_begin / gpt);
+    int c_cg = __builtin_amdgcn_readfirstlane(g_begin - (g_begin / gpt) * gpt);
+    auto edge_tap = [&]() {                                  // (!INTERIOR) the lane's source row at tap c_tap
+        const int src = map_row(m0 + lrow - pad_l + c_tap * dil, rows, p.pad_mode);
+        a_ok = src >= 0;
+        a_voff = (unsigned)(max(src, 0) * ldx + 4 * lk) * 4u;
+    };
+    if (!INTERIOR) edge_tap();
+    constexpr int DEPTH = 4;                                 // groups in flight beside the batch being multiplied (round 4: 2: 47.8, 3: 45.9, 4: 45.7, 6: 47.1 us front end of 3 s)
+    struct Set {
+        float4 a[DEPTH];
+        float b[DEPTH][4];
+        bool ok[DEPTH];
+    };
+    auto request = [&](Set &s, int g0) {                     // groups g0 .. g0 + DEPTH - 1 (those below g_end) at the cursor
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (g0 + d < g_end) {
+                const float *xs = s_ptr_add(xb, ((INTERIOR ? c_tap * dil * ldx : 0) + c_cg * 8) * 4);
+                s.a[d] = g_load_f32x4(xs, a_voff);
+                s.ok[d] = a_ok;
+                const float *ws = s_ptr_add(p.w, (c_tap * cin + c_cg * 8) * cout * 4);
+#pragma unroll
+                for (int st = 0; st < 4; ++st) s.b[d][st] = g_load_f32(ws, w_voff[st]);
+                const int wrap = s_flag_ge(c_cg + 1, gpt);
+                c_cg = s_select(wrap, 0, c_cg + 1);
+                c_tap += wrap;
+                if (!INTERIOR && wrap) edge_tap();
+            }
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    auto consume = [&](Set &s, int g0) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (g0 + d < g_end) {
+                float4 av = s.a[d];
+                if (!INTERIOR) {
+                    av.x = s.ok[d] ? av.x : 0.f;
+                    av.y = s.ok[d] ? av.y : 0.f;
+                    av.z = s.ok[d] ? av.z : 0.f;
+                    av.w = s.ok[d] ? av.w : 0.f;
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, s.b[d][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, s.b[d][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, s.b[d][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, s.b[d][3], acc, 0, 0, 0);
+            }
+        }
+    };
+    Set s0, s1;
+    request(s0, g_begin);
+    for (int g = g_begin; g < g_end; g += 2 * DEPTH) {
+        request(s1, g + DEPTH);
+        consume(s0, g);
+        if (g + DEPTH >= g_end) break;
+        request(s0, g + 2 * DEPTH);
+        consume(s1, g + DEPTH);
+    }
+    // reduce the four K quarters: the waves 1..3 park their partial tile in LDS, wave 0 adds the quarters in wave order
+    auto slot = [&](int w, int r) { return red + ((w * 16 + r) * 64 + lane); };
+    if (wave != 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) *slot(wave, r) = acc[r];
+    }
+    __syncthreads();
+    if (wave != 0 || !col_ok) return;
+    const float bias = p.bias ? p.bias[col] : 0.f;
+    const float slope = p.alpha ? p.alpha[col] : p.leaky;
+    const bool act = p.alpha != nullptr || p.use_leaky;
+    float *ob = p.out + (long long)b * p.out_bstride;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row < rows) {
+            float v = ((acc[r] + *slot(1, r)) + *slot(2, r)) + *slot(3, r) + bias;
+            if (act) v = v > 0.f ? v : slope * v;
+            ob[(long long)row * p.ldo + col] = v;
+        }
+    }
+}
+
+__device__ __forceinline__ void conv1d_small_tile32(const ConvArgs &p, int bx, int by, int b, float *red) {
+    const int rows = __builtin_amdgcn_readfirstlane(item_rows(p.n_frames, b, p.rows_per_frame, p.max_rows));
+    const int m0 = bx * 32;
+    if (m0 >= rows) return;
+    if (m0 - p.pad_l >= 0 && m0 + 31 - p.pad_l + (p.ks - 1) * p.dil < rows) conv1d_small_tile32_body<true>(p, bx, by, b, red, rows);
+    else conv1d_small_tile32_body<false>(p, bx, by, b, red, rows);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // The F0-net's convolutions in float64 (ConvArgs::precise; mbx_config.f0_accumulate, the default).
 // The F0 contour is the one quantity of the graph that is INTEGRATED (phase = running float32 sum of f0 / pulse_rate,
@@ -746,24 +900,6 @@ __device__ __forceinline__ void conv1d_small_tile(const ConvArgs &p, int bx, int
 // for four MFMA steps (step s contracts the channels 16g + 4kq' + s, kq' = 0..3) and W[16g + 4kq + s][col r].
 // C/D layout of the f64 MFMA (MI355X_MICROARCH.md): col = lane & 15, row = (lane >> 4) + 4 * reg.
 // Needs cin % 4 == 0 and 16-byte aligned rows (checked by the launcher; other shapes keep the float32 kernels).
-// scalar 0 / 1 flags and selects that stay on the scalar unit
-__device__ __forceinline__ int s_flag_ge(int a, int b) {
-    int r;
-    asm("s_cmp_ge_i32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(a), "s"(b) : "scc");
-    return r;
-}
-__device__ __forceinline__ int s_select(int flag, int a, int b) {          // flag ? a : b
-    int r;
-    asm("s_cmp_lg_u32 %1, 0\n\ts_cselect_b32 %0, %2, %3" : "=s"(r) : "s"(flag), "s"(a), "s"(b) : "scc");
-    return r;
-}
-__device__ __forceinline__ const float *s_ptr_add(const float *base, int byte_off) {
-    const unsigned long long u = (unsigned long long)(uintptr_t)base;
-    unsigned lo, hi;
-    asm("s_add_u32 %0, %2, %4\n\ts_addc_u32 %1, %3, 0" : "=&s"(lo), "=&s"(hi) : "s"((unsigned)u), "s"((unsigned)(u >> 32)), "s"(byte_off) : "scc");
-    return reinterpret_cast<const float *>((uintptr_t)(((unsigned long long)hi << 32) | lo));
-}
-
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 template <bool F64> struct F64Operand;
@@ -1101,7 +1237,7 @@ __global__ __launch_bounds__(256) void conv1d_f64_kernel(ConvArgs p) {
 
 __global__ __launch_bounds__(256) void conv1d_small_kernel(ConvArgs p) {
     __shared__ float red[4 * 16 * 64];
-    conv1d_small_tile<1, 1>(p, blockIdx.x, blockIdx.y, blockIdx.z, red);
+    conv1d_small_tile32(p, blockIdx.x, blockIdx.y, blockIdx.z, red);
 }
 
 // Up to three independent small convolutions in one launch (the n-th layers of the F0-net, the VTF-net and the
@@ -1122,7 +1258,7 @@ __global__ __launch_bounds__(256) void conv1d_small_group_kernel(SmallConvGroup 
     const int bx = local % g.gx[k];
     const int t = local / g.gx[k];
     if (g.c[k].precise) conv1d_f64_dispatch<1, 1>(g.c[k], bx, t % g.gy[k], t / g.gy[k], reinterpret_cast<double *>(red));   // 16 x 16 tiles
-    else conv1d_small_tile<RT, CT>(g.c[k], bx, t % g.gy[k], t / g.gy[k], red);
+    else conv1d_small_tile32(g.c[k], bx, t % g.gy[k], t / g.gy[k], red);
 }
 
 // The same convolutions at large launches (batch 16 x 10 s: 12 800 rows): an LDS-staged tile kernel with the summation
@@ -1425,7 +1561,9 @@ static bool small_conv_eligible(const ConvArgs &a) {
     // no row limit: the mel-rate convolutions then sum K in the same order at every launch size, which keeps a padded
     // batch bit-identical to one-at-a-time runs (the F0 contour feeds the phase accumulator: rounding there is audible
     // in the last bits everywhere downstream)
-    return a.cin % 8 == 0 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 && (uintptr_t)a.x % 16 == 0;
+    // (32-bit byte offsets inside an item and inside the weight tensor: conv1d_small_tile32)
+    return a.cin % 8 == 0 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 && (uintptr_t)a.x % 16 == 0 &&
+           (long long)a.ks * a.cin * a.cout * 4 < (1LL << 31) && ((long long)a.max_rows + a.ks * a.dil) * a.ldx * 4 < (1LL << 31);
 }
 
 void launch_conv1d_group(const ConvArgs *convs, int n, hipStream_t stream) {
