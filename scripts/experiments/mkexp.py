@@ -383,6 +383,13 @@ PATCHES = {
     # conv_mfma.hip, conv1d_mel_tile_dma (timing only)
     # conv_mfma.hip, conv1d_mel_tile_dma: cycles of a wave from start to "first slice requested", in wait + barrier, in request +
     # cursor code, in the operand reads + MFMAs, in the quarter folds, and in the epilogue (scripts/experiments/mel_tile_stamps.py)
+    # conv_mfma.hip, conv1d_small_tile32: groups in flight per operand set
+    'st_depth6': [('    constexpr int DEPTH = 4;                                 // groups in flight beside the batch being multiplied',
+                   '    constexpr int DEPTH = 6;                                 // groups in flight beside the batch being multiplied')],
+    'st_depth8': [('    constexpr int DEPTH = 4;                                 // groups in flight beside the batch being multiplied',
+                   '    constexpr int DEPTH = 8;                                 // groups in flight beside the batch being multiplied')],
+    'st_depth3': [('    constexpr int DEPTH = 4;                                 // groups in flight beside the batch being multiplied',
+                   '    constexpr int DEPTH = 3;                                 // groups in flight beside the batch being multiplied')],
     'm2_stamp': [      # start / end of every wave + where it ran (no stamps inside the loop)
         ('constexpr int M2_NG = 2, M2_STAGES = 4;',
          '__device__ unsigned long long g_m2_stamps[8192 * 4 * 8];\n#define M2_STAMP(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }\nconstexpr int M2_NG = 2, M2_STAGES = 4;'),
