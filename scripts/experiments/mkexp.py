@@ -411,6 +411,12 @@ PATCHES = {
     ],
     # wn_winograd4w.hip
     # wn_winograd4w.hip
+    # wn_winograd4w.hip, 256-row kernel only: 28 KB of unused LDS -> two blocks per CU instead of three (what a block of two
+    # column tiles would have to live with)
+    'lds2': [
+        ('    __shared__ __attribute__((aligned(16))) float lds[SH::LDS_FLOATS];\n',
+         '    __shared__ __attribute__((aligned(16))) float lds[SH::LDS_FLOATS];\n    __shared__ float lds_pad_[7168];\n    if (p.max_rows == -12345) lds_pad_[threadIdx.x] = 1.f;\n'),
+    ],
     'nocomb': [
         ('        constexpr int J = decltype(jc)::value;\n        if (J == 0) u[0] = ww_fma(4.f, x[0]',
          '        constexpr int J = decltype(jc)::value;\n        u[J & 1] = x[J];\n        return;\n        if (J == 0) u[0] = ww_fma(4.f, x[0]'),
