@@ -408,9 +408,9 @@ def roofline(ctx, workload):
     limiter = {
         "gate0": "vector + transcendental issue of the gate activation, which shares the SIMD with its K = 24 fp32 MFMAs "
                  "(ablation: arithmetic 81 us, block prologue 49, stores 29 of 158 us at 16 x 10 s)",
-        "tail": "32-byte row pieces per lane and a dependent chain of 32x32x2 MFMAs per wave (round 4: loads in batches of six "
-                "groups instead of one branch + wait per load: 136 -> 128 us); a row-owning variant reached 113 us but changes "
-                "the summation order between launch sizes",
+        "tail": "HBM latency under 3 blocks per CU: a wave owns 16 rows over all channels (16x16x4 MFMAs), the 40 KB weight image is "
+                "staged once per 64-row block by LDS-DMA, all activations of the rows are requested at once (round 5: 129 -> 87-91 us; "
+                "one kernel and one summation order at every launch size)",
         "stft_filter": "vector instructions of three FFT-1024 per frame: one wave per frame, radix 16 / 16 / 4 in registers, "
                        "2 900 instructions per frame at two waves per SIMD (round 3: block per frame, 4 x 1 785, 196 us)",
         "wavetable": "the float32 phase chain: 1 000 dependent adds per chunk, kept in the reference's order",
