@@ -390,6 +390,11 @@ PATCHES = {
                    '    constexpr int DEPTH = 8;                                 // groups in flight beside the batch being multiplied')],
     'st_depth3': [('    constexpr int DEPTH = 4;                                 // groups in flight beside the batch being multiplied',
                    '    constexpr int DEPTH = 3;                                 // groups in flight beside the batch being multiplied')],
+    # conv_mfma.hip, launch_conv1d_group: order of the members inside a shared launch (float32 members by work instead of by K)
+    'grp_bywork': [('        return convs[a].ks * convs[a].cin > convs[b].ks * convs[b].cin;',
+                    '        return (long long)convs[a].ks * convs[a].cin * convs[a].cout > (long long)convs[b].ks * convs[b].cin * convs[b].cout;')],
+    'grp_byworkasc': [('        return convs[a].ks * convs[a].cin > convs[b].ks * convs[b].cin;',
+                       '        return (long long)convs[a].ks * convs[a].cin * convs[a].cout < (long long)convs[b].ks * convs[b].cin * convs[b].cout;')],
     'm2_stamp': [      # start / end of every wave + where it ran (no stamps inside the loop)
         ('constexpr int M2_NG = 2, M2_STAGES = 4;',
          '__device__ unsigned long long g_m2_stamps[8192 * 4 * 8];\n#define M2_STAMP(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }\nconstexpr int M2_NG = 2, M2_STAGES = 4;'),
