@@ -1579,7 +1579,8 @@ void launch_conv1d_group(const ConvArgs *convs, int n, hipStream_t stream) {
         const ConvArgs &c = convs[small[k]];
         work += (long long)c.max_rows * c.batch;
         if (f64_conv_eligible(c)) continue;
-        dma_ok = dma_ok && c.zeros && c.cout % 4 == 0 && c.cout >= 4 && (uintptr_t)c.w % 16 == 0 &&
+        // (at least four groups of 8 channels: the tile's slice cursor takes every K quarter to be non-empty)
+        dma_ok = dma_ok && c.zeros && c.cout % 4 == 0 && c.cout >= 4 && (uintptr_t)c.w % 16 == 0 && c.ks * (c.cin >> 3) >= 4 &&
                  (long long)c.ks * c.cin * c.cout * 4 < (1LL << 31) && ((long long)c.max_rows + c.ks * c.dil) * c.ldx * 4 < (1LL << 31);
     }
     const bool big = work >= 3 * 4096 && dma_ok;

@@ -162,6 +162,8 @@ def test_conv1d_f64_tile_shapes_give_the_same_bits(torch):
     (3, 88, 132, "EDGE", 801),
     (5, 24, 36, "CONSTANT", 790),        # taps that change inside a slice
     (3, 16, 4, "CONSTANT", 800),         # one chunk of columns, quarters of 1 / 2 groups
+    (1, 16, 64, "CONSTANT", 800),        # two groups only (empty K quarters): stays on the small-launch tile at every size
+    (1, 8, 36, "CONSTANT", 800),
 ])
 def test_mel_tile_large_launch_same_bits(torch, ks, cin, cout, mode, rows):
     """Large launches (>= 12 288 rows) run the mel-rate convolutions as LDS-DMA tiles of 64 x 128 (csrc/conv_mfma.hip::
