@@ -71,6 +71,13 @@ def dev(torch, arr, dtype=None):
     (340, 680, 3, 2, "CONSTANT", 129, False),
     (256, 240, 1, 1, "CONSTANT", 3, False),
     (80, 1280, 3, 1, "CONSTANT", 1, False),
+    # the reference's default depth reaches d = 2048 (custom_AE_layers.py:229-233): rows on both sides of the taps, items
+    # shorter than the dilation (only the centre tap sees data), a large launch (>= 12 288 rows)
+    (32, 64, 3, 64, "CONSTANT", 300, False),
+    (320, 640, 3, 512, "CONSTANT", 1300, False),
+    (64, 128, 3, 2048, "CONSTANT", 4500, False),
+    (64, 128, 3, 2048, "CONSTANT", 1200, False),
+    (96, 192, 3, 1024, "CONSTANT", 7000, False),
 ])
 def test_conv1d(torch, cin, cout, ks, dil, mode, rows, prelu):
     eng = get_engine("small", *SMALL)[0]

@@ -94,3 +94,44 @@ def test_torch_cpu_port_matches_the_float64_oracle():
         got = TorchOracleModel(cfg, raw, wt).forward(mel, noise)
         assert got.dtype == np.float32
         assert np.max(np.abs(got - ref)) <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+
+
+# the BASELINE lengths and the reference's default depth (tests/golden/make_reference_long.py)
+LONG_CASES = {
+    "speech240": ("SPEECH", {}, 1, 240),
+    "speech800": ("SPEECH", {}, 1, 800),
+    "voice400": ("VOICE", {}, 1, 400),
+    "deep12": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 12}, 1, 240),
+    "deep12_short": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 12}, 1, 60),
+    "cycle12": ("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": 12,
+                           "mbexwn_config:pp_mod_subnet:max_log2_dilation_rate": 4}, 2, 31),
+}
+
+
+@pytest.mark.parametrize("case", sorted(LONG_CASES))
+def test_long_cases_structural_float64_and_float32_phase(golden_dir, case):
+    """The oracle at 3 s / 10 s / 5 s (C = 340) and with 12 layers (dilations to 2048, and in cycles of four): float64 mode
+    against the float64 run of the reference graph to rounding noise; the float32-faithful phase integrator against the
+    float32 run's phase, bit for bit, over every 1000-sample chunk of the utterance."""
+    g32 = np.load(os.path.join(golden_dir, "reference_long_f32.npz"))
+    g64 = np.load(os.path.join(golden_dir, "reference_long_f64.npz"))
+    voice, overrides, batch, frames = LONG_CASES[case]
+    cfg, raw, wt = build_case(voice, overrides)
+    mel, noise = g32[f"{case}/mell"], g32[f"{case}/noise"]
+    assert mel.shape == (batch, frames, 80)
+    om64 = OracleModel(cfg, raw, wt, dtype=np.float64, float32_constants=False)
+    audio, st = om64.forward(mel, noise, return_stages=True)
+    assert _maxdiff(st["f0"], g64[f"{case}/f0"]) < 1e-10
+    assert _maxdiff(audio, g64[f"{case}/audio"]) < 1e-8
+    om = OracleModel(cfg, raw, wt)
+    assert _maxdiff(om.phase_from_f0(g32[f"{case}/f0"]), g32[f"{case}/phase"]) == 0.0
+    # the default oracle (float64 arithmetic on the float32-cast contour, float32-faithful phase / index / table work) is the
+    # float32 run without its rounding noise: inside the stated tolerance of the float32 run at every length.  The float64 run
+    # of the graph is a different object -- its phase integrator runs in float64 too -- and BOTH float32 phase chains sit a few
+    # 1e-4 from it (the float32 running sum of f0 / 8000, reference tf_wavetable.py:429-492, rounds at 1e-6 cycles per add)
+    got = om.forward(mel, noise)
+    ref32, ref64 = g32[f"{case}/audio"], g64[f"{case}/audio"]
+    amp = max(1.0, float(np.abs(ref64).max()))
+    assert _maxdiff(got, ref32) < 1e-4 * amp
+    assert _maxdiff(got, ref64) < 3e-4 * amp and _maxdiff(ref32, ref64) < 3e-4 * amp
+    assert _maxdiff(got, ref32) < _maxdiff(ref32, ref64)
