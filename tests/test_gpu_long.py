@@ -81,7 +81,7 @@ def three_way(torch, eng, g32, g64, case):
     res = {"frames": int(mel.shape[1]), "amplitude": float(np.abs(ref64).max()),
            "ref32_ref64": _maxdiff(ref32, ref64), "hip_ref64": _maxdiff(got, ref64), "hip_ref32": _maxdiff(got, ref32),
            "f0_hip_ref64_hz": _maxdiff(f0, g64[f"{case}/f0"]), "f0_ref32_ref64_hz": _maxdiff(g32[f"{case}/f0"], g64[f"{case}/f0"]),
-           "f0_hip_is_nearest_float32": bool(np.array_equal(f0, g64[f"{case}/f0"].astype(np.float32))),
+           "f0_hip_within_an_ulp_of_ref64": bool(np.all(np.abs(f0.astype(np.float64) - g64[f"{case}/f0"]) <= np.spacing(f0))),
            "excitation_hip_ref32": _maxdiff(exc, g32[f"{case}/excitation"]),
            "first_pulse_sample_where_the_phase_chains_part": int(part[0]) if part.size else -1,
            "phase_samples_that_differ": int(part.size), "phase_samples": int(phase.size)}
@@ -105,7 +105,9 @@ def test_baseline_lengths_against_the_reference_runs(torch, gold, case):
     res, _ = three_way(torch, eng, g32, g64, case)
     print(case, res)
     amp = max(1.0, res["amplitude"])
-    assert res["f0_hip_is_nearest_float32"]
+    # the contour: within one float32 ulp of the float64 run's (whose constants are float64 too; against the oracle, which
+    # keeps the reference's float32 constants, it is the nearest float32: tests/test_gpu_parity.py) -- the float32 run is ~8 x off
+    assert res["f0_hip_within_an_ulp_of_ref64"] and res["f0_hip_ref64_hz"] <= 2e-5 < res["f0_ref32_ref64_hz"]
     assert res["hip_ref32"] <= E2E_TOL * amp, "the stated tolerance against the float32 run, at this length"
     assert res["hip_ref32"] < res["ref32_ref64"], "the HIP path is the float32 run without its rounding noise, not the float64 graph"
     assert res["hip_ref64"] <= 3e-4 * amp and res["ref32_ref64"] <= 3e-4 * amp
@@ -132,7 +134,8 @@ def test_default_depth_12_layers_dilations_to_2048(torch, gold, form):
         ref32, ref64 = g32[f"{case}/audio"], g64[f"{case}/audio"]
         amp = max(1.0, float(np.abs(ref64).max()))
         print(form, case, "hip-ref64 %.3e hip-ref32 %.3e ref32-ref64 %.3e amp %.2f" % (_maxdiff(got, ref64), _maxdiff(got, ref32), _maxdiff(ref32, ref64), amp))
-        assert np.array_equal(eng.stage("f0").cpu().numpy(), g64[f"{case}/f0"].astype(np.float32))
+        f0 = eng.stage("f0").cpu().numpy()
+        assert np.all(np.abs(f0.astype(np.float64) - g64[f"{case}/f0"]) <= np.spacing(f0))
         assert _maxdiff(got, ref32) <= E2E_TOL * amp
         assert _maxdiff(got, ref64) <= 3e-4 * amp
     mel = np.zeros((2, 240, 80), dtype=np.float32)
