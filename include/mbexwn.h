@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MBX_ABI_VERSION 9
+#define MBX_ABI_VERSION 10
 #define MBX_MAX_SUBNET_OPS 32
 #define MBX_MAX_WN_LAYERS 64
 #define MBX_MAX_PRECOND 8
@@ -427,6 +427,12 @@ mbx_status mbx_stage(const mbx_handle *handle, const char *name, const void **de
  * convolution folded in), "res_skip_f16" (res/skip launches of the opt-in split half precision). */
 mbx_status mbx_profile_enable(mbx_handle *handle, int32_t enabled);
 mbx_status mbx_profile_read(mbx_handle *handle, const char *kernel, double *total_ms, int64_t *launches);
+/* The same per launch group, in launch order (ABI 10): writes min(capacity, *launches) device times in ms to launch_ms and
+ * the number of bracketed launch groups since the last read to *launches, and recycles the events.  With "gate" the
+ * entries of one forward are the layers in order (behind the folded first layer, which is "gate0"): the per-layer times
+ * of bench.py's geometry sweep. */
+mbx_status mbx_profile_read_launches(mbx_handle *handle, const char *kernel, float *launch_ms, int64_t capacity,
+                                     int64_t *launches);
 
 /* ---- stage entry points (unit parity; all pointers device memory) ------------------------------- */
 

@@ -1462,7 +1462,28 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                 }
                 done = mbx::launch_wn_gate_f16(gh, stream);
             }
-            const bool use4 = !done && hd->winograd == 4 && !st_in && !st_out;
+            bool use4 = !done && hd->winograd == 4 && !st_in && !st_out;
+            if (use4 && d > 16) {
+                // Dilations above 16 (the reference's default depth reaches 2048, custom_AE_layers.py:229-233): F(4,3) over the
+                // d / 16 interleaved sub-sequences of every item (wn_winograd4w.hip, VS kernels).  A block covers 256 (128) rows
+                // of ONE sub-sequence, so short items pad: cost in 256-row block units, the product-split block 0.56 of one
+                // (half the products, ~12 % slower per product), the direct form twice the multiplies of the unpadded rows.
+                // Both block shapes give the same bits; whether F(4,3) or the direct form runs depends on the launch only
+                // under the default policy (batch_invariant: always F(4,3)).
+                const int vs = d / 16;
+                const long long vrows = ((long long)gs.max_rows + vs - 1) / vs, tiles = (C + 31) / 32;
+                const double cost_full = (double)((vrows + 255) / 256) * B * vs * tiles;
+                const double cost_half = 0.56 * (double)((vrows + 127) / 128) * B * vs * tiles;
+                const double cost_direct = 2.0 * ((double)gs.max_rows / 256.0) * B * tiles;
+                if (hd->gate_small_shape >= 0 && !hd->winograd4_always) {
+                    shape4 = hd->gate_small_shape;              // mbx_config.tune_gate_shape pins the shape (and F(4,3) itself)
+                    split4 = shape4 != 0;
+                } else {
+                    split4 = split4 || cost_half < 0.95 * cost_full;
+                    shape4 = split4 ? 1 : 0;
+                    if (!hd->winograd4_always && std::min(cost_full, cost_half) > 0.9 * cost_direct) use4 = false;
+                }
+            }
             const DevTensor *wino4 = use4 ? find(hd, "wn.conv1D_" + ls + ".wino4w") : nullptr;
             if (wino4 && wino4->ndim == 3 && wino4->shape[0] == (C + 31) / 32 && wino4->shape[1] == (C + 7) / 8 &&
                 wino4->shape[2] == 3072 && gs.cphase == 0) {
@@ -2012,6 +2033,26 @@ mbx_status mbx_profile_read(mbx_handle *handle, const char *kernel, double *tota
         sum += ms;
     }
     *total_ms = sum;
+    *launches = (int64_t)handle->ev_used[kind];
+    handle->ev_used[kind] = 0;
+    return MBX_OK;
+}
+
+mbx_status mbx_profile_read_launches(mbx_handle *handle, const char *kernel, float *launch_ms, int64_t capacity,
+                                     int64_t *launches) {
+    if (!handle || !kernel || !launches || (capacity > 0 && !launch_ms) || capacity < 0)
+        return fail(MBX_ERR_INVALID_ARGUMENT, "null argument");
+    int kind = -1;
+    for (int k = 0; k < PROF_KINDS; ++k)
+        if (std::strcmp(kernel, kProfNames[k]) == 0) kind = k;
+    if (kind < 0) return fail(MBX_ERR_INVALID_ARGUMENT, std::string("unknown profile stage ") + kernel);
+    for (size_t i = 0; i < handle->ev_used[kind]; ++i) {
+        auto &pr = handle->ev_pool[kind][i];
+        HIP_TRY(hipEventSynchronize(pr.second));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+        if ((int64_t)i < capacity) launch_ms[i] = ms;
+    }
     *launches = (int64_t)handle->ev_used[kind];
     handle->ev_used[kind] = 0;
     return MBX_OK;

@@ -89,6 +89,8 @@ struct ConvArgs {
                               // computed (out_rows == 0: all rows; out_row0 a multiple of 2 * dil)
     const float *zeros;       // >= 16 bytes of zeros in global memory (LDS-DMA source of padding lanes)
     int fast_dma;             // set by the launcher: 32-bit source offsets are safe (LDS-DMA with a uniform base)
+    int vstride;              // set by launch_wn_gate_winograd4w for dilations above 16: every item is treated as vstride interleaved
+                              // virtual items (rows s, s + vstride, s + 2 vstride ...) convolved with dilation dil / vstride
     // split half precision (mbx_config.wn_precision): the hidden state as fp16 planes, written by wn_resskip_f16_kernel and read
     // by wn_gate_f16_kernel -- row r: [hi: h_split_ld halves][lo': h_split_ld halves] (h_split_ld = channels rounded up to 8,
     // the padding zero), i.e. h_split_ld float32 words per row

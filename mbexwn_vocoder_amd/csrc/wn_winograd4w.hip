@@ -106,7 +106,15 @@ using ww_int = std::integral_constant<int, N>;
 // With the run-time kind every wn_gate_act call of the epilogue sits behind wave-uniform branches, which cut the epilogue
 // into 32 scheduling regions -- each with its own LDS round trip (s_waitcnt lgkmcnt(0)) in front of a few dozen
 // instructions: 32 000 cycles per block (round 5, in-kernel stamps: 14 of a block's 94 us).
-template <int CR, int GA>
+//
+// VS (round 6): dilations above 16.  WaveNetAE's own default depth is 12 layers without a dilation cycle: d = 1 .. 2048
+// (reference custom_AE_layers.py:120-123, 229-233).  A convolution with dilation d = 16 s over the rows of an item IS the
+// convolution with dilation 16 over each of its s interleaved sub-sequences (rows r, r + s, r + 2 s ...): the launcher turns
+// every item into s virtual items whose row stride is s times the real one (ConvArgs::vstride) and this kernel runs them
+// at log2d = 4.  An LDS-DMA lane fetches 16 bytes of one row either way, so the staging costs the same; what differs is the
+// conditioning: a block's 256 virtual rows span 256 s real rows (~26 s conditioning rows: no LDS tile holds them), so the
+// epilogue reads its two conditioning rows per output from global memory (L2) instead, eight float2 per output pair.
+template <int CR, int GA, bool VS = false>
 __global__ __launch_bounds__(256, CR <= 28 ? 3 : 2) void wn_gate_winograd4w_kernel(ConvArgs p, int log2d) {
     using SH = WwShape<CR>;
     constexpr int ROWS = SH::ROWS, NSTAGE = SH::NSTAGE, STAGE = SH::STAGE, A_FLOATS = SH::A_FLOATS, PHASE = SH::PHASE;
@@ -120,9 +128,13 @@ __global__ __launch_bounds__(256, CR <= 28 ? 3 : 2) void wn_gate_winograd4w_kern
     const int g_ = (l / p.n_tiles) * 8 + (id & 7);
     const int nt = l % p.n_tiles;
     if (g_ >= p.m_tiles_total) return;
-    const int b = g_ / p.m_tiles_per_item;
-    const int mt = g_ - b * p.m_tiles_per_item;
-    const int rows = item_rows(p.n_frames, b, p.rows_per_frame, p.max_rows);
+    const int bv = g_ / p.m_tiles_per_item;                 // (virtual) item
+    const int mt = g_ - bv * p.m_tiles_per_item;
+    const int vs = VS ? p.vstride : 1;
+    const int b = VS ? bv / vs : bv;
+    const int strip = VS ? bv - b * vs : 0;                 // first real row of the virtual item
+    const int rows_item = item_rows(p.n_frames, b, p.rows_per_frame, p.max_rows);
+    const int rows = VS ? (rows_item - strip + vs - 1) / vs : rows_item;      // rows strip, strip + vs, ... < rows_item
     const int m0 = mt * ROWS;
     if (m0 >= rows) return;
     const int C = p.channels;
@@ -135,7 +147,8 @@ __global__ __launch_bounds__(256, CR <= 28 ? 3 : 2) void wn_gate_winograd4w_kern
     // rows are addressed relative to the block's first staged row: 32-bit byte offsets never leave the block's window,
     // however long the item is
     const int xrow0 = max(m0 - WW_HALO, 0);
-    const float *xb = p.x + (long long)b * p.x_bstride + (long long)xrow0 * p.ldx;
+    const int ldxv = VS ? p.ldx * vs : p.ldx;               // floats between (virtual) rows
+    const float *xb = p.x + (long long)b * p.x_bstride + (long long)strip * p.ldx + (long long)xrow0 * ldxv;
     const int nk8 = (p.cin + WW_BK - 1) / WW_BK;            // 8-channel slices of the weight image = stage fills
     const int nst = nk8;
 
@@ -158,7 +171,7 @@ __global__ __launch_bounds__(256, CR <= 28 ? 3 : 2) void wn_gate_winograd4w_kern
         const int hi = (pos & 1) ^ ((cell >> 3) & 1);
         if (row < SH::AROWS && src >= 0 && src < rows) a_bits |= 1u << i;
         a_bits |= (unsigned)hi << (4 + i);
-        a_voff[i] = 4u * (unsigned)((min(max(src, 0), rows - 1) - xrow0) * p.ldx + 4 * hi);
+        a_voff[i] = 4u * (unsigned)((min(max(src, 0), rows - 1) - xrow0) * ldxv + 4 * hi);
     }
     // interior blocks (every staged row exists, whole stage fills): uniform base + per-lane byte offset, no selects
     // (C = 340: every stage fill but the last one is whole, so only that one takes the masked path)
@@ -194,7 +207,7 @@ __global__ __launch_bounds__(256, CR <= 28 ? 3 : 2) void wn_gate_winograd4w_kern
     // wait for a stage covers them
     const int cond_up = p.cond_up;
     const int t2base = m0 / cond_up;
-    {
+    if (!VS) {
         const int n2 = rows / cond_up;
         const float *cbase = p.cond + (long long)b * p.cond_bstride;
 #pragma unroll
@@ -228,10 +241,12 @@ __global__ __launch_bounds__(256, CR <= 28 ? 3 : 2) void wn_gate_winograd4w_kern
     {
         // block row lr = tid: conditioning row offset and interpolation weights (read in the epilogue)
         if (tid < ROWS) {
-            const int row = m0 + tid;
+            const int row = VS ? strip + vs * (m0 + tid) : m0 + tid;          // real row
             const int t2 = row / cond_up;
             const int u = row - t2 * cond_up;
-            reinterpret_cast<int *>(lds + SH::TAB)[tid] = (((t2 - t2base) * 64) << 8) | u;
+            // VS: the conditioning row itself (< 2^24 / cond_up), read from global memory in the epilogue
+            reinterpret_cast<unsigned *>(lds + SH::TAB)[tid] = VS ? ((unsigned)t2 << 8) | (unsigned)u
+                                                                  : (unsigned)((((t2 - t2base) * 64) << 8) | u);
         }
         if (tid < 64) {
             lds[SH::LERP + tid] = tid < cond_up ? p.lerp_w0[tid] : 0.f;
@@ -353,6 +368,7 @@ __global__ __launch_bounds__(256, CR <= 28 ? 3 : 2) void wn_gate_winograd4w_kern
     const float *cl = lds + SH::COND;
     float *obase = p.out + (long long)b * p.out_bstride + n0 + 2 * r16;
     const float *clane = cl + 2 * r16;
+    const float *gcond = p.cond + (long long)b * p.cond_bstride + n0 + 2 * r16;      // (VS)
     // Round 5 (read off the ISA): with the predicated store behind every output the compiler kept each output in a region
     // of its own -- table entry, wait, six conditioning reads, wait, arithmetic, store: 48 serial LDS round trips per block
     // under the LDS traffic of the co-resident blocks' K loops.  Now: all 16 table entries of the lane are requested first;
@@ -375,11 +391,26 @@ __global__ __launch_bounds__(256, CR <= 28 ? 3 : 2) void wn_gate_winograd4w_kern
         for (int o = 0; o < 4; ++o) {
             const int e = etab[vi][o];
             w[o] = make_float2(lds[SH::LERP + (e & 255)], lds[SH::LERP + 64 + (e & 255)]);
-            const float *c0 = clane + (e >> 8);
-            ct0[o] = *reinterpret_cast<const float2 *>(c0);
-            ct1[o] = *reinterpret_cast<const float2 *>(c0 + 64);
-            cs0[o] = *reinterpret_cast<const float2 *>(c0 + 32);
-            cs1[o] = *reinterpret_cast<const float2 *>(c0 + 96);
+            if (VS) {
+                // the two conditioning rows of this output, from global memory: [C tanh | C sigmoid] per row, the lane's
+                // channel pair; rows clamp at the item's last conditioning row like the LDS tile's (edge replication)
+                const int n2 = rows_item / cond_up;
+                const int t2 = (int)((unsigned)e >> 8);
+                const bool live = ch_ok && m0 + lr0 + (o << log2d) < rows;
+                const float *g0 = live ? gcond + (long long)min(t2, n2 - 1) * (2 * C) : p.zeros;
+                const float *g1 = live ? gcond + (long long)min(t2 + 1, n2 - 1) * (2 * C) : p.zeros;
+                const int so = live ? C : 0;
+                ct0[o] = *reinterpret_cast<const float2 *>(g0);
+                ct1[o] = *reinterpret_cast<const float2 *>(g1);
+                cs0[o] = *reinterpret_cast<const float2 *>(g0 + so);
+                cs1[o] = *reinterpret_cast<const float2 *>(g1 + so);
+            } else {
+                const float *c0 = clane + (e >> 8);
+                ct0[o] = *reinterpret_cast<const float2 *>(c0);
+                ct1[o] = *reinterpret_cast<const float2 *>(c0 + 64);
+                cs0[o] = *reinterpret_cast<const float2 *>(c0 + 32);
+                cs1[o] = *reinterpret_cast<const float2 *>(c0 + 96);
+            }
         }
         float y[4][4];                                                           // [column tile][output]
 #pragma unroll
@@ -403,7 +434,8 @@ __global__ __launch_bounds__(256, CR <= 28 ? 3 : 2) void wn_gate_winograd4w_kern
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             const int row = m0 + lr0 + (o << log2d);
-            if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res[o];
+            const long long orow = VS ? (long long)strip + (long long)vs * row : row;          // real row
+            if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + orow * p.ldo) = res[o];
         }
     }
 }
@@ -458,7 +490,8 @@ __device__ __forceinline__ void wp_comb(int PH, const float2 (&x)[6], float2 (&u
     }
 }
 
-template <int GA>
+// VS: virtual items of row stride ConvArgs::vstride (dilations above 16), see wn_gate_winograd4w_kernel
+template <int GA, bool VS = false>
 __global__ __launch_bounds__(256, 3) void wn_gate_winograd4p_kernel(ConvArgs p, int log2d) {
     using SH = WpShape;
     constexpr int ROWS = SH::ROWS, NSTAGE = SH::NSTAGE, STAGE = SH::STAGE, A_FLOATS = SH::A_FLOATS, PHASE = SH::PHASE;
@@ -471,9 +504,13 @@ __global__ __launch_bounds__(256, 3) void wn_gate_winograd4p_kernel(ConvArgs p, 
     const int g_ = (l / p.n_tiles) * 8 + (id & 7);
     const int nt = l % p.n_tiles;
     if (g_ >= p.m_tiles_total) return;
-    const int b = g_ / p.m_tiles_per_item;
-    const int mt = g_ - b * p.m_tiles_per_item;
-    const int rows = item_rows(p.n_frames, b, p.rows_per_frame, p.max_rows);
+    const int bv = g_ / p.m_tiles_per_item;                 // (virtual) item
+    const int mt = g_ - bv * p.m_tiles_per_item;
+    const int vs = VS ? p.vstride : 1;
+    const int b = VS ? bv / vs : bv;
+    const int strip = VS ? bv - b * vs : 0;
+    const int rows_item = item_rows(p.n_frames, b, p.rows_per_frame, p.max_rows);
+    const int rows = VS ? (rows_item - strip + vs - 1) / vs : rows_item;
     const int m0 = mt * ROWS;
     if (m0 >= rows) return;
     const int C = p.channels;
@@ -486,7 +523,8 @@ __global__ __launch_bounds__(256, 3) void wn_gate_winograd4p_kernel(ConvArgs p, 
     // rows are addressed relative to the block's first staged row: 32-bit byte offsets never leave the block's window,
     // however long the item is
     const int xrow0 = max(m0 - WW_HALO, 0);
-    const float *xb = p.x + (long long)b * p.x_bstride + (long long)xrow0 * p.ldx;
+    const int ldxv = VS ? p.ldx * vs : p.ldx;
+    const float *xb = p.x + (long long)b * p.x_bstride + (long long)strip * p.ldx + (long long)xrow0 * ldxv;
     const int nk8 = (p.cin + WW_BK - 1) / WW_BK;
 
     // ---- per-lane DMA sources of the activation rows (see wn_gate_winograd4w_kernel)
@@ -505,7 +543,7 @@ __global__ __launch_bounds__(256, 3) void wn_gate_winograd4p_kernel(ConvArgs p, 
         const int hi = (pos & 1) ^ ((cell >> 3) & 1);
         if (row < SH::AROWS && src >= 0 && src < rows) a_bits |= 1u << i;
         a_bits |= (unsigned)hi << (4 + i);
-        a_voff[i] = 4u * (unsigned)((min(max(src, 0), rows - 1) - xrow0) * p.ldx + 4 * hi);
+        a_voff[i] = 4u * (unsigned)((min(max(src, 0), rows - 1) - xrow0) * ldxv + 4 * hi);
     }
     const bool fast_rows = p.fast_dma && m0 >= WW_HALO && m0 + ROWS + WW_HALO <= rows;
     const int whole_fills = p.cin / WW_BK;
@@ -537,7 +575,7 @@ __global__ __launch_bounds__(256, 3) void wn_gate_winograd4p_kernel(ConvArgs p, 
     // ---- conditioning rows of this block (16 x (32 tanh | 32 sigmoid) columns): one request per wave, in front of the stages
     const int cond_up = p.cond_up;
     const int t2base = m0 / cond_up;
-    {
+    if (!VS) {
         const int n2 = rows / cond_up;
         const float *cbase = p.cond + (long long)b * p.cond_bstride;
         const int pos = wave * 64 + lane;
@@ -563,10 +601,11 @@ __global__ __launch_bounds__(256, 3) void wn_gate_winograd4p_kernel(ConvArgs p, 
             for (int r = 0; r < 4; ++r) acc[j][c][r] = bv;
         }
     if (tid < ROWS) {
-        const int row = m0 + tid;
+        const int row = VS ? strip + vs * (m0 + tid) : m0 + tid;              // real row
         const int t2 = row / cond_up;
         const int u = row - t2 * cond_up;
-        reinterpret_cast<int *>(lds + SH::TAB)[tid] = (((t2 - t2base) * 64) << 8) | u;
+        reinterpret_cast<unsigned *>(lds + SH::TAB)[tid] = VS ? ((unsigned)t2 << 8) | (unsigned)u
+                                                              : (unsigned)((((t2 - t2base) * 64) << 8) | u);
     }
     if (tid < 64) {
         lds[SH::LERP + tid] = tid < cond_up ? p.lerp_w0[tid] : 0.f;
@@ -675,6 +714,7 @@ __global__ __launch_bounds__(256, 3) void wn_gate_winograd4p_kernel(ConvArgs p, 
     const float *cl = lds + SH::COND;
     float *obase = p.out + (long long)b * p.out_bstride + n0 + 2 * r16;
     const float *clane = cl + 2 * r16;
+    const float *gcond = p.cond + (long long)b * p.cond_bstride + n0 + 2 * r16;      // (VS)
     // (as in the 256-row kernel: table entries first, the conditioning reads of a register's outputs together, results formed
     // outside the store branches)
     int etab[4][2];
@@ -694,11 +734,24 @@ __global__ __launch_bounds__(256, 3) void wn_gate_winograd4p_kernel(ConvArgs p, 
         for (int o = 0; o < 2; ++o) {
             const int e = etab[vi][o];
             w[o] = make_float2(lds[SH::LERP + (e & 255)], lds[SH::LERP + 64 + (e & 255)]);
-            const float *c0 = clane + (e >> 8);
-            ct0[o] = *reinterpret_cast<const float2 *>(c0);
-            ct1[o] = *reinterpret_cast<const float2 *>(c0 + 64);
-            cs0[o] = *reinterpret_cast<const float2 *>(c0 + 32);
-            cs1[o] = *reinterpret_cast<const float2 *>(c0 + 96);
+            if (VS) {
+                const int n2 = rows_item / cond_up;
+                const int t2 = (int)((unsigned)e >> 8);
+                const bool live = ch_ok && m0 + lr0 + ((2 * ph + o) << log2d) < rows;
+                const float *g0 = live ? gcond + (long long)min(t2, n2 - 1) * (2 * C) : p.zeros;
+                const float *g1 = live ? gcond + (long long)min(t2 + 1, n2 - 1) * (2 * C) : p.zeros;
+                const int so = live ? C : 0;
+                ct0[o] = *reinterpret_cast<const float2 *>(g0);
+                ct1[o] = *reinterpret_cast<const float2 *>(g1);
+                cs0[o] = *reinterpret_cast<const float2 *>(g0 + so);
+                cs1[o] = *reinterpret_cast<const float2 *>(g1 + so);
+            } else {
+                const float *c0 = clane + (e >> 8);
+                ct0[o] = *reinterpret_cast<const float2 *>(c0);
+                ct1[o] = *reinterpret_cast<const float2 *>(c0 + 64);
+                cs0[o] = *reinterpret_cast<const float2 *>(c0 + 32);
+                cs1[o] = *reinterpret_cast<const float2 *>(c0 + 96);
+            }
         }
         float y[4][2];                                                           // [column tile][this wave's two outputs]
 #pragma unroll
@@ -723,7 +776,8 @@ __global__ __launch_bounds__(256, 3) void wn_gate_winograd4p_kernel(ConvArgs p, 
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
             const int row = m0 + lr0 + ((2 * ph + o) << log2d);
-            if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res[o];
+            const long long orow = VS ? (long long)strip + (long long)vs * row : row;          // real row
+            if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + orow * p.ldo) = res[o];
         }
     }
 }
@@ -1017,22 +1071,29 @@ __global__ __launch_bounds__(256, 4) void wn_gate_winograd4h_kernel(ConvArgs p, 
 // shape: 0 = 256-row blocks, 1 = 128-row product-split blocks, 2 = product-split blocks of half a column tile
 bool launch_wn_gate_winograd4w(const ConvArgs &a, int shape, hipStream_t stream) {
     const bool split = shape != 0;
+    // dilations above the halo: d = 16 s runs as s interleaved virtual items per item at dilation 16 (kernels' VS variants)
+    const int vs = a.dil > WW_HALO ? a.dil / WW_HALO : 1;
+    const int dil_v = vs > 1 ? WW_HALO : a.dil;
     int log2d = 0;
-    while ((1 << log2d) < a.dil) ++log2d;
+    while ((1 << log2d) < dil_v) ++log2d;
     const int rows_blk = split ? 128 : 256;
     const int nk8 = (a.cin + WW_BK - 1) / WW_BK;
-    const int cond_rows = a.cond_up >= 1 ? (rows_blk + a.cond_up - 2) / a.cond_up + 2 : 1 << 30;   // conditioning rows a block touches
-    const bool ok = a.ks == 3 && (1 << log2d) == a.dil && a.dil <= WW_HALO && nk8 >= 4 && a.pad_l == a.dil && a.pad_mode == 0 &&
+    const int cond_rows = vs > 1 ? 1 : a.cond_up >= 1 ? (rows_blk + a.cond_up - 2) / a.cond_up + 2 : 1 << 30;   // conditioning rows a block's tile holds
+    const bool ok = a.ks == 3 && (1 << log2d) == dil_v && dil_v * vs == a.dil && nk8 >= 4 && a.pad_l == a.dil && a.pad_mode == 0 &&
                     a.cin % 4 == 0 && a.ldx % 4 == 0 && a.x_bstride % 4 == 0 && a.channels % 4 == 0 &&
                     a.cout == 2 * a.channels && (uintptr_t)a.x % 16 == 0 && (uintptr_t)a.w % 16 == 0 && a.zeros &&
                     a.cond && (uintptr_t)a.cond % 16 == 0 && a.cond_bstride % 4 == 0 && a.cond_up >= 1 &&
-                    a.cond_up <= 64 && cond_rows <= (split ? 16 : 56) && a.lerp_w0 && a.lerp_w1 && a.max_rows < (1 << 24);
+                    a.cond_up <= 64 && cond_rows <= (split ? 16 : 56) && a.lerp_w0 && a.lerp_w1 && a.max_rows < (1 << 24) &&
+                    (vs == 1 || (shape != 2 && a.max_rows >= a.cond_up &&
+                                 (long long)(rows_blk + 2 * WW_HALO) * vs * a.ldx * 4 < (1LL << 32)));
     if (!ok) return false;
     ConvArgs r = a;
     r.fast_dma = 1;                 // byte offsets are relative to the block's window (< 2^32 for any item length)
+    r.vstride = vs;
     r.n_tiles = (a.channels + 31) / 32;
-    r.m_tiles_per_item = (a.max_rows + rows_blk - 1) / rows_blk;
-    r.m_tiles_total = r.m_tiles_per_item * a.batch;
+    const int vrows = (a.max_rows + vs - 1) / vs;         // rows of the longest virtual item
+    r.m_tiles_per_item = (vrows + rows_blk - 1) / rows_blk;
+    r.m_tiles_total = r.m_tiles_per_item * a.batch * vs;
     const long long blocks = 8LL * ((r.m_tiles_total + 7) / 8) * r.n_tiles;
     const dim3 blk(256);
     const bool gtu = a.gate_act == 0;
@@ -1044,6 +1105,13 @@ bool launch_wn_gate_winograd4w(const ConvArgs &a, int shape, hipStream_t stream)
         return true;
     }
     const dim3 grid((unsigned)blocks);
+    if (vs > 1) {
+        if (split && gtu) hipLaunchKernelGGL((wn_gate_winograd4p_kernel<0, true>), grid, blk, 0, stream, r, log2d);
+        else if (split) hipLaunchKernelGGL((wn_gate_winograd4p_kernel<-1, true>), grid, blk, 0, stream, r, log2d);
+        else if (gtu) hipLaunchKernelGGL((wn_gate_winograd4w_kernel<28, 0, true>), grid, blk, 0, stream, r, log2d);
+        else hipLaunchKernelGGL((wn_gate_winograd4w_kernel<28, -1, true>), grid, blk, 0, stream, r, log2d);
+        return true;
+    }
     if (split && gtu) hipLaunchKernelGGL(wn_gate_winograd4p_kernel<0>, grid, blk, 0, stream, r, log2d);
     else if (split) hipLaunchKernelGGL(wn_gate_winograd4p_kernel<-1>, grid, blk, 0, stream, r, log2d);
     else if (cond_rows <= 28 && gtu) hipLaunchKernelGGL((wn_gate_winograd4w_kernel<28, 0>), grid, blk, 0, stream, r, log2d);

@@ -19,7 +19,7 @@ from .config import ModelDims
 from .subnet import build_subnet
 from .weights import fold_weights, merge_channel_groups
 
-MBX_ABI_VERSION = 9
+MBX_ABI_VERSION = 10
 MBX_MAX_SUBNET_OPS = 32
 MBX_MAX_WN_LAYERS = 64
 MBX_MAX_PRECOND = 8
@@ -161,6 +161,8 @@ def load_library():
     lib.mbx_profile_enable.argtypes = [vp, i32]
     lib.mbx_profile_read.restype = i32
     lib.mbx_profile_read.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), i64p]
+    lib.mbx_profile_read_launches.restype = i32
+    lib.mbx_profile_read_launches.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_float), ctypes.c_int64, i64p]
     lib.mbx_pqmf_synthesis.restype = i32
     lib.mbx_pqmf_synthesis.argtypes = [vp, fp, i32, i32, fp, vp]
     lib.mbx_conv1d.restype = i32
@@ -183,7 +185,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = ["mbx_last_error", "mbx_create", "mbx_destroy", "mbx_conv_form", "mbx_calibrate", "mbx_workspace_size", "mbx_forward",
                     "mbx_forward_stream", "mbx_forward_ex", "mbx_layer_state_info", "mbx_window_advance", "mbx_stage",
-                    "mbx_profile_enable", "mbx_profile_read", "mbx_pqmf_synthesis", "mbx_conv1d", "mbx_conv1d_f64acc", "mbx_lin_interp", "mbx_wavetable", "mbx_stft_filter", "mbx_norm_mel", "mbx_mel_analysis"]
+                    "mbx_profile_enable", "mbx_profile_read", "mbx_profile_read_launches", "mbx_pqmf_synthesis", "mbx_conv1d", "mbx_conv1d_f64acc", "mbx_lin_interp", "mbx_wavetable", "mbx_stft_filter", "mbx_norm_mel", "mbx_mel_analysis"]
 
 
 def _check(status):
@@ -978,6 +980,14 @@ class MBExWNEngine:
         ms, cnt = ctypes.c_double(), ctypes.c_int64()
         _check(self._lib.mbx_profile_read(self._handle, kernel.encode(), ctypes.byref(ms), ctypes.byref(cnt)))
         return ms.value, cnt.value
+
+    def profile_read_launches(self, kernel, capacity=4096):
+        """Device ms of every bracketed launch group of a stage since the last read, in launch order (mbx_profile_read_launches);
+        "gate": the layers of each forward in order (behind the folded first layer)."""
+        buf = (ctypes.c_float * capacity)()
+        cnt = ctypes.c_int64()
+        _check(self._lib.mbx_profile_read_launches(self._handle, kernel.encode(), buf, capacity, ctypes.byref(cnt)))
+        return [float(buf[ii]) for ii in range(min(capacity, cnt.value))]
 
     def conv_form_info(self):
         """What the handle decided about the dilated convolution (mbx_conv_form): dict with ``requested`` / ``form`` /

@@ -117,15 +117,18 @@ def test_baseline_lengths_against_the_reference_runs(torch, gold, case):
     assert res["hip_with_ref32_contour_ref32"] <= E2E_TIGHT * amp
 
 
-@pytest.mark.parametrize("form", ["default", "direct", "f43"])
+FORM_KW = {"default": {}, "direct": {"conv_form": "direct"}, "f23": {"conv_form": "f23"}, "f43": {"conv_form": "f43"},
+           "f43_invariant": {"conv_form": "f43", "batch_invariant": True}}
+
+
+@pytest.mark.parametrize("form", ["default", "direct", "f43_invariant"])
 def test_default_depth_12_layers_dilations_to_2048(torch, gold, form):
     """WaveNetAE's own defaults (reference custom_AE_layers.py:120-123, 229-233): 12 layers, d = 1 .. 2048.  One item of
     240 frames (4800 rows: the widest layers have real rows on both sides), one of 60 frames (1200 rows: shorter than the
     dilation of the last two layers, only their centre tap sees data) -- each against the reference's runs, as single items
     and as a ragged batch of two (bit-equal to the single runs)."""
     g32, g64 = gold
-    kw = {} if form == "default" else {"conv_form": form}
-    eng = get_engine("deep12", **kw)
+    eng = get_engine("deep12", **FORM_KW[form])
     outs = {}
     for case in ("deep12", "deep12_short"):
         mel, noise = g32[f"{case}/mell"], g32[f"{case}/noise"]
@@ -156,8 +159,7 @@ def test_default_depth_12_layers_dilations_to_2048(torch, gold, form):
 def test_12_layers_in_dilation_cycles(torch, gold, form):
     """max_log2_dilation_rate = 4: d = 1, 2, 4, 8 three times (reference custom_AE_layers.py:229-231)."""
     g32, g64 = gold
-    kw = {} if form == "default" else {"conv_form": form}
-    eng = get_engine("cycle12", **kw)
+    eng = get_engine("cycle12", **FORM_KW[form])
     mel, noise = g32["cycle12/mell"], g32["cycle12/noise"]
     got = eng.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
     ref32, ref64 = g32["cycle12/audio"], g64["cycle12/audio"]
@@ -165,3 +167,39 @@ def test_12_layers_in_dilation_cycles(torch, gold, form):
     print(form, "hip-ref64 %.3e hip-ref32 %.3e ref32-ref64 %.3e amp %.2f" % (_maxdiff(got, ref64), _maxdiff(got, ref32), _maxdiff(ref32, ref64), amp))
     assert _maxdiff(got, ref32) <= E2E_TOL * amp
     assert _maxdiff(got, ref64) <= 3e-4 * amp
+
+
+def test_f43_at_dilations_above_16_runs_the_interleaved_sub_sequences(torch):
+    """Dilations 32 .. 2048 in Winograd F(4,3) form (csrc/wn_winograd4w.hip, VS kernels: an item is d / 16 interleaved
+    virtual items at dilation 16).  MW-VO-FD width (C = 340: partial column tile, partial last slice), 12 layers, ragged
+    batch of two whose items end inside blocks of every sub-sequence: both block shapes give the same bits; they, the default
+    policy (F(4,3) where padding the sub-sequences to blocks costs less than the direct form's multiplies) and the direct
+    form agree with the oracle; under batch_invariant a ragged batch is bit-equal to single runs."""
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    from oracle.mbexwn_oracle import OracleModel
+    from helpers import synthetic_inputs
+    cfg, raw, wt = build_case("VOICE", {"mbexwn_config:pp_mod_subnet:n_layers": 12})
+    lengths = [400, 173]
+    mel, noise = synthetic_inputs(123, 2, 400)
+    nf = torch.as_tensor(lengths, dtype=torch.int32).cuda()
+    outs = {}
+    for name, kw in (("shape0", {"conv_form": "f43", "tune": {"gate_shape": 1}}), ("shape1", {"conv_form": "f43", "tune": {"gate_shape": 2}}),
+                     ("default", {}), ("direct", {"conv_form": "direct"}), ("invariant", {"conv_form": "f43", "batch_invariant": True})):
+        eng = MBExWNEngine(cfg, raw, wt, **kw)
+        outs[name] = eng.forward(dev(torch, mel), n_frames=nf, noise=dev(torch, noise)).cpu().numpy()
+        if name == "invariant":
+            for ii, ll in enumerate(lengths):
+                single = eng.forward(dev(torch, mel[ii:ii + 1, :ll]), noise=dev(torch, noise[ii:ii + 1, :ll * 20])).cpu().numpy()
+                assert np.array_equal(outs[name][ii, :ll * 300], single[0])
+        del eng
+    assert np.array_equal(outs["shape0"], outs["shape1"]), "256-row and product-split blocks: the same sums in the same order"
+    om = OracleModel(cfg, raw, wt)
+    for ii, ll in enumerate(lengths):
+        ref = om.forward(mel[ii:ii + 1, :ll], noise[ii:ii + 1, :ll * 20])[0]
+        amp = max(1.0, float(np.abs(ref).max()))
+        for name, got in outs.items():
+            err = _maxdiff(got[ii, :ll * 300], ref)
+            print(name, "item", ii, "max|d| %.3e (amp %.2f)" % (err, amp))
+            assert err <= E2E_TOL * amp, name
+            assert np.all(got[ii, ll * 300:] == 0.0)
+    assert not np.array_equal(outs["shape0"], outs["direct"])
