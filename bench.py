@@ -47,8 +47,25 @@ WORKLOADS = {
     # precision of the gate and res/skip layers behind the first one (mbx_config.wn_precision: fp16-split operands, three
     # products on the 16-bit matrix pipe, float32 accumulation)
     "config3_split_f16": ("SING", 16, 800),
+    # builder-run secondary: GEOMETRY_SWEEP below (each geometry at the config-3 shape)
+    "geometry_sweep": ("SING", 16, 800),
 }
 ENGINE_KW = {"config3_split_f16": {"precision": "split_f16"}}
+# builder-run secondary: the canonical L = 5 / k = 3 / d = 2^l is an inference of SURVEY.md; the
+# reference's own default is 12 layers without a dilation cycle (custom_AE_layers.py:120-123, 229-233).  The config-3 shape
+# (16 x 10 s) over the geometries a shipped model might have: per geometry ms per step, the kernel that ran every gate layer,
+# per-layer launch times and executed fraction of the fp32 MFMA peak.
+GEOMETRY_SWEEP = {
+    "C320_L5_canonical": ("SING", {}),
+    "C320_L12_d2048": ("SING", {"mbexwn_config:pp_mod_subnet:n_layers": 12}),
+    "C320_L12_cycle8": ("SING", {"mbexwn_config:pp_mod_subnet:n_layers": 12, "mbexwn_config:pp_mod_subnet:max_log2_dilation_rate": 4}),
+    "C340_L8_d128": ("VOICE", {"mbexwn_config:pp_mod_subnet:n_layers": 8}),
+    "C320_L5_k5": ("SING", {"mbexwn_config:pp_mod_subnet:kernel_size": 5}),
+    "C320_L5_groups2": ("SING", {"mbexwn_config:pp_mod_subnet:n_ch_groups": 2}),
+    "C512_L5": ("SING", {"mbexwn_config:pp_mod_subnet:n_channels": 512}),
+}
+GATE_EXECUTED = {"direct": 1.0, "f23": 2.0 / 3.0, "f43": 0.5, "f43_psplit": 0.5, "f43_hsplit": 0.5, "f43_strided": 0.5,
+                 "f43_strided_psplit": 0.5}
 FP16_MATRIX_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16 / FP16 MFMA dense peak (spec)
 WORKLOAD_OVERRIDES = {
     "variant_blocks2": {"mbexwn_config:pp_mod_subnet_upsampling_factors": [2, 1],
@@ -226,6 +243,29 @@ def max_abs_delta_small(eng, cfg, raw, wt, mel_h, noise_h, torch):
                                           f"{eng.gate_form(1, nf)})"}
 
 
+def delta_vs_reference_f32(torch):
+    """max|HIP - reference float32 run| over a whole 10 s utterance (and the 3 s one): the default handle on the inputs of
+    the golden cases speech800 / speech240 (tests/golden/make_reference_long.py: the reference's own MBExWN.call executed in
+    float32).  The float32 phase integrator of the reference makes this distance grow with the utterance (DESIGN.md
+    section 5), so it is stated per length; tolerance 1e-4 max(1, |audio|)."""
+    path = os.path.join(ROOT, "tests", "golden", "reference_long_f32.npz")
+    if not os.path.exists(path):
+        return {}
+    gold = np.load(path)
+    cfg, raw, wt, dims, eng = build_engine("SPEECH")
+    out = {}
+    for case, key in (("speech800", "max_abs_delta_vs_ref_f32"), ("speech240", "max_abs_delta_vs_ref_f32_3s")):
+        mel, noise, ref = gold[f"{case}/mell"], gold[f"{case}/noise"], gold[f"{case}/audio"]
+        got = eng.forward(torch.as_tensor(mel).cuda(), noise=torch.as_tensor(noise).cuda()).cpu().numpy()
+        amp = float(np.abs(ref).max())
+        out[key] = float(np.max(np.abs(got.astype(np.float64) - ref)))
+        out[key + "_tolerance"] = DELTA_TOL * max(1.0, amp)
+        out[key + "_ok"] = bool(out[key] <= out[key + "_tolerance"])
+    out["max_abs_delta_vs_ref_f32_what"] = ("default handle vs the float32 run of the reference's own graph (numpy stand-in for the TF "
+                                            "kernels), whole utterance: 800 frames / 240 frames, C = 320")
+    return out
+
+
 class Fence:
     def __init__(self, torch, dist):
         self.torch, self.dist = torch, dist
@@ -295,6 +335,67 @@ def run_batch(args, name, rank, world, fence, torch, profile, steps=None, warmup
         ctx["stages"] = stages
 
     return res, ctx
+
+
+def run_geometry_sweep(args, rank, world, fence, torch, steps, warmup, batch=16, frames=800):
+    """GEOMETRY_SWEEP at the config-3 shape.  Per geometry: wall-clock ms per step like every other workload, then a
+    separate pass with HIP events around every gate launch (mbx_profile_read_launches: per-layer device times), the kernel
+    each layer ran (mbx_conv_form_info.gate_kernel) and the executed FLOPs of that form against the fp32 MFMA peak."""
+    out = {}
+    for name, (voice, overrides) in GEOMETRY_SWEEP.items():
+        cached = set(_ENGINES)
+        cfg, raw, wt, dims, eng = build_engine(voice, overrides)
+        rng = np.random.default_rng(42 + rank)
+        mel_h, noise_h = synthetic_batch(rng, batch, frames, dims.wn_in_rows_per_frame)
+        mel, noise = torch.as_tensor(mel_h).cuda(), torch.as_tensor(noise_h).cuda()
+        audio = torch.empty((batch, frames * dims.hop_size), dtype=torch.float32, device=mel.device)
+        elapsed = time_steps(lambda: eng.forward(mel, noise=noise, out=audio), steps, warmup, fence)
+        finite = bool(torch.isfinite(audio).all().item())
+        eng.profile_enable(True)
+        n_prof = 3
+        for _ in range(n_prof):
+            eng.forward(mel, noise=noise, out=audio)
+        torch.cuda.synchronize()
+        per_launch = eng.profile_read_launches("gate")
+        rs_ms, rs_n = eng.profile_read("res_skip")
+        g0_ms, g0_n = eng.profile_read("gate0")
+        fe_ms, fe_n = eng.profile_read("frontend")
+        eng.profile_enable(False)
+        info = eng.conv_form_info()
+        kernels = info["gate_kernels"]
+        L, C, ks = dims.wn_layers, dims.wn_channels, dims.wn_kernel_size
+        first = 1 if kernels and kernels[0] == "folded_start" else 0
+        n_gate = L - first
+        rows = batch * frames * dims.steps_per_frame
+        flop_alg = 2.0 * rows * (ks * C) * (2 * C)
+        layers = []
+        for ll in range(first, L):
+            ts = [per_launch[ff * n_gate + ll - first] for ff in range(n_prof) if ff * n_gate + ll - first < len(per_launch)]
+            ms = float(np.mean(ts)) if ts else None
+            ex = GATE_EXECUTED.get(kernels[ll], 1.0)
+            layers.append({"layer": ll, "dilation": dims.wn_dilation(ll), "kernel": kernels[ll], "ms": round(ms, 4) if ms else None,
+                           "frac": round(flop_alg * ex / (ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4) if ms else None})
+        small = [ly["ms"] for ly in layers if ly["dilation"] <= 16 and ly["kernel"].startswith("f43") and ly["ms"]]
+        base = float(np.mean(small)) if small else None
+        gate_total = sum(ly["ms"] for ly in layers if ly["ms"])
+        exec_total = sum(flop_alg * GATE_EXECUTED.get(ly["kernel"], 1.0) for ly in layers)
+        samples = world * batch * frames * dims.hop_size * steps
+        out[name] = {"channels": C, "layers": L, "kernel_size": ks, "groups": dims.wn_groups, "form": info["form"],
+                     "ms_per_step": round(elapsed / steps * 1e3, 4), "x_realtime": round(samples / elapsed / 24000.0, 1),
+                     "steps": steps, "finite": finite,
+                     "gate_ms_per_step": round(gate_total, 4), "res_skip_ms_per_step": round(rs_ms / max(n_prof, 1), 4),
+                     "gate0_ms": round(g0_ms / max(g0_n, 1), 4) if g0_n else None,
+                     "frontend_ms_per_step": round(fe_ms / max(n_prof, 1), 4),
+                     "gate_frac_executed": round(exec_total / (gate_total * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4) if gate_total else None,
+                     "gate_frac_algorithmic": round(flop_alg * n_gate / (gate_total * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4) if gate_total else None,
+                     "direct_form_share_of_gate_time": round(sum(ly["ms"] for ly in layers if ly["kernel"] == "direct" and ly["ms"]) / gate_total, 4) if gate_total else None,
+                     "slowest_layer_over_d_le_16_layer": round(max(ly["ms"] for ly in layers if ly["ms"]) / base, 4) if base else None,
+                     "gate_layers": layers}
+        del eng, mel, noise, audio
+        for kk in set(_ENGINES) - cached:          # the sweep's own engines (weights + images of up to 12 layers) go again
+            del _ENGINES[kk]
+        torch.cuda.empty_cache()
+    return out
 
 
 def split_report(ress, ctxs):
@@ -704,6 +805,20 @@ def main():
     voice, batch, frames = WORKLOADS[args.workload]
     line = {"metric": "24 kHz audio samples/sec (whole job; x real-time = value / 24000) + max|delta| vs the CPU oracle"}
     ctx = None
+    if args.workload == "geometry_sweep":
+        sweep = run_geometry_sweep(args, rank, world, fence, torch, steps=args.steps, warmup=args.warmup)
+        if rank == 0:
+            worst = min(sweep, key=lambda kk: sweep[kk]["x_realtime"])
+            print(json.dumps({"metric": "geometry sweep at the config-3 shape (16 x 10 s per GPU): 24 kHz audio samples/s of the slowest geometry",
+                              "value": sweep[worst]["x_realtime"] * 24000.0, "unit": "audio samples/s", "x_realtime": sweep[worst]["x_realtime"],
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sweep[worst]["ms_per_step"],
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "config": {"workload": f"geometry_sweep, slowest: {worst}", "parallelism": f"utterance-sharded x{world}"},
+                              "geometry_sweep": sweep, "env": mbx_env()}))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if frames is None:
         main_res = run_sharded(args, args.workload, rank, world, dist, fence, torch, check_delta=not args.no_secondary)
         later = main_res.pop("_delta_later", None)
@@ -742,7 +857,15 @@ def main():
                                                          steps=max(20, min(args.steps, 50)), warmup=3)
         secondary["config5_sp_stream64_80ms"] = run_streaming(args, "config5_sp_stream64_80ms", rank, world, fence, torch,
                                                               steps=max(20, min(args.steps, 50)), warmup=5)
+        # the geometry sweep (builder-run secondary): the config-3 shape over WaveNet geometries other than the inferred one
+        sweep = run_geometry_sweep(args, rank, world, fence, torch, steps=min(args.steps, 5), warmup=2)
         if rank == 0:
+            secondary["geometry_sweep"] = sweep
+        # config 2's input from the reference's own float32 run (tests/golden/reference_long_f32.npz: 80 x 800 mel, MW-SP-FD):
+        # the distance to what a user of the TF-CPU path gets for a 10 s utterance (float32 emulation of the reference graph)
+        ref32 = delta_vs_reference_f32(torch) if rank == 0 else {}
+        if rank == 0:
+            res2.update(ref32)
             res2.update(max_abs_delta_timed([("item 0", ctx2["timed_out"][0], ctx2["mel_h"][0], ctx2["noise_h"][0])],
                                             ctx2["cfg"], ctx2["raw"], ctx2["wt"], "config 2 batch"))
             res2.update(max_abs_delta_full(ctx2, "config 2 batch"))
@@ -838,8 +961,27 @@ def compact_summary(line, main_res, secondary):
             "c2_delta_full_10s": float(f"{secondary['config2_sp_b1_10s']['max_abs_delta_full']:.3e}") if "max_abs_delta_full" in secondary.get("config2_sp_b1_10s", {}) else None,
             "c3_delta": float(f"{line['max_abs_delta']:.3e}") if "max_abs_delta" in line else None,
             "c4_delta": dd("config4_vo_256utt"), "split_f16_delta": dd("config3_split_f16"),
+            "c2_delta_vs_ref_f32_10s": float(f"{secondary['config2_sp_b1_10s']['max_abs_delta_vs_ref_f32']:.3e}") if "max_abs_delta_vs_ref_f32" in secondary.get("config2_sp_b1_10s", {}) else None,
+            "c1_delta_vs_ref_f32_3s": float(f"{secondary['config2_sp_b1_10s']['max_abs_delta_vs_ref_f32_3s']:.3e}") if "max_abs_delta_vs_ref_f32_3s" in secondary.get("config2_sp_b1_10s", {}) else None,
+            **sweep_summary(secondary.get("geometry_sweep")),
             "deltas_ok": bool(flags) and all(ok is True for ok in flags), "deltas_checked": len(flags),
             "worst_delta_over_tol": round(max(rr for _, rr in ratios), 4) if ratios else None}
+
+
+def sweep_summary(sweep):
+    """Short scalars of the geometry sweep: ms per step of the reference's default depth (12 layers, d <= 2048) and of the
+    slowest geometry, the lowest executed fraction of the fp32 MFMA peak over the gate launches of a geometry, and the worst
+    ratio of a gate layer's time to the d <= 16 F(4,3) layers of the same model."""
+    if not sweep:
+        return {}
+    worst = min(sweep, key=lambda kk: sweep[kk]["x_realtime"])
+    fracs = [vv["gate_frac_executed"] for vv in sweep.values() if vv.get("gate_frac_executed")]
+    ratios = [vv["slowest_layer_over_d_le_16_layer"] for kk, vv in sweep.items() if vv.get("slowest_layer_over_d_le_16_layer") and vv["kernel_size"] == 3]
+    return {"sweep_L12_d2048_ms": sweep.get("C320_L12_d2048", {}).get("ms_per_step"),
+            "sweep_L12_d2048_xrt": sweep.get("C320_L12_d2048", {}).get("x_realtime"),
+            "sweep_slowest_ms": sweep[worst]["ms_per_step"], "sweep_slowest_xrt": sweep[worst]["x_realtime"],
+            "sweep_min_gate_frac": min(fracs) if fracs else None,
+            "sweep_worst_layer_ratio_k3": max(ratios) if ratios else None}
 
 
 def _delta_flags(node, path="line"):

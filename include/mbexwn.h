@@ -219,11 +219,19 @@ typedef struct {
     int32_t wn_precision;
     /* ABI 9 (the former reserved word; 0 keeps its meaning "default"): arithmetic of the F0-net, the one stage whose output
      * the graph integrates (phase = running sum of f0 / pulse_rate, reference tf_wavetable.py:429-492), so that its rounding
-     * moves every pulse behind it.  MBX_F0_ACC_F64 (0, default): float32 inputs, weights and hidden layers as in the
-     * reference, every contraction accumulated in float64 (v_mfma_f64_16x16x4_f64) and rounded to float32 once; the head
-     * (final 1x1 convolution, interpolation to the pulse rate, final activation, map onto [f0_min, f0_max]; reference
-     * custom_pulsed_generator.py:126-146, 773-791) one float64 kernel.  MBX_F0_ACC_F32 (1): the float32 kernels of the
-     * other mel-rate sub-nets (ABI <= 8 behaviour; contour error ~1e-3 Hz against ~2e-5 Hz) */
+     * moves every pulse behind it.  MBX_F0_ACC_F64 (0, default): the whole net in float64 -- float32 mel input, float64
+     * weights, float64 hidden layers, contractions on v_mfma_f64_16x16x4_f64, the head (final 1x1 convolution,
+     * interpolation to the pulse rate, final activation, map onto [f0_min, f0_max]; reference
+     * custom_pulsed_generator.py:126-146, 773-791) one float64 kernel, ONE rounding to float32 at the end (contour = the
+     * float32 nearest to the exact one).  This full chain needs, for EVERY convolution of the F0-net, the tensor
+     * "<layer>.w64" next to "<layer>.w": the weight-norm fold W = g v / sqrt(max(sum v^2, 1e-12)) evaluated in float64,
+     * shape (ks, cin, cout) as float64 viewed as 2 x the float32 words (mbexwn_vocoder_amd/engine.py::tensor_table builds
+     * them); an op list of the shape (conv [prelu | leaky])* head; channel counts that are multiples of 4.  If any of that
+     * is missing the handle falls back -- silently as far as results go, visibly in mbx_conv_form_info.f0_float64_chain --
+     * to float32 weights and hidden layers with float64 accumulation per contraction (contour error ~1e-5 Hz instead of
+     * half an ulp).  A mel pointer that is not 16-byte aligned is copied into the workspace first (same bits as an aligned
+     * one).  MBX_F0_ACC_F32 (1): the float32 kernels of the other mel-rate sub-nets (ABI <= 8 behaviour; contour error
+     * ~1e-3 Hz against ~2e-5 Hz) */
     int32_t f0_accumulate;
 } mbx_config;
 
@@ -265,7 +273,24 @@ typedef struct {
     float err_split;          /* ABI 8: max |audio(this handle in split precision) - audio(float32 direct form)| of the calibration
                                * run (mbx_create runs it for every handle that asks for MBX_PRECISION_SPLIT_F16); < 0: not measured */
     int32_t split_rejected;   /* 1: that error was above the threshold (or not finite): the handle runs float32 after all */
+    /* ABI 10 */
+    int32_t f0_float64_chain; /* 1: the F0-net runs with float64 weights ("<layer>.w64"), float64 hidden layers and the float64
+                               * head; 0: mbx_config.f0_accumulate's fallback (float32 weights and hidden layers, float64
+                               * accumulation) or MBX_F0_ACC_F32 -- see f0_accumulate */
+    int32_t n_gate_layers;    /* entries of gate_kernel that the most recent forward filled (0 before the first one) */
+    int32_t gate_kernel[MBX_MAX_WN_LAYERS];   /* MBX_GATE_K_*: what ran the dilated convolution + gate of layer l in the most
+                                               * recent forward (first WaveNet block) */
 } mbx_conv_form_info;
+#define MBX_GATE_K_NONE 0
+#define MBX_GATE_K_DIRECT 1          /* conv1d_mfma_dma_kernel<EPI_GATE> */
+#define MBX_GATE_K_F23 2             /* wn_gate_winograd2w_kernel */
+#define MBX_GATE_K_F43 3             /* wn_gate_winograd4w_kernel, 256-row blocks */
+#define MBX_GATE_K_F43_PSPLIT 4      /* wn_gate_winograd4p_kernel, 128-row product-split blocks */
+#define MBX_GATE_K_F43_HSPLIT 5      /* wn_gate_winograd4h_kernel, product-split blocks of half a column tile */
+#define MBX_GATE_K_F43_STRIDED 6     /* F(4,3) over d / 16 interleaved sub-sequences (d > 16), 256-row blocks */
+#define MBX_GATE_K_F43_STRIDED_PSPLIT 7
+#define MBX_GATE_K_FOLDED_START 8    /* wn_gate0_kernel: layer 0 with the start convolution folded in */
+#define MBX_GATE_K_SPLIT_F16 9       /* wn_gate_f16_kernel (opt-in split half precision) */
 mbx_status mbx_conv_form(const mbx_handle *handle, mbx_conv_form_info *info);
 
 /* Re-runs the calibration of MBX_CONV_AUTO on the caller's own input (same argument meaning as mbx_forward) and adopts

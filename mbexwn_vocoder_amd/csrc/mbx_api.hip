@@ -89,6 +89,8 @@ struct mbx_handle {
     // derived
     int f0_time_factor = 1, vtf_time_factor = 1;
     long long subnet_buf_per_frame = 0;   // floats per frame of one ping-pong buffer
+    int last_gate_kernel[MBX_MAX_WN_LAYERS] = {};   // MBX_GATE_K_* of the most recent forward (mbx_conv_form_info.gate_kernel)
+    int last_gate_layers = 0;
     bool f0_full64 = false;               // mbx_config.f0_accumulate == MBX_F0_ACC_F64 and the F0-net has the shape (conv [prelu | leaky])* head
                                           // with its "<layer>.w64" tensors: float64 weights and hidden layers (f0_chain_is_full64)
     std::vector<mbx_subnet_op> cond_ops;  // pre-conditioning convolutions + the conditioning layer (empty: conditioning disabled)
@@ -175,7 +177,7 @@ Workspace carve(const mbx_handle *hd, char *base, int B, int T) {
     const size_t npulse = (size_t)T * c.pulse_per_frame, nsteps = (size_t)T * c.steps_per_frame;
     const int chunks = (int)((npulse + c.phase_chunk - 1) / c.phase_chunk) + 1;
     const bool nm = c.nm_iters > 0;
-    w.mel_norm = take(nm ? BT * c.mel_channels : 0);
+    w.mel_norm = take((nm || hd->f0_full64) ? BT * c.mel_channels : 0);    // (also: aligned copy of a misaligned mel for the float64 F0 chain)
     w.nm_a = take(nm ? BT : 0);
     w.nm_b = take(nm ? BT : 0);
     w.sub0 = take(BT * hd->subnet_buf_per_frame);
@@ -1162,6 +1164,14 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                                            w.nm_a, w.nm_b, w.mel_norm, stream);
         mel = w.mel_norm;
     }
+    // the float64 F0 chain reads the mel rows as 16-byte pieces: a caller's mel that starts in the middle of one (a view
+    // into a larger buffer) is copied into the workspace first, so that the same handle and the same mel give the same
+    // bits however the call was made
+    if (hd->f0_full64 && c.nm_iters == 0 && (reinterpret_cast<uintptr_t>(mel) & 15) != 0 && c.mel_channels % 4 == 0) {
+        if (hipMemcpyAsync(w.mel_norm, mel, (size_t)B * T * c.mel_channels * sizeof(float), hipMemcpyDeviceToDevice, stream) != hipSuccess)
+            return fail(MBX_ERR_HIP, "hipMemcpyAsync of a misaligned mel failed");
+        mel = w.mel_norm;
+    }
     const int cond_cout = 2 * C * c.cond_conv_upsampling;
     mbx::StftConsts sc = stft_consts(hd);
     // ---- conditioning conv (reference custom_AE_layers.py:214-227,287), VTF-net -> cepstrum (reference
@@ -1189,8 +1199,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
         SubnetRun f0(hd, c.f0_ops, c.n_f0_ops, mel_fe, c.mel_channels, nf_fe, B, Tf, w.sub0, w.sub1,
                      f0_wide ? w.f0_wide : w.f0 + f_off * c.pulse_per_frame, true, c.f0_max - c.f0_min, c.f0_min, stream);
         f0.precise = c.f0_accumulate == MBX_F0_ACC_F64;
-        // (a mel pointer that is not 16-byte aligned keeps the float32 hidden layers: the first layer then runs whatever
-        // kernel takes its rows, and that kernel writes float32)
+        // (a misaligned mel was copied into the workspace above; mel_channels % 4 != 0 keeps the float32 hidden layers)
         if (hd->f0_full64 && (reinterpret_cast<uintptr_t>(mel_fe) & 15) == 0 && c.mel_channels % 4 == 0) {
             f0.buf64_0 = w.f0h0;
             f0.buf64_1 = w.f0h1;
@@ -1353,6 +1362,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     }
     auto lerp = hd->lerp[cond_up];
     bool planes_valid = false;        // split half precision: the last res/skip launch also wrote h as fp16 planes (w.h16)
+    hd->last_gate_layers = L;
     for (int l = 0; l < L; ++l) {
         const std::string ls = std::to_string(l);
         const int d = c.wn_dilations[l];
@@ -1402,6 +1412,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
             g0.write_inputs = L > 1;
             if (gs.cphase != 0 || !mbx::launch_wn_gate0(g0, stream))
                 return fail(MBX_ERR_INVALID_ARGUMENT, "folded first layer does not fit its kernel");
+            hd->last_gate_kernel[l] = MBX_GATE_K_FOLDED_START;
         } else {
             ScopedEvents ev(hd, PROF_GATE, stream);
             // per-layer state of a stream: the rows this layer reads from in front of its own come from the item's slot,
@@ -1461,6 +1472,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                     gh.h_split_bstride = nsteps * (long long)gh.h_split_ld;
                 }
                 done = mbx::launch_wn_gate_f16(gh, stream);
+                if (done) hd->last_gate_kernel[l] = MBX_GATE_K_SPLIT_F16;
             }
             bool use4 = !done && hd->winograd == 4 && !st_in && !st_out;
             if (use4 && d > 16) {
@@ -1490,7 +1502,15 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                 mbx::ConvArgs gw = g;
                 gw.w = wino4->ptr;
                 // (the product-split shape holds 16 conditioning rows: cond_up >= 10; the 256-row shape takes cond_up >= 5)
-                done = mbx::launch_wn_gate_winograd4w(gw, shape4, stream) || (split4 && mbx::launch_wn_gate_winograd4w(gw, 0, stream));
+                int ran = shape4;
+                done = mbx::launch_wn_gate_winograd4w(gw, shape4, stream);
+                if (!done && split4) {
+                    ran = 0;
+                    done = mbx::launch_wn_gate_winograd4w(gw, 0, stream);
+                }
+                if (done)
+                    hd->last_gate_kernel[l] = d > 16 ? (ran ? MBX_GATE_K_F43_STRIDED_PSPLIT : MBX_GATE_K_F43_STRIDED)
+                                                     : (ran == 2 ? MBX_GATE_K_F43_HSPLIT : ran == 1 ? MBX_GATE_K_F43_PSPLIT : MBX_GATE_K_F43);
             }
             // F(2,3): wave-tiled kernel on v_mfma_f32_16x16x4_f32 (wn_winograd2w.hip): streams, per-layer regions, MBX_CONV_F23
             const DevTensor *wino = (!done && hd->winograd) ? find(hd, "wn.conv1D_" + ls + ".wino2w") : nullptr;
@@ -1499,10 +1519,14 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                 mbx::ConvArgs gw = g;
                 gw.w = wino->ptr;
                 done = mbx::launch_wn_gate_winograd2w(gw, stream);
+                if (done) hd->last_gate_kernel[l] = MBX_GATE_K_F23;
             }
             if (!done && (gs.cphase != 0 || gs.out_rows != 0))
                 return fail(MBX_ERR_UNSUPPORTED, "per-layer regions need the Winograd F(2,3) gate kernel");
-            if (!done) mbx::launch_conv1d(g, mbx::EPI_GATE, stream);
+            if (!done) {
+                mbx::launch_conv1d(g, mbx::EPI_GATE, stream);
+                hd->last_gate_kernel[l] = MBX_GATE_K_DIRECT;
+            }
         }
         const bool last = (l == L - 1);
         const Span &rs = res_sp[l];
@@ -1784,6 +1808,7 @@ static mbx_status calibrate_run(mbx_handle *hd, const float *mel, const int32_t 
         // the calibration forwards filled the stage table with pointers into their own (temporary, or by now overwritten)
         // workspace and strides of the calibration batch: mbx_stage answers "unknown stage" until the caller's next forward
         hd->stages.clear();
+        hd->last_gate_layers = 0;
         if (st != MBX_OK) {
             set_form(hd, form_before);
             hd->split_f16 = split_req;
@@ -1916,6 +1941,9 @@ mbx_status mbx_conv_form(const mbx_handle *hd, mbx_conv_form_info *info) {
     info->err_f23 = hd->calib_err23;
     info->ref_max = hd->calib_ref;
     info->threshold = hd->calib_threshold;
+    info->f0_float64_chain = hd->f0_full64 ? 1 : 0;
+    info->n_gate_layers = hd->last_gate_layers;
+    for (int l = 0; l < MBX_MAX_WN_LAYERS; ++l) info->gate_kernel[l] = l < hd->last_gate_layers ? hd->last_gate_kernel[l] : MBX_GATE_K_NONE;
     return MBX_OK;
 }
 

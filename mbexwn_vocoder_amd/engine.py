@@ -83,7 +83,12 @@ class mbx_conv_form_info(ctypes.Structure):
                 ("fold_skip", ctypes.c_int32), ("fold_start", ctypes.c_int32), ("split_f16_layers", ctypes.c_int32),
                 ("split_f16_gate_layers", ctypes.c_int32), ("err_f43", ctypes.c_float),
                 ("err_f23", ctypes.c_float), ("ref_max", ctypes.c_float), ("threshold", ctypes.c_float),
-                ("err_split", ctypes.c_float), ("split_rejected", ctypes.c_int32)]
+                ("err_split", ctypes.c_float), ("split_rejected", ctypes.c_int32), ("f0_float64_chain", ctypes.c_int32),
+                ("n_gate_layers", ctypes.c_int32), ("gate_kernel", ctypes.c_int32 * MBX_MAX_WN_LAYERS)]
+
+
+GATE_KERNEL_NAMES = {0: "none", 1: "direct", 2: "f23", 3: "f43", 4: "f43_psplit", 5: "f43_hsplit", 6: "f43_strided",
+                     7: "f43_strided_psplit", 8: "folded_start", 9: "split_f16"}
 
 
 CONV_FORMS = {"auto": 0, "direct": 1, "f23": 2, "f43": 3}
@@ -1009,7 +1014,8 @@ class MBExWNEngine:
                 "err_f23": None if info.err_f23 < 0 else float(info.err_f23),
                 "ref_max": float(info.ref_max), "threshold": float(info.threshold),
                 "err_split": None if info.err_split < 0 else float(info.err_split),
-                "split_rejected": bool(info.split_rejected)}
+                "split_rejected": bool(info.split_rejected), "f0_float64_chain": bool(info.f0_float64_chain),
+                "gate_kernels": [GATE_KERNEL_NAMES[info.gate_kernel[ll]] for ll in range(info.n_gate_layers)]}
 
     def calibrate(self, mel, n_frames=None, noise=None):
         """mbx_calibrate: repeat the form calibration on the caller's own mel batch (device tensors as for
