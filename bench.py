@@ -74,6 +74,7 @@ WORKLOAD_OVERRIDES = {
 }
 DEFAULT_WORKLOAD = "config3_si_b16_10s"
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+NOMINAL_CLOCK_GHZ = 2.4           # the clock the guide's peak figures are priced at
 HBM_PEAK_GBS = 8000.0             # same guide: HBM3E 8 TB/s (spec; 6.3 TB/s measured for a float4 copy)
 DELTA_FRAMES = 80                 # prefix of the benchmark input the oracle is run on for max|delta|
 DELTA_MARGIN = 12                 # frames at the end of a prefix that reach into what follows (receptive field of the path)
@@ -333,6 +334,18 @@ def run_batch(args, name, rank, world, fence, torch, profile, steps=None, warmup
                                                        "start", "tail", "pqmf", "stft_filter", "overlap_add")}
         eng.profile_enable(False)
         ctx["stages"] = stages
+        # the shader clock the part delivers under this workload (one-wave probe on a second stream, mbx_clock_probe): the
+        # guide's fp32 MFMA peak is priced at 2.4 GHz
+        reps = max(2, int(0.03 / max(elapsed / steps, 1e-4)) + 1)
+
+        def busy():
+            for _ in range(reps):
+                eng.forward(mel, noise=noise, out=out)
+        try:
+            ctx["shader_clock_ghz"] = eng.shader_clock_under(busy, seconds=0.02)
+        except Exception as exc:                              # noqa: BLE001 -- evidence only: never fail the measurement
+            ctx["shader_clock_ghz"] = None
+            ctx["shader_clock_error"] = str(exc)
 
     return res, ctx
 
@@ -540,6 +553,11 @@ def roofline(ctx, workload):
                     "convolution's 2*rows*3C*2C) / launch time: <= 1, comparable with MfmaUtil in profiles/; "
                     "*_algorithmic = the direct convolution's FLOPs / launch time (can exceed 1)",
             "avg_launch_ms": gate_s * 1e3, "launches_timed": gate_n,
+            "shader_clock_ghz_under_load": ctx.get("shader_clock_ghz"),
+            "frac_at_delivered_clock": (flop_exec / gate_s / 1e12 / (FP32_MATRIX_PEAK_TFLOPS * ctx["shader_clock_ghz"] / NOMINAL_CLOCK_GHZ)
+                                        if ctx.get("shader_clock_ghz") else None),
+            "clock_note": "peak = 157.3 TFLOP/s at the nominal 2.4 GHz; shader_clock_ghz_under_load = s_memtime cycles per s_memrealtime "
+                          "tick of a one-wave probe that runs beside the timed forward passes on a second stream",
             "launches_per_step": L - 1 if eng.folds_start else L,
             "first_layer": ("start convolution folded into layer 0: a K=24 contraction of the excitation (wn_gate0_kernel, "
                             "listed under stages), not one of these launches") if eng.folds_start else "same kernel",

@@ -434,6 +434,18 @@ mbx_status mbx_forward_ex(mbx_handle *handle, const float *mel, const int32_t *n
  * form of the "persistent-kernel path" of BASELINE config 5; streaming.py).  noise_window / noise_new may both be NULL. */
 mbx_status mbx_window_advance(mbx_handle *handle, float *mel_window, const float *mel_new, float *noise_window,
                               const float *noise_new, int32_t batch, int32_t frames, int32_t step_frames, void *hip_stream);
+/* The general move of the device-resident windows (ABI 10): every item's window is `window_frames` long; its frames
+ * [shift_frames, shift_frames + keep_frames) move to the front and `new_frames` frames of mel_new (batch, new_frames,
+ * mel_channels) / noise_new (batch, new_frames * steps_per_frame) are written behind them, in one launch -- the tick of a
+ * schedule whose chunk differs from the frames the window start moved by (80 ms = 6 / 6 / 7 / 6 / 7 frames). */
+mbx_status mbx_window_update(mbx_handle *handle, float *mel_window, const float *mel_new, float *noise_window,
+                             const float *noise_new, int32_t batch, int32_t window_frames, int32_t shift_frames,
+                             int32_t keep_frames, int32_t new_frames, void *hip_stream);
+/* What a tick hands back (ABI 10): the samples [first, first + count) of every item's row of `audio` (batch rows of
+ * row_floats floats on the device) as one strided device-to-host copy into host_out (batch, count; pinned memory for an
+ * asynchronous copy), enqueued on the stream (capturable into a graph). */
+mbx_status mbx_emit_rows(mbx_handle *handle, const float *audio, int64_t row_floats, int32_t batch, int64_t first,
+                         int64_t count, float *host_out, void *hip_stream);
 
 /* Intermediate tensors of the most recent mbx_forward (pointers into its workspace), for stage parity
  * tests.  Names: "f0" "pulse" "cond" "wn_hidden" "wn_skip" "wn_out" "subbands" "excitation" "cepstrum"
@@ -458,6 +470,12 @@ mbx_status mbx_profile_read(mbx_handle *handle, const char *kernel, double *tota
  * of bench.py's geometry sweep. */
 mbx_status mbx_profile_read_launches(mbx_handle *handle, const char *kernel, float *launch_ms, int64_t capacity,
                                      int64_t *launches);
+
+/* Delivered shader clock for bench.py (ABI 10): enqueues ONE wave on the stream that spins for real_ticks ticks of the
+ * constant 100 MHz clock (10 ns each; at most 1 s) and writes {shader cycles at start, at end, 100 MHz ticks at start, at
+ * end} to device_out4 -- launched on a second stream while the kernels under measurement run, (cycles / ticks) x 100 MHz is
+ * the shader clock the part delivers under that load (the fp32 MFMA peak of the guide assumes 2.4 GHz). */
+mbx_status mbx_clock_probe(mbx_handle *handle, uint64_t *device_out4, int64_t real_ticks, void *hip_stream);
 
 /* ---- stage entry points (unit parity; all pointers device memory) ------------------------------- */
 

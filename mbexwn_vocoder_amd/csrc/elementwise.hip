@@ -414,6 +414,67 @@ __global__ void window_advance_kernel(float *mel, const float *mel_new, int mel_
     for (int i = threadIdx.x; i < step; i += blockDim.x) row[keep + i] = src[i];
 }
 
+// Delivered shader clock (mbx_clock_probe, bench.py): one wave spins for `real_ticks` ticks of the constant 100 MHz clock
+// (s_memrealtime) and reports the shader-clock cycles (s_memtime) that passed: out = {cycles at start, at end, ticks at start,
+// at end}.  Launched on a second stream beside the kernels under measurement it needs one wave slot and no LDS.
+__global__ void clock_probe_kernel(unsigned long long *out, unsigned long long real_ticks) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < real_ticks) {
+        __builtin_amdgcn_s_sleep(64);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    out[0] = c0;
+    out[1] = c1;
+    out[2] = r0;
+    out[3] = r1;
+}
+
+void launch_clock_probe(unsigned long long *out, unsigned long long real_ticks, hipStream_t stream) {
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, stream, out, real_ticks);
+}
+
+// The general move of a device-resident window (mbx_window_update): rows of `pitch` floats; the floats [shift, shift + keep)
+// of every row move to [0, keep), `fresh` (batch, step) lands behind them at [keep, keep + step).  One launch for a tick of a
+// schedule whose chunk is not the frames the window moved by (the 80 ms schedule 6 / 6 / 7 / 6 / 7).
+__global__ void window_update_kernel(float *mel, const float *mel_new, int mel_pitch, int mel_shift, int mel_keep, int mel_step,
+                                     float *noise, const float *noise_new, int noise_pitch, int noise_shift, int noise_keep,
+                                     int noise_step) {
+    extern __shared__ float adv_buf[];
+    const int b = blockIdx.x, second = blockIdx.y;
+    float *win = second ? noise : mel;
+    const float *fresh = second ? noise_new : mel_new;
+    const int pitch = second ? noise_pitch : mel_pitch, shift = second ? noise_shift : mel_shift;
+    const int keep = second ? noise_keep : mel_keep, step = second ? noise_step : mel_step;
+    if (!win) return;
+    float *row = win + (long long)b * pitch;
+    if (shift > 0) {
+        for (int i = threadIdx.x; i < keep; i += blockDim.x) adv_buf[i] = row[shift + i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < keep; i += blockDim.x) row[i] = adv_buf[i];
+    }
+    const float *src = fresh + (long long)b * step;
+    for (int i = threadIdx.x; i < step; i += blockDim.x) row[keep + i] = src[i];
+}
+
+bool launch_window_update(float *mel, const float *mel_new, float *noise, const float *noise_new, int batch, int win_frames,
+                          int shift_frames, int keep_frames, int new_frames, int mel_channels, int steps_per_frame,
+                          hipStream_t stream) {
+    if (batch <= 0 || win_frames <= 0 || shift_frames < 0 || keep_frames < 0 || new_frames < 0 ||
+        shift_frames + keep_frames > win_frames || keep_frames + new_frames > win_frames)
+        return false;
+    const size_t smem = sizeof(float) * (size_t)keep_frames * std::max(mel_channels, noise ? steps_per_frame : 0);
+    if (smem > 64 * 1024) return false;
+    hipLaunchKernelGGL(window_update_kernel, dim3(batch, noise ? 2 : 1), dim3(256), smem, stream, mel, mel_new,
+                       win_frames * mel_channels, shift_frames * mel_channels, keep_frames * mel_channels, new_frames * mel_channels,
+                       noise, noise_new, win_frames * steps_per_frame, shift_frames * steps_per_frame,
+                       keep_frames * steps_per_frame, new_frames * steps_per_frame);
+    return true;
+}
+
 bool launch_window_advance(float *mel, const float *mel_new, float *noise, const float *noise_new, int batch, int frames,
                            int step_frames, int mel_channels, int steps_per_frame, hipStream_t stream) {
     if (batch <= 0 || frames <= 0 || step_frames <= 0 || step_frames > frames) return false;

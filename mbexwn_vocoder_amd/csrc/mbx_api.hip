@@ -2010,6 +2010,42 @@ mbx_status mbx_window_advance(mbx_handle *hd, float *mel_window, const float *me
     return e == hipSuccess ? MBX_OK : fail(MBX_ERR_HIP, hipGetErrorString(e));
 }
 
+mbx_status mbx_clock_probe(mbx_handle *hd, uint64_t *device_out4, int64_t real_ticks, void *hip_stream) {
+    if (!hd || !device_out4 || real_ticks <= 0 || real_ticks > 100000000LL)
+        return fail(MBX_ERR_INVALID_ARGUMENT, "clock probe: need a device buffer of 4 x uint64 and 0 < real_ticks <= 1e8 (1 s)");
+    DeviceGuard guard(hd->device);
+    if (!guard.ok) return fail(MBX_ERR_HIP, "cannot select the handle's device");
+    mbx::launch_clock_probe(reinterpret_cast<unsigned long long *>(device_out4), (unsigned long long)real_ticks,
+                            static_cast<hipStream_t>(hip_stream));
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MBX_OK : fail(MBX_ERR_HIP, hipGetErrorString(e));
+}
+
+mbx_status mbx_window_update(mbx_handle *hd, float *mel_window, const float *mel_new, float *noise_window,
+                             const float *noise_new, int32_t batch, int32_t window_frames, int32_t shift_frames,
+                             int32_t keep_frames, int32_t new_frames, void *hip_stream) {
+    if (!hd || !mel_window || !mel_new || (noise_window != nullptr) != (noise_new != nullptr))
+        return fail(MBX_ERR_INVALID_ARGUMENT, "null argument (noise_window and noise_new go together)");
+    DeviceGuard guard(hd->device);
+    if (!guard.ok) return fail(MBX_ERR_HIP, "cannot select the handle's device");
+    if (!mbx::launch_window_update(mel_window, mel_new, noise_window, noise_new, batch, window_frames, shift_frames, keep_frames,
+                                   new_frames, hd->cfg.mel_channels, hd->cfg.steps_per_frame, static_cast<hipStream_t>(hip_stream)))
+        return fail(MBX_ERR_INVALID_ARGUMENT, "window update: need shift + keep <= window, keep + new <= window and at most 64 KB kept per item");
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MBX_OK : fail(MBX_ERR_HIP, hipGetErrorString(e));
+}
+
+mbx_status mbx_emit_rows(mbx_handle *hd, const float *audio, int64_t row_floats, int32_t batch, int64_t first, int64_t count,
+                         float *host_out, void *hip_stream) {
+    if (!hd || !audio || !host_out || batch <= 0 || count <= 0 || first < 0 || first + count > row_floats)
+        return fail(MBX_ERR_INVALID_ARGUMENT, "emit rows: need 0 <= first, first + count <= row_floats");
+    DeviceGuard guard(hd->device);
+    if (!guard.ok) return fail(MBX_ERR_HIP, "cannot select the handle's device");
+    HIP_TRY(hipMemcpy2DAsync(host_out, (size_t)count * sizeof(float), audio + first, (size_t)row_floats * sizeof(float),
+                             (size_t)count * sizeof(float), (size_t)batch, hipMemcpyDeviceToHost, static_cast<hipStream_t>(hip_stream)));
+    return MBX_OK;
+}
+
 mbx_status mbx_mel_analysis(const float *audio, const int32_t *n_samples, int32_t batch, int32_t max_samples,
                             int32_t win, int32_t hop, int32_t fft_size, int32_t n_mels, const float *window,
                             const float *twiddle, const float *basis, const int32_t *bin_lo, const int32_t *bin_hi,

@@ -214,6 +214,10 @@ struct FrontendCarryArgs {
 };
 void launch_frontend_carry(const FrontendCarryArgs &a, int batch, hipStream_t stream);
 // device-resident streaming windows: shift every item's window left by step_frames and append the new frames
+void launch_clock_probe(unsigned long long *out, unsigned long long real_ticks, hipStream_t stream);
+bool launch_window_update(float *mel, const float *mel_new, float *noise, const float *noise_new, int batch, int win_frames,
+                          int shift_frames, int keep_frames, int new_frames, int mel_channels, int steps_per_frame,
+                          hipStream_t stream);
 bool launch_window_advance(float *mel, const float *mel_new, float *noise, const float *noise_new, int batch, int frames,
                            int step_frames, int mel_channels, int steps_per_frame, hipStream_t stream);
 void launch_activation(const float *x, long long x_bstride, const int *n_frames, int rows_per_frame, int max_rows,

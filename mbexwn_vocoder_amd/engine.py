@@ -160,6 +160,12 @@ def load_library():
     lib.mbx_layer_state_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
     lib.mbx_window_advance.restype = i32
     lib.mbx_window_advance.argtypes = [vp, fp, fp, fp, fp, i32, i32, i32, vp]
+    lib.mbx_clock_probe.restype = i32
+    lib.mbx_clock_probe.argtypes = [vp, vp, ctypes.c_int64, vp]
+    lib.mbx_window_update.restype = i32
+    lib.mbx_window_update.argtypes = [vp, fp, fp, fp, fp, i32, i32, i32, i32, i32, vp]
+    lib.mbx_emit_rows.restype = i32
+    lib.mbx_emit_rows.argtypes = [vp, fp, ctypes.c_int64, i32, ctypes.c_int64, ctypes.c_int64, fp, vp]
     lib.mbx_stage.restype = i32
     lib.mbx_stage.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p), i64p, i64p]
     lib.mbx_profile_enable.restype = i32
@@ -189,8 +195,8 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = ["mbx_last_error", "mbx_create", "mbx_destroy", "mbx_conv_form", "mbx_calibrate", "mbx_workspace_size", "mbx_forward",
-                    "mbx_forward_stream", "mbx_forward_ex", "mbx_layer_state_info", "mbx_window_advance", "mbx_stage",
-                    "mbx_profile_enable", "mbx_profile_read", "mbx_profile_read_launches", "mbx_pqmf_synthesis", "mbx_conv1d", "mbx_conv1d_f64acc", "mbx_lin_interp", "mbx_wavetable", "mbx_stft_filter", "mbx_norm_mel", "mbx_mel_analysis"]
+                    "mbx_forward_stream", "mbx_forward_ex", "mbx_layer_state_info", "mbx_window_advance", "mbx_window_update", "mbx_emit_rows", "mbx_stage",
+                    "mbx_profile_enable", "mbx_profile_read", "mbx_profile_read_launches", "mbx_clock_probe", "mbx_pqmf_synthesis", "mbx_conv1d", "mbx_conv1d_f64acc", "mbx_lin_interp", "mbx_wavetable", "mbx_stft_filter", "mbx_norm_mel", "mbx_mel_analysis"]
 
 
 def _check(status):
@@ -958,6 +964,38 @@ class MBExWNEngine:
                                             noise_window.data_ptr() if noise_window is not None else None,
                                             noise_new.data_ptr() if noise_window is not None else None, B, T, step,
                                             self._stream()))
+
+    def shader_clock_under(self, work, seconds=0.02):
+        """Shader clock (GHz) the part delivers while ``work()`` -- a callable that enqueues kernels on the engine's stream --
+        runs: a one-wave probe (mbx_clock_probe) spins on a second stream for ``seconds`` and counts shader cycles against the
+        constant 100 MHz clock.  ``work`` should enqueue at least that much device time.  Synchronises."""
+        torch = self._torch
+        out = torch.zeros(4, dtype=torch.int64, device=self.device)
+        side = torch.cuda.Stream(device=self.device)
+        work()                                                    # the chip is busy before the probe starts
+        _check(self._lib.mbx_clock_probe(self._handle, out.data_ptr(), int(seconds * 1e8), ctypes.c_void_p(side.cuda_stream)))
+        work()
+        torch.cuda.synchronize(self.device)
+        c0, c1, r0, r1 = (int(vv) for vv in out.cpu().numpy())
+        return (c1 - c0) / max(r1 - r0, 1) * 0.1                    # cycles per 10 ns tick -> GHz
+
+    def window_update(self, mel_window, mel_new, noise_window, noise_new, shift, keep):
+        """mbx_window_update: frames [shift, shift + keep) of the device-resident windows move to the front, the frames of
+        mel_new / noise_new land behind them; one launch."""
+        B, T, step = int(mel_window.shape[0]), int(mel_window.shape[1]), int(mel_new.shape[1])
+        _check(self._lib.mbx_window_update(self._handle, mel_window.data_ptr(), mel_new.data_ptr(),
+                                           noise_window.data_ptr() if noise_window is not None else None,
+                                           noise_new.data_ptr() if noise_window is not None else None, B, T, int(shift), int(keep),
+                                           step, self._stream()))
+
+    def emit_rows(self, audio, first, count, host_out):
+        """mbx_emit_rows: samples [first, first + count) of every row of the device tensor `audio` (B, n) into the pinned
+        host tensor host_out (B, count) as one strided copy on the engine's stream."""
+        B, n = int(audio.shape[0]), int(audio.shape[1])
+        if tuple(host_out.shape) != (B, count) or not host_out.is_contiguous() or not audio.is_contiguous():
+            raise ValueError("emit_rows: host_out must be a contiguous (batch, count) tensor, audio contiguous")
+        _check(self._lib.mbx_emit_rows(self._handle, audio.data_ptr(), n, B, int(first), int(count), host_out.data_ptr(),
+                                       self._stream()))
 
     @property
     def frontend_carry_supported(self):

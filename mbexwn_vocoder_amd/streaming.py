@@ -637,26 +637,15 @@ class StreamingSynthesizer:
         use_fe = ctx["use_fe"] and fe_new + fe_margin <= ctx["T"]
         ints = {kk: torch.as_tensor(ctx[kk], device=dev) for kk in ("act", "wn", "nfr", "desc", "ldesc")}
         audio_buf, state_out, state_host = shared["audio_buf"], shared["state_out"], shared["state_host"]
-        emit_buf = torch.empty((B, ctx["hi"] - ctx["lo"]), dtype=torch.float32, device=dev)
         audio_host = torch.empty((B, ctx["hi"] - ctx["lo"]), dtype=torch.float32).pin_memory()
-        one_launch = shift == chunk and ctx["T"] == tpad
-        # source of the frames a pure shift "appends" (they land behind the kept part, where the new frames are written next)
-        pad_mel = torch.zeros((B, shift, dims.mel_channels), dtype=torch.float32, device=dev) if shift and not one_launch else None
-        pad_noise = torch.zeros((B, shift * spf), dtype=torch.float32, device=dev) if pad_mel is not None and use_noise else None
         graph = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(dev)
         # thread_local: another thread of the process (the RCCL watchdog of a multi-rank job) may touch the runtime while
         # this one captures
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             stage_dev.copy_(stage_host, non_blocking=True)
-            if one_launch:
-                eng.window_advance(mel_win, mel_new, noise_win, noise_new)         # shift and append in one launch
-            else:
-                if shift > 0:
-                    eng.window_advance(mel_win, pad_mel, noise_win, pad_noise)
-                mel_win[:, keep:keep + chunk].copy_(mel_new)
-                if use_noise:
-                    noise_win[:, keep * spf:(keep + chunk) * spf].copy_(noise_new)
+            # shift the kept frames to the front and append the tick's new ones: one launch whatever the schedule
+            eng.window_update(mel_win, mel_new, noise_win, noise_new, shift, keep)
             eng.forward(mel_win, n_frames=ints["nfr"], noise=noise_win, stream_state=states_d,
                         active=(ctx["a0"], ints["act"], int(ctx["act"].max())),
                         wavenet=(ctx["wa"], ints["wn"], int(ctx["wn"].max())),
@@ -665,14 +654,14 @@ class StreamingSynthesizer:
                         frontend=(self._fe_store, fpos_d, fe_new if use_fe else 0, fe_margin if use_fe else 0, ctx["T"])
                         if ctx["use_fe"] else None,
                         out=audio_buf, state_out=state_out)
-            emit_buf.copy_(audio_buf[:, ctx["lo"]:ctx["hi"]])
-            audio_host.copy_(emit_buf, non_blocking=True)
+            # the emitted samples of every stream: one strided device-to-host copy (no device-side gather in between)
+            eng.emit_rows(audio_buf, ctx["lo"], ctx["hi"] - ctx["lo"], audio_host)
             state_host.copy_(state_out, non_blocking=True)
         n_state = n_mel + n_noise
         return {"graph": graph, "stage_host": stage_host, "stage_np": stage_host.numpy(), "n_mel": n_mel,
                 "arange": np.arange(chunk, dtype=np.int64), "n_noise": n_noise, "n_state": n_state,
                 "audio_host": audio_host, "state_host": state_host, "shift": shift, "keep": keep,
-                "keep_alive": (stage_dev, ints, emit_buf, pad_mel, pad_noise)}
+                "keep_alive": (stage_dev, ints)}
 
     def _graph_tick(self):
         """A steady tick as one graph launch: gather and upload the new frames and the phase states, replay, read the

@@ -287,11 +287,24 @@ def test_split_f16_large_launch_against_the_float32_handle(torch):
     mel, noise = synthetic_inputs(23, 16, 400)
     e32 = MBExWNEngine(cfg, raw, wt, conv_form="f43")
     e16 = MBExWNEngine(cfg, raw, wt, conv_form="f43", precision="split_f16")
-    a32 = e32.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
-    a16 = e16.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
-    b16 = e16.forward(dev(torch, mel), noise=dev(torch, noise)).cpu().numpy()
+    lengths = [400] * 16
+    lengths[3] = 60                                       # one whole short item inside the batch, for the oracle
+    nf = torch.as_tensor(lengths, dtype=torch.int32).cuda()
+    a32 = e32.forward(dev(torch, mel), n_frames=nf, noise=dev(torch, noise)).cpu().numpy()
+    a16 = e16.forward(dev(torch, mel), n_frames=nf, noise=dev(torch, noise)).cpu().numpy()
+    b16 = e16.forward(dev(torch, mel), n_frames=nf, noise=dev(torch, noise)).cpu().numpy()
     assert np.array_equal(a16, b16)
     amp = max(1.0, float(np.abs(a32).max()))
     worst = float(np.abs(a16 - a32).max())
     print(f"\nsplit f16 vs float32 at 16 x 400 frames: max difference {worst:.2e} (amplitude {amp:.2f})")
     assert worst <= 2e-5 * amp
+    # ... and against the float64 oracle: the short item over its whole length, the first 80 frames
+    # of two full-length items (prefix property: the oracle runs on 92 frames, margin 12)
+    from oracle.mbexwn_oracle import OracleModel
+    om = OracleModel(cfg, raw, wt)
+    ref = om.forward(mel[3:4, :60], noise[3:4, :60 * 20])[0]
+    assert np.abs(a16[3, :60 * 300] - ref).max() <= 2e-5 * max(1.0, float(np.abs(ref).max()))
+    assert np.all(a16[3, 60 * 300:] == 0.0)
+    for ii in (0, 15):
+        ref = om.forward(mel[ii:ii + 1, :92], noise[ii:ii + 1, :92 * 20])[0][:80 * 300]
+        assert np.abs(a16[ii, :80 * 300] - ref).max() <= 2e-5 * max(1.0, float(np.abs(ref).max())), f"item {ii}"
