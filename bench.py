@@ -253,7 +253,15 @@ def delta_vs_reference_f32(torch):
     if not os.path.exists(path):
         return {}
     gold = np.load(path)
-    cfg, raw, wt, dims, eng = build_engine("SPEECH")
+    # the golden cases' own variables (tests/helpers.py::build_case: seed 1234 with bias and PReLU jitter), not the bench's
+    from mbexwn_vocoder_amd.config import ModelDims, canonical_config
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    from mbexwn_vocoder_amd.tables import WaveTables
+    from mbexwn_vocoder_amd.weights import synthetic_weights
+    cfg = canonical_config("SPEECH")
+    dims = ModelDims(cfg)
+    raw = synthetic_weights(cfg, seed=1234, bias_std=0.05, alpha_jitter=0.05)
+    eng = MBExWNEngine(cfg, raw, WaveTables(sample_rate=dims.pulse_rate, **cfg["mbexwn_config"]["wavetable_config"]))
     out = {}
     for case, key in (("speech800", "max_abs_delta_vs_ref_f32"), ("speech240", "max_abs_delta_vs_ref_f32_3s")):
         mel, noise, ref = gold[f"{case}/mell"], gold[f"{case}/noise"], gold[f"{case}/audio"]
@@ -342,6 +350,7 @@ def run_batch(args, name, rank, world, fence, torch, profile, steps=None, warmup
             for _ in range(reps):
                 eng.forward(mel, noise=noise, out=out)
         try:
+            ctx["shader_clock_ghz_no_load"] = eng.shader_clock_under(lambda: None, seconds=0.005)   # the probe alone, for scale
             ctx["shader_clock_ghz"] = eng.shader_clock_under(busy, seconds=0.02)
         except Exception as exc:                              # noqa: BLE001 -- evidence only: never fail the measurement
             ctx["shader_clock_ghz"] = None
@@ -554,6 +563,7 @@ def roofline(ctx, workload):
                     "*_algorithmic = the direct convolution's FLOPs / launch time (can exceed 1)",
             "avg_launch_ms": gate_s * 1e3, "launches_timed": gate_n,
             "shader_clock_ghz_under_load": ctx.get("shader_clock_ghz"),
+            "shader_clock_ghz_probe_alone": ctx.get("shader_clock_ghz_no_load"),
             "frac_at_delivered_clock": (flop_exec / gate_s / 1e12 / (FP32_MATRIX_PEAK_TFLOPS * ctx["shader_clock_ghz"] / NOMINAL_CLOCK_GHZ)
                                         if ctx.get("shader_clock_ghz") else None),
             "clock_note": "peak = 157.3 TFLOP/s at the nominal 2.4 GHz; shader_clock_ghz_under_load = s_memtime cycles per s_memrealtime "
