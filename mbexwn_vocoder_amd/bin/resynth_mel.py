@@ -116,7 +116,8 @@ if __name__ == "__main__":
     parser.add_argument("-q", "--quiet", action="store_true", help="dont display progress")
     parser.add_argument("--calibrate", default=0, type=int, metavar="N",
                         help="decide the form of the WaveNet's convolution on the first N input files before synthesis "
-                             "(Def: %(default)s = keep the decision made at model load on a synthetic mel)")
+                             "(Def: %(default)s = keep the decision made at model load on a synthetic mel); the decision then "
+                             "binds every file of the job, so the output depends on which N files come first")
     args = parser.parse_args()
 
     if not args.model_id:

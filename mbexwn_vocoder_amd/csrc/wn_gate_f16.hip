@@ -25,6 +25,7 @@
 // PLANES = true: the producer (wn_resskip_f16_kernel) has written the hidden state as fp16 planes already (ConvArgs::h_split:
 // per row hi and lo' halves): the rows are requested straight into the operand layout, X becomes a second operand stage, the
 // conversion and one barrier per step go, and a step's requests are in flight during the whole step before it.
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 #include "mbx_kernels.h"
@@ -287,6 +288,225 @@ __global__ __launch_bounds__(512, 2) void wn_gate_f16_kernel(ConvArgs p, int log
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the plane-fed kernel with 256 x 128 tiles.  What the ablations of wn_gate_f16_kernel<true> said at 16 x 10 s (946 us
+// per launch, profiles/r06_gate_f16_ablations.txt): no LDS operand reads at all 953 us (NOT the bound, against round 4's
+// reading of the first version), a sixth of the MFMAs 740, no LDS-DMA 727, no epilogue 859, no barrier 916; launch time
+// against the K steps per block (C = 160 / 224 / 320): 6.9 us fixed per block + 1.80 us per K step, where the matrix pipe
+// needs 0.96 us -- a step lasts as long as the round trip of its 60 KB of operands (256 CUs x 60 KB / 1.8 us = 8.5 TB/s out
+// of the L2s), one step of look-ahead being all the LDS holds.  (Persistent blocks that request the next tile's first
+// operands during the last step of the current one measured the same 929 us: the fixed part is not the tile change.)  So the
+// tile has to do more arithmetic per byte it stages: here a block owns TWO column tiles (128 weight columns) of its 256 rows
+// -- the activation rows are staged once for both: 84 KB per step for twice the MFMAs (42 KB per 64 columns instead of 60)
+// and the fixed part once per two tiles.  Wave w: rows 64 (w & 3) .. + 63 (four 16-row tiles) x column tile w >> 2: 4 x 4
+// tiles x 2 accumulator sets = 128 registers; per tap 8 + 8 operand reads for 48 MFMAs (0.33 KB per MFMA instead of 0.5).
+// LDS: two activation stages (72 KB) + the weights as a RING of four tap chunks of 16 KB (a step's 48 KB twice would not
+// fit): chunk g = (step, tap) lives in slot g & 3 and is requested three taps ahead, behind the barrier in front of tap
+// g - 3 (every wave is past tap g - 4, the slot's last reader); the activation rows of step s + 1 are requested at tap 0 of
+// step s.  Requests complete in order, so "chunk g has landed" = at most the requests issued behind it outstanding:
+// s_waitcnt vmcnt(4) in front of tap 0, vmcnt(9) in front of taps 1 and 2 (5 activation + 2 weight requests per wave and
+// slot), vmcnt(2) / vmcnt(0) in the last step, where nothing is requested any more.  Same products, same order of accumulation per output as wn_gate_f16_kernel: same bits.
+constexpr int GW_A = 0;                                     // two operand stages of GH_A_FLOATS
+constexpr int GW_B = 2 * GH_A_FLOATS;                       // ring of four tap chunks
+constexpr int GW_CHUNK = 2 * 2048;                          // one tap, two column tiles: 16 KB
+constexpr int GW_COND = GW_B + 4 * GW_CHUNK;                // 28 conditioning rows x 128 floats
+constexpr int GW_TAB = GW_COND + GH_COND_ROWS * 128;
+constexpr int GW_LERP = GW_TAB + GH_ROWS;
+constexpr int GW_LDS_FLOATS = GW_LERP + 128;                // 18432 + 16384 + 3584 + 256 + 128 floats = 151.5 KB
+
+__global__ __launch_bounds__(512, 1) void wn_gate_f16w_kernel(ConvArgs p, int log2d) {
+    typedef __attribute__((address_space(3))) float lds_float;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float *)lds);
+
+    // XCD-aware decode; p.n_tiles counts PAIRS of column tiles here
+    const int id = blockIdx.x;
+    const int l = id >> 3;
+    const int g_ = (l / p.n_tiles) * 8 + (id & 7);
+    const int np = l % p.n_tiles;
+    if (g_ >= p.m_tiles_total) return;
+    const int b = g_ / p.m_tiles_per_item;
+    const int mt = g_ - b * p.m_tiles_per_item;
+    const int rows = item_rows(p.n_frames, b, p.rows_per_frame, p.max_rows);
+    const int m0 = mt * GH_ROWS;
+    if (m0 >= rows) return;
+    const int C = p.channels;
+    const int d = 1 << log2d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rw = wave & 3, cw = wave >> 2;                  // row quarter and column tile of this wave
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int nk = (p.cin + GH_BK - 1) / GH_BK;
+    const int n_ct = (C + 31) / 32;                           // column tiles of the layer
+    const int nt = 2 * np + cw;                               // this wave's column tile (may not exist: C / 32 odd)
+    const int n0 = nt * 32;
+
+    // ---- per-lane sources of the activation requests (fixed for the block except the channel offset): piece j = staged rows
+    // 8 j .. 8 j + 7 (lane -> row 8 j + (lane >> 3), chunk position lane & 7); 36 pieces, five per wave (32 .. 35 twice)
+    const _Float16 *pb = reinterpret_cast<const _Float16 *>(p.h_split + (long long)b * p.h_split_bstride);
+    const _Float16 *asrc[5];
+    int achl[5];
+    bool arow_ok[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        int piece = wave + 8 * i;
+        if (piece >= GH_AROWS / 8) piece -= 8;                // (the duplicate requests keep the counts of all waves equal)
+        const int r = 8 * piece + (lane >> 3);
+        const int src_row = m0 - GH_HALO + r;
+        const int c8 = (lane & 7) ^ ((r >> 1) & 7);
+        achl[i] = 8 * (c8 & 3);
+        arow_ok[i] = src_row >= 0 && src_row < rows;
+        asrc[i] = pb + (long long)min(max(src_row, 0), rows - 1) * (2 * p.h_split_ld) + (c8 >> 2) * p.h_split_ld + achl[i];
+    }
+    auto issue_a = [&](int kt) {
+        const unsigned adst = lds_base + 4u * (unsigned)(GW_A + (kt & 1) * GH_A_FLOATS);
+        const int ci0 = kt * GH_BK;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            int piece = wave + 8 * i;
+            if (piece >= GH_AROWS / 8) piece -= 8;
+            const bool ok = arow_ok[i] && ci0 + achl[i] < p.cin;
+            gh_lds_dma16(ok ? reinterpret_cast<const float *>(asrc[i] + ci0) : p.zeros, adst + 1024u * (unsigned)piece);
+        }
+    };
+    // tap chunk g = 3 kt + tap of both column tiles -> slot g & 3: piece `wave` of each tile's 8 KB
+    const unsigned b_voff = 16u * (unsigned)lane;
+    auto issue_b = [&](int g) {
+        const int kt = g / 3, tap = g - 3 * kt;
+        const unsigned bdst = lds_base + 4u * (unsigned)(GW_B + (g & 3) * GW_CHUNK);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int ct = 2 * np + t;
+            const float *bsrc = p.w + ((long long)min(ct, n_ct - 1) * nk + kt) * GH_B_FLOATS + tap * 2048 + wave * 256;
+            gh_lds_dma16_s(bsrc, b_voff, bdst + 4u * (unsigned)(t * 2048) + 1024u * (unsigned)wave);
+        }
+    };
+    // ---- conditioning rows of this block: 28 x 2 tiles x (32 tanh | 32 sigmoid) columns = 14 pieces
+    const int cond_up = p.cond_up;
+    const int t2base = m0 / cond_up;
+    {
+        const int n2 = rows / cond_up;
+        const float *cbase = p.cond + (long long)b * p.cond_bstride;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = wave + 8 * i;
+            if (piece >= GH_COND_ROWS / 2) break;
+            const int pos = piece * 64 + lane;
+            const int crow = pos >> 5, cq = pos & 31;
+            const int chn = (2 * np + (cq >> 4)) * 32 + 4 * (cq & 7);
+            const int t = min(t2base + crow, n2 - 1);
+            gh_lds_dma16(chn < C ? cbase + (long long)t * (2 * C) + ((cq >> 3) & 1) * C + chn : p.zeros,
+                         lds_base + 4u * (unsigned)GW_COND + 1024u * (unsigned)piece);
+        }
+    }
+    issue_a(0);
+    issue_b(0);
+    issue_b(1);
+    issue_b(2);
+
+    const bool ch_ok = n0 + 2 * r16 < C;
+    f32x4 accm[4][4], accx[4][4];          // [row tile][column tile: 2 e + (0 tanh | 1 sigmoid)]: hi hi | cross products
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float bv = (p.bias && ch_ok) ? p.bias[(c & 1) * C + n0 + 2 * r16 + (c >> 1)] : 0.f;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                accm[rt][c][v] = bv;
+                accx[rt][c][v] = 0.f;
+            }
+    }
+    if (tid < GH_ROWS) {
+        const int row = m0 + tid;
+        const int t2 = row / cond_up;
+        const int u = row - t2 * cond_up;
+        reinterpret_cast<int *>(lds + GW_TAB)[tid] = (((t2 - t2base) * 128) << 8) | u;
+    }
+    if (tid < 64) {
+        lds[GW_LERP + tid] = tid < cond_up ? p.lerp_w0[tid] : 0.f;
+        lds[GW_LERP + 64 + tid] = tid < cond_up ? p.lerp_w1[tid] : 0.f;
+    }
+
+    const f16x8 *bring = reinterpret_cast<const f16x8 *>(lds) + GW_B / 4 + cw * 512 + lane;     // + slot * (GW_CHUNK / 4) + (c * 2 + image) * 64
+    const int ntap = 3 * nk;
+    for (int kt = 0; kt < nk; ++kt) {
+        const char *ys = reinterpret_cast<const char *>(lds + GW_A + (kt & 1) * GH_A_FLOATS);
+        const bool last = kt + 1 == nk;
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            const int g = 3 * kt + tap;
+            // chunk g (and, at tap 0, the rows of this step) have landed when at most the requests issued behind them are out
+            // (last step: nothing is requested any more, the counts run out)
+            if (tap == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (!last) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else if (tap == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                   // ... for every wave; and every wave is past tap g - 1
+            if (tap == 0 && !last) issue_a(kt + 1);
+            if (g + 3 < ntap) issue_b(g + 3);
+            const f16x8 *bs = bring + (g & 3) * (GW_CHUNK / 4);
+            f16x8 bh[4], bl[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                bh[c] = bs[(c * 2 + 0) * 64];
+                bl[c] = bs[(c * 2 + 1) * 64];
+            }
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                const int r = 64 * rw + 16 * rt + r16 + GH_HALO + (tap - 1) * d;
+                const int key = (r >> 1) & 7;
+                const f16x8 ah = *reinterpret_cast<const f16x8 *>(ys + 128 * r + 16 * (kq ^ key));
+                const f16x8 al = *reinterpret_cast<const f16x8 *>(ys + 128 * r + 16 * ((4 + kq) ^ key));
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    accm[rt][c] = GH_MFMA(ah, bh[c], accm[rt][c]);
+                    accx[rt][c] = GH_MFMA(ah, bl[c], accx[rt][c]);
+                    accx[rt][c] = GH_MFMA(al, bh[c], accx[rt][c]);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue (as in wn_gate_f16_kernel): main + 2^-11 cross, conditioning, gate, store
+    float *obase = p.out + (long long)b * p.out_bstride + n0 + 2 * r16;
+    const float *clane = lds + GW_COND + cw * 64 + 2 * r16;
+    int etab[4][4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) etab[rt][v] = reinterpret_cast<const int *>(lds + GW_TAB)[64 * rw + 16 * rt + 4 * kq + v];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        float2 w[4], ct0[4], ct1[4], cs0[4], cs1[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int e = etab[rt][v];
+            w[v] = make_float2(lds[GW_LERP + (e & 255)], lds[GW_LERP + 64 + (e & 255)]);
+            const float *c0 = clane + (e >> 8);
+            ct0[v] = *reinterpret_cast<const float2 *>(c0);
+            ct1[v] = *reinterpret_cast<const float2 *>(c0 + 128);
+            cs0[v] = *reinterpret_cast<const float2 *>(c0 + 32);
+            cs1[v] = *reinterpret_cast<const float2 *>(c0 + 160);
+        }
+        float2 res[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            float y[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) y[c] = fmaf(accx[rt][c][v], 1.0f / 2048.0f, accm[rt][c][v]);
+            res[v].x = wn_gate_act(p.gate_act, y[0] + fmaf(ct0[v].x, w[v].x, ct1[v].x * w[v].y), y[1] + fmaf(cs0[v].x, w[v].x, cs1[v].x * w[v].y));
+            res[v].y = wn_gate_act(p.gate_act, y[2] + fmaf(ct0[v].y, w[v].x, ct1[v].y * w[v].y), y[3] + fmaf(cs0[v].y, w[v].x, cs1[v].y * w[v].y));
+            asm volatile("" : "+v"(res[v].x), "+v"(res[v].y));
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int row = m0 + 64 * rw + 16 * rt + 4 * kq + v;
+            if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res[v];
+        }
+    }
+}
+
 // a.w must point at the image of engine.pack_gate_f16_weights (ceil(C/32) column tiles, ceil(C/32) steps, 6144 floats);
 // returns false if the layer does not fit (the caller then runs the float32 kernels)
 bool launch_wn_gate_f16(const ConvArgs &a, hipStream_t stream) {
@@ -306,7 +526,10 @@ bool launch_wn_gate_f16(const ConvArgs &a, hipStream_t stream) {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) return false;
     const bool attr_set = dev >= 0 && dev < 64 && ((attr_devices >> dev) & 1ull);
+    static bool gw_ok = false;
     if (!attr_set) {
+        gw_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(wn_gate_f16w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    GW_LDS_FLOATS * (int)sizeof(float)) == hipSuccess;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(wn_gate_f16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GH_LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(wn_gate_f16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -319,7 +542,13 @@ bool launch_wn_gate_f16(const ConvArgs &a, hipStream_t stream) {
     r.m_tiles_per_item = (a.max_rows + GH_ROWS - 1) / GH_ROWS;
     r.m_tiles_total = r.m_tiles_per_item * a.batch;
     const long long blocks = 8LL * ((r.m_tiles_total + 7) / 8) * r.n_tiles;
-    if (a.h_split)
+    // 256 x 128 tiles (pairs of column tiles) for launches of several rounds of blocks: 0.83 against 0.93 ms at 16 x 10 s; one
+    // utterance of 10 s is 315 such blocks on 256 CUs and keeps the 256 x 64 tiles (72.5 against 78.7 us).  Same bits.
+    const long long blocks2 = 8LL * ((r.m_tiles_total + 7) / 8) * ((r.n_tiles + 1) / 2);
+    if (a.h_split && gw_ok && (a.cin + GH_BK - 1) / GH_BK >= 2 && blocks2 >= 4 * 256) {
+        r.n_tiles = (r.n_tiles + 1) / 2;
+        hipLaunchKernelGGL(wn_gate_f16w_kernel, dim3((unsigned)blocks2), dim3(512), GW_LDS_FLOATS * sizeof(float), stream, r, log2d);
+    } else if (a.h_split)
         hipLaunchKernelGGL(wn_gate_f16_kernel<true>, dim3((unsigned)blocks), dim3(512), GH_LDS_FLOATS * sizeof(float), stream, r, log2d);
     else
         hipLaunchKernelGGL(wn_gate_f16_kernel<false>, dim3((unsigned)blocks), dim3(512), GH_LDS_FLOATS * sizeof(float), stream, r, log2d);

@@ -271,7 +271,10 @@ bool launch_wn_tail(const float *skip, long long skip_bstride, const int *n_fram
     const int nc8 = (C + 7) / 8, nj = (8 * nc8 + 15) / 16;
     const size_t lds2 = std::max((size_t)nc8 * 256, (size_t)(4 * T2_YT + 32 * 16 + 16)) * sizeof(float);
     if (nj <= 22 && C >= 16) {
-        auto kern = nj <= 20 ? wn_tail2_kernel<20> : wn_tail2_kernel<22>;
+        // the smallest instantiation that holds the row: a lane issues NJ loads and keeps 4 NJ registers whatever C is
+        // (same arithmetic in the same order for every NJ >= nj; ADVICE round 5: C = 64 used to issue 20 loads for 4)
+        auto kern = nj <= 4 ? wn_tail2_kernel<4> : nj <= 8 ? wn_tail2_kernel<8> : nj <= 12 ? wn_tail2_kernel<12> :
+                    nj <= 20 ? wn_tail2_kernel<20> : wn_tail2_kernel<22>;
         hipLaunchKernelGGL(kern, dim3((max_rows + T2_ROWS - 1) / T2_ROWS, batch), dim3(256), lds2, stream, skip, skip_bstride,
                            n_frames, rows_per_frame, max_rows, C, w_end_packed, b_end, n_out, w_post, b_post, M, y_acc, y,
                            y_bstride, sub, sub_bstride);

@@ -124,8 +124,18 @@ class MELInverter(object):
 
         ``noise`` optionally injects the N(0,1) draw of the noise channel (shape (B, T*steps_per_frame));
         by default it is drawn on the device, as the reference draws tf.random.normal."""
-        if self._calibrate_pending:                 # load_model(..., calibrate=True): the first real mel decides the form
-            self.calibrate([scaled_mell], verbose=self._verbose)
+        if self._calibrate_pending:
+            # load_model(..., calibrate=True): the FIRST mel synthesised decides the form for every later call (at most 400 of
+            # its frames are used) -- results therefore depend on which utterance came first; calibrate([...]) on a fixed set
+            # (resynth_mel.py --calibrate N) is the reproducible way.  A calibration that cannot run (e.g. a form pinned by the
+            # configuration) must not fail the synthesis: keep the creation-time form and say so.
+            self._calibrate_pending = False
+            try:
+                self.calibrate([scaled_mell], verbose=self._verbose)
+            except Exception as exc:                # noqa: BLE001 -- any engine error: the form of mbx_create stays
+                import warnings
+                warnings.warn(f"MELInverter: calibration on the first mel failed ({exc}); keeping the convolution form "
+                              f"chosen at creation ({self.model.conv_form_info()['form']})", RuntimeWarning)
         syn_audio = self.model.infer(scaled_mell, sigma=None, synth_length=scaled_mell.shape[1] * self.hop_size,
                                      noise=noise).numpy()
         return syn_audio.ravel()
@@ -208,7 +218,9 @@ class MELInverter(object):
         """reference mel_inverter.py:184-239: resolve the model directory, read ``config.yaml``, build the
         generator, restore the weights and copy the pre-processing parameters onto the instance.
 
-        ``calibrate=True`` (this build): the first mel handed to :meth:`synth_from_mel` goes through :meth:`calibrate`
+        ``calibrate=True`` (this build; ORDER DEPENDENT: the decision is taken on at most 400 frames of the first utterance and
+        binds every later one, a failing calibration keeps the creation-time form with a warning): the first mel handed to
+        :meth:`synth_from_mel` goes through :meth:`calibrate`
         before it is synthesised -- the form of the WaveNet's convolution is then decided on the job's own data instead
         of on the synthetic mel of ``mbx_create`` (``resynth_mel.py --calibrate N`` does the same on the first N files)."""
         from . import get_config_file

@@ -358,6 +358,46 @@ PATCHES = {
         ('            if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res;',
          '            if (ch_ok && row < rows && res.x == 123.456f) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res;'),
     ],
+    # round 6: where the time of the plane-fed kernel goes (wn_gate_f16_kernel<true>, 0.93 ms per launch at 16 x 10 s).  The
+    # ablations switch on above 4000 rows per item only: the calibration forward of mbx_create (2 x 40 frames) sees the real
+    # kernel and keeps the split precision, the measured launch (16 000 rows per item) runs the ablated one
+    'g3_noepi': [
+        ('    // ---- epilogue: main + 2^-11 cross, conditioning, gate, store (layout of wn_gate_winograd4w_kernel',
+         '    if (p.max_rows > 4000) {\n        float ssum = 0.f;\n#pragma unroll\n        for (int rt = 0; rt < 2; ++rt)\n#pragma unroll\n            for (int c = 0; c < 4; ++c)\n#pragma unroll\n                for (int v = 0; v < 4; ++v) ssum += accm[rt][c][v] + accx[rt][c][v];\n        if (ssum == 123.456f) p.out[tid] = ssum;\n        return;\n    }\n    // ---- epilogue: main + 2^-11 cross, conditioning, gate, store (layout of wn_gate_winograd4w_kernel'),
+    ],
+    'g3_nobar': [
+        ('        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n        __syncthreads();                       // this step\'s operands are complete',
+         '        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n        if (kt == 0 || p.max_rows <= 4000) __syncthreads();                       // this step\'s operands are complete'),
+    ],
+    'g3_nowait': [
+        ('        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n        __syncthreads();                       // this step\'s operands are complete',
+         '        if (kt == 0 || p.max_rows <= 4000) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }      // this step\'s operands are complete'),
+    ],
+    'g3_nodma': [
+        ('            if (kt + 1 < nk) {\n                issue_a(kt + 1, stage ^ 1);\n                issue_b(kt + 1, stage ^ 1);\n            }',
+         '            if (kt + 1 < nk && p.max_rows <= 4000) {\n                issue_a(kt + 1, stage ^ 1);\n                issue_b(kt + 1, stage ^ 1);\n            }'),
+    ],
+    'g3_nomfma': [
+        ('                    accm[rt][c] = GH_MFMA(ah, bh[c], accm[rt][c]);\n                    accx[rt][c] = GH_MFMA(ah, bl[c], accx[rt][c]);\n                    accx[rt][c] = GH_MFMA(al, bh[c], accx[rt][c]);',
+         '                    if (c == 0 || p.max_rows <= 4000) accm[rt][c] = GH_MFMA(ah, bh[c], accm[rt][c]);\n                    if (p.max_rows <= 4000) accx[rt][c] = GH_MFMA(ah, bl[c], accx[rt][c]);\n                    if (c == 1 || p.max_rows <= 4000) accx[rt][c] = GH_MFMA(al, bh[c], accx[rt][c]);'),
+    ],
+    'g3_noA': [
+        ('            if (kt + 1 < nk) {\n                issue_a(kt + 1, stage ^ 1);\n                issue_b(kt + 1, stage ^ 1);\n            }',
+         '            if (kt + 1 < nk) {\n                if (p.max_rows <= 4000) issue_a(kt + 1, stage ^ 1);\n                issue_b(kt + 1, stage ^ 1);\n            }'),
+    ],
+    'g3_noB': [
+        ('            if (kt + 1 < nk) {\n                issue_a(kt + 1, stage ^ 1);\n                issue_b(kt + 1, stage ^ 1);\n            }',
+         '            if (kt + 1 < nk) {\n                issue_a(kt + 1, stage ^ 1);\n                if (p.max_rows <= 4000) issue_b(kt + 1, stage ^ 1);\n            }'),
+    ],
+    # all LDS operand reads gone (A and B): the MFMAs run on whatever the registers hold
+    'g3_noldsB': [
+        ('                bh[c] = bs[((tap * 4 + c) * 2 + 0) * 64];\n                bl[c] = bs[((tap * 4 + c) * 2 + 1) * 64];',
+         '                if (p.max_rows <= 4000 || (tap == 0 && kt == 0)) {\n                    bh[c] = bs[((tap * 4 + c) * 2 + 0) * 64];\n                    bl[c] = bs[((tap * 4 + c) * 2 + 1) * 64];\n                }\n                asm volatile("" : "+v"(bh[c]), "+v"(bl[c]));'),
+    ],
+    'g3_nolds': [
+        ('                const f16x8 ah = *reinterpret_cast<const f16x8 *>(ys + 128 * r + 16 * (kq ^ key));\n                const f16x8 al = *reinterpret_cast<const f16x8 *>(ys + 128 * r + 16 * ((4 + kq) ^ key));',
+         '                f16x8 ah, al;\n                if (p.max_rows <= 4000) {\n                    ah = *reinterpret_cast<const f16x8 *>(ys + 128 * r + 16 * (kq ^ key));\n                    al = *reinterpret_cast<const f16x8 *>(ys + 128 * r + 16 * ((4 + kq) ^ key));\n                } else {\n                    ah = bh[rt];\n                    al = bl[rt];\n                    asm volatile("" : "+v"(ah), "+v"(al));\n                }'),
+    ],
     # (the round-4 'noside' A/B of the VTF-net side stream patched a constant of commit 42f4fb7; the side stream was removed
     # with ab37db2, so the A/B is reproduced from that commit: git checkout 42f4fb7 -- mbexwn_vocoder_amd/csrc/mbx_api.hip)
     # stft_filter.hip: the block-per-frame kernel at fft_size 2048 as well (round-4 A/B of the wave-per-frame kernel)

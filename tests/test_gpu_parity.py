@@ -714,6 +714,27 @@ def test_large_launch_equals_single_runs_under_batch_invariant(torch):
     assert _maxdiff(out[3, :123 * 300], ref) <= _tol(ref, E2E_TOL)
 
 
+def test_mel_rate_group_launch_large_ragged_equals_small_launches_stage_by_stage(torch):
+    """the shared mel-rate launches at a large launch size (conv1d_mel_group_kernel: 64 x 128 float32 tiles and
+    32 x 32 float64 tiles, three members per launch -- F0-net in float64, VTF-net and conditioning convolution in float32 --,
+    ragged n_frames, 6 x 900 = 5400 frames >= the 4096-frame switch) against the small-launch group kernel that each item takes
+    alone: the F0 contour, the cepstrum and the conditioning rows agree bit for bit (one summation order at every launch size).
+    (ISA check of the same commit: conv1d_mel_group_kernel 141 VGPRs, no scratch, 3 blocks per CU at 48 KB of LDS.)"""
+    eng = get_engine("canon", *CANON)[0]
+    lengths = [900, 611, 900, 37, 768, 899]
+    mel, noise = synthetic_inputs(91, len(lengths), 900)
+    nf = torch.as_tensor(lengths, dtype=torch.int32).cuda()
+    eng.forward(dev(torch, mel), n_frames=nf, noise=dev(torch, noise))
+    big = {kk: eng.stage(kk).cpu().numpy() for kk in ("f0", "cepstrum", "cond")}
+    per_frame = {"f0": eng.dims.pulse_per_frame, "cepstrum": eng.dims.n_ceps, "cond": eng.dims.cond_conv_upsampling * 2 * eng.dims.wn_channels}
+    for ii in (0, 1, 3, 5):
+        ll = lengths[ii]
+        eng.forward(dev(torch, mel[ii:ii + 1, :ll]), noise=dev(torch, noise[ii:ii + 1, :ll * 20]))
+        for kk, pf in per_frame.items():
+            single = eng.stage(kk).cpu().numpy()[0]
+            assert np.array_equal(big[kk][ii, :ll * pf], single[:ll * pf]), f"stage {kk} of item {ii}"
+
+
 @pytest.mark.parametrize("batch,frames", [(2, 30), (1, 800), (16, 800)])
 def test_deterministic(torch, batch, frames):
     """Same input, same bits -- also at the BASELINE sizes, where the large-launch kernels (F(4,3) with its three-stage
