@@ -1300,6 +1300,7 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     const int wn_rows = wn_frames_max * c.steps_per_frame;
     int act_frames_max = T - (int)act0;
     if (active_frames && active_max_frames > 0) act_frames_max = std::min(act_frames_max, active_max_frames);
+    bool planes_only_run = false;      // set by single_block: split precision ran with the fp16 planes as the hidden state
     // ---- WaveNet (reference custom_AE_layers.py:273-346): one block (the measured path) or several (generic kernels)
     auto single_block = [&]() -> mbx_status {
     const bool fold_start = hd->fold_start;
@@ -1362,6 +1363,15 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     }
     auto lerp = hd->lerp[cond_up];
     bool planes_valid = false;        // split half precision: the last res/skip launch also wrote h as fp16 planes (w.h16)
+    // split half precision, round 6: where every consumer of the hidden state takes the planes -- the split gate of every layer
+    // behind the first one (dilation <= 16: wn_gate_f16.hip) and the split res/skip layer of every layer in front of the last
+    // one, layer 0's with the folded start convolution included -- the planes ARE the hidden state: hi + 2^-11 lo' keeps 22-23 of
+    // float32's 24 bits, and the float32 tensor h (328 MB written and read again per layer at 16 x 10 s) is not touched
+    bool planes_only = hd->split_f16 && hd->split_f16_gate && fold && fold_start && !st_in && !st_out && !active_frames && !lay && L >= 2 &&
+                       find(hd, "wn.res_skip_0.fold_start_f16") != nullptr;
+    for (int l = 1; l < L && planes_only; ++l) planes_only = c.wn_dilations[l] <= 16;
+    for (int l = 1; l + 1 < L && planes_only; ++l) planes_only = find(hd, "wn.res_skip_" + std::to_string(l) + ".fold_f16") != nullptr;
+    planes_only_run = planes_only;
     hd->last_gate_layers = L;
     for (int l = 0; l < L; ++l) {
         const std::string ls = std::to_string(l);
@@ -1473,6 +1483,8 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                 }
                 done = mbx::launch_wn_gate_f16(gh, stream);
                 if (done) hd->last_gate_kernel[l] = MBX_GATE_K_SPLIT_F16;
+                if (planes_only && !(done && planes_valid))
+                    return fail(MBX_ERR_INVALID_ARGUMENT, "split precision: a gate layer did not take the plane-only hidden state");
             }
             bool use4 = !done && hd->winograd == 4 && !st_in && !st_out;
             if (use4 && d > 16) {
@@ -1566,11 +1578,15 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                         rh.h_split = w.h16;
                         rh.h_split_ld = (C + 7) / 8 * 8;
                         rh.h_split_bstride = nsteps * (long long)rh.h_split_ld;
+                        rh.h_planes_only = planes_only ? 1 : 0;
                     }
                     done = mbx::launch_wn_resskip_f16(rh, stream);
                     planes_valid = done && rh.h_split != nullptr;
+                    if (planes_only && !planes_valid)
+                        return fail(MBX_ERR_INVALID_ARGUMENT, "split precision: a res/skip layer did not take the plane-only hidden state");
                 } else {
                     planes_valid = false;
+                    if (planes_only) return fail(MBX_ERR_INVALID_ARGUMENT, "split precision: a res/skip image is missing behind a plane-only layer");
                 }
                 const DevTensor *fww = done ? nullptr : find(hd, "wn.res_skip_" + ls + (ext ? ".fold_start_wide" : ".fold_wide"));
                 const long long wide_blocks = ((nsteps + 127) / 128) * B;
@@ -1725,7 +1741,15 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
     sg["f0"] = {w_base.f0, npulse, npulse};
     sg["pulse"] = {pulse_osc, npulse * (1 + c.wt_subharm_channels), npulse * (1 + c.wt_subharm_channels)};
     sg["cond"] = {w_base.cond, (long long)T * cond_cout, (long long)T * cond_cout};
-    sg["wn_hidden"] = {w_base.h, nsteps * C, nsteps * C};
+    if (planes_only_run) {
+        // split precision with the planes as the hidden state: the float32 tensor was not written; per row [C8 hi halves | C8 lo'
+        // halves] = C8 float32 words (engine.py::stage rebuilds hi + 2^-11 lo' from it)
+        sg.erase("wn_hidden");
+        sg["wn_hidden_planes"] = {w_base.h16, nsteps * (long long)((C + 7) / 8 * 8), nsteps * (long long)((C + 7) / 8 * 8)};
+    } else {
+        sg.erase("wn_hidden_planes");
+        sg["wn_hidden"] = {w_base.h, nsteps * C, nsteps * C};
+    }
     if (!hd->fold_skip) sg["wn_skip"] = {w_base.skip, nsteps * C, nsteps * C};
     else sg.erase("wn_skip");
     sg["wn_out"] = {w_base.wn_out, nsteps * c.wn_out_channels, nsteps * c.wn_out_channels};

@@ -97,6 +97,8 @@ struct ConvArgs {
     float *h_split;
     long long h_split_bstride;   // float32 words between batch items
     int h_split_ld;
+    int h_planes_only;        // wn_resskip_f16_kernel: the planes ARE the hidden state -- old values are read from them (hi + 2^-11 lo'),
+                              // the float32 tensor h is neither read nor written (every consumer of h takes the planes)
     int tune_split;           // wave-tiled res/skip kernel: 1..3 pins its column split (mbx_config.tune_resskip_split; same bits), 0: by launch size
     // EPI_LINEAR, the F0-net (conv1d_f64_tile): contraction on v_mfma_f64_16x16x4_f64
     int precise;              // 1: float64 accumulation; with only this set x, w and out are the float32 ones above (one rounding per output)

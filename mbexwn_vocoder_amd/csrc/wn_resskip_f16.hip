@@ -129,6 +129,9 @@ __global__ __launch_bounds__(512, 4) void wn_resskip_f16_kernel(ConvArgs p) {
     // (groups of three pairs: all requests of a group first, then the arithmetic -- pair by pair the compiler waits for every
     // bias load on its own, which also drains the previous pair's row loads: wn_resskip_wide.hip)
     const float *bias_src = p.bias ? p.bias : p.zeros;
+    const bool planes_only = p.h_planes_only != 0 && p.h_split != nullptr;
+    const _Float16 *planes_in = p.h_split ? reinterpret_cast<const _Float16 *>(p.h_split + (long long)b * p.h_split_bstride) : nullptr;
+    const int pld_in = 2 * p.h_split_ld;
 #pragma unroll
     for (int g0 = 0; g0 < RH_NP; g0 += 3) {
         float2 bias3[3], old3[3][4];
@@ -138,10 +141,21 @@ __global__ __launch_bounds__(512, 4) void wn_resskip_f16_kernel(ConvArgs p) {
             const int colc = min(32 * (pair0 + pr) + 2 * r16, p.cout - 2);
             const bool to_h = colc < C;
             bias3[j] = *reinterpret_cast<const float2 *>(bias_src + (p.bias ? colc : 0));
-            const float *src = to_h ? hb + colc : sb + (colc - C);
-            const int ld = to_h ? C : skip_ld;
+            if (planes_only && to_h) {
+                // the hidden state lives in the fp16 planes only: old value = hi + 2^-11 lo' (exact in float32)
+                typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int v = 0; v < 4; ++v) old3[j][v] = *reinterpret_cast<const float2 *>(src + (long long)min(row0 + v, row_last) * ld);
+                for (int v = 0; v < 4; ++v) {
+                    const _Float16 *pr_ = planes_in + (long long)min(row0 + v, row_last) * pld_in + colc;
+                    const f16x2 hh = *reinterpret_cast<const f16x2 *>(pr_), ll = *reinterpret_cast<const f16x2 *>(pr_ + p.h_split_ld);
+                    old3[j][v] = make_float2(fmaf((float)ll[0], 1.0f / 2048.0f, (float)hh[0]), fmaf((float)ll[1], 1.0f / 2048.0f, (float)hh[1]));
+                }
+            } else {
+                const float *src = to_h ? hb + colc : sb + (colc - C);
+                const int ld = to_h ? C : skip_ld;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) old3[j][v] = *reinterpret_cast<const float2 *>(src + (long long)min(row0 + v, row_last) * ld);
+            }
         }
         RH_FENCE();
 #pragma unroll
@@ -212,6 +226,7 @@ __global__ __launch_bounds__(512, 4) void wn_resskip_f16_kernel(ConvArgs p) {
         }
         if (col >= p.cout) continue;
         const bool to_h = col < C;
+        if (to_h && planes_only) continue;             // the planes above are the hidden state
         float *dst = to_h ? hb + col : sb + (col - C);
         const int ld = to_h ? C : skip_ld;
 #pragma unroll

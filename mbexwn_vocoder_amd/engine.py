@@ -1104,8 +1104,15 @@ class MBExWNEngine:
         """Intermediate tensor of the last forward (copy), shaped (B, count); see mbx_stage."""
         torch = self._torch
         ptr, cnt, stride = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int64()
-        _check(self._lib.mbx_stage(self._handle, name.encode(), ctypes.byref(ptr), ctypes.byref(cnt),
-                                   ctypes.byref(stride)))
+        status = self._lib.mbx_stage(self._handle, name.encode(), ctypes.byref(ptr), ctypes.byref(cnt), ctypes.byref(stride))
+        if status != 0 and name == "wn_hidden":
+            # split precision with the fp16 planes as the hidden state (csrc/mbx_api.hip: planes_only): the float32 tensor was
+            # not written; rebuild hi + 2^-11 lo' from the planes -- per row [C8 hi halves | C8 lo' halves]
+            planes = self.stage("wn_hidden_planes")
+            C, c8 = self.dims.wn_channels, (self.dims.wn_channels + 7) // 8 * 8
+            halves = planes.view(torch.float16).view(planes.shape[0], -1, 2, c8).float()
+            return (halves[:, :, 0, :C] + halves[:, :, 1, :C] / 2048.0).reshape(planes.shape[0], -1)
+        _check(status)
         B = self._last_shape[0]
         dtype = torch.int32 if name == "ceps_index" else torch.float32
         ws = self._workspace
