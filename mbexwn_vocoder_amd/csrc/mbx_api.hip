@@ -1496,7 +1496,8 @@ static mbx_status forward_impl(mbx_handle *hd, const float *mel, const int32_t *
                 // under the default policy (batch_invariant: always F(4,3)).
                 const int vs = d / 16;
                 const long long vrows = ((long long)gs.max_rows + vs - 1) / vs, tiles = (C + 31) / 32;
-                const double cost_full = (double)((vrows + 255) / 256) * B * vs * tiles;
+                // (sub-sequences of at most 128 rows: a 256-row block takes two of them)
+                const double cost_full = (vrows <= 128 ? 0.5 : (double)((vrows + 255) / 256)) * B * vs * tiles;
                 const double cost_half = 0.56 * (double)((vrows + 127) / 128) * B * vs * tiles;
                 const double cost_direct = 2.0 * ((double)gs.max_rows / 256.0) * B * tiles;
                 if (hd->gate_small_shape >= 0 && !hd->winograd4_always) {

@@ -114,7 +114,12 @@ using ww_int = std::integral_constant<int, N>;
 // at log2d = 4.  An LDS-DMA lane fetches 16 bytes of one row either way, so the staging costs the same; what differs is the
 // conditioning: a block's 256 virtual rows span 256 s real rows (~26 s conditioning rows: no LDS tile holds them), so the
 // epilogue reads its two conditioning rows per output from global memory (L2) instead, eight float2 per output pair.
-template <int CR, int GA, bool VS = false>
+// VS == 2: virtual items of at most 128 rows (d = 2048 at 10 s: 125 rows per sub-sequence) would leave half of a 256-row
+// block empty: the block takes TWO neighbouring sub-sequences instead -- waves 0, 1 (rows 0 .. 127 of the block) those of
+// sub-sequence `strip`, waves 2, 3 those of `strip + 1`.  The staged cells hold 20 rows-of-sixteen (m = 0 .. 19: 320 cells,
+// all the LDS stage has): m < 10 the rows [-16, 144) of the first, m >= 10 of the second sub-sequence.  Same groups, same
+// sums: the same bits as the other shapes.
+template <int CR, int GA, int VS = 0>
 __global__ __launch_bounds__(256, CR <= 28 ? 3 : 2) void wn_gate_winograd4w_kernel(ConvArgs p, int log2d) {
     using SH = WwShape<CR>;
     constexpr int ROWS = SH::ROWS, NSTAGE = SH::NSTAGE, STAGE = SH::STAGE, A_FLOATS = SH::A_FLOATS, PHASE = SH::PHASE;
@@ -131,10 +136,12 @@ __global__ __launch_bounds__(256, CR <= 28 ? 3 : 2) void wn_gate_winograd4w_kern
     const int bv = g_ / p.m_tiles_per_item;                 // (virtual) item
     const int mt = g_ - bv * p.m_tiles_per_item;
     const int vs = VS ? p.vstride : 1;
-    const int b = VS ? bv / vs : bv;
-    const int strip = VS ? bv - b * vs : 0;                 // first real row of the virtual item
+    const int vper = VS == 2 ? vs / 2 : vs;                 // (pairs of) virtual items per item
+    const int b = VS ? bv / vper : bv;
+    const int strip = VS ? (bv - b * vper) * (VS == 2 ? 2 : 1) : 0;          // first real row of the (first) virtual item
     const int rows_item = item_rows(p.n_frames, b, p.rows_per_frame, p.max_rows);
     const int rows = VS ? (rows_item - strip + vs - 1) / vs : rows_item;      // rows strip, strip + vs, ... < rows_item
+    const int rows2 = VS == 2 ? max(rows_item - strip - 1 + vs - 1, 0) / vs : 0;      // ... of the second sub-sequence (VS == 2)
     const int m0 = mt * ROWS;
     if (m0 >= rows) return;
     const int C = p.channels;
@@ -166,12 +173,22 @@ __global__ __launch_bounds__(256, CR <= 28 ? 3 : 2) void wn_gate_winograd4w_kern
         const int cell = pos >> 1;
         const int phase = cell / PHASE, sidx = cell - phase * PHASE;
         const int m = 4 * (sidx >> log2d) + phase;
-        const int row = (m << log2d) + (sidx & (d - 1)) + WW_HALO - d;       // staged row index, m0 - 16 + row = source
-        const int src = m0 - WW_HALO + row;
         const int hi = (pos & 1) ^ ((cell >> 3) & 1);
-        if (row < SH::AROWS && src >= 0 && src < rows) a_bits |= 1u << i;
-        a_bits |= (unsigned)hi << (4 + i);
-        a_voff[i] = 4u * (unsigned)((min(max(src, 0), rows - 1) - xrow0) * ldxv + 4 * hi);
+        if (VS == 2) {
+            // (d = 16, m0 = 0) m < 10: rows -16 + 16 m + b of the first sub-sequence, m >= 10: of the second one (one real row on)
+            const int sub = m >= 10 ? 1 : 0;
+            const int src = 16 * (m - 10 * sub) + (sidx & 15) - WW_HALO;
+            const int rs = sub ? rows2 : rows;
+            if (m < 20 && src >= 0 && src < rs) a_bits |= 1u << i;
+            a_bits |= (unsigned)hi << (4 + i);
+            a_voff[i] = 4u * (unsigned)(min(max(src, 0), max(rs - 1, 0)) * ldxv + sub * p.ldx + 4 * hi);
+        } else {
+            const int row = (m << log2d) + (sidx & (d - 1)) + WW_HALO - d;       // staged row index, m0 - 16 + row = source
+            const int src = m0 - WW_HALO + row;
+            if (row < SH::AROWS && src >= 0 && src < rows) a_bits |= 1u << i;
+            a_bits |= (unsigned)hi << (4 + i);
+            a_voff[i] = 4u * (unsigned)((min(max(src, 0), rows - 1) - xrow0) * ldxv + 4 * hi);
+        }
     }
     // interior blocks (every staged row exists, whole stage fills): uniform base + per-lane byte offset, no selects
     // (C = 340: every stage fill but the last one is whole, so only that one takes the masked path)
@@ -241,7 +258,8 @@ __global__ __launch_bounds__(256, CR <= 28 ? 3 : 2) void wn_gate_winograd4w_kern
     {
         // block row lr = tid: conditioning row offset and interpolation weights (read in the epilogue)
         if (tid < ROWS) {
-            const int row = VS ? strip + vs * (m0 + tid) : m0 + tid;          // real row
+            const int row = VS == 2 ? strip + (tid >> 7) + vs * (tid & 127)    // real row: the block's second half = second sub-sequence
+                                    : VS ? strip + vs * (m0 + tid) : m0 + tid;
             const int t2 = row / cond_up;
             const int u = row - t2 * cond_up;
             // VS: the conditioning row itself (< 2^24 / cond_up), read from global memory in the epilogue
@@ -259,7 +277,9 @@ __global__ __launch_bounds__(256, CR <= 28 ? 3 : 2) void wn_gate_winograd4w_kern
     const float *xptr[6];     // LDS addresses (stage 0) of h[t-d] .. h[t+4d]
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
-        const int cell = (q & 3) * PHASE + grp + ((q >> 2) << log2d);
+        // row-of-sixteen m = 4 rw + q of the staged window (VS == 2, second sub-sequence: its rows start at m = 10)
+        const int m = 4 * rw + q + ((VS == 2 && rw >= 2) ? 2 : 0);
+        const int cell = VS == 2 ? (m & 3) * PHASE + ((m >> 2) << 4) + r16 : (q & 3) * PHASE + grp + ((q >> 2) << log2d);
         xptr[q] = lds + 8 * cell + 4 * ((kq >> 1) ^ ((cell >> 3) & 1)) + 2 * (kq & 1);
     }
     const float *bptr = lds + A_FLOATS + lane * 4;
@@ -396,7 +416,7 @@ __global__ __launch_bounds__(256, CR <= 28 ? 3 : 2) void wn_gate_winograd4w_kern
                 // channel pair; rows clamp at the item's last conditioning row like the LDS tile's (edge replication)
                 const int n2 = rows_item / cond_up;
                 const int t2 = (int)((unsigned)e >> 8);
-                const bool live = ch_ok && m0 + lr0 + (o << log2d) < rows;
+                const bool live = ch_ok && (VS == 2 ? ((lr0 + (o << log2d)) & 127) < (rw >= 2 ? rows2 : rows) : m0 + lr0 + (o << log2d) < rows);
                 const float *g0 = live ? gcond + (long long)min(t2, n2 - 1) * (2 * C) : p.zeros;
                 const float *g1 = live ? gcond + (long long)min(t2 + 1, n2 - 1) * (2 * C) : p.zeros;
                 const int so = live ? C : 0;
@@ -433,9 +453,10 @@ __global__ __launch_bounds__(256, CR <= 28 ? 3 : 2) void wn_gate_winograd4w_kern
         }
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            const int row = m0 + lr0 + (o << log2d);
-            const long long orow = VS ? (long long)strip + (long long)vs * row : row;          // real row
-            if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + orow * p.ldo) = res[o];
+            const int row = VS == 2 ? (lr0 + (o << log2d)) & 127 : m0 + lr0 + (o << log2d);      // (virtual) row of the output
+            const int sub = (VS == 2 && rw >= 2) ? 1 : 0;
+            const long long orow = VS ? (long long)strip + sub + (long long)vs * row : row;        // real row
+            if (ch_ok && row < (sub ? rows2 : rows)) *reinterpret_cast<float2 *>(obase + orow * p.ldo) = res[o];
         }
     }
 }
@@ -491,7 +512,7 @@ __device__ __forceinline__ void wp_comb(int PH, const float2 (&x)[6], float2 (&u
 }
 
 // VS: virtual items of row stride ConvArgs::vstride (dilations above 16), see wn_gate_winograd4w_kernel
-template <int GA, bool VS = false>
+template <int GA, int VS = 0>
 __global__ __launch_bounds__(256, 3) void wn_gate_winograd4p_kernel(ConvArgs p, int log2d) {
     using SH = WpShape;
     constexpr int ROWS = SH::ROWS, NSTAGE = SH::NSTAGE, STAGE = SH::STAGE, A_FLOATS = SH::A_FLOATS, PHASE = SH::PHASE;
@@ -1094,6 +1115,9 @@ bool launch_wn_gate_winograd4w(const ConvArgs &a, int shape, hipStream_t stream)
     const int vrows = (a.max_rows + vs - 1) / vs;         // rows of the longest virtual item
     r.m_tiles_per_item = (vrows + rows_blk - 1) / rows_blk;
     r.m_tiles_total = r.m_tiles_per_item * a.batch * vs;
+    // sub-sequences of at most 128 rows: a 256-row block takes two of them (VS == 2)
+    const bool two = vs > 1 && !split && vrows <= 128 && vs % 2 == 0 && log2d == 4;
+    if (two) r.m_tiles_total = a.batch * (vs / 2);
     const long long blocks = 8LL * ((r.m_tiles_total + 7) / 8) * r.n_tiles;
     const dim3 blk(256);
     const bool gtu = a.gate_act == 0;
@@ -1106,10 +1130,12 @@ bool launch_wn_gate_winograd4w(const ConvArgs &a, int shape, hipStream_t stream)
     }
     const dim3 grid((unsigned)blocks);
     if (vs > 1) {
-        if (split && gtu) hipLaunchKernelGGL((wn_gate_winograd4p_kernel<0, true>), grid, blk, 0, stream, r, log2d);
-        else if (split) hipLaunchKernelGGL((wn_gate_winograd4p_kernel<-1, true>), grid, blk, 0, stream, r, log2d);
-        else if (gtu) hipLaunchKernelGGL((wn_gate_winograd4w_kernel<28, 0, true>), grid, blk, 0, stream, r, log2d);
-        else hipLaunchKernelGGL((wn_gate_winograd4w_kernel<28, -1, true>), grid, blk, 0, stream, r, log2d);
+        if (split && gtu) hipLaunchKernelGGL((wn_gate_winograd4p_kernel<0, 1>), grid, blk, 0, stream, r, log2d);
+        else if (split) hipLaunchKernelGGL((wn_gate_winograd4p_kernel<-1, 1>), grid, blk, 0, stream, r, log2d);
+        else if (two && gtu) hipLaunchKernelGGL((wn_gate_winograd4w_kernel<28, 0, 2>), grid, blk, 0, stream, r, log2d);
+        else if (two) hipLaunchKernelGGL((wn_gate_winograd4w_kernel<28, -1, 2>), grid, blk, 0, stream, r, log2d);
+        else if (gtu) hipLaunchKernelGGL((wn_gate_winograd4w_kernel<28, 0, 1>), grid, blk, 0, stream, r, log2d);
+        else hipLaunchKernelGGL((wn_gate_winograd4w_kernel<28, -1, 1>), grid, blk, 0, stream, r, log2d);
         return true;
     }
     if (split && gtu) hipLaunchKernelGGL(wn_gate_winograd4p_kernel<0>, grid, blk, 0, stream, r, log2d);

@@ -26,8 +26,8 @@ for WL in config3_si_b16_10s config2_sp_b1_10s config1_sp_b1_3s config5_sp_strea
       python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $R/gpurun_out/${TAG}_pmc_sq_$WL.log 2>&1
   echo "$WL: $(tail -1 $R/gpurun_out/${TAG}_trace_$WL.log | cut -c1-200)"
 done
-# builder-run secondaries (kernel trace only): the opt-in split half precision and the two-block variant
-for WL in config3_split_f16 variant_blocks2; do
+# builder-run secondaries (kernel trace only): the opt-in split half precision, the two-block variant, the geometry sweep
+for WL in config3_split_f16 variant_blocks2 geometry_sweep; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_trace_$WL -- \
       python3 $R/bench.py --workload $WL --steps 10 --warmup 5 --no-cpu-baseline --no-secondary > $R/gpurun_out/${TAG}_trace_$WL.log 2>&1
   echo "$WL: $(tail -1 $R/gpurun_out/${TAG}_trace_$WL.log | cut -c1-200)"

@@ -29,13 +29,13 @@ os.makedirs(dst, exist_ok=True)
 summary = {}
 FP32_MATRIX_PEAK_TFLOPS = 157.3
 PMC_WORKLOADS = ("config1_sp_b1_3s", "config2_sp_b1_10s", "config3_si_b16_10s", "config5_sp_stream64", "config5_sp_stream64_80ms")
-TRACE_ONLY = ("config3_split_f16", "variant_blocks2")
+TRACE_ONLY = ("config3_split_f16", "variant_blocks2", "geometry_sweep")
 
 
 def short(name):
     if "wn_gate_winograd" in name or ("conv1d_mfma_dma_kernel" in name and ", 1>" in name):
         return "gate"
-    if "wn_gate_f16_kernel" in name:
+    if "wn_gate_f16_kernel" in name or "wn_gate_f16w_kernel" in name:
         return "gate_f16"
     if "wn_resskip_f16_kernel" in name:
         return "res_skip_f16"
