@@ -286,6 +286,37 @@ def test_steady_ticks_replay_a_graph_and_stay_bit_equal(engine, offline_f23_engi
         assert np.array_equal(graphed[sid], offline[sid]), f"stream {sid} differs from the offline synthesis"
 
 
+@pytest.mark.parametrize("layers", [8, 12])
+def test_streaming_a_model_with_dilations_above_16(layers):
+    """The reference's default depth (12 layers, d <= 2048; and 8 layers, d <= 128): no per-layer state (the F(2,3) stream kernel
+    stops at d = 16), so every tick runs its whole window -- look-ahead 2.7 s at 12 layers, what the receptive field is -- and
+    the layers above d = 16 run the direct form; the streams stay bit-equal to the offline synthesis in the stream form."""
+    import torch
+    from mbexwn_vocoder_amd.engine import MBExWNEngine
+    from mbexwn_vocoder_amd.streaming import StreamingSynthesizer
+    cfg, raw, wt = build_case("SPEECH", {"mbexwn_config:pp_mod_subnet:n_channels": 32, "mbexwn_config:pp_mod_subnet:n_layers": layers})
+    eng = MBExWNEngine(cfg, raw, wt)
+    assert eng.layer_state_info()[0] == 0
+    syn = StreamingSynthesizer(eng, chunk_frames=8)
+    assert not syn.layer_carry
+    frames = 300 if layers == 12 else 120
+    mel, noise = synthetic_inputs(5, 2, frames)
+    got = {0: [], 1: []}
+    for sid in (0, 1):
+        syn.open(sid)
+        syn.push(sid, mel[sid], noise[sid], last=True)
+    for _ in range(200):
+        out = syn.tick()
+        for sid, audio in out.items():
+            got[sid].append(audio)
+        if all(syn.finished(sid) for sid in (0, 1)):
+            break
+    offline = MBExWNEngine(cfg, raw, wt, conv_form=eng.conv_form_info()["stream_form"]).forward(
+        torch.as_tensor(mel).cuda(), noise=torch.as_tensor(noise).cuda()).cpu().numpy()
+    for sid in (0, 1):
+        assert np.array_equal(np.concatenate(got[sid]), offline[sid])
+
+
 def test_window_advance(engine):
     """mbx_window_advance: in-place shift of the device-resident windows + append of the new frames."""
     import torch
@@ -303,6 +334,24 @@ def test_window_advance(engine):
     assert np.array_equal(mel_d.cpu().numpy()[:, -step:], mel_new)
     with pytest.raises(ValueError):
         engine.window_advance(mel_d, torch.as_tensor(mel_new[:, :, :40]).cuda())
+    # mbx_window_update: frames [shift, shift + keep) to the front, the new frames behind them, the rest of the window untouched
+    mel2, noise2 = rng.normal(size=(B, T, 80)).astype(np.float32), rng.normal(size=(B, T * 20)).astype(np.float32)
+    mel_d, noise_d = torch.as_tensor(mel2).cuda(), torch.as_tensor(noise2).cuda()
+    shift, keep, new = 5, 20, 7
+    engine.window_update(mel_d, torch.as_tensor(mel_new[:, :new]).cuda(), noise_d, torch.as_tensor(noise_new[:, :new * 20]).cuda(), shift, keep)
+    want = mel2.copy()
+    want[:, :keep] = mel2[:, shift:shift + keep]
+    want[:, keep:keep + new] = mel_new[:, :new]
+    assert np.array_equal(mel_d.cpu().numpy(), want)
+    wantn = noise2.copy()
+    wantn[:, :keep * 20] = noise2[:, shift * 20:(shift + keep) * 20]
+    wantn[:, keep * 20:(keep + new) * 20] = noise_new[:, :new * 20]
+    assert np.array_equal(noise_d.cpu().numpy(), wantn)
+    # mbx_emit_rows: a strided device-to-host copy of a slice of every row
+    host = torch.empty((B, 100), dtype=torch.float32).pin_memory()
+    engine.emit_rows(noise_d, 37, 100, host)
+    torch.cuda.synchronize()
+    assert np.array_equal(host.numpy(), wantn[:, 37:137])
 
 
 def test_frontend_ring_equals_whole_window_and_checks_its_arguments(engine):
