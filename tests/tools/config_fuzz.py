@@ -47,6 +47,17 @@ for case in range(n_cases):
         over[W + "n_ch_groups"] = 2
     if rng.random() < 0.15:
         over[M + "use_prelu"] = False
+    deep = len(sys.argv) > 3 and sys.argv[3] == "deep"
+    if deep:
+        # round 6: the reference's default depth and its neighbourhood -- 6 .. 12 layers without (mostly) a dilation cycle, so that
+        # dilations up to 2048 run (F(4,3) over interleaved sub-sequences, pairs of sub-sequences per block, the direct-form
+        # fall-back for short items), items of up to 260 frames with ragged batches
+        over[W + "n_layers"] = int(rng.integers(6, 13))
+        over[W + "dilation_rate_step"] = 1
+        over.pop(W + "max_log2_dilation_rate", None)
+        if rng.random() < 0.25:
+            over[W + "max_log2_dilation_rate"] = int(rng.integers(6, 10))
+        over[W + "cond_lin_upsampling"] = int(rng.choice([10, 10, 20, 5]))
     if len(sys.argv) > 3 and sys.argv[3] == "structure":     # structural variants: blocks, padding, excitation / filter paths
         pick = rng.random()
         if pick < 0.3:
@@ -91,6 +102,8 @@ for case in range(n_cases):
         eng = MBExWNEngine(cfg, raw, wt, conv_form=form.rstrip("i"), batch_invariant=form.endswith("i"))
         om, om32 = OracleModel(cfg, raw, wt), OracleModel(cfg, raw, wt, dtype=np.float32)
         B, T = int(rng.integers(1, 5)), int(rng.integers(1, 45))
+        if deep:
+            B, T = int(rng.integers(1, 4)), int(rng.choice([int(rng.integers(1, 60)), int(rng.integers(60, 261))]))
         lengths = [T] + [int(rng.integers(1, T + 1)) for _ in range(B - 1)]
         mel = np.clip(np.log(np.exp(rng.normal(-5.0, 2.0, size=(B, T, 80))) + 1e-5), -11.5, 2.0).astype(np.float32)
         rpf = dims.wn_in_rows_per_frame
@@ -164,6 +177,8 @@ for case in range(n_cases):
                 if np.any(np.abs(ph_hip[ii, :ph_ref.shape[0]] - ph_ref) > 0.5):
                     ok = "wrap"
         fails += not ok
+        if deep:
+            note += " kernels " + ",".join(kk.replace("f43_strided", "S").replace("folded_start", "0") for kk in eng.conv_form_info()["gate_kernels"])
         print(case, "OK  " if ok is True else ({"wrap": "WRAP", "row": "ROW "}.get(ok, "FAIL")), f"{worst:.1e}", f"(f32 port {yard:.1e}){note}", "form", form + "->" + eng.conv_form_info()["form"], "B", B, "T", T, {kk.split(':')[-1]: vv for kk, vv in over.items()}, flush=True)
         del eng
     except Exception:                                        # noqa: BLE001
