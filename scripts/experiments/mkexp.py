@@ -398,6 +398,27 @@ PATCHES = {
         ('                const f16x8 ah = *reinterpret_cast<const f16x8 *>(ys + 128 * r + 16 * (kq ^ key));\n                const f16x8 al = *reinterpret_cast<const f16x8 *>(ys + 128 * r + 16 * ((4 + kq) ^ key));',
          '                f16x8 ah, al;\n                if (p.max_rows <= 4000) {\n                    ah = *reinterpret_cast<const f16x8 *>(ys + 128 * r + 16 * (kq ^ key));\n                    al = *reinterpret_cast<const f16x8 *>(ys + 128 * r + 16 * ((4 + kq) ^ key));\n                } else {\n                    ah = bh[rt];\n                    al = bl[rt];\n                    asm volatile("" : "+v"(ah), "+v"(al));\n                }'),
     ],
+    # round 6: cycle account of a wave of wn_gate_f16w_kernel (s_memtime; each stamp costs ~150 cycles and waits for the wave's
+    # outstanding LDS reads): per wave summed over the 3 nk taps -- cycles in s_waitcnt vmcnt, at the barrier, in the request
+    # code, in operand reads + MFMAs; plus kernel start, loop start, loop end, kernel end
+    'gw_stamp': [
+        ('constexpr int GW_A = 0;                                     // two operand stages of GH_A_FLOATS',
+         '__device__ unsigned long long g_gw_stamps[8192 * 8 * 8];\n#define GW_STAMP(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }\nconstexpr int GW_A = 0;                                     // two operand stages of GH_A_FLOATS'),
+        ('    // XCD-aware decode; p.n_tiles counts PAIRS of column tiles here\n    const int id = blockIdx.x;',
+         '    unsigned long long gt0_, gt1_, gt2_, gt3_, s0_, s1_, s2_, s3_, s4_, aw_ = 0, ab_ = 0, ai_ = 0, ac_ = 0;\n    GW_STAMP(gt0_);\n    // XCD-aware decode; p.n_tiles counts PAIRS of column tiles here\n    const int id = blockIdx.x;'),
+        ('    const int ntap = 3 * nk;\n    for (int kt = 0; kt < nk; ++kt) {',
+         '    const int ntap = 3 * nk;\n    GW_STAMP(gt1_);\n    for (int kt = 0; kt < nk; ++kt) {'),
+        ('            // (last step: nothing is requested any more, the counts run out)\n            if (tap == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");',
+         '            GW_STAMP(s0_);\n            if (tap == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");'),
+        ('            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n            __syncthreads();                   // ... for every wave; and every wave is past tap g - 1\n            if (tap == 0 && !last) issue_a(kt + 1);\n            if (g + 3 < ntap) issue_b(g + 3);',
+         '            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n            GW_STAMP(s1_);\n            __syncthreads();                   // ... for every wave; and every wave is past tap g - 1\n            GW_STAMP(s2_);\n            if (tap == 0 && !last) issue_a(kt + 1);\n            if (g + 3 < ntap) issue_b(g + 3);\n            GW_STAMP(s3_);'),
+        ('                    accx[rt][c] = GH_MFMA(al, bh[c], accx[rt][c]);\n                }\n            }\n        }\n    }\n\n    // ---- epilogue (as in wn_gate_f16_kernel): main + 2^-11 cross, conditioning, gate, store',
+         '                    accx[rt][c] = GH_MFMA(al, bh[c], accx[rt][c]);\n                }\n            }\n            GW_STAMP(s4_);\n            aw_ += s1_ - s0_; ab_ += s2_ - s1_; ai_ += s3_ - s2_; ac_ += s4_ - s3_;\n        }\n    }\n    GW_STAMP(gt2_);\n\n    // ---- epilogue (as in wn_gate_f16_kernel): main + 2^-11 cross, conditioning, gate, store'),
+        ('            if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res[v];\n        }\n    }\n}\n\n// a.w must point at the image of engine.pack_gate_f16_weights',
+         '            if (ch_ok && row < rows) *reinterpret_cast<float2 *>(obase + (long long)row * p.ldo) = res[v];\n        }\n    }\n    GW_STAMP(gt3_);\n    if (lane == 0 && blockIdx.x < 8192) {\n        unsigned long long *o_ = g_gw_stamps + ((long long)blockIdx.x * 8 + wave) * 8;\n        o_[0] = gt0_; o_[1] = gt1_; o_[2] = gt2_; o_[3] = gt3_; o_[4] = aw_; o_[5] = ab_; o_[6] = ai_; o_[7] = ac_;\n    }\n}\n\n// a.w must point at the image of engine.pack_gate_f16_weights'),
+        ('}  // namespace mbx\n',
+         '}  // namespace mbx\n\nextern "C" int mbx_exp_stamps(void *dst, size_t bytes) {\n    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mbx::g_gw_stamps), bytes, 0, hipMemcpyDeviceToHost);\n}\n'),
+    ],
     # (the round-4 'noside' A/B of the VTF-net side stream patched a constant of commit 42f4fb7; the side stream was removed
     # with ab37db2, so the A/B is reproduced from that commit: git checkout 42f4fb7 -- mbexwn_vocoder_amd/csrc/mbx_api.hip)
     # stft_filter.hip: the block-per-frame kernel at fft_size 2048 as well (round-4 A/B of the wave-per-frame kernel)
