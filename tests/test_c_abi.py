@@ -106,3 +106,20 @@ def test_engine_refuses_to_run_without_gpu():
     cfg, raw, wt = build_case("SPEECH", {})
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         engine.MBExWNEngine(cfg, raw, wt)
+
+
+def test_gate_kernel_codes_match_the_header():
+    """mbx_conv_form_info.gate_kernel[] (ABI 10): the MBX_GATE_K_* codes of include/mbexwn.h and the names engine.py reports."""
+    import re
+    from mbexwn_vocoder_amd import engine
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mbexwn.h")).read()
+    codes = {name: int(val) for name, val in re.findall(r"#define MBX_GATE_K_(\w+) (\d+)", header)}
+    assert sorted(codes.values()) == sorted(engine.GATE_KERNEL_NAMES)
+    want = {"NONE": "none", "DIRECT": "direct", "F23": "f23", "F43": "f43", "F43_PSPLIT": "f43_psplit", "F43_HSPLIT": "f43_hsplit",
+            "F43_STRIDED": "f43_strided", "F43_STRIDED_PSPLIT": "f43_strided_psplit", "FOLDED_START": "folded_start",
+            "SPLIT_F16": "split_f16"}
+    assert {engine.GATE_KERNEL_NAMES[vv]: kk for kk, vv in codes.items()} == {vv: kk for kk, vv in want.items()}
+    assert int(re.search(r"#define MBX_ABI_VERSION (\d+)", header).group(1)) == engine.MBX_ABI_VERSION == 10
+    # bench.py's executed-FLOP factors know every kernel that multiplies
+    import bench
+    assert set(bench.GATE_EXECUTED) == set(engine.GATE_KERNEL_NAMES.values()) - {"none", "folded_start", "split_f16"}
